@@ -1,0 +1,142 @@
+"""Headline benchmark: stereo-pairs/s, GwcNet-gc forward (inference), 540x960 padded to 544x960,
+D=192 (BASELINE.json configs[1]) on N MI355X -- one process per GPU, independent pairs, no
+data-path collective (weak scaling).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     : the dominant kernel (fp32-MFMA 3x3x3 conv, 32->32 @ 48x136x240), timed live with
+                 HIP events on the launch stream in an instrumented replay of the same forward
+  cpu_baseline : the CPU oracle (torch fp32 restatement of the reference path) on this box's host
+                 cores, one full-size pair (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_IMG, W_IMG, H_PAD, W_PAD, MAXDISP = 540, 960, 544, 960, 192
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# algorithmic MACs per pair of one 3x3x3 32->32 layer at 48x136x240 (43.32 GMAC)
+DOM_GFLOP = 2 * 27 * 32 * 32 * 48 * 136 * 240 / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from openstereo_amd import _lib, engine
+    from openstereo_amd.models.gwcnet import GwcNet
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    _lib.load()
+
+    net = GwcNet()
+    sd = synth_state_dict(net, seed=0)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    B = args.batch
+    # 540x960 SceneFlow-shaped pair, edge-padded top/right to 544x960 (RightTopPad, stereo_trans.py:243-267)
+    L0, R0 = synth_images(B, H_IMG, W_IMG, seed=1 + rank)
+    pad = lambda t: torch.nn.functional.pad(t, (0, W_PAD - W_IMG, H_PAD - H_IMG, 0), mode="replicate")
+    L, R = pad(L0).to(dev), pad(R0).to(dev)        # inputs resident in HBM before timing starts
+
+    def step():
+        with torch.no_grad():
+            return net({"left": L, "right": R})["disp_pred"]
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all()
+    pairs_per_s = world * B * args.steps / dt
+
+    # ---- instrumented replay: per-layer HIP events on the launch stream ----
+    roofline = None
+    if rank == 0:
+        rec = engine.enable_timing()
+        for _ in range(max(2, min(args.steps, 5))):
+            step()
+        torch.cuda.synchronize()
+        stats = engine.collect_timing(rec)
+        dom = [v for k, v in stats.items() if k[0] == "conv3d" and k[1:] == (32, 32, 3, 1, 48, 136, 240)]
+        if dom:
+            ms = sum(sum(v) for v in dom) / sum(len(v) for v in dom) / B      # per pair
+            ach = DOM_GFLOP / ms                                               # GFLOP / ms = TFLOP/s
+            roofline = {"kernel": "conv_mfma_f32_kernel<2,1,4,1,8,8> 3x3x3 32->32 @48x136x240",
+                        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(ms * B, 4),
+                        "stage_ms_per_step": {"/".join(map(str, k)): round(sum(v) / len(v), 4) for k, v in
+                                              sorted(stats.items(), key=lambda kv: -sum(kv[1]) / len(kv[1]))[:12]}}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_ref as O      # CPU baseline leg only
+        Lc, Rc = L[:1].cpu(), R[:1].cpu()
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            ref = O.gwcnet_forward(Lc, Rc, sd)
+            tc = time.perf_counter() - t1
+        epe = float((out[:1].cpu() - ref).abs().mean())
+        cpu_baseline = {"value": round(1.0 / tc, 5), "unit": "stereo-pairs/s", "cores": torch.get_num_threads(),
+                        "kind": "port", "sample": "1 full 544x960 D=192 GwcNet forward (oracle/torch_ref.py, fp32, no warm-up)",
+                        "epe_gpu_vs_cpu_px": epe}
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "stereo-pairs/s at 540x960 D=192 (GwcNet fwd)", "value": round(pairs_per_s, 3),
+            "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GwcNet-gc inference, SceneFlow-shaped 540x960 padded to 544x960, D=192, "
+                                   "G=40 + 12ch concat (BASELINE configs[1])",
+                       "pairs_per_gpu_per_step": B, "parallelism": f"independent pairs x{world}",
+                       "weights": "deterministic synthetic (sharpened), random-init architecture"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

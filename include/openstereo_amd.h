@@ -1,0 +1,157 @@
+/*
+ * openstereo_amd.h -- C ABI of the MI355X (gfx950) cost-volume engine.
+ *
+ * Every entry point takes plain device pointers + sizes and a HIP stream
+ * (`void* stream` == hipStream_t, NULL = default stream).  No torch types.
+ * All tensors are fp32 and live in HBM.  Return value: 0 on success, <0 on
+ * error; the message is available from osa_last_error() (thread local).
+ * Nothing here ever falls back to a CPU path.
+ *
+ * Two HBM layouts are understood for 5-D volumes:
+ *   OSA_NCDHW  reference layout  [B][C][D][H][W]        (what OpenStereo returns)
+ *   OSA_NDHWC  engine layout     [B][D][H][W][C]        (channels innermost; what
+ *              the MFMA aggregation kernels consume: one voxel = one contiguous
+ *              channel vector, 16-byte aligned).
+ *
+ * Reference interfaces replaced (paths relative to the OpenStereo tree):
+ *   osa_build_volume_f32        stereo/modeling/cost_volume/cost_volume.py:59-92
+ *                               models/gwcnet/gwcnet_cost_processor.py:13-68
+ *                               models/psmnet/psmnet_cost_processor.py:9-50
+ *                               models/igev/submodule.py:158-177,216-227
+ *   osa_corr_volume_f32         stereo/modeling/cost_volume/cost_volume.py:32-41,95-105
+ *   osa_conv3d_* / osa_deconv3d_*  nn.Conv3d/ConvTranspose3d + BatchNorm3d(eval) + act of
+ *                               models/gwcnet/gwcnet_disp_processor.py:8-81,
+ *                               models/gwcnet/hourglass.py:5-56,
+ *                               models/psmnet/psmnet_cost_processor.py:53-221,
+ *                               stereo/modeling/common/basic_block_3d.py:5-38
+ *   osa_softargmin_f32          stereo/modeling/disp_pred/disp_regression.py:8-12,
+ *                               models/gwcnet/gwcnet_disp_processor.py:22-26,
+ *                               models/psmnet/psmnet_disp_processor.py:6-74
+ *   osa_softmax_softargmin_f32  F.softmax(dim=1) + the above (stereobase_gru.py:163-164,
+ *                               lightstereo.py:55-56, igev_stereo.py:164-165)
+ *   osa_upsample_softargmin_f32 F.interpolate(trilinear)+softmax+regression,
+ *                               models/gwcnet/gwcnet_disp_processor.py:99-133,
+ *                               models/psmnet/psmnet_cost_processor.py:201-214
+ */
+#ifndef OPENSTEREO_AMD_H
+#define OPENSTEREO_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSA_ABI_VERSION 1
+
+enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
+enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2 };
+
+/* ---- misc ------------------------------------------------------------- */
+int         osa_abi_version(void);
+const char* osa_last_error(void);
+/* device the library was built for ("gfx950") */
+const char* osa_target_arch(void);
+
+/* ---- cost-volume constructors (a1-a4) ----------------------- */
+/*
+ * Fused group-wise-correlation + concatenation volume.
+ *   gwc part   : vol[b, c_off+g, d, h, w]        = (1/K) sum_k L[b,gK+k,h,w] * R[b,gK+k,h,w-d]
+ *   concat part: vol[b, c_off+G+c, d, h, w]      = Lc[b,c,h,w]
+ *                vol[b, c_off+G+Cc+c, d, h, w]   = Rc[b,c,h,w-d]
+ *   everything is 0 where w < d (mask_left_concat=0 reproduces the IGEV copy
+ *   that leaves the left half unmasked).
+ * Either part may be absent: C==0 (no gwc part) or Cc==0 (no concat part).
+ * left/right feature maps are NCHW contiguous.  `vol` has `vol_channels`
+ * channels in `layout`; this call writes channels [c_off, c_off+G+2*Cc).
+ */
+int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups,
+                         const float* left_cat, const float* right_cat, int Cc,
+                         float* vol, int layout, int vol_channels, int c_off,
+                         int B, int H, int W, int maxdisp, int mask_left_concat,
+                         void* stream);
+
+/* correlation layer: vol[b,d,h,w] = mean_c L[b,c,h,w]*R[b,c,h,w-d], 0 for w<d. vol is [B,D,H,W]. */
+int osa_corr_volume_f32(const float* left, const float* right, float* vol,
+                        int B, int C, int H, int W, int maxdisp, void* stream);
+
+/* ---- layout helpers ---------------------------------------------------- */
+/* x [B][C][S] -> y [B][S][yCs] channels [c_off, c_off+C)   (S = D*H*W) */
+int osa_ncdhw_to_ndhwc_f32(const float* x, float* y, int B, int C, long long S,
+                           int yCs, int c_off, void* stream);
+/* x [B][S][xCs] channels [c_off, c_off+C) -> y [B][C][S] */
+int osa_ndhwc_to_ncdhw_f32(const float* x, float* y, int B, int C, long long S,
+                           int xCs, int c_off, void* stream);
+
+/* ---- 3-D aggregation convolutions (a6-a8) ------------------- */
+/*
+ * Weights are packed once per layer into the MFMA operand order
+ *   [cin-chunk][tap][k-octet][half][CoutPadded][4]   (fp32)
+ * by osa_conv3d_pack_f32 (ordinary conv, reference layout [Co][Ci][kd][kh][kw])
+ * or osa_deconv3d_pack_f32 (transposed conv, reference layout [Ci][Co][kd][kh][kw];
+ * stride 2; the 8 output-parity classes are packed back to back).
+ * osa_*_packed_floats gives the size of the packed buffer in floats.
+ */
+size_t osa_conv3d_packed_floats(int Ci, int Co, int kd, int kh, int kw);
+int    osa_conv3d_pack_f32(const float* w_ref, float* w_packed,
+                           int Ci, int Co, int kd, int kh, int kw, void* stream);
+size_t osa_deconv3d_packed_floats(int Ci, int Co, int k);
+int    osa_deconv3d_pack_f32(const float* w_ref, float* w_packed,
+                             int Ci, int Co, int k, int pad, void* stream);
+
+/*
+ * y = act( conv3d(x, w) * scale[co] + shift[co] + residual )
+ *   x        : NDHWC, voxel stride xCs floats (>= Ci, multiple of 4), reads channels [0,Ci)
+ *   y        : NDHWC, voxel stride yCs floats, writes channels [0,Co)
+ *   residual : NDHWC with voxel stride rCs, same spatial size as y, or NULL
+ *   scale/shift: per-output-channel (folded eval-mode BatchNorm; NULL = 1 / 0)
+ *   stride is isotropic (1 or 2) -- a dimension of size 1 with kernel 1 is not strided;
+ *   pad_* / dil_* per dimension.  act: OSA_ACT_*; slope for leaky.
+ *   Output dims follow the PyTorch formula.
+ */
+int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
+                         const float* scale, const float* shift, const float* residual,
+                         float* y,
+                         int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                         int Co, int yCs, int rCs,
+                         int kd, int kh, int kw, int stride,
+                         int pad_d, int pad_h, int pad_w,
+                         int dil_d, int dil_h, int dil_w,
+                         int act, float slope, void* stream);
+
+/*
+ * y = act( conv_transpose3d(x, w, stride=2, padding=pad, output_padding=opad) * scale + shift + residual )
+ * k = 3 (pad 1, opad 1: GwcNet/PSMNet) or k = 4 (pad 1, opad 0: StereoBase/IGEV); Do = 2*Di.
+ * Implemented as 8 output-parity sub-convolutions, no zero insertion.
+ */
+int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
+                           const float* scale, const float* shift, const float* residual,
+                           float* y,
+                           int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                           int Co, int yCs, int rCs,
+                           int k, int pad, int opad,
+                           int act, float slope, void* stream);
+
+/* small-Cout direct convolution (Co <= 4, e.g. the 32->1 classifier). Reference weight
+ * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer). */
+int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,
+                                  float* y,
+                                  int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
+                                  int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
+                                  void* stream);
+
+/* ---- disparity regression (a10-a12) ------------------------- */
+/* out[b,h,w] = sum_d d * prob[b,d,h,w] */
+int osa_softargmin_f32(const float* prob, float* out, int B, int D, int H, int W, void* stream);
+/* out[b,h,w] = sum_d d * softmax_d(cost[b,:,h,w]) ; optionally also writes prob (may be NULL) */
+int osa_softmax_softargmin_f32(const float* cost, float* prob, float* out,
+                               int B, int D, int H, int W, void* stream);
+/* fused trilinear upsample [B,Dl,Hl,Wl] -> [B,D,H,W] + softmax over D + expectation */
+int osa_upsample_softargmin_f32(const float* cost_lowres, float* out,
+                                int B, int Dl, int Hl, int Wl, int D, int H, int W,
+                                int align_corners, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENSTEREO_AMD_H */

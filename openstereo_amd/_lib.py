@@ -1,0 +1,94 @@
+"""ctypes binding of the C-ABI library (include/openstereo_amd.h).
+
+The product path has NO fallback: if the gfx950 library is missing or a call fails, a
+RuntimeError is raised.  Nothing in here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libopenstereo_amd.so")
+
+_lock = threading.Lock()
+_lib = None
+
+c_fp = C.c_void_p      # device float*
+c_i = C.c_int
+c_f = C.c_float
+c_st = C.c_void_p      # hipStream_t
+c_ll = C.c_longlong
+
+# name -> (restype, argtypes).  Mirrors include/openstereo_amd.h one to one; tests check that
+# every symbol declared in the header is listed here and exported by the .so.
+SIGNATURES = {
+    "osa_abi_version": (c_i, []),
+    "osa_last_error": (C.c_char_p, []),
+    "osa_target_arch": (C.c_char_p, []),
+    "osa_build_volume_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i,
+                                   c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_corr_volume_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_ncdhw_to_ndhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_ll, c_i, c_i, c_st]),
+    "osa_ndhwc_to_ncdhw_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_ll, c_i, c_i, c_st]),
+    "osa_conv3d_packed_floats": (C.c_size_t, [c_i, c_i, c_i, c_i, c_i]),
+    "osa_conv3d_pack_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_deconv3d_packed_floats": (C.c_size_t, [c_i, c_i, c_i]),
+    "osa_deconv3d_pack_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
+    "osa_conv3d_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                   c_i, c_i, c_i, c_i, c_i, c_i,
+                                   c_i, c_i, c_i,
+                                   c_i, c_i, c_i, c_i,
+                                   c_i, c_i, c_i,
+                                   c_i, c_i, c_i,
+                                   c_i, c_f, c_st]),
+    "osa_deconv3d_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                     c_i, c_i, c_i, c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_i, c_f, c_st]),
+    "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp,
+                                            c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                            c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
+    "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
+    "osa_upsample_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (once) and declare every prototype. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"{LIB_PATH} is missing: build it with `python -m openstereo_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if lib.osa_abi_version() != 1:
+            raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}")
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; turn a non-zero status into EngineError."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.osa_last_error()
+        raise EngineError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+    return rc

@@ -1,0 +1,513 @@
+// 3-D cost-aggregation convolutions for gfx950.
+//
+// im2col-free implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+//   M = output voxels (32 per MFMA tile), N = output channels (32 per tile),
+//   K = taps x input channels.
+// A workgroup owns a (TD x TH x TW) brick of "a-space" positions; the input brick it needs
+// (halo included) is staged channels-last into LDS one 16-channel chunk at a time with a
+// voxel stride of 20 floats (80 B: 16-byte aligned and conflict-free for ds_read_b128).  Every
+// tap is then just a wave-uniform LDS offset: the A operand of 4 consecutive MFMAs is one
+// ds_read_b128 per lane, the B operand one 16-byte load of the pre-packed weights
+// ([chunk][tap][octet][half][Cout][4]) that all waves of all workgroups share through L2.
+//
+// One kernel covers every layer shape through a tap table:
+//   out[a*os + oo] = sum_t  in[a*is + delta_t] . W_t
+//   stride-1/2 conv : os=1, is=stride, delta = k*dil - pad
+//   1x1x1           : one tap
+//   transposed conv (stride 2): 8 output-parity classes, os=2, oo=parity, is=1, only the
+//                     taps that hit real (non-inserted) inputs -> no zero insertion, no wasted MACs
+// Epilogue (fused): folded eval-mode BatchNorm (scale/shift), residual add, ReLU/LeakyReLU.
+#include "osa_common.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace osa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CC = 16;        // input channels staged per pass (packed-weight format constant)
+constexpr int VS = CC + 4;    // LDS voxel stride in floats
+constexpr int JO = CC / 8;    // k-octets per chunk
+constexpr int MAX_TAPS = 32;
+
+struct ConvArgs {
+    const float* x; const float4* w; const float* scale; const float* shift; const float* res; float* y;
+    int B, Di, Hi, Wi, Ci, xCs;
+    int Do, Ho, Wo, Co, yCs, rCs;
+    int Ad, Ah, Aw;               // a-space extent of this launch
+    int isd, ish, isw;            // input step per a (per dim)
+    int os, ood, ooh, oow;        // output position = a*os + oo
+    int T;                        // taps
+    int dmin, hmin, wmin;         // min delta per dim
+    int LD, LH, LW;               // LDS brick dims
+    int tilesD, tilesH, tilesW;
+    int nchunks, CoP;
+    int act; float slope;
+    signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
+};
+
+// CFG: MT m-tiles x NT n-tiles per wave, WM x WN waves, brick TD x TH x TW (TD derived)
+template <int MT, int NT, int WM, int WN, int TH, int TW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TD = WM * MT * 32 / (TH * TW);
+    static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
+    static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "TH/TW powers of two");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 31, hh = lane >> 5;
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int twi = bid % p.tilesW; bid /= p.tilesW;
+    const int thi = bid % p.tilesH; bid /= p.tilesH;
+    const int tdi = bid % p.tilesD;
+    const int b = bid / p.tilesD;
+    const int a0d = tdi * TD, a0h = thi * TH, a0w = twi * TW;
+    const int g0d = a0d * p.isd + p.dmin, g0h = a0h * p.ish + p.hmin, g0w = a0w * p.isw + p.wmin;
+    const int n0 = blockIdx.y * (WN * NT * 32);
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int q = (wm * MT + m) * 32 + col;
+        const int tw_ = q % TW, th_ = (q / TW) % TH, td_ = q / (TW * TH);
+        abase[m] = ((td_ * p.isd) * p.LH + th_ * p.ish) * p.LW + tw_ * p.isw;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int rows = p.LD * p.LH;
+    const int rowItems = p.LW * (CC / 4);
+    const size_t wstep = (size_t)JO * 2 * p.CoP;   // float4s per tap
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        if (ch) __syncthreads();
+        // ---- stage 16 channels of the input brick (zero outside the tensor) ----
+        const int c0 = ch * CC;
+        for (int rr = wave; rr < rows; rr += NW) {
+            const int ld = rr / p.LH, lh = rr - ld * p.LH;
+            const int gd = g0d + ld, gh = g0h + lh;
+            const bool rowok = ((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi);
+            const float* grow = p.x + (((size_t)b * p.Di + gd) * p.Hi + gh) * (size_t)p.Wi * p.xCs + c0;
+            float* lrow = smem + (size_t)rr * p.LW * VS;
+            for (int e = lane; e < rowItems; e += 64) {
+                const int lw = e >> 2, c4 = e & 3;
+                const int gw = g0w + lw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowok && ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
+                    v = *reinterpret_cast<const float4*>(grow + (size_t)gw * p.xCs + c4 * 4);
+                *reinterpret_cast<float4*>(lrow + lw * VS + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- taps x octets on the matrix cores ----
+        const float4* wch = p.w + (size_t)ch * p.T * wstep + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
+        for (int t = 0; t < p.T; ++t) {
+            const int toff = ((p.td[t] - p.dmin) * p.LH + (p.th[t] - p.hmin)) * p.LW + (p.tw[t] - p.wmin);
+            const float4* wt = wch + (size_t)t * wstep;
+#pragma unroll
+            for (int j = 0; j < JO; ++j) {
+                float4 bv[NT], av[MT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = wt[(size_t)(j * 2) * p.CoP + n * 32];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    av[m] = *reinterpret_cast<const float4*>(smem + (size_t)(abase[m] + toff) * VS + j * 8 + hh * 4);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: BN affine + residual + activation, NDHWC store ----
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n0 + (wn * NT + n) * 32 + col;
+        const bool cok = co < p.Co;
+        const float sc = (cok && p.scale) ? p.scale[co] : 1.f;
+        const float sh = (cok && p.shift) ? p.shift[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int q = (wm * MT + m) * 32 + row;
+                const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+                if (cok && ad < p.Ad && ah < p.Ah && aw < p.Aw) {
+                    const size_t vox = (((size_t)b * p.Do + (ad * p.os + p.ood)) * p.Ho + (ah * p.os + p.ooh)) * p.Wo +
+                                       (aw * p.os + p.oow);
+                    float v = fmaf(acc[m][n][r], sc, sh);
+                    if (p.res) v += p.res[vox * p.rCs + co];
+                    if (p.act == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                    p.y[vox * p.yCs + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ dispatch --
+struct KernelCfg {
+    const char* name;
+    int M, N;              // voxels / channels per workgroup
+    int TD, TH, TW, threads;
+    void (*fn)(const ConvArgs);
+};
+
+#define OSA_CFG(MT, NT, WM, WN, TH, TW)                                                      \
+    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
+      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64, conv_mfma_f32_kernel<MT, NT, WM, WN, TH, TW> }
+
+static const KernelCfg g_cfgs[] = {
+    OSA_CFG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
+    OSA_CFG(2, 2, 4, 1, 8, 8),   // 1: 256 vox x  64 ch   brick 4x8x8
+    OSA_CFG(2, 2, 2, 2, 8, 8),   // 2: 128 vox x 128 ch   brick 2x8x8
+    OSA_CFG(1, 1, 4, 1, 4, 8),   // 3: 128 vox x  32 ch   brick 4x4x8
+    OSA_CFG(1, 2, 4, 1, 4, 8),   // 4: 128 vox x  64 ch   brick 4x4x8
+    OSA_CFG(1, 1, 2, 2, 4, 8),   // 5:  64 vox x  64 ch   brick 2x4x8   (stride-2 layers)
+    OSA_CFG(1, 2, 2, 2, 4, 8),   // 6:  64 vox x 128 ch   brick 2x4x8
+    OSA_CFG(2, 1, 4, 1, 16, 16), // 7: 256 vox x  32 ch   brick 1x16x16 (2-D layers)
+    OSA_CFG(2, 2, 4, 1, 16, 16), // 8: 256 vox x  64 ch   brick 1x16x16
+    OSA_CFG(2, 2, 2, 2, 8, 16),  // 9: 128 vox x 128 ch   brick 1x8x16
+    OSA_CFG(4, 1, 4, 1, 8, 8),   // 10: 512 vox x 32 ch   brick 8x8x8
+    OSA_CFG(1, 1, 1, 4, 4, 8),   // 11: 32 vox x 128 ch   brick 1x4x8   (tiny layers: more workgroups)
+};
+constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
+
+static int pick_cfg(const ConvArgs& a, int stride) {
+    const char* ov = getenv("OSA_CONV_CFG");
+    if (ov && *ov) {
+        int v = atoi(ov);
+        if (v >= 0 && v < N_CFGS && a.CoP % g_cfgs[v].N == 0) return v;
+    }
+    const bool flat = (a.Ad == 1);
+    const long long vox = (long long)a.B * a.Ad * a.Ah * a.Aw;
+    if (flat) {
+        if (a.CoP % 128 == 0) return 9;
+        if (a.CoP % 64 == 0) return 8;
+        return 7;
+    }
+    if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 3);
+    if (a.CoP % 128 == 0) return (vox < 256 * 128 * 4) ? 11 : 2;
+    if (a.CoP % 64 == 0) return (vox < 256 * 256 * 2) ? 4 : 1;
+    return (vox < 256 * 256 * 2) ? 3 : 0;
+}
+
+static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what) {
+    const int ci = pick_cfg(a, stride);
+    const KernelCfg& k = g_cfgs[ci];
+    a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
+    int dmax = -128, hmax = -128, wmax = -128;
+    a.dmin = a.hmin = a.wmin = 127;
+    for (int t = 0; t < a.T; ++t) {
+        a.dmin = a.td[t] < a.dmin ? a.td[t] : a.dmin; dmax = a.td[t] > dmax ? a.td[t] : dmax;
+        a.hmin = a.th[t] < a.hmin ? a.th[t] : a.hmin; hmax = a.th[t] > hmax ? a.th[t] : hmax;
+        a.wmin = a.tw[t] < a.wmin ? a.tw[t] : a.wmin; wmax = a.tw[t] > wmax ? a.tw[t] : wmax;
+    }
+    a.LD = (k.TD - 1) * a.isd + (dmax - a.dmin) + 1;
+    a.LH = (k.TH - 1) * a.ish + (hmax - a.hmin) + 1;
+    a.LW = (k.TW - 1) * a.isw + (wmax - a.wmin) + 1;
+    const size_t lds = (size_t)a.LD * a.LH * a.LW * VS * sizeof(float);
+    OSA_REQUIRE(lds <= 160 * 1024, "%s: LDS brick %dx%dx%d needs %zu B (> 160 KiB)", what, a.LD, a.LH, a.LW, lds);
+    const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
+    OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
+    hipLaunchKernelGGL(k.fn, grid, block, lds, st, a);
+    OSA_LAUNCH_CHECK(what);
+    return 0;
+}
+
+// ------------------------------------------------------------------ packing --
+// dst float index: ((((ch*T + t)*JO + j)*2 + h)*CoP + co)*4 + e   <-  W_t[ci = ch*16 + 8j + 4h + e][co]
+struct PackArgs {
+    const float* src; float* dst;
+    int Ci, Co, CoP, kd, kh, kw, T, nchunks, transposed;
+    signed char kz[MAX_TAPS], ky[MAX_TAPS], kx[MAX_TAPS];   // kernel index of every tap
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs p) {
+    const size_t total = (size_t)p.nchunks * p.T * JO * 2 * p.CoP * 4;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = i & 3; size_t r = i >> 2;
+    const int co = r % p.CoP; r /= p.CoP;
+    const int h = r & 1; r >>= 1;
+    const int j = r % JO; r /= JO;
+    const int t = r % p.T; const int ch = r / p.T;
+    const int ci = ch * CC + 8 * j + 4 * h + e;
+    float v = 0.f;
+    if (ci < p.Ci && co < p.Co) {
+        const size_t kvol = (size_t)p.kd * p.kh * p.kw;
+        const size_t kidx = ((size_t)p.kz[t] * p.kh + p.ky[t]) * p.kw + p.kx[t];
+        v = p.transposed ? p.src[((size_t)ci * p.Co + co) * kvol + kidx]
+                         : p.src[((size_t)co * p.Ci + ci) * kvol + kidx];
+    }
+    p.dst[i] = v;
+}
+
+static inline int pad32(int c) { return (c + 31) / 32 * 32; }
+static inline int nchunks_of(int ci) { return (ci + CC - 1) / CC; }
+static inline size_t packed_floats(int Ci, int Co, int T) {
+    return (size_t)nchunks_of(Ci) * T * JO * 2 * pad32(Co) * 4;
+}
+
+// transposed-conv parity class: taps of one dimension. o = 2a+par ; i = a + delta ; kernel index kk
+static int deconv_dim_taps(int k, int pad, int par, int* delta, int* kk) {
+    int n = 0;
+    for (int t = 0; t < k; ++t) {
+        const int num = par + pad - t;
+        if (((num % 2) + 2) % 2 != 0) continue;
+        delta[n] = (num >= 0) ? num / 2 : -((-num) / 2);
+        kk[n] = t;
+        ++n;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ small Co --
+struct DirectArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, D, H, W, Ci, xCs, Co, yCs;
+    int kd, kh, kw, pd, ph, pw;
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv_small_co_kernel(const DirectArgs p) {
+    const size_t nvox = (size_t)p.B * p.D * p.H * p.W;
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvox) return;
+    int w = v % p.W; size_t r = v / p.W;
+    int h = r % p.H; r /= p.H;
+    int d = r % p.D; const int b = r / p.D;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = p.bias ? p.bias[o] : 0.f;
+    const size_t kvol = (size_t)p.kd * p.kh * p.kw;
+    for (int z = 0; z < p.kd; ++z) {
+        const int gd = d + z - p.pd;
+        if ((unsigned)gd >= (unsigned)p.D) continue;
+        for (int yy = 0; yy < p.kh; ++yy) {
+            const int gh = h + yy - p.ph;
+            if ((unsigned)gh >= (unsigned)p.H) continue;
+            for (int xx = 0; xx < p.kw; ++xx) {
+                const int gw = w + xx - p.pw;
+                if ((unsigned)gw >= (unsigned)p.W) continue;
+                const float* px = p.x + ((((size_t)b * p.D + gd) * p.H + gh) * p.W + gw) * p.xCs;
+                const size_t kidx = ((size_t)z * p.kh + yy) * p.kw + xx;
+                for (int c = 0; c < p.Ci; c += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(px + c);
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        const float* wp = p.w + ((size_t)o * p.Ci + c) * kvol + kidx;   // wave-uniform
+                        acc[o] = fmaf(a.x, wp[0], acc[o]);
+                        if (c + 1 < p.Ci) acc[o] = fmaf(a.y, wp[kvol], acc[o]);
+                        if (c + 2 < p.Ci) acc[o] = fmaf(a.z, wp[2 * kvol], acc[o]);
+                        if (c + 3 < p.Ci) acc[o] = fmaf(a.w, wp[3 * kvol], acc[o]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) p.y[v * p.yCs + o] = acc[o];
+}
+
+}  // namespace osa
+
+using namespace osa;
+
+// ------------------------------------------------------------------ C ABI -----
+extern "C" size_t osa_conv3d_packed_floats(int Ci, int Co, int kd, int kh, int kw) {
+    return packed_floats(Ci, Co, kd * kh * kw);
+}
+
+extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                   int kd, int kh, int kw, void* stream) {
+    OSA_REQUIRE(w_ref && w_packed, "conv3d_pack: NULL pointer");
+    const int T = kd * kh * kw;
+    OSA_REQUIRE(T >= 1 && T <= MAX_TAPS, "conv3d_pack: %dx%dx%d kernel has %d taps (max %d)", kd, kh, kw, T, MAX_TAPS);
+    OSA_REQUIRE(Ci > 0 && Co > 0, "conv3d_pack: bad channels %d->%d", Ci, Co);
+    PackArgs p;
+    p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
+    p.kd = kd; p.kh = kh; p.kw = kw; p.T = T; p.nchunks = nchunks_of(Ci); p.transposed = 0;
+    int t = 0;
+    for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int x = 0; x < kw; ++x, ++t) {
+        p.kz[t] = (signed char)z; p.ky[t] = (signed char)y; p.kx[t] = (signed char)x;
+    }
+    const size_t total = packed_floats(Ci, Co, T);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    OSA_LAUNCH_CHECK("conv3d_pack");
+    return 0;
+}
+
+extern "C" size_t osa_deconv3d_packed_floats(int Ci, int Co, int k) {
+    // every kernel tap belongs to exactly one parity class -> k^3 taps in total
+    return packed_floats(Ci, Co, k * k * k);
+}
+
+extern "C" int osa_deconv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                     int k, int pad, void* stream) {
+    OSA_REQUIRE(w_ref && w_packed, "deconv3d_pack: NULL pointer");
+    OSA_REQUIRE(k == 3 || k == 4, "deconv3d_pack: kernel %d unsupported (3 or 4)", k);
+    size_t off = 0;
+    for (int cls = 0; cls < 8; ++cls) {
+        int dd[4], kd_[4], dh[4], kh_[4], dw[4], kw_[4];
+        const int nd = deconv_dim_taps(k, pad, (cls >> 2) & 1, dd, kd_);
+        const int nh = deconv_dim_taps(k, pad, (cls >> 1) & 1, dh, kh_);
+        const int nw = deconv_dim_taps(k, pad, cls & 1, dw, kw_);
+        PackArgs p;
+        p.src = w_ref; p.dst = w_packed + off; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
+        p.kd = k; p.kh = k; p.kw = k; p.T = nd * nh * nw; p.nchunks = nchunks_of(Ci); p.transposed = 1;
+        int t = 0;
+        for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c, ++t) {
+            p.kz[t] = (signed char)kd_[a]; p.ky[t] = (signed char)kh_[b]; p.kx[t] = (signed char)kw_[c];
+        }
+        const size_t total = packed_floats(Ci, Co, p.T);
+        if (total)
+            hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0,
+                               (hipStream_t)stream, p);
+        off += total;
+    }
+    OSA_LAUNCH_CHECK("deconv3d_pack");
+    return 0;
+}
+
+static int check_common(const char* what, const float* x, const float* w, float* y,
+                        int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs,
+                        const float* residual) {
+    OSA_REQUIRE(x && w && y, "%s: NULL pointer", what);
+    OSA_REQUIRE(B > 0 && Di > 0 && Hi > 0 && Wi > 0, "%s: bad dims", what);
+    OSA_REQUIRE(Ci > 0 && Co > 0, "%s: bad channels %d->%d", what, Ci, Co);
+    OSA_REQUIRE(Ci % 4 == 0 && xCs % 4 == 0 && xCs >= Ci, "%s: Ci=%d / xCs=%d must be multiples of 4, xCs>=Ci", what, Ci, xCs);
+    OSA_REQUIRE(((size_t)x & 15) == 0, "%s: x not 16-byte aligned", what);
+    OSA_REQUIRE(yCs >= Co, "%s: yCs=%d < Co=%d", what, yCs, Co);
+    if (residual) OSA_REQUIRE(rCs >= Co, "%s: rCs=%d < Co=%d", what, rCs, Co);
+    return 0;
+}
+
+extern "C" int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
+                                    const float* scale, const float* shift, const float* residual,
+                                    float* y,
+                                    int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                    int Co, int yCs, int rCs,
+                                    int kd, int kh, int kw, int stride,
+                                    int pad_d, int pad_h, int pad_w,
+                                    int dil_d, int dil_h, int dil_w,
+                                    int act, float slope, void* stream) {
+    if (check_common("conv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
+    const int T = kd * kh * kw;
+    OSA_REQUIRE(T >= 1 && T <= MAX_TAPS, "conv3d: %dx%dx%d kernel unsupported", kd, kh, kw);
+    OSA_REQUIRE(stride == 1 || stride == 2, "conv3d: stride %d unsupported", stride);
+    OSA_REQUIRE(dil_d >= 1 && dil_h >= 1 && dil_w >= 1, "conv3d: bad dilation");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = reinterpret_cast<const float4*>(w_packed); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
+    a.isd = (Di == 1 && kd == 1) ? 1 : stride; a.ish = stride; a.isw = stride;
+    a.Do = (Di + 2 * pad_d - dil_d * (kd - 1) - 1) / a.isd + 1;
+    a.Ho = (Hi + 2 * pad_h - dil_h * (kh - 1) - 1) / a.ish + 1;
+    a.Wo = (Wi + 2 * pad_w - dil_w * (kw - 1) - 1) / a.isw + 1;
+    OSA_REQUIRE(a.Do > 0 && a.Ho > 0 && a.Wo > 0, "conv3d: empty output");
+    a.Co = Co; a.yCs = yCs; a.rCs = rCs;
+    a.Ad = a.Do; a.Ah = a.Ho; a.Aw = a.Wo;
+    a.os = 1; a.ood = a.ooh = a.oow = 0;
+    a.T = T;
+    int t = 0;
+    for (int z = 0; z < kd; ++z) for (int yy = 0; yy < kh; ++yy) for (int xx = 0; xx < kw; ++xx, ++t) {
+        a.td[t] = (signed char)(z * dil_d - pad_d);
+        a.th[t] = (signed char)(yy * dil_h - pad_h);
+        a.tw[t] = (signed char)(xx * dil_w - pad_w);
+    }
+    a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
+    a.act = act; a.slope = slope;
+    return launch_conv(a, stride, (hipStream_t)stream, "conv3d");
+}
+
+extern "C" int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
+                                      const float* scale, const float* shift, const float* residual,
+                                      float* y,
+                                      int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                      int Co, int yCs, int rCs,
+                                      int k, int pad, int opad,
+                                      int act, float slope, void* stream) {
+    if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
+    OSA_REQUIRE((k == 3 && pad == 1 && opad == 1) || (k == 4 && pad == 1 && opad == 0),
+                "deconv3d: only (k=3,p=1,op=1) and (k=4,p=1,op=0) with stride 2 are supported (got k=%d p=%d op=%d)", k, pad, opad);
+    const int Do = (Di - 1) * 2 - 2 * pad + k + opad, Ho = (Hi - 1) * 2 - 2 * pad + k + opad, Wo = (Wi - 1) * 2 - 2 * pad + k + opad;
+    size_t off = 0;
+    for (int cls = 0; cls < 8; ++cls) {
+        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+        int dd[4], kd_[4], dh[4], kh_[4], dw[4], kw_[4];
+        const int nd = deconv_dim_taps(k, pad, pd, dd, kd_);
+        const int nh = deconv_dim_taps(k, pad, ph, dh, kh_);
+        const int nw = deconv_dim_taps(k, pad, pw, dw, kw_);
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x; a.w = reinterpret_cast<const float4*>(w_packed + off);
+        a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+        a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
+        a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.yCs = yCs; a.rCs = rCs;
+        a.Ad = (Do - pd + 1) / 2; a.Ah = (Ho - ph + 1) / 2; a.Aw = (Wo - pw + 1) / 2;
+        a.isd = a.ish = a.isw = 1;
+        a.os = 2; a.ood = pd; a.ooh = ph; a.oow = pw;
+        a.T = nd * nh * nw;
+        int t = 0;
+        for (int i = 0; i < nd; ++i) for (int j = 0; j < nh; ++j) for (int l = 0; l < nw; ++l, ++t) {
+            a.td[t] = (signed char)dd[i]; a.th[t] = (signed char)dh[j]; a.tw[t] = (signed char)dw[l];
+        }
+        a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
+        a.act = act; a.slope = slope;
+        if (a.T > 0 && a.Ad > 0 && a.Ah > 0 && a.Aw > 0) {
+            const int rc = launch_conv(a, 1, (hipStream_t)stream, "deconv3d");
+            if (rc) return rc;
+        }
+        off += packed_floats(Ci, Co, a.T);
+    }
+    return 0;
+}
+
+extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,
+                                             float* y,
+                                             int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
+                                             int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
+                                             void* stream) {
+    OSA_REQUIRE(x && w_ref && y, "conv3d_small_co: NULL pointer");
+    OSA_REQUIRE(Co >= 1 && Co <= 4, "conv3d_small_co: Co=%d unsupported (1..4)", Co);
+    OSA_REQUIRE(xCs % 4 == 0 && xCs >= Ci && ((size_t)x & 15) == 0, "conv3d_small_co: x must be 16-byte aligned, xCs %% 4 == 0");
+    OSA_REQUIRE(kd == 2 * pad_d + 1 && kh == 2 * pad_h + 1 && kw == 2 * pad_w + 1, "conv3d_small_co: only 'same' convolutions");
+    OSA_REQUIRE(yCs >= Co, "conv3d_small_co: yCs < Co");
+    DirectArgs a;
+    a.x = x; a.w = w_ref; a.bias = bias; a.y = y;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.xCs = xCs; a.Co = Co; a.yCs = yCs;
+    a.kd = kd; a.kh = kh; a.kw = kw; a.pd = pad_d; a.ph = pad_h; a.pw = pad_w;
+    const long long nvox = (long long)B * D * H * W;
+    dim3 grid(cdiv(nvox, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Co) {
+        case 1: hipLaunchKernelGGL(conv_small_co_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(conv_small_co_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(conv_small_co_kernel<3>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(conv_small_co_kernel<4>, grid, block, 0, st, a); break;
+    }
+    OSA_LAUNCH_CHECK("conv3d_small_co");
+    return 0;
+}

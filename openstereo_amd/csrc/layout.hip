@@ -1,0 +1,69 @@
+// Layout converters between the reference's NCDHW volumes and the engine's NDHWC volumes.
+// Tiled 32x32 transpose through LDS (padded to 33 -> conflict free); both sides coalesced.
+#include "osa_common.h"
+
+namespace osa {
+
+// x [B][C][S] -> y [B][S][yCs] (+c_off)
+__global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int C, long long S, int yCs, int c_off) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long long s0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r; const long long s = s0 + tx;
+        tile[r][tx] = (c < C && s < S) ? x[((size_t)b * C + c) * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long s = s0 + r; const int c = c0 + tx;
+        if (c < C && s < S) y[((size_t)b * S + s) * yCs + c_off + c] = tile[tx][r];
+    }
+}
+
+// x [B][S][xCs] (+c_off) -> y [B][C][S]
+__global__ __launch_bounds__(256) void to_ncdhw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int C, long long S, int xCs, int c_off) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long long s0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long long s = s0 + r; const int c = c0 + tx;
+        tile[r][tx] = (c < C && s < S) ? x[((size_t)b * S + s) * xCs + c_off + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r; const long long s = s0 + tx;
+        if (c < C && s < S) y[((size_t)b * C + c) * S + s] = tile[tx][r];
+    }
+}
+
+}  // namespace osa
+
+using namespace osa;
+
+extern "C" int osa_ncdhw_to_ndhwc_f32(const float* x, float* y, int B, int C, long long S,
+                                      int yCs, int c_off, void* stream) {
+    OSA_REQUIRE(x && y, "ncdhw_to_ndhwc: NULL pointer");
+    OSA_REQUIRE(B > 0 && C > 0 && S > 0 && c_off >= 0 && c_off + C <= yCs, "ncdhw_to_ndhwc: bad dims");
+    OSA_REQUIRE(B <= 65535 && cdiv(C, 32) <= 65535, "ncdhw_to_ndhwc: grid too large");
+    dim3 grid(cdiv(S, 32), cdiv(C, 32), B);
+    hipLaunchKernelGGL(to_ndhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, S, yCs, c_off);
+    OSA_LAUNCH_CHECK("ncdhw_to_ndhwc");
+    return 0;
+}
+
+extern "C" int osa_ndhwc_to_ncdhw_f32(const float* x, float* y, int B, int C, long long S,
+                                      int xCs, int c_off, void* stream) {
+    OSA_REQUIRE(x && y, "ndhwc_to_ncdhw: NULL pointer");
+    OSA_REQUIRE(B > 0 && C > 0 && S > 0 && c_off >= 0 && c_off + C <= xCs, "ndhwc_to_ncdhw: bad dims");
+    OSA_REQUIRE(B <= 65535 && cdiv(C, 32) <= 65535, "ndhwc_to_ncdhw: grid too large");
+    dim3 grid(cdiv(S, 32), cdiv(C, 32), B);
+    hipLaunchKernelGGL(to_ncdhw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, S, xCs, c_off);
+    OSA_LAUNCH_CHECK("ndhwc_to_ncdhw");
+    return 0;
+}

@@ -1,0 +1,139 @@
+"""3-D aggregation layers on the gfx950 engine: packed convolutions with fused BN/activation/residual.
+
+A PackedConv3d is built once from the *reference-shaped* torch parameters (nn.Conv3d /
+nn.ConvTranspose3d weight + eval-mode BatchNorm3d statistics), so state_dict keys and shapes stay
+exactly the reference's (SURVEY 8b "checkpoint compatibility"); only forward() changes.
+Activations travel NDHWC (torch.channels_last_3d strides) between layers.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib, timing
+from .ops import _stream, _p, empty_cl, is_cl
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+enable_timing, collect_timing = timing.enable, timing.collect
+
+
+def bn_scale_shift(bn):
+    """Eval-mode BatchNorm as y = x*scale + shift (eps from the module, default 1e-5)."""
+    if bn is None:
+        return None, None
+    w = bn.weight if bn.weight is not None else torch.ones_like(bn.running_mean)
+    b = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_mean)
+    scale = (w.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).contiguous()
+    shift = (b.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+    return scale, shift
+
+
+def _t3(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+class PackedConv3d:
+    """conv (or stride-2 transposed conv) + folded BN + activation, weights in MFMA operand order."""
+
+    def __init__(self, conv, bn=None, act=ACT_NONE, slope=0.01):
+        w = conv.weight.detach()
+        if not w.is_cuda:
+            raise _lib.EngineError("PackedConv3d needs parameters on the GPU (no CPU path)")
+        w = w.float().contiguous()
+        self.transposed = isinstance(conv, nn.ConvTranspose3d)
+        self.k = tuple(conv.kernel_size)
+        self.stride = _t3(conv.stride)
+        self.pad = _t3(conv.padding)
+        self.dil = _t3(conv.dilation)
+        self.act, self.slope = act, float(slope)
+        if conv.bias is not None and bn is not None:
+            raise NotImplementedError("conv bias together with BN")
+        self.scale, self.shift = bn_scale_shift(bn)
+        if conv.bias is not None:
+            self.shift = conv.bias.detach().float().contiguous()
+            self.scale = torch.ones_like(self.shift)
+        st = _stream()
+        if self.transposed:
+            self.Ci, self.Co = w.shape[0], w.shape[1]
+            assert self.k[0] == self.k[1] == self.k[2] and self.stride == (2, 2, 2)
+            self.opad = _t3(conv.output_padding)
+            n = _lib.load().osa_deconv3d_packed_floats(self.Ci, self.Co, self.k[0])
+            self.packed = torch.empty(n, device=w.device, dtype=torch.float32)
+            _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
+                      self.k[0], self.pad[0], st)
+        else:
+            self.Co, self.Ci = w.shape[0], w.shape[1]
+            assert conv.groups == 1
+            s = self.stride
+            assert s[1] == s[2] and (s[0] == s[1] or (self.k[0] == 1)), f"anisotropic stride {s}"
+            n = _lib.load().osa_conv3d_packed_floats(self.Ci, self.Co, *self.k)
+            self.packed = torch.empty(n, device=w.device, dtype=torch.float32)
+            _lib.call("osa_conv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, st)
+
+    def out_shape(self, D, H, W):
+        if self.transposed:
+            k, p, op = self.k[0], self.pad[0], self.opad[0]
+            return tuple((n - 1) * 2 - 2 * p + k + op for n in (D, H, W))
+        s = self.stride[1]
+        sd = 1 if (D == 1 and self.k[0] == 1) else s
+        f = lambda n, k, p, d, st: (n + 2 * p - d * (k - 1) - 1) // st + 1
+        return (f(D, self.k[0], self.pad[0], self.dil[0], sd), f(H, self.k[1], self.pad[1], self.dil[1], s),
+                f(W, self.k[2], self.pad[2], self.dil[2], s))
+
+    def __call__(self, x, residual=None, out=None):
+        """x: logical [B,Cs>=Ci,D,H,W] NDHWC.  Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC."""
+        assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
+        B, Cs, D, H, W = x.shape
+        assert Cs >= self.Ci and Cs % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
+        Ci = (self.Ci + 3) // 4 * 4     # padded channels of x are zero by construction
+        Do, Ho, Wo = self.out_shape(D, H, W)
+        if out is None:
+            CoS = (self.Co + 3) // 4 * 4
+            out = empty_cl(B, CoS, Do, Ho, Wo, x.device)
+            if CoS != self.Co:
+                out.zero_()
+        yCs = out.shape[1]
+        rCs = 0
+        if residual is not None:
+            assert is_cl(residual) and tuple(residual.shape[2:]) == (Do, Ho, Wo)
+            rCs = residual.shape[1]
+        with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
+            self._launch(x, residual, out, B, D, H, W, Ci, Cs, yCs, rCs)
+        return out
+
+    def _launch(self, x, residual, out, B, D, H, W, Ci, Cs, yCs, rCs):
+        if self.transposed:
+            _lib.call("osa_deconv3d_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                      _p(residual), out.data_ptr(), B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
+                      self.k[0], self.pad[0], self.opad[0], self.act, self.slope, _stream())
+        else:
+            _lib.call("osa_conv3d_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                      _p(residual), out.data_ptr(), B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
+                      self.k[0], self.k[1], self.k[2], self.stride[1],
+                      self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
+                      self.act, self.slope, _stream())
+
+
+class SmallCoConv3d:
+    """'same' convolution with <= 4 output channels (the 32->1 classifier heads); reads the
+    reference-layout weight directly."""
+
+    def __init__(self, conv):
+        assert isinstance(conv, nn.Conv3d) and conv.out_channels <= 4
+        assert _t3(conv.stride) == (1, 1, 1) and _t3(conv.dilation) == (1, 1, 1)
+        self.w = conv.weight.detach().float().contiguous()
+        if not self.w.is_cuda:
+            raise _lib.EngineError("SmallCoConv3d needs parameters on the GPU (no CPU path)")
+        self.bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
+        self.Co, self.Ci = self.w.shape[:2]
+        self.k, self.pad = tuple(conv.kernel_size), _t3(conv.padding)
+
+    def __call__(self, x):
+        """x NDHWC logical [B,Cs,D,H,W] -> contiguous [B,Co,D,H,W] (Co==1) i.e. plain [B,1,D,H,W]."""
+        assert is_cl(x)
+        B, Cs, D, H, W = x.shape
+        y = torch.empty((B, D, H, W, self.Co), device=x.device, dtype=torch.float32)
+        with timing.span("conv3d_small_co", self.Ci, self.Co, self.k[0], 1, D, H, W):
+            _lib.call("osa_conv3d_small_co_ndhwc_f32", x.data_ptr(), self.w.data_ptr(), _p(self.bias), y.data_ptr(),
+                      B, D, H, W, self.Ci, Cs, self.Co, self.Co, *self.k, *self.pad, _stream())
+        return y.permute(0, 4, 1, 2, 3)

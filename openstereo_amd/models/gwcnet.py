@@ -1,0 +1,261 @@
+"""GwcNet on the gfx950 cost-volume engine.
+
+Module tree and parameter names reproduce the reference's state_dict layout
+(`Backbone.feature_extraction.*`, `DispProcessor.dres0.0.0.weight`, ... -- stereo/modeling/models/
+gwcnet/{gwcnet,gwcnet_backbone,gwcnet_cost_processor,gwcnet_disp_processor,hourglass}.py) so that
+OpenStereo checkpoints load unchanged; the forward pass of the cost-volume / aggregation /
+regression stages runs on the engine:
+
+  features --build_cost_volume_cl--> NDHWC volume --PackedConv3d chain (MFMA)--> cost3
+           --upsample_softargmin--> disparity [B,H,W]
+
+The 2-D feature extractor is not part of the engine: it runs as ordinary
+PyTorch-ROCm modules.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops, timing
+from ..engine import PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+
+
+# ----------------------------------------------------------------------------- 2-D backbone
+def _cb2(cin, cout, k, stride, pad, dil):
+    return nn.Sequential(
+        nn.Conv2d(cin, cout, k, stride, dil if dil > 1 else pad, dil, bias=False),
+        nn.BatchNorm2d(cout))
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, cin, cout, stride, shortcut, pad, dil):
+        super().__init__()
+        self.conv1 = nn.Sequential(_cb2(cin, cout, 3, stride, pad, dil), nn.ReLU(inplace=True))
+        self.conv2 = _cb2(cout, cout, 3, 1, pad, dil)
+        self.downsample = shortcut
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class _Features(nn.Module):
+    """gwcnet_backbone.py:38-91: 320-channel gwc feature (+ 12-channel concat feature) at 1/4 res."""
+
+    def __init__(self, concat_feature=True, concat_feature_channel=12):
+        super().__init__()
+        self.concat_feature = concat_feature
+        self.firstconv = nn.Sequential(
+            _cb2(3, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
+            _cb2(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            _cb2(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        self._cin = 32
+        self.layer1 = self._stage(32, 3, 1, 1, 1)
+        self.layer2 = self._stage(64, 16, 2, 1, 1)
+        self.layer3 = self._stage(128, 3, 1, 1, 1)
+        self.layer4 = self._stage(128, 3, 1, 1, 2)
+        if concat_feature:
+            self.lastconv = nn.Sequential(
+                _cb2(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                nn.Conv2d(128, concat_feature_channel, 1, 1, 0, bias=False))
+
+    def _stage(self, cout, n, stride, pad, dil):
+        shortcut = None
+        if stride != 1 or self._cin != cout:
+            shortcut = nn.Sequential(nn.Conv2d(self._cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        blocks = [_ResBlock(self._cin, cout, stride, shortcut, pad, dil)]
+        self._cin = cout
+        blocks += [_ResBlock(cout, cout, 1, None, pad, dil) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.layer1(self.firstconv(x))
+        l2 = self.layer2(x)
+        l3 = self.layer3(l2)
+        l4 = self.layer4(l3)
+        out = {"gwc_feature": torch.cat((l2, l3, l4), dim=1)}
+        if self.concat_feature:
+            out["concat_feature"] = self.lastconv(out["gwc_feature"])
+        return out
+
+
+class GwcBackbone(nn.Module):
+    def __init__(self, use_concat_volume=True, concat_channels=12):
+        super().__init__()
+        self.use_concat_volume = use_concat_volume
+        self.concat_channels = concat_channels if use_concat_volume else 0
+        self.feature_extraction = _Features(use_concat_volume, self.concat_channels)
+
+    def forward(self, inputs):
+        # left and right go through the extractor as one batch of 2B images
+        left, right = inputs["left"], inputs["right"]
+        B = left.shape[0]
+        with timing.span("backbone2d", left.shape[2], left.shape[3]):
+            f = self.feature_extraction(torch.cat((left, right), 0))
+        ref = {k: v[:B] for k, v in f.items()}
+        tgt = {k: v[B:] for k, v in f.items()}
+        return {"ref_feature": ref, "tgt_feature": tgt}
+
+
+# ----------------------------------------------------------------------------- cost volume
+class GwcVolumeCostProcessor(nn.Module):
+    """gwcnet_cost_processor.py: same constructor / method names; volumes come from the engine."""
+
+    def __init__(self, maxdisp=192, downsample=4, num_groups=40, use_concat_volume=True, *args, **kwargs):
+        super().__init__()
+        self.maxdisp, self.downsample = maxdisp, downsample
+        self.num_groups, self.use_concat_volume = num_groups, use_concat_volume
+
+    def build_gwc_volume(self, refimg_fea, targetimg_fea):
+        return ops.build_gwc_volume(refimg_fea, targetimg_fea, self.maxdisp // self.downsample, self.num_groups)
+
+    def build_concat_volume(self, refimg_fea, targetimg_fea):
+        return ops.build_concat_volume(refimg_fea, targetimg_fea, self.maxdisp // self.downsample)
+
+    def forward(self, inputs):
+        l, r = inputs["ref_feature"], inputs["tgt_feature"]
+        cat = self.use_concat_volume
+        vol = ops.build_cost_volume_cl(
+            l["gwc_feature"], r["gwc_feature"], self.num_groups,
+            l["concat_feature"] if cat else None, r["concat_feature"] if cat else None,
+            maxdisp=self.maxdisp // self.downsample)
+        return {"cost_volume": vol}
+
+    def input_output(self):
+        return {"inputs": ["ref_feature", "tgt_feature"], "outputs": ["cost_volume"]}
+
+
+# ----------------------------------------------------------------------------- 3-D aggregation
+def _cb3(cin, cout, k, stride, pad):
+    return nn.Sequential(nn.Conv3d(cin, cout, k, stride, pad, bias=False), nn.BatchNorm3d(cout))
+
+
+class Hourglass(nn.Module):
+    """models/gwcnet/hourglass.py:19-56 (same parameter names); forward on the engine."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+        self.conv1 = nn.Sequential(_cb3(c, 2 * c, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(_cb3(2 * c, 2 * c, 3, 1, 1), nn.ReLU(inplace=True))
+        self.conv3 = nn.Sequential(_cb3(2 * c, 4 * c, 3, 2, 1), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(_cb3(4 * c, 4 * c, 3, 1, 1), nn.ReLU(inplace=True))
+        self.conv5 = nn.Sequential(
+            nn.ConvTranspose3d(4 * c, 2 * c, 3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.BatchNorm3d(2 * c))
+        self.conv6 = nn.Sequential(
+            nn.ConvTranspose3d(2 * c, c, 3, padding=1, output_padding=1, stride=2, bias=False),
+            nn.BatchNorm3d(c))
+        self.redir1 = _cb3(c, c, 1, 1, 0)
+        self.redir2 = _cb3(2 * c, 2 * c, 1, 1, 0)
+        self._packed = None
+
+    def _pack(self):
+        if self._packed is None:
+            P = PackedConv3d
+            self._packed = dict(
+                c1=P(self.conv1[0][0], self.conv1[0][1], ACT_RELU), c2=P(self.conv2[0][0], self.conv2[0][1], ACT_RELU),
+                c3=P(self.conv3[0][0], self.conv3[0][1], ACT_RELU), c4=P(self.conv4[0][0], self.conv4[0][1], ACT_RELU),
+                c5=P(self.conv5[0], self.conv5[1], ACT_RELU), c6=P(self.conv6[0], self.conv6[1], ACT_RELU),
+                r1=P(self.redir1[0], self.redir1[1], ACT_NONE), r2=P(self.redir2[0], self.redir2[1], ACT_NONE))
+        return self._packed
+
+    def forward_cl(self, x):
+        p = self._pack()
+        c1 = p["c1"](x)
+        c2 = p["c2"](c1)
+        c4 = p["c4"](p["c3"](c2))
+        c5 = p["c5"](c4, residual=p["r2"](c2))     # relu(conv5(c4) + redir2(c2))
+        return p["c6"](c5, residual=p["r1"](x))    # relu(conv6(c5) + redir1(x))
+
+    def forward(self, x):
+        """Drop-in: NCDHW in -> NCDHW out (eval-mode BN)."""
+        if self.training:
+            raise NotImplementedError("engine Hourglass: training-mode BatchNorm is not built yet")
+        return ops.to_ncdhw(self.forward_cl(ops.to_cl(x)), channels=x.shape[1])
+
+
+class GwcDispProcessor(nn.Module):
+    """gwcnet_disp_processor.py:29-146, inference branch, on the engine."""
+
+    def __init__(self, maxdisp=192, downsample=4, num_groups=40, use_concat_volume=True, concat_channels=12,
+                 *args, **kwargs):
+        super().__init__()
+        self.maxdisp, self.downsample, self.num_groups = maxdisp, downsample, num_groups
+        self.use_concat_volume = use_concat_volume
+        self.concat_channels = concat_channels if use_concat_volume else 0
+        cin = self.num_groups + self.concat_channels * 2
+        relu = lambda: nn.ReLU(inplace=True)
+        self.dres0 = nn.Sequential(_cb3(cin, 32, 3, 1, 1), relu(), _cb3(32, 32, 3, 1, 1), relu())
+        self.dres1 = nn.Sequential(_cb3(32, 32, 3, 1, 1), relu(), _cb3(32, 32, 3, 1, 1))
+        self.dres2, self.dres3, self.dres4 = Hourglass(32), Hourglass(32), Hourglass(32)
+        for i in range(4):
+            setattr(self, f"classif{i}", nn.Sequential(
+                _cb3(32, 32, 3, 1, 1), relu(), nn.Conv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False)))
+        self._packed = None
+
+    def reset_engine(self):
+        """Drop packed weights (call after loading a checkpoint or changing parameters)."""
+        self._packed = None
+        for h in (self.dres2, self.dres3, self.dres4):
+            h._packed = None
+
+    def _pack(self):
+        if self._packed is None:
+            P = PackedConv3d
+            self._packed = dict(
+                d00=P(self.dres0[0][0], self.dres0[0][1], ACT_RELU), d02=P(self.dres0[2][0], self.dres0[2][1], ACT_RELU),
+                d10=P(self.dres1[0][0], self.dres1[0][1], ACT_RELU), d12=P(self.dres1[2][0], self.dres1[2][1], ACT_NONE),
+                k0=P(self.classif3[0][0], self.classif3[0][1], ACT_RELU), k2=SmallCoConv3d(self.classif3[2]))
+        return self._packed
+
+    def aggregate_cl(self, volume):
+        """NDHWC volume -> low-res cost [B,1,D/4,H/4,W/4] (classif3 output)."""
+        p = self._pack()
+        cost0 = p["d02"](p["d00"](volume))
+        cost0 = p["d12"](p["d10"](cost0), residual=cost0)      # dres1(cost0) + cost0
+        out3 = self.dres4.forward_cl(self.dres3.forward_cl(self.dres2.forward_cl(cost0)))
+        return p["k2"](p["k0"](out3))
+
+    def forward(self, inputs):
+        if self.training:
+            raise NotImplementedError("engine GwcDispProcessor: training branch is not built yet")
+        volume = inputs["cost_volume"]
+        h, w = inputs["left"].shape[2:]
+        if not ops.is_cl(volume) or volume.shape[1] % 4:
+            volume = ops.to_cl(volume)
+        cost3 = self.aggregate_cl(volume)
+        pred3 = ops.upsample_softargmin(cost3, self.maxdisp, h, w, align_corners=False)
+        return {"inference_disp": {"disp_est": pred3}}
+
+    def input_output(self):
+        return {"inputs": ["cost_volume", "disp_shape"],
+                "outputs": ["training_disp", "inference_disp", "visual_summary"]}
+
+
+# ----------------------------------------------------------------------------- model
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+GWCNET_G_SCENEFLOW = _Cfg(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40)
+
+
+class GwcNet(nn.Module):
+    """models/gwcnet/gwcnet.py:11-39: forward(dict{'left','right'}) -> {'disp_pred': [B,H,W]}."""
+
+    def __init__(self, cfgs=GWCNET_G_SCENEFLOW):
+        super().__init__()
+        self.maxdisp = cfgs.MAX_DISP
+        kw = dict(maxdisp=self.maxdisp, downsample=cfgs.DOWNSAMPLE, num_groups=cfgs.NUM_GROUPS,
+                  use_concat_volume=cfgs.USE_CONCAT_VOLUME)
+        self.Backbone = GwcBackbone(use_concat_volume=cfgs.USE_CONCAT_VOLUME, concat_channels=cfgs.CONCAT_CHANNELS)
+        self.CostProcessor = GwcVolumeCostProcessor(**kw)
+        self.DispProcessor = GwcDispProcessor(concat_channels=cfgs.CONCAT_CHANNELS, **kw)
+
+    def forward(self, inputs):
+        inputs.update(self.Backbone(inputs))
+        inputs.update(self.CostProcessor(inputs))
+        disp_out = self.DispProcessor(inputs)
+        return {"disp_pred": disp_out["inference_disp"]["disp_est"]}

@@ -1,0 +1,245 @@
+"""Python mirror of OpenStereo's hot-path *functions* on top of the gfx950 C-ABI library.
+
+Same names, argument meaning, output shapes/dtypes and error behaviour as the reference
+helpers; every call lands in a hand-written HIP kernel.  torch is used for device
+memory and the current stream only.
+
+Reference                                                      here
+  cost_volume.build_gwc_volume(ref,tgt,maxdisp,groups)         build_gwc_volume
+  cost_volume.build_concat_volume(ref,tgt,maxdisp)             build_concat_volume
+  cost_volume.correlation_volume / build_corr_volume           correlation_volume / build_corr_volume
+  psmnet_cost_processor.cat_fms                                cat_fms
+  igev.submodule.build_concat_volume (left half unmasked)      build_concat_volume(..., mask_left=False)
+  disp_pred.disparity_regression (keepdim=True)                disparity_regression
+  gwcnet_disp_processor.disparity_regression (keepdim=False)   disparity_regression(..., keepdim=False)
+  psmnet_disp_processor.FasterSoftArgmin                       FasterSoftArgmin
+Engine-only fused entry points (no reference equivalent, they replace op chains):
+  build_cost_volume_cl, softmax_disparity_regression, upsample_softargmin
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, timing
+
+NCDHW, NDHWC = 0, 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, ndim: int | None = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.EngineError(f"{name} is on {t.device}: the gfx950 engine has no CPU path")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name} must be {ndim}-D, got shape {tuple(t.shape)}")
+    return t
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32 contiguous view/copy (kernels compute in fp32; callers cast back)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------- layouts
+def empty_cl(B, C, D, H, W, device, dtype=torch.float32) -> torch.Tensor:
+    """Logical [B,C,D,H,W] tensor stored NDHWC (torch.channels_last_3d strides)."""
+    return torch.empty((B, D, H, W, C), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
+
+
+def is_cl(t: torch.Tensor) -> bool:
+    return t.dim() == 5 and t.permute(0, 2, 3, 4, 1).is_contiguous()
+
+
+def to_cl(x: torch.Tensor, pad_to: int = 4) -> torch.Tensor:
+    """NCDHW -> NDHWC through the engine's transpose kernel.  Channel count is padded up to a
+    multiple of `pad_to` (zero filled) because conv inputs are read as float4."""
+    _chk(x, "x", 5)
+    if is_cl(x) and x.shape[1] % pad_to == 0 and x.dtype == torch.float32:
+        return x
+    xs = _f32c(x)
+    B, Cn, D, H, W = xs.shape
+    Cp = (Cn + pad_to - 1) // pad_to * pad_to
+    y = empty_cl(B, Cp, D, H, W, x.device)
+    if Cp != Cn:
+        y.zero_()
+    _lib.call("osa_ncdhw_to_ndhwc_f32", xs.data_ptr(), y.data_ptr(), B, Cn, D * H * W, Cp, 0, _stream())
+    return y
+
+
+def to_ncdhw(x: torch.Tensor, channels: int | None = None) -> torch.Tensor:
+    """NDHWC -> contiguous NCDHW (first `channels` channels)."""
+    _chk(x, "x", 5)
+    if not is_cl(x):
+        return x.contiguous()
+    B, Cs, D, H, W = x.shape
+    Cn = Cs if channels is None else channels
+    y = torch.empty((B, Cn, D, H, W), device=x.device, dtype=torch.float32)
+    _lib.call("osa_ndhwc_to_ncdhw_f32", x.data_ptr(), y.data_ptr(), B, Cn, D * H * W, Cs, 0, _stream())
+    return y
+
+
+# --------------------------------------------------------------------------- volumes
+def _build(lg, rg, G, lc, rc, maxdisp, layout, mask_left=True, out=None, vol_channels=None, c_off=0):
+    ref = lg if lg is not None else lc
+    B, _, H, W = ref.shape
+    Cg = lg.shape[1] if lg is not None else 0
+    Cc = lc.shape[1] if lc is not None else 0
+    nch = (G if Cg else 0) + 2 * Cc
+    VC = nch if vol_channels is None else vol_channels
+    if out is None:
+        if layout == NDHWC:
+            out = empty_cl(B, VC, maxdisp, H, W, ref.device)
+            if VC > c_off + nch or c_off > 0:
+                out.zero_()
+        else:
+            out = torch.empty((B, VC, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+    with timing.span("build_volume", Cg, G, Cc, layout, maxdisp, H, W):
+        _lib.call("osa_build_volume_f32", _p(lg), _p(rg), Cg, G, _p(lc), _p(rc), Cc,
+                  out.data_ptr(), layout, VC, c_off, B, H, W, maxdisp, 1 if mask_left else 0, _stream())
+    return out
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """cost_volume.py:68-78 -> [B, num_groups, maxdisp, H, W], contiguous, input dtype."""
+    _chk(refimg_fea, "refimg_fea", 4); _chk(targetimg_fea, "targetimg_fea", 4)
+    B, Cn, H, W = refimg_fea.shape
+    assert Cn % num_groups == 0                                   # cost_volume.py:61
+    v = _build(_f32c(refimg_fea), _f32c(targetimg_fea), num_groups, None, None, maxdisp, NCDHW)
+    return v if refimg_fea.dtype == torch.float32 else v.to(refimg_fea.dtype)
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp, mask_left=True):
+    """cost_volume.py:81-92 -> [B, 2C, maxdisp, H, W]. mask_left=False is IGEV's copy (submodule.py:216-227)."""
+    _chk(refimg_fea, "refimg_fea", 4); _chk(targetimg_fea, "targetimg_fea", 4)
+    v = _build(None, None, 0, _f32c(refimg_fea), _f32c(targetimg_fea), maxdisp, NCDHW, mask_left=mask_left)
+    return v if refimg_fea.dtype == torch.float32 else v.to(refimg_fea.dtype)
+
+
+def correlation_volume(left_feature, right_feature, max_disp):
+    """cost_volume.py:32-41 -> [B, max_disp, H, W] (mean over all channels)."""
+    _chk(left_feature, "left_feature", 4); _chk(right_feature, "right_feature", 4)
+    l, r = _f32c(left_feature), _f32c(right_feature)
+    B, Cn, H, W = l.shape
+    out = torch.empty((B, max_disp, H, W), device=l.device, dtype=torch.float32)
+    _lib.call("osa_corr_volume_f32", l.data_ptr(), r.data_ptr(), out.data_ptr(), B, Cn, H, W, max_disp, _stream())
+    return out if left_feature.dtype == torch.float32 else out.to(left_feature.dtype)
+
+
+def build_corr_volume(img_left, img_right, max_disp):
+    """cost_volume.py:95-105: correlation_volume, except planes d >= W repeat the d=0 plane
+    (the reference's `(i > 0) & (i < W)` guard sends them to the unshifted branch)."""
+    vol = correlation_volume(img_left, img_right, max_disp)
+    W = img_left.shape[-1]
+    if max_disp > W:
+        vol[:, W:] = vol[:, :1]
+    return vol
+
+
+def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
+    """psmnet_cost_processor.py:9-50 with the configuration PSMNet uses (start_disp=0, dilation=1);
+    always returns fp32 like the reference (its buffer is torch.zeros(...).to(device))."""
+    if start_disp != 0 or dilation != 1:
+        raise NotImplementedError("cat_fms: only start_disp=0, dilation=1 (what cfgs/psmnet uses)")
+    return _build(None, None, 0, _f32c(_chk(reference_fm, "reference_fm", 4)),
+                  _f32c(_chk(target_fm, "target_fm", 4)), max_disp, NCDHW)
+
+
+def build_cost_volume_cl(gwc_left, gwc_right, num_groups, cat_left=None, cat_right=None, maxdisp=48,
+                         mask_left=True):
+    """Fused gwc(+concat) volume written straight into one NDHWC buffer
+    (replaces build_gwc_volume + build_concat_volume + torch.cat, gwcnet_cost_processor.py:55-68).
+    Returns logical [B, G+2Cc (padded to 4), D, H, W] with channels_last_3d strides."""
+    lg, rg = _f32c(_chk(gwc_left, "gwc_left", 4)), _f32c(_chk(gwc_right, "gwc_right", 4))
+    assert lg.shape[1] % num_groups == 0
+    lc = rc = None
+    Cc = 0
+    if cat_left is not None:
+        lc, rc = _f32c(_chk(cat_left, "cat_left", 4)), _f32c(_chk(cat_right, "cat_right", 4))
+        Cc = lc.shape[1]
+    nch = num_groups + 2 * Cc
+    VC = (nch + 3) // 4 * 4
+    return _build(lg, rg, num_groups, lc, rc, maxdisp, NDHWC, mask_left=mask_left, vol_channels=VC)
+
+
+# --------------------------------------------------------------------------- regression
+def disparity_regression(x, maxdisp, keepdim=True):
+    """disp_regression.py:8-12 (keepdim=True) / gwcnet_disp_processor.py:22-26 (keepdim=False)."""
+    assert len(x.shape) == 4                                      # disp_regression.py:9
+    _chk(x, "x")
+    B, D, H, W = x.shape
+    assert D == maxdisp, f"x has {D} disparity planes, maxdisp={maxdisp}"
+    xs = _f32c(x)
+    out = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+    _lib.call("osa_softargmin_f32", xs.data_ptr(), out.data_ptr(), B, D, H, W, _stream())
+    out = out if x.dtype == torch.float32 else out.to(x.dtype)
+    return out.unsqueeze(1) if keepdim else out
+
+
+def softmax_disparity_regression(cost, maxdisp=None, keepdim=True, return_prob=False):
+    """F.softmax(cost, dim=1) + disparity_regression in one kernel (stereobase_gru.py:163-164)."""
+    assert len(cost.shape) == 4
+    _chk(cost, "cost")
+    B, D, H, W = cost.shape
+    if maxdisp is not None:
+        assert D == maxdisp
+    cs = _f32c(cost)
+    out = torch.empty((B, H, W), device=cost.device, dtype=torch.float32)
+    prob = torch.empty_like(cs) if return_prob else None
+    _lib.call("osa_softmax_softargmin_f32", cs.data_ptr(), _p(prob), out.data_ptr(), B, D, H, W, _stream())
+    out = out.unsqueeze(1) if keepdim else out
+    return (out, prob) if return_prob else out
+
+
+def upsample_softargmin(cost_lowres, maxdisp, h, w, align_corners=False):
+    """F.interpolate(cost[:,None], [maxdisp,h,w], 'trilinear') -> squeeze -> softmax(dim=1) ->
+    disparity_regression(keepdim=False), fused (gwcnet_disp_processor.py:128-133; PSMNet uses
+    align_corners=True, psmnet_cost_processor.py:201-214).  cost_lowres: [B,Dl,Hl,Wl] or [B,1,Dl,Hl,Wl]."""
+    _chk(cost_lowres, "cost_lowres")
+    if cost_lowres.dim() == 5:
+        assert cost_lowres.shape[1] == 1
+        cost_lowres = cost_lowres[:, 0]
+    assert cost_lowres.dim() == 4
+    cs = _f32c(cost_lowres)
+    B, Dl, Hl, Wl = cs.shape
+    out = torch.empty((B, h, w), device=cs.device, dtype=torch.float32)
+    with timing.span("upsample_softargmin", Dl, Hl, Wl, int(maxdisp), int(h), int(w)):
+        _lib.call("osa_upsample_softargmin_f32", cs.data_ptr(), out.data_ptr(), B, Dl, Hl, Wl,
+                  int(maxdisp), int(h), int(w), 1 if align_corners else 0, _stream())
+    return out
+
+
+class FasterSoftArgmin(torch.nn.Module):
+    """psmnet_disp_processor.py:6-74: softmax over D + expectation; keeps the frozen
+    `disp_regression.weight` buffer name so PSMNet checkpoints load."""
+
+    def __init__(self, max_disp, start_disp=0, dilation=1, alpha=1.0, normalize=True):
+        super().__init__()
+        self.max_disp, self.start_disp, self.dilation = max_disp, start_disp, dilation
+        self.end_disp = start_disp + max_disp - 1
+        self.disp_sample_number = (max_disp + dilation - 1) // dilation
+        self.alpha, self.normalize = alpha, normalize
+        self.disp_regression = torch.nn.Conv3d(1, 1, (self.disp_sample_number, 1, 1), 1, 0, bias=False)
+        with torch.no_grad():
+            self.disp_regression.weight.copy_(
+                torch.linspace(self.start_disp, self.end_disp, self.disp_sample_number).view(1, 1, -1, 1, 1))
+        self.disp_regression.weight.requires_grad = False
+
+    def forward(self, cost_volume):
+        if cost_volume.dim() != 4:                                # psmnet_disp_processor.py:56-58
+            raise ValueError('expected 4D input (got {}D input)'.format(cost_volume.dim()))
+        if self.start_disp != 0 or self.dilation != 1:
+            raise NotImplementedError("FasterSoftArgmin: only start_disp=0, dilation=1")
+        c = cost_volume * self.alpha if self.alpha != 1.0 else cost_volume
+        if self.normalize:
+            return softmax_disparity_regression(c, keepdim=False)
+        return disparity_regression(c, c.shape[1], keepdim=False)

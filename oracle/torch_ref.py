@@ -1,0 +1,198 @@
+"""CPU ORACLE -- test infrastructure only.  Never imported by the product path.
+
+A restatement of OpenStereo's hot path (cost-volume build -> 3-D aggregation -> soft-argmin) as
+plain functions over a flat state_dict, executed with torch *CPU* fp32 operators -- the same
+arithmetic the reference's nn.Modules run on its CPU path.  Every function cites the reference
+file:line it follows (paths relative to the OpenStereo tree, stereo/modeling/...).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
+
+Pinning: tests/golden/*.npz hold outputs of the REAL reference (imported from /root/reference by
+tests/golden/make_golden.py in the build container); tests/test_oracle_golden.py checks this
+restatement against them.  Parity status: pinned for GwcNet (full model + every stage) and for
+the shared/PSMNet/IGEV volume + regression helpers; StereoBase/LightStereo/IGEV full models are
+"parity unpinned" (timm backbone unavailable offline).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- volumes
+def gwc_volume(left, right, maxdisp, num_groups):
+    """cost_volume.py:59-78 / gwcnet_cost_processor.py:13-39 / igev/submodule.py:158-177.
+    V[b,g,d,h,w] = mean_k L[b,gK+k,h,w] * R[b,gK+k,h,w-d]  (w >= d), else 0."""
+    B, C, H, W = left.shape
+    assert C % num_groups == 0
+    K = C // num_groups
+    vol = left.new_zeros(B, num_groups, maxdisp, H, W)
+    for d in range(min(maxdisp, W)):
+        prod = left[..., d:] * right[..., : W - d]
+        vol[:, :, d, :, d:] = prod.view(B, num_groups, K, H, W - d).mean(dim=2)
+    return vol
+
+
+def concat_volume(left, right, maxdisp, mask_left=True):
+    """cost_volume.py:81-92 / gwcnet_cost_processor.py:41-53 / psmnet_cost_processor.py:9-50
+    (start_disp=0, dilation=1).  mask_left=False: igev/submodule.py:216-227 (left half unmasked)."""
+    B, C, H, W = left.shape
+    vol = left.new_zeros(B, 2 * C, maxdisp, H, W)
+    for d in range(maxdisp):
+        if mask_left:
+            if d < W:
+                vol[:, :C, d, :, d:] = left[..., d:]
+        else:
+            vol[:, :C, d] = left
+        if d < W:
+            vol[:, C:, d, :, d:] = right[..., : W - d]
+    return vol
+
+
+def corr_volume(left, right, maxdisp):
+    """cost_volume.py:32-41 (correlation_volume): one group, mean over C."""
+    B, C, H, W = left.shape
+    vol = left.new_zeros(B, maxdisp, H, W)
+    for d in range(min(maxdisp, W)):
+        vol[:, d, :, d:] = (left[..., d:] * right[..., : W - d]).mean(dim=1)
+    return vol
+
+
+def build_corr_volume(left, right, maxdisp):
+    """cost_volume.py:95-105: as correlation_volume, except that planes d >= W take the *else*
+    branch of `(i > 0) & (i < W)` and therefore repeat the unshifted d=0 correlation."""
+    vol = corr_volume(left, right, maxdisp)
+    W = left.shape[-1]
+    if maxdisp > W:
+        vol[:, W:] = vol[:, :1]
+    return vol
+
+
+# ----------------------------------------------------------------------------- regression
+def disparity_regression(prob, maxdisp, keepdim=True):
+    """disp_regression.py:8-12 (keepdim=True); gwcnet_disp_processor.py:22-26 (keepdim=False)."""
+    assert prob.dim() == 4
+    d = torch.arange(0, maxdisp, dtype=prob.dtype).view(1, maxdisp, 1, 1)
+    return torch.sum(prob * d, 1, keepdim=keepdim)
+
+
+def softmax_regression(cost, keepdim=True):
+    """F.softmax(dim=1) + regression (stereobase_gru.py:163-164, igev_stereo.py:164-165,
+    psmnet_disp_processor.py:64-71 with alpha=1, normalize=True)."""
+    return disparity_regression(F.softmax(cost, dim=1), cost.shape[1], keepdim)
+
+
+def upsample_regression(cost_lowres, maxdisp, h, w, align_corners=False):
+    """gwcnet_disp_processor.py:128-133: trilinear upsample of [B,1,Dl,Hl,Wl] to [maxdisp,h,w],
+    squeeze, softmax over D, expectation (keepdim=False).  PSMNet: align_corners=True
+    (psmnet_cost_processor.py:201-214)."""
+    if cost_lowres.dim() == 4:
+        cost_lowres = cost_lowres[:, None]
+    c = F.interpolate(cost_lowres, [maxdisp, h, w], mode="trilinear", align_corners=align_corners)
+    return disparity_regression(F.softmax(c.squeeze(1), dim=1), maxdisp, keepdim=False)
+
+
+# ----------------------------------------------------------------------------- conv blocks
+def _bn(x, sd, p, eps=1e-5):
+    """eval-mode BatchNorm (running statistics), default eps (gwcnet_disp_processor.py:8-19)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        training=False, eps=eps)
+
+
+def convbn3d(x, sd, p, stride=1, pad=1):
+    """convbn_3d = Sequential(Conv3d(bias=False), BatchNorm3d): keys p.0.weight, p.1.*"""
+    return _bn(F.conv3d(x, sd[p + ".0.weight"], None, stride, pad), sd, p + ".1")
+
+
+def gwc_hourglass(x, sd, p):
+    """models/gwcnet/hourglass.py:46-56."""
+    c1 = F.relu(convbn3d(x, sd, p + ".conv1.0", 2, 1))
+    c2 = F.relu(convbn3d(c1, sd, p + ".conv2.0", 1, 1))
+    c3 = F.relu(convbn3d(c2, sd, p + ".conv3.0", 2, 1))
+    c4 = F.relu(convbn3d(c3, sd, p + ".conv4.0", 1, 1))
+    up5 = _bn(F.conv_transpose3d(c4, sd[p + ".conv5.0.weight"], None, 2, 1, 1), sd, p + ".conv5.1")
+    c5 = F.relu(up5 + convbn3d(c2, sd, p + ".redir2", 1, 0))
+    up6 = _bn(F.conv_transpose3d(c5, sd[p + ".conv6.0.weight"], None, 2, 1, 1), sd, p + ".conv6.1")
+    return F.relu(up6 + convbn3d(x, sd, p + ".redir1", 1, 0))
+
+
+def gwc_aggregate(volume, sd, p="DispProcessor", taps=None):
+    """gwcnet_disp_processor.py:83-91,128-129 (inference branch): volume [B,64,D4,H4,W4] -> cost3 [B,1,D4,H4,W4].
+    `taps` (dict) receives every intermediate stage tensor when given."""
+    t = {} if taps is None else taps
+    x = F.relu(convbn3d(volume, sd, p + ".dres0.0"))
+    x = F.relu(convbn3d(x, sd, p + ".dres0.2"))
+    t["dres0"] = x
+    y = F.relu(convbn3d(x, sd, p + ".dres1.0"))
+    cost0 = convbn3d(y, sd, p + ".dres1.2") + x
+    t["cost0"] = cost0
+    out1 = gwc_hourglass(cost0, sd, p + ".dres2"); t["out1"] = out1
+    out2 = gwc_hourglass(out1, sd, p + ".dres3"); t["out2"] = out2
+    out3 = gwc_hourglass(out2, sd, p + ".dres4"); t["out3"] = out3
+    z = F.relu(convbn3d(out3, sd, p + ".classif3.0"))
+    cost3 = F.conv3d(z, sd[p + ".classif3.2.weight"], None, 1, 1)
+    t["cost3"] = cost3
+    return cost3
+
+
+# ----------------------------------------------------------------------------- GwcNet 2-D features
+def _convbn2d(x, sd, p, stride, pad, dil):
+    """gwcnet_backbone.py:6-10 (padding = dilation if dilation > 1 else pad)."""
+    return _bn(F.conv2d(x, sd[p + ".0.weight"], None, stride, dil if dil > 1 else pad, dil), sd, p + ".1")
+
+
+def _basic_block(x, sd, p, stride, pad, dil):
+    """gwcnet_backbone.py:13-35 (no ReLU after the residual add)."""
+    y = F.relu(_convbn2d(x, sd, p + ".conv1.0", stride, pad, dil))
+    y = _convbn2d(y, sd, p + ".conv2", 1, pad, dil)
+    if (p + ".downsample.0.weight") in sd:
+        x = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride), sd, p + ".downsample.1")
+    return y + x
+
+
+def gwc_features(img, sd, p="Backbone.feature_extraction", concat=True):
+    """gwcnet_backbone.py:78-91."""
+    x = F.relu(_convbn2d(img, sd, p + ".firstconv.0", 2, 1, 1))
+    x = F.relu(_convbn2d(x, sd, p + ".firstconv.2", 1, 1, 1))
+    x = F.relu(_convbn2d(x, sd, p + ".firstconv.4", 1, 1, 1))
+    for i in range(3):
+        x = _basic_block(x, sd, f"{p}.layer1.{i}", 1, 1, 1)
+    l2 = x
+    for i in range(16):
+        l2 = _basic_block(l2, sd, f"{p}.layer2.{i}", 2 if i == 0 else 1, 1, 1)
+    l3 = l2
+    for i in range(3):
+        l3 = _basic_block(l3, sd, f"{p}.layer3.{i}", 1, 1, 1)
+    l4 = l3
+    for i in range(3):
+        l4 = _basic_block(l4, sd, f"{p}.layer4.{i}", 1, 1, 2)
+    gwc = torch.cat((l2, l3, l4), dim=1)
+    if not concat:
+        return gwc, None
+    y = F.relu(_convbn2d(gwc, sd, p + ".lastconv.0", 1, 1, 1))
+    return gwc, F.conv2d(y, sd[p + ".lastconv.2.weight"])
+
+
+def gwcnet_forward(left, right, sd, maxdisp=192, downsample=4, num_groups=40, concat=True, taps=None):
+    """models/gwcnet/gwcnet.py:27-39, inference: {'left','right'} -> disp_pred [B,H,W]."""
+    t = {} if taps is None else taps
+    lg, lc = gwc_features(left, sd, concat=concat)
+    rg, rc = gwc_features(right, sd, concat=concat)
+    t["left_gwc"], t["right_gwc"], t["left_cat"], t["right_cat"] = lg, rg, lc, rc
+    D4 = maxdisp // downsample
+    vol = gwc_volume(lg, rg, D4, num_groups)
+    if concat:
+        vol = torch.cat((vol, concat_volume(lc, rc, D4)), 1)      # gwcnet_cost_processor.py:65
+    t["volume"] = vol
+    cost3 = gwc_aggregate(vol, sd, taps=t)
+    h, w = left.shape[2:]
+    disp = upsample_regression(cost3, maxdisp, h, w, align_corners=False)
+    t["disp"] = disp
+    return disp
+
+
+def gwc_hot_path(lg, rg, lc, rc, sd, maxdisp, h, w, num_groups=40):
+    """Features -> disparity: the engine's scope (everything after the 2-D backbone)."""
+    D4 = maxdisp // 4
+    vol = torch.cat((gwc_volume(lg, rg, D4, num_groups), concat_volume(lc, rc, D4)), 1)
+    return upsample_regression(gwc_aggregate(vol, sd), maxdisp, h, w, align_corners=False)

@@ -1,0 +1,152 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL OpenStereo reference.
+
+Runs only in the build container (needs /root/reference; CPU torch).  The reference is imported
+through stub parent packages so that stereo/modeling/__init__.py (which pulls cv2/timm/...) is
+never executed.  Inputs and parameters are regenerated deterministically from seeds
+by openstereo_amd.utils.weights, so fixtures store mostly *outputs*.
+
+    python tests/golden/make_golden.py [--full]      # --full also writes the 544x960 GwcNet disparity
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = os.environ.get("OPENSTEREO_REF", "/root/reference")
+sys.path.insert(0, ROOT)
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit(f"{REF} not found: golden vectors can only be generated where the reference is mounted")
+    sys.path.insert(0, REF)
+    for name, path in [("stereo", "stereo"), ("stereo.modeling", "stereo/modeling"),
+                       ("stereo.modeling.models", "stereo/modeling/models")]:
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, path)]
+        sys.modules[name] = m
+
+
+def rnd(shape, seed):
+    return torch.from_numpy(np.random.default_rng(seed).normal(0, 1, shape).astype(np.float32))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                      for k, v in arrays.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    import_reference()
+    torch.set_grad_enabled(False)
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+
+    # ------------------------------------------------------------------ volumes (a1-a4)
+    from stereo.modeling.cost_volume import cost_volume as cv
+    from stereo.modeling.models.gwcnet.gwcnet_cost_processor import GwcVolumeCostProcessor
+    from stereo.modeling.models.igev import submodule as igev_sub
+    from stereo.modeling.models.psmnet.psmnet_cost_processor import cat_fms
+
+    out = {}
+    for tag, (B, C, H, W, D, G) in {"a": (2, 16, 5, 23, 9, 4), "narrow": (1, 24, 3, 6, 9, 2),
+                                    "k12": (1, 24, 4, 19, 8, 2)}.items():
+        L, R = rnd((B, C, H, W), 100 + len(tag)), rnd((B, C, H, W), 200 + len(tag))
+        out[f"{tag}_meta"] = np.array([B, C, H, W, D, G])
+        out[f"{tag}_L"], out[f"{tag}_R"] = L, R
+        out[f"{tag}_gwc"] = cv.build_gwc_volume(L, R, D, G)
+        out[f"{tag}_concat"] = cv.build_concat_volume(L, R, D)
+        out[f"{tag}_corr"] = cv.correlation_volume(L, R, D)
+        out[f"{tag}_corr2"] = cv.build_corr_volume(L, R, D)
+        out[f"{tag}_igev_gwc"] = igev_sub.build_gwc_volume(L, R, D, G)
+        out[f"{tag}_igev_concat"] = igev_sub.build_concat_volume(L, R, D)
+        out[f"{tag}_psm_cat"] = cat_fms(L, R, max_disp=D, start_disp=0, dilation=1)
+        cp = GwcVolumeCostProcessor(maxdisp=D * 4, downsample=4, num_groups=G, use_concat_volume=True)
+        feats = {"ref_feature": {"gwc_feature": L, "concat_feature": L[:, :6]},
+                 "tgt_feature": {"gwc_feature": R, "concat_feature": R[:, :6]}}
+        out[f"{tag}_gwcnet_volume"] = cp(feats)["cost_volume"]
+    save("volumes.npz", **out)
+
+    # ------------------------------------------------------------------ regression (a10-a12)
+    import torch.nn.functional as F
+    from stereo.modeling.disp_pred.disp_regression import disparity_regression as dr_keep
+    from stereo.modeling.models.gwcnet.gwcnet_disp_processor import disparity_regression as dr_nokeep
+    from stereo.modeling.models.psmnet.psmnet_disp_processor import FasterSoftArgmin
+    cost = rnd((2, 12, 7, 9), 7) * 3.0
+    prob = F.softmax(cost, dim=1)
+    low = rnd((2, 1, 6, 5, 7), 8) * 2.0
+    up_f = F.interpolate(low, [24, 20, 28], mode="trilinear")
+    up_t = F.interpolate(low, [24, 20, 28], mode="trilinear", align_corners=True)
+    low2 = rnd((1, 1, 5, 4, 6), 9) * 2.0           # non-integer scale factors
+    up_odd = F.interpolate(low2, [17, 13, 21], mode="trilinear")
+    save("regression.npz", cost=cost, prob=prob,
+         reg_keep=dr_keep(prob, 12), reg_nokeep=dr_nokeep(prob, 12),
+         faster_softargmin=FasterSoftArgmin(max_disp=12, start_disp=0, dilation=1, alpha=1.0, normalize=True)(cost),
+         low=low,
+         up_false=dr_nokeep(F.softmax(up_f.squeeze(1), dim=1), 24),
+         up_true=dr_nokeep(F.softmax(up_t.squeeze(1), dim=1), 24),
+         low2=low2, up_odd=dr_nokeep(F.softmax(up_odd.squeeze(1), dim=1), 17))
+
+    # ------------------------------------------------------------------ GwcNet hourglass + disp processor (a6, a10)
+    from stereo.modeling.models.gwcnet.hourglass import Hourglass
+    from stereo.modeling.models.gwcnet.gwcnet_disp_processor import GwcDispProcessor
+    hg = Hourglass(8).eval()
+    hg.load_state_dict(synth_state_dict(hg, seed=3))
+    x = rnd((1, 8, 8, 8, 16), 11)
+    save("gwc_hourglass.npz", x=x, y=hg(x))
+
+    dp = GwcDispProcessor(maxdisp=32, downsample=4, num_groups=40, use_concat_volume=True, concat_channels=12).eval()
+    dp.load_state_dict(synth_state_dict(dp, seed=4))
+    taps = {}
+    dp.dres2.register_forward_pre_hook(lambda m, i: taps.__setitem__("cost0", i[0].clone()))
+    dp.dres2.register_forward_hook(lambda m, i, o: taps.__setitem__("out1", o.clone()))
+    dp.dres4.register_forward_hook(lambda m, i, o: taps.__setitem__("out3", o.clone()))
+    dp.classif3.register_forward_hook(lambda m, i, o: taps.__setitem__("cost3", o.clone()))
+    vol = rnd((1, 64, 8, 8, 16), 12).abs()
+    disp = dp({"cost_volume": vol, "left": torch.zeros(1, 3, 32, 64)})["inference_disp"]["disp_est"]
+    save("gwc_disp.npz", volume=vol, disp=disp, **taps)
+
+    # ------------------------------------------------------------------ full GwcNet, small image
+    from stereo.modeling.models.gwcnet.gwcnet import GwcNet
+    cfg = Cfg(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40)
+    net = GwcNet(cfg).eval()
+    net.load_state_dict(synth_state_dict(net, seed=0))
+    taps = {}
+    net.Backbone.register_forward_hook(lambda m, i, o: taps.update(
+        left_gwc=o["ref_feature"]["gwc_feature"].clone(), right_gwc=o["tgt_feature"]["gwc_feature"].clone(),
+        left_cat=o["ref_feature"]["concat_feature"].clone(), right_cat=o["tgt_feature"]["concat_feature"].clone()))
+    net.DispProcessor.classif3.register_forward_hook(lambda m, i, o: taps.__setitem__("cost3", o.clone()))
+    L, R = synth_images(1, 64, 128, seed=1)
+    disp = net({"left": L, "right": R})["disp_pred"]
+    print("small GwcNet disp range", disp.min().item(), disp.max().item(), disp.std().item())
+    save("gwcnet_small.npz", disp=disp, **taps)
+
+    if args.full:
+        L, R = synth_images(1, 544, 960, seed=1)
+        t = time.time()
+        taps.clear()
+        disp = net({"left": L, "right": R})["disp_pred"]
+        print(f"full GwcNet reference forward: {time.time() - t:.1f} s on {torch.get_num_threads()} threads;"
+              f" disp range {disp.min().item():.2f}..{disp.max().item():.2f} std {disp.std().item():.2f}")
+        save("gwcnet_full_disp.npz", disp=disp.numpy().astype(np.float32),
+             cost3=taps["cost3"].numpy().astype(np.float32)[:, :, ::4, ::4, ::4])
+
+
+if __name__ == "__main__":
+    main()

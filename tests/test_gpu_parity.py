@@ -1,0 +1,273 @@
+"""GPU parity: the HIP engine (through the C ABI) against the golden vectors of the real reference
+and against the CPU oracle on seeded inputs.  fp32 everywhere; tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import golden
+from openstereo_amd.utils.weights import synth_state_dict, synth_images, synth_tensor
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def g2(x):
+    return (T(x) if isinstance(x, np.ndarray) else x).to(DEV)
+
+
+def close(a, b, atol=1e-6, rtol=1e-6, what=""):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    if not (err <= tol).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: max|err|={err.max():.3e} at {i}: got {a[i]} want {b[i]} "
+                             f"({(err > tol).mean() * 100:.2f}% out of tol)")
+
+
+# ----------------------------------------------------------------------------- volumes
+@pytest.mark.parametrize("tag", ["a", "narrow", "k12"])
+def test_volume_functions_vs_reference_golden(tag):
+    from openstereo_amd import ops
+    g = golden("volumes.npz")
+    B, C, H, W, D, G = (int(v) for v in g[f"{tag}_meta"])
+    L, R = g2(g[f"{tag}_L"]), g2(g[f"{tag}_R"])
+    close(ops.build_gwc_volume(L, R, D, G), g[f"{tag}_gwc"], what="build_gwc_volume")
+    close(ops.build_concat_volume(L, R, D), g[f"{tag}_concat"], 0, 0, "build_concat_volume")
+    close(ops.build_concat_volume(L, R, D, mask_left=False), g[f"{tag}_igev_concat"], 0, 0, "igev concat")
+    close(ops.cat_fms(L, R, max_disp=D), g[f"{tag}_psm_cat"], 0, 0, "cat_fms")
+    close(ops.correlation_volume(L, R, D), g[f"{tag}_corr"], what="correlation_volume")
+    close(ops.build_corr_volume(L, R, D), g[f"{tag}_corr2"], what="build_corr_volume")
+    v = ops.build_cost_volume_cl(L, R, G, L[:, :6].contiguous(), R[:, :6].contiguous(), maxdisp=D)
+    assert ops.is_cl(v)
+    ref = g[f"{tag}_gwcnet_volume"]
+    close(v[:, :ref.shape[1]], ref, what="fused NDHWC volume")
+    close(ops.to_ncdhw(v, ref.shape[1]), ref, what="fused NDHWC volume via layout kernel")
+
+
+def test_volume_gwcnet_shape_vs_oracle():
+    """GwcNet channel configuration (320ch/40 groups + 12 concat) on a short row block."""
+    from openstereo_amd import ops
+    from oracle import torch_ref as O
+    rng = np.random.default_rng(5)
+    lg, rg = (T(rng.normal(0, 1, (1, 320, 3, 50)).astype(np.float32)) for _ in range(2))
+    lc, rc = (T(rng.normal(0, 1, (1, 12, 3, 50)).astype(np.float32)) for _ in range(2))
+    ref = torch.cat((O.gwc_volume(lg, rg, 48, 40), O.concat_volume(lc, rc, 48)), 1)
+    v = ops.build_cost_volume_cl(g2(lg), g2(rg), 40, g2(lc), g2(rc), maxdisp=48)
+    assert v.shape == ref.shape and ops.is_cl(v)
+    close(v, ref, atol=2e-6, rtol=1e-5, what="gwcnet fused volume")
+
+
+def test_volume_errors():
+    from openstereo_amd import ops, _lib
+    x = torch.zeros(1, 10, 4, 8, device=DEV)
+    with pytest.raises(AssertionError):
+        ops.build_gwc_volume(x, x, 4, 3)                  # C % groups != 0 (cost_volume.py:61)
+    with pytest.raises(_lib.EngineError):
+        ops.build_gwc_volume(x.cpu(), x.cpu(), 4, 2)      # no CPU path
+    with pytest.raises(AssertionError):
+        ops.disparity_regression(torch.zeros(1, 4, 4, device=DEV), 4)
+
+
+def test_layout_roundtrip():
+    from openstereo_amd import ops
+    x = torch.randn(2, 7, 3, 5, 9, device=DEV)
+    y = ops.to_cl(x)
+    assert y.shape[1] == 8 and ops.is_cl(y)
+    assert torch.equal(y[:, :7], x) and torch.count_nonzero(y[:, 7:]) == 0
+    assert torch.equal(ops.to_ncdhw(y, 7), x)
+
+
+# ----------------------------------------------------------------------------- regression
+def test_regression_vs_reference_golden():
+    from openstereo_amd import ops
+    g = golden("regression.npz")
+    prob, cost = g2(g["prob"]), g2(g["cost"])
+    close(ops.disparity_regression(prob, 12), g["reg_keep"], atol=1e-5, what="disparity_regression keepdim")
+    close(ops.disparity_regression(prob, 12, keepdim=False), g["reg_nokeep"], atol=1e-5, what="gwc regression")
+    close(ops.FasterSoftArgmin(12).to(DEV)(cost), g["faster_softargmin"], atol=1e-5, what="FasterSoftArgmin")
+    d, p = ops.softmax_disparity_regression(cost, keepdim=False, return_prob=True)
+    close(p, g["prob"], atol=1e-6, what="softmax prob")
+    close(ops.upsample_softargmin(g2(g["low"]), 24, 20, 28, False), g["up_false"], atol=2e-5, what="upsample F")
+    close(ops.upsample_softargmin(g2(g["low"]), 24, 20, 28, True), g["up_true"], atol=2e-5, what="upsample T")
+    close(ops.upsample_softargmin(g2(g["low2"]), 17, 13, 21, False), g["up_odd"], atol=2e-5, what="upsample odd")
+    with pytest.raises(ValueError):
+        ops.FasterSoftArgmin(12)(torch.zeros(1, 1, 12, 4, 4, device=DEV))
+
+
+# ----------------------------------------------------------------------------- single conv layers
+def _bn_for(c, seed, name):
+    bn = nn.BatchNorm3d(c)
+    bn.load_state_dict({k: synth_tensor(f"{name}.{k}", v.shape, seed) for k, v in bn.state_dict().items()})
+    return bn.eval()
+
+
+CONV_CASES = [
+    # name, Ci, Co, k, stride, pad, dil, (D,H,W), act, residual
+    ("32-32 s1", 32, 32, 3, 1, 1, 1, (6, 9, 20), "relu", False),
+    ("64-32 s1 ragged", 64, 32, 3, 1, 1, 1, (5, 7, 11), "relu", True),
+    ("32-64 s2", 32, 64, 3, 2, 1, 1, (8, 12, 20), "relu", False),
+    ("64-128 s2 odd", 64, 128, 3, 2, 1, 1, (6, 10, 14), "relu", False),
+    ("128-128 s1", 128, 128, 3, 1, 1, 1, (3, 6, 10), "relu", False),
+    ("64-64 s1", 64, 64, 3, 1, 1, 1, (4, 8, 8), "none", True),
+    ("1x1 32-32", 32, 32, 1, 1, 0, 1, (4, 5, 9), "none", False),
+    ("1x1 64-64", 64, 64, 1, 1, 0, 1, (3, 4, 7), "none", False),
+    ("24-48 leaky", 24, 48, 3, 1, 1, 1, (4, 6, 10), "leaky", False),
+    ("8-16", 8, 16, 3, 1, 1, 1, (5, 6, 7), "relu", False),
+    ("48-24 s2", 48, 24, 3, 2, 1, 1, (8, 8, 12), "leaky", False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_bn_act_vs_oracle(case):
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d
+    name, Ci, Co, k, s, p, dil, (D, H, W), act, use_res = case
+    conv = nn.Conv3d(Ci, Co, k, s, p, dil, bias=False)
+    conv.weight.data = synth_tensor(name + ".w", conv.weight.shape, 1)
+    bn = _bn_for(Co, 2, name)
+    x = T(np.random.default_rng(3).normal(0, 1, (2, Ci, D, H, W)).astype(np.float32))
+    with torch.no_grad():
+        ref = bn(conv(x))
+        res = torch.randn(ref.shape, generator=torch.Generator().manual_seed(4)) if use_res else None
+        if res is not None:
+            ref = ref + res
+        ref = {"relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.01), "none": lambda t: t}[act](ref)
+    pc = PackedConv3d(conv.to(DEV), bn.to(DEV), {"none": 0, "relu": 1, "leaky": 2}[act], 0.01)
+    y = pc(ops.to_cl(x.to(DEV)), residual=None if res is None else ops.to_cl(res.to(DEV)))
+    assert ops.is_cl(y)
+    close(y[:, :Co], ref, atol=2e-5, rtol=2e-5, what=name)
+
+
+DECONV_CASES = [("k3 128-64", 128, 64, 3, 1, 1, (3, 5, 7)), ("k3 64-32", 64, 32, 3, 1, 1, (4, 6, 9)),
+                ("k4 48-24", 48, 24, 4, 1, 0, (3, 4, 6)), ("k4 16-8", 16, 8, 4, 1, 0, (4, 5, 5))]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
+def test_deconv3d_bn_residual_vs_oracle(case):
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d
+    name, Ci, Co, k, p, op, (D, H, W) = case
+    dc = nn.ConvTranspose3d(Ci, Co, k, stride=2, padding=p, output_padding=op, bias=False)
+    dc.weight.data = synth_tensor(name + ".w", dc.weight.shape, 1)
+    bn = _bn_for(Co, 2, name)
+    x = T(np.random.default_rng(3).normal(0, 1, (2, Ci, D, H, W)).astype(np.float32))
+    with torch.no_grad():
+        up = bn(dc(x))
+        res = torch.randn(up.shape, generator=torch.Generator().manual_seed(4))
+        ref = F.relu(up + res)
+    pc = PackedConv3d(dc.to(DEV), bn.to(DEV), 1)
+    y = pc(ops.to_cl(x.to(DEV)), residual=ops.to_cl(res.to(DEV)))
+    close(y[:, :Co], ref, atol=2e-5, rtol=2e-5, what=name)
+
+
+def test_conv2d_as_flat_conv3d_dilated():
+    """2-D layers (D=1, 1x3x3 kernel, dilation 2) run through the same kernel."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d
+    conv = nn.Conv3d(32, 32, (1, 3, 3), 1, (0, 2, 2), (1, 2, 2), bias=False)
+    conv.weight.data = synth_tensor("flat.w", conv.weight.shape, 1)
+    x = T(np.random.default_rng(3).normal(0, 1, (2, 32, 1, 21, 37)).astype(np.float32))
+    with torch.no_grad():
+        ref = conv(x)
+    y = PackedConv3d(conv.to(DEV))(ops.to_cl(x.to(DEV)))
+    close(y, ref, atol=2e-5, rtol=2e-5, what="flat dilated conv")
+
+
+def test_small_co_classifier_vs_oracle():
+    from openstereo_amd import ops
+    from openstereo_amd.engine import SmallCoConv3d
+    conv = nn.Conv3d(32, 1, 3, 1, 1, bias=False)
+    conv.weight.data = synth_tensor("cls.w", conv.weight.shape, 1)
+    x = T(np.random.default_rng(3).normal(0, 1, (2, 32, 5, 7, 9)).astype(np.float32))
+    with torch.no_grad():
+        ref = conv(x)
+    y = SmallCoConv3d(conv.to(DEV))(ops.to_cl(x.to(DEV)))
+    close(y, ref, atol=2e-4, rtol=2e-5, what="classifier head")
+
+
+# ----------------------------------------------------------------------------- GwcNet stages / model
+def test_gwc_hourglass_vs_reference_golden():
+    from openstereo_amd.models.gwcnet import Hourglass
+    g = golden("gwc_hourglass.npz")
+    hg = Hourglass(8)
+    hg.load_state_dict(synth_state_dict(hg, seed=3))
+    hg = hg.to(DEV).eval()
+    close(hg(g2(g["x"])), g["y"], atol=2e-5, rtol=2e-5, what="Hourglass(8) drop-in forward")
+
+
+def test_gwc_disp_processor_vs_reference_golden():
+    from openstereo_amd import ops
+    from openstereo_amd.models.gwcnet import GwcDispProcessor
+    g = golden("gwc_disp.npz")
+    dp = GwcDispProcessor(maxdisp=32)
+    dp.load_state_dict(synth_state_dict(dp, seed=4))
+    dp = dp.to(DEV).eval()
+    vol = g2(g["volume"])
+    p = dp._pack()
+    x = ops.to_cl(vol)
+    cost0 = p["d02"](p["d00"](x))
+    cost0 = p["d12"](p["d10"](cost0), residual=cost0)
+    close(cost0, g["cost0"], atol=3e-5, rtol=3e-5, what="cost0")
+    out1 = dp.dres2.forward_cl(cost0)
+    close(out1, g["out1"], atol=5e-5, rtol=5e-5, what="out1")
+    cost3 = dp.aggregate_cl(x)
+    close(cost3, g["cost3"], atol=5e-4, rtol=1e-4, what="cost3")
+    disp = dp({"cost_volume": vol, "left": torch.zeros(1, 3, 32, 64, device=DEV)})["inference_disp"]["disp_est"]
+    epe = (disp.cpu().numpy() - g["disp"]).__abs__().mean()
+    assert epe < 1e-3, f"EPE {epe}"
+    close(disp, g["disp"], atol=5e-3, what="disp")
+
+
+def _gwcnet():
+    from openstereo_amd.models.gwcnet import GwcNet
+    net = GwcNet()
+    net.load_state_dict(synth_state_dict(net, seed=0))
+    return net.to(DEV).eval()
+
+
+def test_gwcnet_small_vs_reference_golden():
+    g = golden("gwcnet_small.npz")
+    net = _gwcnet()
+    L, R = synth_images(1, 64, 128, seed=1)
+    with torch.no_grad():
+        inputs = {"left": L.to(DEV), "right": R.to(DEV)}
+        disp = net(inputs)["disp_pred"]
+    close(inputs["ref_feature"]["gwc_feature"], g["left_gwc"], atol=1e-4, rtol=1e-4, what="backbone gwc feature")
+    epe = (disp.cpu().numpy() - g["disp"]).__abs__().mean()
+    assert disp.shape == (1, 64, 128)
+    assert epe < 1e-3, f"EPE {epe}"
+
+
+def test_gwcnet_engine_from_reference_features_small():
+    """Engine-only parity: feed the reference's own feature maps, compare cost3 + disparity."""
+    from openstereo_amd import ops
+    g = golden("gwcnet_small.npz")
+    net = _gwcnet()
+    vol = ops.build_cost_volume_cl(g2(g["left_gwc"]), g2(g["right_gwc"]), 40, g2(g["left_cat"]), g2(g["right_cat"]), 48)
+    cost3 = net.DispProcessor.aggregate_cl(vol)
+    close(cost3, g["cost3"], atol=1e-3, rtol=1e-4, what="cost3 from reference features")
+    disp = ops.upsample_softargmin(cost3, 192, 64, 128)
+    epe = (disp.cpu().numpy() - g["disp"]).__abs__().mean()
+    assert epe < 1e-3, f"EPE {epe}"
+
+
+def test_gwcnet_full_size_vs_reference_golden():
+    """BASELINE configs[1]: 540x960 padded to 544x960, D=192; disparity within 1e-3 EPE of the
+    reference CPU path (golden produced by the real reference)."""
+    g = golden("gwcnet_full_disp.npz")
+    net = _gwcnet()
+    L, R = synth_images(1, 544, 960, seed=1)
+    with torch.no_grad():
+        disp = net({"left": L.to(DEV), "right": R.to(DEV)})["disp_pred"]
+    torch.cuda.synchronize()
+    d = disp.cpu().numpy()
+    assert np.isfinite(d).all()
+    err = np.abs(d - g["disp"])
+    print(f"full-size EPE {err.mean():.3e}, max {err.max():.3e}, >0.01px: {(err > 1e-2).mean() * 100:.4f}%")
+    assert err.mean() < 1e-3, f"EPE {err.mean()}"

@@ -1,0 +1,80 @@
+"""CPU: the oracle restatement (oracle/torch_ref.py) against vectors produced by the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import torch
+
+from conftest import golden
+from oracle import torch_ref as O
+from openstereo_amd.utils.weights import synth_state_dict, synth_images
+
+T = torch.from_numpy
+
+
+def close(a, b, atol=1e-6, rtol=1e-6):
+    a = a.numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def test_volumes_against_reference():
+    g = golden("volumes.npz")
+    for tag in ("a", "narrow", "k12"):
+        B, C, H, W, D, G = g[f"{tag}_meta"]
+        L, R = T(g[f"{tag}_L"]), T(g[f"{tag}_R"])
+        close(O.gwc_volume(L, R, D, G), g[f"{tag}_gwc"])
+        close(O.gwc_volume(L, R, D, G), g[f"{tag}_igev_gwc"])
+        close(O.concat_volume(L, R, D), g[f"{tag}_concat"], 0, 0)
+        close(O.concat_volume(L, R, D), g[f"{tag}_psm_cat"], 0, 0)
+        close(O.concat_volume(L, R, D, mask_left=False), g[f"{tag}_igev_concat"], 0, 0)
+        close(O.corr_volume(L, R, D), g[f"{tag}_corr"])
+        close(O.build_corr_volume(L, R, D), g[f"{tag}_corr2"])
+        fused = torch.cat((O.gwc_volume(L, R, D, G), O.concat_volume(L[:, :6], R[:, :6], D)), 1)
+        close(fused, g[f"{tag}_gwcnet_volume"])
+
+
+def test_regression_against_reference():
+    g = golden("regression.npz")
+    prob, cost = T(g["prob"]), T(g["cost"])
+    close(O.disparity_regression(prob, 12, keepdim=True), g["reg_keep"])
+    close(O.disparity_regression(prob, 12, keepdim=False), g["reg_nokeep"])
+    close(O.softmax_regression(cost, keepdim=False), g["faster_softargmin"], atol=1e-5)
+    close(O.upsample_regression(T(g["low"]), 24, 20, 28, False), g["up_false"], atol=1e-5)
+    close(O.upsample_regression(T(g["low"]), 24, 20, 28, True), g["up_true"], atol=1e-5)
+    close(O.upsample_regression(T(g["low2"]), 17, 13, 21, False), g["up_odd"], atol=1e-5)
+
+
+def _shapes(prefix_model):
+    return {k: tuple(v.shape) for k, v in prefix_model.state_dict().items()}
+
+
+def test_gwc_hourglass_against_reference():
+    from openstereo_amd.models.gwcnet import Hourglass
+    g = golden("gwc_hourglass.npz")
+    sd = {"hg." + k: v for k, v in synth_state_dict(Hourglass(8), seed=3).items()}
+    close(O.gwc_hourglass(T(g["x"]), sd, "hg"), g["y"], atol=1e-5, rtol=1e-5)
+
+
+def test_gwc_disp_processor_against_reference():
+    from openstereo_amd.models.gwcnet import GwcDispProcessor
+    g = golden("gwc_disp.npz")
+    dp = GwcDispProcessor(maxdisp=32)
+    sd = {"DispProcessor." + k: v for k, v in synth_state_dict(dp, seed=4).items()}
+    taps = {}
+    cost3 = O.gwc_aggregate(T(g["volume"]), sd, taps=taps)
+    for k in ("cost0", "out1", "out3", "cost3"):
+        close(taps[k], g[k], atol=2e-5, rtol=1e-5)
+    close(O.upsample_regression(cost3, 32, 32, 64), g["disp"], atol=1e-4)
+
+
+def test_gwcnet_small_against_reference():
+    from openstereo_amd.models.gwcnet import GwcNet
+    g = golden("gwcnet_small.npz")
+    sd = synth_state_dict(GwcNet(), seed=0)
+    L, R = synth_images(1, 64, 128, seed=1)
+    taps = {}
+    with torch.no_grad():
+        disp = O.gwcnet_forward(L, R, sd, taps=taps)
+    for k in ("left_gwc", "right_gwc", "left_cat", "right_cat"):
+        close(taps[k], g[k], atol=1e-5, rtol=1e-5)
+    close(taps["cost3"], g["cost3"], atol=1e-4, rtol=1e-4)
+    epe = (disp.numpy() - g["disp"]).__abs__().mean()
+    assert epe < 1e-4, epe
