@@ -20,7 +20,8 @@ def _rng(seed: int, name: str) -> np.random.Generator:
     return np.random.default_rng([seed, zlib.crc32(name.encode())])
 
 
-def synth_tensor(name: str, shape, seed: int = 0, head_gain: float = 12.0, bn_names=()) -> torch.Tensor:
+def synth_tensor(name: str, shape, seed: int = 0, head_gain: float = 12.0, gain: float = 1.2,
+                 res_gain: float = 0.35) -> torch.Tensor:
     shape = tuple(shape)
     r = _rng(seed, name)
     leaf = name.rsplit(".", 1)[-1]
@@ -36,13 +37,25 @@ def synth_tensor(name: str, shape, seed: int = 0, head_gain: float = 12.0, bn_na
         a = r.normal(0.0, 0.1, shape)
     else:                                           # conv / deconv kernels
         fan_in = int(np.prod(shape[1:]))
-        a = r.normal(0.0, np.sqrt(2.0 / max(fan_in, 1)), shape)
+        a = r.normal(0.0, gain * np.sqrt(1.0 / max(fan_in, 1)), shape)
         if len(shape) == 5 and 1 in shape[:2]:      # single-channel classifier head -> sharpen
             a = a * head_gain
+        elif _is_residual_tail(name):               # last conv of a residual branch: keep the sum tame
+            a = a * res_gain
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 
-def synth_state_dict(model_or_shapes, seed: int = 0, head_gain: float = 12.0) -> dict:
+def _is_residual_tail(name: str) -> bool:
+    """Convs whose output is ADDED to a skip path without normalisation of the sum
+    (BasicBlock.conv2, dres1's second conv, hourglass conv5/conv6 + redir*): scaled down so the
+    un-normalised residual sums do not blow activations up layer after layer."""
+    parts = name.split(".")
+    return ("conv2" in parts and any(p.startswith("layer") for p in parts)) or ".dres1.2." in name \
+        or any(p in ("conv5", "conv6", "redir1", "redir2") for p in parts)
+
+
+def synth_state_dict(model_or_shapes, seed: int = 0, head_gain: float = 12.0, gain: float = 1.2,
+                     res_gain: float = 0.35) -> dict:
     """model_or_shapes: an nn.Module (its state_dict() gives names+shapes) or {name: shape}."""
     if hasattr(model_or_shapes, "state_dict"):
         shapes = {k: tuple(v.shape) for k, v in model_or_shapes.state_dict().items()}
@@ -52,7 +65,7 @@ def synth_state_dict(model_or_shapes, seed: int = 0, head_gain: float = 12.0) ->
     for k, shp in shapes.items():
         if k.endswith("disp_regression.weight"):    # PSMNet's frozen linspace kernel: keep as is
             continue
-        out[k] = synth_tensor(k, shp, seed, head_gain)
+        out[k] = synth_tensor(k, shp, seed, head_gain, gain, res_gain)
     return out
 
 
