@@ -43,8 +43,46 @@ struct ConvArgs {
     int tilesD, tilesH, tilesW;
     int nchunks, CoP;
     int act; float slope;
+    unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
+    int toff[MAX_TAPS];           // LDS voxel offset of every tap (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
 };
+
+// Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
+// Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
+template <int NTHR>
+__device__ __forceinline__ void stage_brick(const ConvArgs& p, float* smem, int b, int c0,
+                                            int g0d, int g0h, int g0w, int tid) {
+    constexpr int U = 4;
+    const int total = p.LD * p.LH * p.LW * (CC / 4);
+    const int LHW = p.LH * p.LW;
+    for (int base = tid; base < total; base += NTHR * U) {
+        float4 v[U];
+        int lo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = base + u * NTHR;
+            lo[u] = -1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < total) {
+                const int c4 = it & 3, vx = it >> 2;
+                const int ld = __umulhi((unsigned)vx, p.magicHW);
+                const int r = vx - ld * LHW;
+                const int lh = __umulhi((unsigned)r, p.magicW);
+                const int lw = r - lh * p.LW;
+                const int gd = g0d + ld, gh = g0h + lh, gw = g0w + lw;
+                lo[u] = vx * VS + c4 * 4;
+                if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) &&
+                    ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
+                    v[u] = *reinterpret_cast<const float4*>(
+                        p.x + ((((size_t)b * p.Di + gd) * p.Hi + gh) * (size_t)p.Wi + gw) * p.xCs + c0 + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lo[u] >= 0) *reinterpret_cast<float4*>(smem + lo[u]) = v[u];
+    }
+}
 
 // CFG: MT m-tiles x NT n-tiles per wave, WM x WN waves, brick TD x TH x TW (TD derived)
 template <int MT, int NT, int WM, int WN, int TH, int TW>
@@ -85,53 +123,52 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int rows = p.LD * p.LH;
-    const int rowItems = p.LW * (CC / 4);
-    const size_t wstep = (size_t)JO * 2 * p.CoP;   // float4s per tap
+    // One linear stream of B operands: [chunk][tap][octet] steps of 2*CoP float4 each.  The B
+    // operands of the NEXT tap are requested before the current tap's MFMAs start (register ring,
+    // one tap = JO steps deep), so their L2 latency hides behind 4*JO*MT*NT MFMAs; sched_barrier
+    // pins the issue order.  The packed buffer carries JO steps of slack for the last prefetch.
+    const size_t bstep = (size_t)2 * p.CoP;
+    const float4* wp = p.w + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
+    float4 bcur[JO][NT];
+#pragma unroll
+    for (int j = 0; j < JO; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bcur[j][n] = wp[j * bstep + n * 32];
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         if (ch) __syncthreads();
-        // ---- stage 16 channels of the input brick (zero outside the tensor) ----
-        const int c0 = ch * CC;
-        for (int rr = wave; rr < rows; rr += NW) {
-            const int ld = rr / p.LH, lh = rr - ld * p.LH;
-            const int gd = g0d + ld, gh = g0h + lh;
-            const bool rowok = ((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi);
-            const float* grow = p.x + (((size_t)b * p.Di + gd) * p.Hi + gh) * (size_t)p.Wi * p.xCs + c0;
-            float* lrow = smem + (size_t)rr * p.LW * VS;
-            for (int e = lane; e < rowItems; e += 64) {
-                const int lw = e >> 2, c4 = e & 3;
-                const int gw = g0w + lw;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rowok && ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
-                    v = *reinterpret_cast<const float4*>(grow + (size_t)gw * p.xCs + c4 * 4);
-                *reinterpret_cast<float4*>(lrow + lw * VS + c4 * 4) = v;
-            }
-        }
+        stage_brick<NW * 64>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
         __syncthreads();
-        // ---- taps x octets on the matrix cores ----
-        const float4* wch = p.w + (size_t)ch * p.T * wstep + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
         for (int t = 0; t < p.T; ++t) {
-            const int toff = ((p.td[t] - p.dmin) * p.LH + (p.th[t] - p.hmin)) * p.LW + (p.tw[t] - p.wmin);
-            const float4* wt = wch + (size_t)t * wstep;
+            const int toff = p.toff[t];
+            float4 bnx[JO][NT], av[JO][MT];
 #pragma unroll
-            for (int j = 0; j < JO; ++j) {
-                float4 bv[NT], av[MT];
+            for (int j = 0; j < JO; ++j)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bv[n] = wt[(size_t)(j * 2) * p.CoP + n * 32];
+                for (int n = 0; n < NT; ++n) bnx[j][n] = wp[(JO + j) * bstep + n * 32];
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    av[m] = *reinterpret_cast<const float4*>(smem + (size_t)(abase[m] + toff) * VS + j * 8 + hh * 4);
+                    av[j][m] = *reinterpret_cast<const float4*>(smem + (size_t)(abase[m] + toff) * VS + j * 8 + hh * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].x, bcur[j][n].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].y, bcur[j][n].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].z, bcur[j][n].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].w, bcur[j][n].w, acc[m][n], 0, 0, 0);
                     }
-            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the ring rotation (and its vmcnt wait) behind the MFMAs
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bcur[j][n] = bnx[j][n];
+            wp += JO * bstep;
         }
     }
 
@@ -224,6 +261,11 @@ static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what
     a.LD = (k.TD - 1) * a.isd + (dmax - a.dmin) + 1;
     a.LH = (k.TH - 1) * a.ish + (hmax - a.hmin) + 1;
     a.LW = (k.TW - 1) * a.isw + (wmax - a.wmin) + 1;
+    for (int t = 0; t < a.T; ++t)
+        a.toff[t] = ((a.td[t] - a.dmin) * a.LH + (a.th[t] - a.hmin)) * a.LW + (a.tw[t] - a.wmin);
+    OSA_REQUIRE((long long)a.LD * a.LH * a.LW < 65536, "%s: LDS brick too large", what);
+    a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
     const size_t lds = (size_t)a.LD * a.LH * a.LW * VS * sizeof(float);
     OSA_REQUIRE(lds <= 160 * 1024, "%s: LDS brick %dx%dx%d needs %zu B (> 160 KiB)", what, a.LD, a.LH, a.LW, lds);
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
@@ -269,6 +311,7 @@ static inline int nchunks_of(int ci) { return (ci + CC - 1) / CC; }
 static inline size_t packed_floats(int Ci, int Co, int T) {
     return (size_t)nchunks_of(Ci) * T * JO * 2 * pad32(Co) * 4;
 }
+static inline size_t slack_floats(int Co) { return (size_t)JO * 2 * pad32(Co) * 4; }   // one prefetched tap
 
 // transposed-conv parity class: taps of one dimension. o = 2a+par ; i = a + delta ; kernel index kk
 static int deconv_dim_taps(int k, int pad, int par, int* delta, int* kk) {
@@ -284,51 +327,65 @@ static int deconv_dim_taps(int k, int pad, int par, int* delta, int* kk) {
 }
 
 // ------------------------------------------------------------------ small Co --
-struct DirectArgs {
-    const float* x; const float* w; const float* bias; float* y;
-    int B, D, H, W, Ci, xCs, Co, yCs;
-    int kd, kh, kw, pd, ph, pw;
-};
-
+// Classifier heads (32 -> 1): N is far too small for the matrix cores, so this is a VALU kernel
+// on the same LDS brick: one thread per output voxel, all taps x 16-channel chunks read from LDS
+// as float4, the (tiny) weight set re-ordered into LDS as [chunk][tap][co][16] and read by
+// broadcast.  HBM traffic = one pass over the input; LDS-read bound.
 template <int CO>
-__global__ __launch_bounds__(256) void conv_small_co_kernel(const DirectArgs p) {
-    const size_t nvox = (size_t)p.B * p.D * p.H * p.W;
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (v >= nvox) return;
-    int w = v % p.W; size_t r = v / p.W;
-    int h = r % p.H; r /= p.H;
-    int d = r % p.D; const int b = r / p.D;
+__global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs p, const float* __restrict__ wref,
+                                                                  const float* __restrict__ bias) {
+    constexpr int TD = 4, TH = 8, TW = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    float* wl = smem + (size_t)p.LD * p.LH * p.LW * VS;       // [nchunks][T][CO][16]
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int twi = bid % p.tilesW; bid /= p.tilesW;
+    const int thi = bid % p.tilesH; bid /= p.tilesH;
+    const int tdi = bid % p.tilesD;
+    const int b = bid / p.tilesD;
+    const int a0d = tdi * TD, a0h = thi * TH, a0w = twi * TW;
+    const int g0d = a0d + p.dmin, g0h = a0h + p.hmin, g0w = a0w + p.wmin;
+
+    const int nw = p.nchunks * p.T * CO * 16;
+    for (int i = tid; i < nw; i += 256) {
+        const int e = i & 15; int r = i >> 4;
+        const int co = r % CO; r /= CO;
+        const int t = r % p.T; const int ch = r / p.T;
+        const int ci = ch * CC + e;
+        wl[i] = (ci < p.Ci) ? wref[((size_t)co * p.Ci + ci) * p.T + t] : 0.f;
+    }
+    const int tw_ = tid % TW, th_ = (tid / TW) % TH, td_ = tid / (TW * TH);
+    const int abase = (td_ * p.LH + th_) * p.LW + tw_;
     float acc[CO];
 #pragma unroll
-    for (int o = 0; o < CO; ++o) acc[o] = p.bias ? p.bias[o] : 0.f;
-    const size_t kvol = (size_t)p.kd * p.kh * p.kw;
-    for (int z = 0; z < p.kd; ++z) {
-        const int gd = d + z - p.pd;
-        if ((unsigned)gd >= (unsigned)p.D) continue;
-        for (int yy = 0; yy < p.kh; ++yy) {
-            const int gh = h + yy - p.ph;
-            if ((unsigned)gh >= (unsigned)p.H) continue;
-            for (int xx = 0; xx < p.kw; ++xx) {
-                const int gw = w + xx - p.pw;
-                if ((unsigned)gw >= (unsigned)p.W) continue;
-                const float* px = p.x + ((((size_t)b * p.D + gd) * p.H + gh) * p.W + gw) * p.xCs;
-                const size_t kidx = ((size_t)z * p.kh + yy) * p.kw + xx;
-                for (int c = 0; c < p.Ci; c += 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(px + c);
+    for (int o = 0; o < CO; ++o) acc[o] = bias ? bias[o] : 0.f;
+
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        if (ch) __syncthreads();
+        stage_brick<256>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
+        __syncthreads();
+        for (int t = 0; t < p.T; ++t) {
+            const float* xp = smem + (size_t)(abase + p.toff[t]) * VS;
+            const float* wq = wl + (size_t)(ch * p.T + t) * CO * 16;
 #pragma unroll
-                    for (int o = 0; o < CO; ++o) {
-                        const float* wp = p.w + ((size_t)o * p.Ci + c) * kvol + kidx;   // wave-uniform
-                        acc[o] = fmaf(a.x, wp[0], acc[o]);
-                        if (c + 1 < p.Ci) acc[o] = fmaf(a.y, wp[kvol], acc[o]);
-                        if (c + 2 < p.Ci) acc[o] = fmaf(a.z, wp[2 * kvol], acc[o]);
-                        if (c + 3 < p.Ci) acc[o] = fmaf(a.w, wp[3 * kvol], acc[o]);
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const float4 xv = *reinterpret_cast<const float4*>(xp + q * 4);
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wq + o * 16 + q * 4);
+                    acc[o] = fmaf(xv.x, wv.x, acc[o]); acc[o] = fmaf(xv.y, wv.y, acc[o]);
+                    acc[o] = fmaf(xv.z, wv.z, acc[o]); acc[o] = fmaf(xv.w, wv.w, acc[o]);
                 }
             }
         }
     }
+    const int ad = a0d + td_, ah = a0h + th_, aw = a0w + tw_;
+    if (ad < p.Ad && ah < p.Ah && aw < p.Aw) {
+        const size_t vox = (((size_t)b * p.Do + ad) * p.Ho + ah) * p.Wo + aw;
 #pragma unroll
-    for (int o = 0; o < CO; ++o) p.y[v * p.yCs + o] = acc[o];
+        for (int o = 0; o < CO; ++o) p.y[vox * p.yCs + o] = acc[o];
+    }
 }
 
 }  // namespace osa
@@ -337,7 +394,7 @@ using namespace osa;
 
 // ------------------------------------------------------------------ C ABI -----
 extern "C" size_t osa_conv3d_packed_floats(int Ci, int Co, int kd, int kh, int kw) {
-    return packed_floats(Ci, Co, kd * kh * kw);
+    return packed_floats(Ci, Co, kd * kh * kw) + slack_floats(Co);
 }
 
 extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
@@ -361,7 +418,7 @@ extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, 
 
 extern "C" size_t osa_deconv3d_packed_floats(int Ci, int Co, int k) {
     // every kernel tap belongs to exactly one parity class -> k^3 taps in total
-    return packed_floats(Ci, Co, k * k * k);
+    return packed_floats(Ci, Co, k * k * k) + slack_floats(Co);
 }
 
 extern "C" int osa_deconv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
@@ -494,20 +551,48 @@ extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref,
     OSA_REQUIRE(Co >= 1 && Co <= 4, "conv3d_small_co: Co=%d unsupported (1..4)", Co);
     OSA_REQUIRE(xCs % 4 == 0 && xCs >= Ci && ((size_t)x & 15) == 0, "conv3d_small_co: x must be 16-byte aligned, xCs %% 4 == 0");
     OSA_REQUIRE(kd == 2 * pad_d + 1 && kh == 2 * pad_h + 1 && kw == 2 * pad_w + 1, "conv3d_small_co: only 'same' convolutions");
+    OSA_REQUIRE(kd * kh * kw <= MAX_TAPS, "conv3d_small_co: too many taps");
     OSA_REQUIRE(yCs >= Co, "conv3d_small_co: yCs < Co");
-    DirectArgs a;
-    a.x = x; a.w = w_ref; a.bias = bias; a.y = y;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.xCs = xCs; a.Co = Co; a.yCs = yCs;
-    a.kd = kd; a.kh = kh; a.kw = kw; a.pd = pad_d; a.ph = pad_h; a.pw = pad_w;
-    const long long nvox = (long long)B * D * H * W;
-    dim3 grid(cdiv(nvox, 256)), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (Co) {
-        case 1: hipLaunchKernelGGL(conv_small_co_kernel<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(conv_small_co_kernel<2>, grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(conv_small_co_kernel<3>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(conv_small_co_kernel<4>, grid, block, 0, st, a); break;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y;
+    a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Ci = Ci; a.xCs = xCs;
+    a.Do = D; a.Ho = H; a.Wo = W; a.Co = Co; a.yCs = yCs;
+    a.Ad = D; a.Ah = H; a.Aw = W;
+    a.isd = a.ish = a.isw = 1; a.os = 1;
+    a.T = kd * kh * kw;
+    int t = 0;
+    for (int z = 0; z < kd; ++z) for (int yy = 0; yy < kh; ++yy) for (int xx = 0; xx < kw; ++xx, ++t) {
+        a.td[t] = (signed char)(z - pad_d); a.th[t] = (signed char)(yy - pad_h); a.tw[t] = (signed char)(xx - pad_w);
     }
+    a.nchunks = nchunks_of(Ci); a.CoP = Co;
+    a.dmin = -pad_d; a.hmin = -pad_h; a.wmin = -pad_w;
+    a.LD = 4 + 2 * pad_d; a.LH = 8 + 2 * pad_h; a.LW = 8 + 2 * pad_w;
+    a.tilesD = cdiv(D, 4); a.tilesH = cdiv(H, 8); a.tilesW = cdiv(W, 8);
+    for (t = 0; t < a.T; ++t)
+        a.toff[t] = ((a.td[t] - a.dmin) * a.LH + (a.th[t] - a.hmin)) * a.LW + (a.tw[t] - a.wmin);
+    a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
+    const size_t lds = ((size_t)a.LD * a.LH * a.LW * VS + (size_t)a.nchunks * a.T * Co * 16) * sizeof(float);
+    OSA_REQUIRE(lds <= 160 * 1024, "conv3d_small_co: %zu B of LDS needed", lds);
+    const long long nblk = (long long)B * a.tilesD * a.tilesH * a.tilesW;
+    OSA_REQUIRE(nblk < (1ll << 31), "conv3d_small_co: grid too large");
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define OSA_SC_LAUNCH(CO)                                                                                   \
+    do {                                                                                                    \
+        if (lds > 64 * 1024)                                                                                \
+            (void)hipFuncSetAttribute((const void*)conv_small_co_tiled_kernel<CO>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL(conv_small_co_tiled_kernel<CO>, grid, block, lds, st, a, w_ref, bias);           \
+    } while (0)
+    switch (Co) {
+        case 1: OSA_SC_LAUNCH(1); break;
+        case 2: OSA_SC_LAUNCH(2); break;
+        case 3: OSA_SC_LAUNCH(3); break;
+        default: OSA_SC_LAUNCH(4); break;
+    }
+#undef OSA_SC_LAUNCH
     OSA_LAUNCH_CHECK("conv3d_small_co");
     return 0;
 }

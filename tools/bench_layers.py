@@ -1,0 +1,84 @@
+"""Per-layer timing of the GwcNet 3-D aggregation shapes on the engine, optionally sweeping the
+kernel tile configuration (OSA_CONV_CFG).  GPU only.
+
+    python tools/bench_layers.py [--cfgs 0,1,3,10] [--iters 20] [--batch 1]
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from openstereo_amd import ops  # noqa: E402
+from openstereo_amd.engine import PackedConv3d, SmallCoConv3d  # noqa: E402
+
+V0, V1, V2 = (48, 136, 240), (24, 68, 120), (12, 34, 60)
+LAYERS = [  # name, kind, Ci, Co, k, stride, input dims, count per forward
+    ("dres0.0 64->32 V0", "conv", 64, 32, 3, 1, V0, 1),
+    ("32->32 V0", "conv", 32, 32, 3, 1, V0, 4),
+    ("conv1 32->64 s2", "conv", 32, 64, 3, 2, V0, 3),
+    ("conv2 64->64 V1", "conv", 64, 64, 3, 1, V1, 3),
+    ("conv3 64->128 s2", "conv", 64, 128, 3, 2, V1, 3),
+    ("conv4 128->128 V2", "conv", 128, 128, 3, 1, V2, 3),
+    ("conv5 deconv 128->64", "deconv", 128, 64, 3, 2, V2, 3),
+    ("conv6 deconv 64->32", "deconv", 64, 32, 3, 2, V1, 3),
+    ("redir1 1x1 32->32 V0", "conv", 32, 32, 1, 1, V0, 3),
+    ("redir2 1x1 64->64 V1", "conv", 64, 64, 1, 1, V1, 3),
+    ("classif 32->1 V0", "small", 32, 1, 3, 1, V0, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfgs", default="")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = "cuda:0"
+    cfgs = [None] + [int(c) for c in args.cfgs.split(",") if c != ""]
+    total = {}
+    for name, kind, Ci, Co, k, s, dims, count in LAYERS:
+        if args.only and args.only not in name:
+            continue
+        if kind == "deconv":
+            m = nn.ConvTranspose3d(Ci, Co, k, stride=2, padding=1, output_padding=1, bias=False)
+        else:
+            m = nn.Conv3d(Ci, Co, k, s, k // 2, bias=False)
+        m = m.to(dev)
+        x = ops.empty_cl(args.batch, Ci, *dims, dev)
+        x.normal_()
+        layer = SmallCoConv3d(m) if kind == "small" else PackedConv3d(m, nn.BatchNorm3d(Co).to(dev).eval(), 1)
+        od = layer.out_shape(*dims) if kind != "small" else dims
+        macs = args.batch * Ci * Co * (k ** 3) * (od[0] * od[1] * od[2]) / (8 if kind == "deconv" else 1)
+        line = f"{name:26s} {macs / 1e9:7.2f} GMAC x{count}"
+        for cfg in cfgs:
+            if cfg is None:
+                os.environ.pop("OSA_CONV_CFG", None)
+            else:
+                os.environ["OSA_CONV_CFG"] = str(cfg)
+            try:
+                for _ in range(3):
+                    layer(x)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    layer(x)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / args.iters
+                line += f" | cfg {cfg if cfg is not None else 'auto'}: {ms:7.3f} ms {2 * macs / ms / 1e9:6.1f} TF"
+                if cfg is None:
+                    total["auto"] = total.get("auto", 0) + ms * count
+            except Exception as ex:  # config not applicable to this layer
+                line += f" | cfg {cfg}: n/a ({str(ex)[:40]})"
+        print(line, flush=True)
+    os.environ.pop("OSA_CONV_CFG", None)
+    print(f"sum over one forward (auto cfg): {total.get('auto', 0):.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
