@@ -54,6 +54,7 @@ def main():
     from openstereo_amd import _lib, engine
     from openstereo_amd.models.gwcnet import GwcNet
     from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    from openstereo_amd.parallel import reduce_step_time, whole_job_rate
     _lib.load()
 
     net = GwcNet()
@@ -83,13 +84,9 @@ def main():
     for _ in range(args.steps):
         out = step()
     sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = reduce_step_time(time.perf_counter() - t0, dev)       # MAX over ranks
     assert torch.isfinite(out).all()
-    pairs_per_s = world * B * args.steps / dt
+    pairs_per_s = whole_job_rate(B, args.steps, world, dt)
 
     # ---- instrumented replay: per-layer HIP events on the launch stream ----
     roofline = None

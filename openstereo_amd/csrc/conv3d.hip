@@ -39,19 +39,21 @@ struct ConvArgs {
     int os, ood, ooh, oow;        // output position = a*os + oo
     int T;                        // taps
     int dmin, hmin, wmin;         // min delta per dim
-    int LD, LH, LW;               // LDS brick dims
+    int LD, LH, LW;               // LDS brick dims (voxels)
+    int RowQ, PlaneQ;             // LDS float4s per brick row (padded) / per d-plane (16-byte units keep ds_read_b128)
+    int dbg;                      // debug switch (OSA_DBG): 1 = skip staging (timing experiments only)
     int tilesD, tilesH, tilesW;
     int nchunks, CoP;
     int act; float slope;
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
-    int toff[MAX_TAPS];           // LDS voxel offset of every tap (host computed -> scalar loads)
+    int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
 };
 
 // Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
 // Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
 template <int NTHR>
-__device__ __forceinline__ void stage_brick(const ConvArgs& p, float* smem, int b, int c0,
+__device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int b, int c0,
                                             int g0d, int g0h, int g0w, int tid) {
     constexpr int U = 4;
     const int total = p.LD * p.LH * p.LW * (CC / 4);
@@ -71,7 +73,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float* smem, int 
                 const int lh = __umulhi((unsigned)r, p.magicW);
                 const int lw = r - lh * p.LW;
                 const int gd = g0d + ld, gh = g0h + lh, gw = g0w + lw;
-                lo[u] = vx * VS + c4 * 4;
+                lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * (VS / 4) + c4;
                 if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) &&
                     ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
                     v[u] = *reinterpret_cast<const float4*>(
@@ -80,7 +82,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float* smem, int 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (lo[u] >= 0) *reinterpret_cast<float4*>(smem + lo[u]) = v[u];
+            if (lo[u] >= 0) smem[lo[u]] = v[u];
     }
 }
 
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
     static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "TH/TW powers of two");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
     for (int m = 0; m < MT; ++m) {
         const int q = (wm * MT + m) * 32 + col;
         const int tw_ = q % TW, th_ = (q / TW) % TH, td_ = q / (TW * TH);
-        abase[m] = ((td_ * p.isd) * p.LH + th_ * p.ish) * p.LW + tw_ * p.isw;
+        abase[m] = (td_ * p.isd) * p.PlaneQ + (th_ * p.ish) * p.RowQ + (tw_ * p.isw) * (VS / 4) + hh;
     }
 
     f32x16 acc[MT][NT];
@@ -137,11 +139,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         if (ch) __syncthreads();
-        stage_brick<NW * 64>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
+        if (!(p.dbg & 1)) stage_brick<NW * 64>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
         __syncthreads();
+        // A operands of tap 0 of this chunk
+        float4 anx[JO][MT];
+        {
+            const int toff0 = p.toff[0];
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    anx[j][m] = smem[abase[m] + toff0 + j * 2];
+        }
         for (int t = 0; t < p.T; ++t) {
-            const int toff = p.toff[t];
-            float4 bnx[JO][NT], av[JO][MT];
+            // rotate: what was prefetched during the previous tap is consumed now
+            float4 av[JO][MT], bnx[JO][NT];
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[j][m] = anx[j][m];
+            // request the next tap's B (global, L2) and A (LDS) operands before this tap's MFMAs
+            const int toffn = p.toff[(t + 1 < p.T) ? t + 1 : t];
 #pragma unroll
             for (int j = 0; j < JO; ++j)
 #pragma unroll
@@ -150,7 +168,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
             for (int j = 0; j < JO; ++j)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    av[j][m] = *reinterpret_cast<const float4*>(smem + (size_t)(abase[m] + toff) * VS + j * 8 + hh * 4);
+                    anx[j][m] = smem[abase[m] + toffn + j * 2];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < JO; ++j)
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].z, bcur[j][n].z, acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].w, bcur[j][n].w, acc[m][n], 0, 0, 0);
                     }
-            __builtin_amdgcn_sched_barrier(0);   // keep the ring rotation (and its vmcnt wait) behind the MFMAs
+            __builtin_amdgcn_sched_barrier(0);   // keep the ring rotation (and its waits) behind the MFMAs
 #pragma unroll
             for (int j = 0; j < JO; ++j)
 #pragma unroll
@@ -242,9 +260,29 @@ static int pick_cfg(const ConvArgs& a, int stride) {
         return 7;
     }
     if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 3);
-    if (a.CoP % 128 == 0) return (vox < 256 * 128 * 4) ? 11 : 2;
-    if (a.CoP % 64 == 0) return (vox < 256 * 256 * 2) ? 4 : 1;
-    return (vox < 256 * 256 * 2) ? 3 : 0;
+    // measured on MI355X (tools/bench_layers.py): few-tap launches (1x1x1, transposed-conv parity
+    // classes) and sub-megavoxel volumes prefer the 128-voxel bricks (more workgroups in flight)
+    if (a.T <= 8) return 3;
+    if (vox < (1ll << 20)) return (a.CoP % 64 == 0) ? 4 : 3;
+    return (a.CoP % 64 == 0) ? 1 : 0;
+}
+
+// LDS row padding: consecutive w voxels sit 5 16-byte slots apart (conflict free within a row); an
+// M tile of 32 voxels spans 4 rows (TW=8) or 2 rows (TW=16).  ds_read_b128 is serviced in 16-lane
+// groups that mix rows, so the row stride is padded to 8 (mod 16) slots for TW=8 and to 0 (mod 16)
+// for TW=16: each group then touches 16 distinct slots.
+static void finish_geometry(ConvArgs& a, int TW) {
+    const int want = (TW == 8) ? 32 : 0;                 // floats mod 64
+    int rowf = a.LW * VS;
+    while ((rowf & 63) != want) rowf += 4;
+    if (getenv("OSA_NOPAD")) rowf = a.LW * VS;
+    a.RowQ = rowf / 4; a.PlaneQ = a.LH * a.RowQ;
+    for (int t = 0; t < a.T; ++t)
+        a.toff[t] = (a.td[t] - a.dmin) * a.PlaneQ + (a.th[t] - a.hmin) * a.RowQ + (a.tw[t] - a.wmin) * (VS / 4);
+    a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
+    const char* dbg = getenv("OSA_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
 }
 
 static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what) {
@@ -261,12 +299,9 @@ static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what
     a.LD = (k.TD - 1) * a.isd + (dmax - a.dmin) + 1;
     a.LH = (k.TH - 1) * a.ish + (hmax - a.hmin) + 1;
     a.LW = (k.TW - 1) * a.isw + (wmax - a.wmin) + 1;
-    for (int t = 0; t < a.T; ++t)
-        a.toff[t] = ((a.td[t] - a.dmin) * a.LH + (a.th[t] - a.hmin)) * a.LW + (a.tw[t] - a.wmin);
     OSA_REQUIRE((long long)a.LD * a.LH * a.LW < 65536, "%s: LDS brick too large", what);
-    a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
-    a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
-    const size_t lds = (size_t)a.LD * a.LH * a.LW * VS * sizeof(float);
+    finish_geometry(a, k.TW);
+    const size_t lds = (size_t)a.LD * a.PlaneQ * sizeof(float4);
     OSA_REQUIRE(lds <= 160 * 1024, "%s: LDS brick %dx%dx%d needs %zu B (> 160 KiB)", what, a.LD, a.LH, a.LW, lds);
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
@@ -335,9 +370,10 @@ template <int CO>
 __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs p, const float* __restrict__ wref,
                                                                   const float* __restrict__ bias) {
     constexpr int TD = 4, TH = 8, TW = 8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
-    float* wl = smem + (size_t)p.LD * p.LH * p.LW * VS;       // [nchunks][T][CO][16]
+    float4* wl4 = smem + (size_t)p.LD * p.PlaneQ;             // [nchunks][T][CO][16 floats]
+    float* wl = reinterpret_cast<float*>(wl4);
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int twi = bid % p.tilesW; bid /= p.tilesW;
@@ -356,7 +392,7 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
         wl[i] = (ci < p.Ci) ? wref[((size_t)co * p.Ci + ci) * p.T + t] : 0.f;
     }
     const int tw_ = tid % TW, th_ = (tid / TW) % TH, td_ = tid / (TW * TH);
-    const int abase = (td_ * p.LH + th_) * p.LW + tw_;
+    const int abase = td_ * p.PlaneQ + th_ * p.RowQ + tw_ * (VS / 4);
     float acc[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) acc[o] = bias ? bias[o] : 0.f;
@@ -366,14 +402,14 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
         stage_brick<256>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
         __syncthreads();
         for (int t = 0; t < p.T; ++t) {
-            const float* xp = smem + (size_t)(abase + p.toff[t]) * VS;
-            const float* wq = wl + (size_t)(ch * p.T + t) * CO * 16;
+            const float4* xp = smem + abase + p.toff[t];
+            const float4* wq = wl4 + (size_t)(ch * p.T + t) * CO * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 xv = *reinterpret_cast<const float4*>(xp + q * 4);
+                const float4 xv = xp[q];
 #pragma unroll
                 for (int o = 0; o < CO; ++o) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wq + o * 16 + q * 4);
+                    const float4 wv = wq[o * 4 + q];
                     acc[o] = fmaf(xv.x, wv.x, acc[o]); acc[o] = fmaf(xv.y, wv.y, acc[o]);
                     acc[o] = fmaf(xv.z, wv.z, acc[o]); acc[o] = fmaf(xv.w, wv.w, acc[o]);
                 }
@@ -569,11 +605,8 @@ extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref,
     a.dmin = -pad_d; a.hmin = -pad_h; a.wmin = -pad_w;
     a.LD = 4 + 2 * pad_d; a.LH = 8 + 2 * pad_h; a.LW = 8 + 2 * pad_w;
     a.tilesD = cdiv(D, 4); a.tilesH = cdiv(H, 8); a.tilesW = cdiv(W, 8);
-    for (t = 0; t < a.T; ++t)
-        a.toff[t] = ((a.td[t] - a.dmin) * a.LH + (a.th[t] - a.hmin)) * a.LW + (a.tw[t] - a.wmin);
-    a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
-    a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
-    const size_t lds = ((size_t)a.LD * a.LH * a.LW * VS + (size_t)a.nchunks * a.T * Co * 16) * sizeof(float);
+    finish_geometry(a, 8);
+    const size_t lds = ((size_t)a.LD * a.PlaneQ * 4 + (size_t)a.nchunks * a.T * Co * 16) * sizeof(float);
     OSA_REQUIRE(lds <= 160 * 1024, "conv3d_small_co: %zu B of LDS needed", lds);
     const long long nblk = (long long)B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "conv3d_small_co: grid too large");
