@@ -100,11 +100,14 @@ int    osa_deconv3d_pack_f32(const float* w_ref, float* w_packed,
                              int Ci, int Co, int k, int pad, void* stream);
 
 /*
- * y = act( conv3d(x, w) * scale[co] + shift[co] + residual )
+ * y = act( conv3d(x, w) * scale[co] + shift[co] + residual ) [* sigmoid(gate)]
  *   x        : NDHWC, voxel stride xCs floats (>= Ci, multiple of 4), reads channels [0,Ci)
  *   y        : NDHWC, voxel stride yCs floats, writes channels [0,Co)
  *   residual : NDHWC with voxel stride rCs, same spatial size as y, or NULL
  *   scale/shift: per-output-channel (folded eval-mode BatchNorm; NULL = 1 / 0)
+ *   gate_logits: NULL, or NHWC [B][Ho][Wo][gCs] logits: the result is multiplied by
+ *                sigmoid(gate[b,h,w,co]) broadcast over D -- the FeatureAtt channel gating of
+ *                models/stereobase/igev_blocks.py:35-48 / models/igev/submodule.py (cv = sigmoid(att) * cv)
  *   stride is isotropic (1 or 2) -- a dimension of size 1 with kernel 1 is not strided;
  *   pad_* / dil_* per dimension.  act: OSA_ACT_*; slope for leaky.
  *   Output dims follow the PyTorch formula.
@@ -117,6 +120,7 @@ int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
                          int kd, int kh, int kw, int stride,
                          int pad_d, int pad_h, int pad_w,
                          int dil_d, int dil_h, int dil_w,
+                         const float* gate_logits, int gCs,
                          int act, float slope, void* stream);
 
 /*
@@ -130,12 +134,14 @@ int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
                            int B, int Di, int Hi, int Wi, int Ci, int xCs,
                            int Co, int yCs, int rCs,
                            int k, int pad, int opad,
+                           const float* gate_logits, int gCs,
                            int act, float slope, void* stream);
 
-/* small-Cout direct convolution (Co <= 4, e.g. the 32->1 classifier). Reference weight
- * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer). */
+/* small-Cout 'same' convolution (Co <= 4, e.g. the 32->1 classifier heads). Reference weight
+ * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer).
+ * y = conv(x) + bias[co] + residual ; residual (or NULL) has y's layout (voxel stride yCs). */
 int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,
-                                  float* y,
+                                  const float* residual, float* y,
                                   int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
                                   int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
                                   void* stream);

@@ -42,13 +42,15 @@ SIGNATURES = {
                                    c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_i,
                                    c_i, c_i, c_i,
+                                   c_fp, c_i,
                                    c_i, c_f, c_st]),
     "osa_deconv3d_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                      c_i, c_i, c_i, c_i, c_i, c_i,
                                      c_i, c_i, c_i,
                                      c_i, c_i, c_i,
+                                     c_fp, c_i,
                                      c_i, c_f, c_st]),
-    "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp,
+    "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),

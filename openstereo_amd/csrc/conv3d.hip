@@ -32,6 +32,7 @@ constexpr int MAX_TAPS = 32;
 
 struct ConvArgs {
     const float* x; const float4* w; const float* scale; const float* shift; const float* res; float* y;
+    const float* gate; int gCs;   // optional sigmoid channel gate, NHWC logits [B][Ho][Wo][gCs]
     int B, Di, Hi, Wi, Ci, xCs;
     int Do, Ho, Wo, Co, yCs, rCs;
     int Ad, Ah, Aw;               // a-space extent of this launch
@@ -211,6 +212,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
                     if (p.res) v += p.res[vox * p.rCs + co];
                     if (p.act == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                    if (p.gate) {
+                        const float gl = p.gate[(((size_t)b * p.Ho + (ah * p.os + p.ooh)) * p.Wo + (aw * p.os + p.oow)) * p.gCs + co];
+                        v *= 1.0f / (1.0f + expf(-gl));
+                    }
                     p.y[vox * p.yCs + co] = v;
                 }
             }
@@ -285,10 +290,7 @@ static void finish_geometry(ConvArgs& a, int TW) {
     a.dbg = dbg ? atoi(dbg) : 0;
 }
 
-static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what) {
-    const int ci = pick_cfg(a, stride);
-    const KernelCfg& k = g_cfgs[ci];
-    a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
+static size_t brick_bytes(ConvArgs& a, const KernelCfg& k) {
     int dmax = -128, hmax = -128, wmax = -128;
     a.dmin = a.hmin = a.wmin = 127;
     for (int t = 0; t < a.T; ++t) {
@@ -299,6 +301,20 @@ static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what
     a.LD = (k.TD - 1) * a.isd + (dmax - a.dmin) + 1;
     a.LH = (k.TH - 1) * a.ish + (hmax - a.hmin) + 1;
     a.LW = (k.TW - 1) * a.isw + (wmax - a.wmin) + 1;
+    return (size_t)a.LD * a.LH * (a.LW * VS + 64) * sizeof(float);   // upper bound incl. row padding
+}
+
+static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what) {
+    int ci = pick_cfg(a, stride);
+    if (brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
+        // e.g. a stride-2 3x3x3 layer whose output depth collapses to 1: fall back to the small bricks
+        static const int fallback[] = {5, 3, 11};
+        for (int f : fallback)
+            if (a.CoP % g_cfgs[f].N == 0 && brick_bytes(a, g_cfgs[f]) <= 160 * 1024) { ci = f; break; }
+    }
+    const KernelCfg& k = g_cfgs[ci];
+    a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
+    (void)brick_bytes(a, k);
     OSA_REQUIRE((long long)a.LD * a.LH * a.LW < 65536, "%s: LDS brick too large", what);
     finish_geometry(a, k.TW);
     const size_t lds = (size_t)a.LD * a.PlaneQ * sizeof(float4);
@@ -420,7 +436,8 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
     if (ad < p.Ad && ah < p.Ah && aw < p.Aw) {
         const size_t vox = (((size_t)b * p.Do + ad) * p.Ho + ah) * p.Wo + aw;
 #pragma unroll
-        for (int o = 0; o < CO; ++o) p.y[vox * p.yCs + o] = acc[o];
+        for (int o = 0; o < CO; ++o)
+            p.y[vox * p.yCs + o] = acc[o] + (p.res ? p.res[vox * p.yCs + o] : 0.f);
     }
 }
 
@@ -505,7 +522,9 @@ extern "C" int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
                                     int kd, int kh, int kw, int stride,
                                     int pad_d, int pad_h, int pad_w,
                                     int dil_d, int dil_h, int dil_w,
+                                    const float* gate_logits, int gCs,
                                     int act, float slope, void* stream) {
+    if (gate_logits) OSA_REQUIRE(gCs >= Co, "conv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("conv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= MAX_TAPS, "conv3d: %dx%dx%d kernel unsupported", kd, kh, kw);
@@ -514,6 +533,7 @@ extern "C" int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = reinterpret_cast<const float4*>(w_packed); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.gate = gate_logits; a.gCs = gCs;
     a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
     a.isd = (Di == 1 && kd == 1) ? 1 : stride; a.ish = stride; a.isw = stride;
     a.Do = (Di + 2 * pad_d - dil_d * (kd - 1) - 1) / a.isd + 1;
@@ -541,7 +561,9 @@ extern "C" int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
                                       int B, int Di, int Hi, int Wi, int Ci, int xCs,
                                       int Co, int yCs, int rCs,
                                       int k, int pad, int opad,
+                                      const float* gate_logits, int gCs,
                                       int act, float slope, void* stream) {
+    if (gate_logits) OSA_REQUIRE(gCs >= Co, "deconv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     OSA_REQUIRE((k == 3 && pad == 1 && opad == 1) || (k == 4 && pad == 1 && opad == 0),
                 "deconv3d: only (k=3,p=1,op=1) and (k=4,p=1,op=0) with stride 2 are supported (got k=%d p=%d op=%d)", k, pad, opad);
@@ -557,6 +579,7 @@ extern "C" int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
         memset(&a, 0, sizeof(a));
         a.x = x; a.w = reinterpret_cast<const float4*>(w_packed + off);
         a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+        a.gate = gate_logits; a.gCs = gCs;
         a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
         a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.yCs = yCs; a.rCs = rCs;
         a.Ad = (Do - pd + 1) / 2; a.Ah = (Ho - ph + 1) / 2; a.Aw = (Wo - pw + 1) / 2;
@@ -579,7 +602,7 @@ extern "C" int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
 }
 
 extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,
-                                             float* y,
+                                             const float* residual, float* y,
                                              int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
                                              int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
                                              void* stream) {
@@ -591,7 +614,7 @@ extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref,
     OSA_REQUIRE(yCs >= Co, "conv3d_small_co: yCs < Co");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.y = y;
+    a.x = x; a.y = y; a.res = residual;
     a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Ci = Ci; a.xCs = xCs;
     a.Do = D; a.Ho = H; a.Wo = W; a.Co = Co; a.yCs = yCs;
     a.Ad = D; a.Ah = H; a.Aw = W;

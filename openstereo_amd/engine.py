@@ -80,11 +80,14 @@ class PackedConv3d:
         return (f(D, self.k[0], self.pad[0], self.dil[0], sd), f(H, self.k[1], self.pad[1], self.dil[1], s),
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
-    def __call__(self, x, residual=None, out=None):
-        """x: logical [B,Cs>=Ci,D,H,W] NDHWC.  Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC."""
+    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0):
+        """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
+        Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
+        (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
+        multiplied by sigmoid(gate) broadcast over D (FeatureAtt)."""
         assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
         B, Cs, D, H, W = x.shape
-        assert Cs >= self.Ci and Cs % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
+        assert Cs >= x_off + self.Ci and Cs % 4 == 0 and x_off % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
         Ci = (self.Ci + 3) // 4 * 4     # padded channels of x are zero by construction
         Do, Ho, Wo = self.out_shape(D, H, W)
         if out is None:
@@ -92,26 +95,29 @@ class PackedConv3d:
             out = empty_cl(B, CoS, Do, Ho, Wo, x.device)
             if CoS != self.Co:
                 out.zero_()
+        assert is_cl(out) and tuple(out.shape[2:]) == (Do, Ho, Wo) and out.shape[1] >= out_off + self.Co
         yCs = out.shape[1]
         rCs = 0
         if residual is not None:
             assert is_cl(residual) and tuple(residual.shape[2:]) == (Do, Ho, Wo)
             rCs = residual.shape[1]
+        gCs = 0
+        if gate is not None:
+            assert gate.is_contiguous() and tuple(gate.shape[:3]) == (B, Ho, Wo) and gate.shape[3] >= self.Co
+            gCs = gate.shape[3]
+        xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
-            self._launch(x, residual, out, B, D, H, W, Ci, Cs, yCs, rCs)
+            if self.transposed:
+                _lib.call("osa_deconv3d_ndhwc_f32", xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                          _p(residual), yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
+                          self.k[0], self.pad[0], self.opad[0], _p(gate), gCs, self.act, self.slope, _stream())
+            else:
+                _lib.call("osa_conv3d_ndhwc_f32", xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                          _p(residual), yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
+                          self.k[0], self.k[1], self.k[2], self.stride[1],
+                          self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
+                          _p(gate), gCs, self.act, self.slope, _stream())
         return out
-
-    def _launch(self, x, residual, out, B, D, H, W, Ci, Cs, yCs, rCs):
-        if self.transposed:
-            _lib.call("osa_deconv3d_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
-                      _p(residual), out.data_ptr(), B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
-                      self.k[0], self.pad[0], self.opad[0], self.act, self.slope, _stream())
-        else:
-            _lib.call("osa_conv3d_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
-                      _p(residual), out.data_ptr(), B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
-                      self.k[0], self.k[1], self.k[2], self.stride[1],
-                      self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
-                      self.act, self.slope, _stream())
 
 
 class SmallCoConv3d:
@@ -128,12 +134,15 @@ class SmallCoConv3d:
         self.Co, self.Ci = self.w.shape[:2]
         self.k, self.pad = tuple(conv.kernel_size), _t3(conv.padding)
 
-    def __call__(self, x):
-        """x NDHWC logical [B,Cs,D,H,W] -> contiguous [B,Co,D,H,W] (Co==1) i.e. plain [B,1,D,H,W]."""
+    def __call__(self, x, residual=None):
+        """x NDHWC logical [B,Cs,D,H,W] -> logical [B,Co,D,H,W] stored [B,D,H,W,Co] (for Co==1 this
+        is plain contiguous [B,1,D,H,W]).  residual: an earlier output of the same shape (added)."""
         assert is_cl(x)
         B, Cs, D, H, W = x.shape
         y = torch.empty((B, D, H, W, self.Co), device=x.device, dtype=torch.float32)
+        if residual is not None:
+            assert tuple(residual.shape) == (B, self.Co, D, H, W) and is_cl(residual)
         with timing.span("conv3d_small_co", self.Ci, self.Co, self.k[0], 1, D, H, W):
-            _lib.call("osa_conv3d_small_co_ndhwc_f32", x.data_ptr(), self.w.data_ptr(), _p(self.bias), y.data_ptr(),
+            _lib.call("osa_conv3d_small_co_ndhwc_f32", x.data_ptr(), self.w.data_ptr(), _p(self.bias), _p(residual), y.data_ptr(),
                       B, D, H, W, self.Ci, Cs, self.Co, self.Co, *self.k, *self.pad, _stream())
         return y.permute(0, 4, 1, 2, 3)

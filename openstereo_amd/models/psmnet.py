@@ -1,0 +1,254 @@
+"""PSMNet on the gfx950 cost-volume engine (BASELINE configs[0]).
+
+Parameter names reproduce the reference's state_dict (stereo/modeling/models/psmnet/
+{psmnet,psmnet_backbone,psmnet_cost_processor,psmnet_disp_processor,submodule}.py) so checkpoints
+load unchanged.  On the engine: cat_fms concat volume (NDHWC), the stacked-hourglass aggregator with
+its cross-hourglass skips (pre/post) and cost accumulation (cost2 = classif2(out2) + cost1), and the
+three trilinear(align_corners=True)+softmax+regression heads, fused.  The SPP 2-D backbone runs as
+ordinary PyTorch-ROCm modules.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops, timing
+from ..engine import PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+
+
+# ----------------------------------------------------------------------------- 2-D backbone (submodule.py factories)
+def _pad(p, d):
+    return d if d > 1 else p
+
+
+def _conv_bn(cin, cout, k, s, p, d, bias=True, relu=False):
+    layers = [nn.Conv2d(cin, cout, k, s, _pad(p, d), d, bias=bias), nn.BatchNorm2d(cout)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class _Block(nn.Module):
+    def __init__(self, cin, cout, stride, downsample, pad, dil):
+        super().__init__()
+        self.conv1 = _conv_bn(cin, cout, 3, stride, pad, dil, bias=False, relu=True)
+        self.conv2 = _conv_bn(cout, cout, 3, 1, pad, dil, bias=False)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class PSMBackbone(nn.Module):
+    """psmnet_backbone.py:7-133 (SPP feature extractor -> 32 channels at 1/4 res)."""
+
+    def __init__(self, in_planes=3):
+        super().__init__()
+        self.firstconv = nn.Sequential(
+            _conv_bn(in_planes, 32, 3, 2, 1, 1, False, True), _conv_bn(32, 32, 3, 1, 1, 1, False, True),
+            _conv_bn(32, 32, 3, 1, 1, 1, False, True))
+        self._cin = 32
+        self.layer1 = self._stage(32, 3, 1, 1, 1)
+        self.layer2 = self._stage(64, 16, 2, 1, 1)
+        self.layer3 = self._stage(128, 3, 1, 1, 1)
+        self.layer4 = self._stage(128, 3, 1, 2, 2)
+        for i, k in zip((1, 2, 3, 4), (64, 32, 16, 8)):
+            setattr(self, f"branch{i}", nn.Sequential(nn.AvgPool2d((k, k), stride=(k, k)),
+                                                      _conv_bn(128, 32, 1, 1, 0, 1, False, True)))
+        self.lastconv = nn.Sequential(_conv_bn(320, 128, 3, 1, 1, 1, False, True),
+                                      nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, dilation=1, bias=False))
+
+    def _stage(self, cout, n, stride, pad, dil):
+        ds = None
+        if stride != 1 or self._cin != cout:
+            ds = _conv_bn(self._cin, cout, 1, stride, 0, 1)           # bias=True by default (submodule.py:32)
+        blocks = [_Block(self._cin, cout, stride, ds, pad, dil)]
+        self._cin = cout
+        blocks += [_Block(cout, cout, 1, None, pad, dil) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+    def _forward(self, x):
+        o2 = self.layer1(self.firstconv(x))
+        o4 = self.layer2(o2)
+        o8 = self.layer4(self.layer3(o4))
+        size = (o8.size(2), o8.size(3))
+        br = [F.interpolate(getattr(self, f"branch{i}")(o8), size, mode="bilinear", align_corners=True)
+              for i in (1, 2, 3, 4)]
+        return self.lastconv(torch.cat((o4, o8, br[3], br[2], br[1], br[0]), 1))
+
+    def forward(self, inputs):
+        left, right = inputs["left"], inputs["right"]
+        B = left.shape[0]
+        with timing.span("backbone2d", left.shape[2], left.shape[3]):
+            f = self._forward(torch.cat((left, right), 0))
+        return {"ref_feature": f[:B], "tgt_feature": f[B:]}
+
+
+# ----------------------------------------------------------------------------- 3-D aggregator
+def _c3(cin, cout, k, s, p, relu):
+    layers = [nn.Conv3d(cin, cout, k, s, p, bias=False), nn.BatchNorm3d(cout)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+def _d3(cin, cout):
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False),
+                         nn.BatchNorm3d(cout))
+
+
+class Hourglass(nn.Module):
+    """psmnet_cost_processor.py:53-132: forward(x, presqu, postsqu) -> (out, pre, post)."""
+
+    def __init__(self, in_planes, batch_norm=True):
+        super().__init__()
+        assert batch_norm
+        c = in_planes
+        self.conv1 = _c3(c, 2 * c, 3, 2, 1, True)
+        self.conv2 = _c3(2 * c, 2 * c, 3, 1, 1, False)
+        self.conv3 = _c3(2 * c, 2 * c, 3, 2, 1, True)
+        self.conv4 = _c3(2 * c, 2 * c, 3, 1, 1, True)
+        self.conv5 = _d3(2 * c, 2 * c)
+        self.conv6 = _d3(2 * c, c)
+        self._packed = None
+
+    def _pack(self):
+        if self._packed is None:
+            P = PackedConv3d
+            self._packed = dict(c1=P(self.conv1[0], self.conv1[1], ACT_RELU), c2=P(self.conv2[0], self.conv2[1], ACT_RELU),
+                                c3=P(self.conv3[0], self.conv3[1], ACT_RELU), c4=P(self.conv4[0], self.conv4[1], ACT_RELU),
+                                c5=P(self.conv5[0], self.conv5[1], ACT_RELU), c6=P(self.conv6[0], self.conv6[1], ACT_NONE))
+        return self._packed
+
+    def forward_cl(self, x, presqu=None, postsqu=None, out_residual=None):
+        """NDHWC tensors. out_residual is added to conv6's output (the aggregator's `out + cost0`)."""
+        p = self._pack()
+        out = p["c1"](x)
+        pre = p["c2"](out, residual=postsqu)                   # relu(conv2(out) [+ postsqu])
+        out = p["c4"](p["c3"](pre))
+        post = p["c5"](out, residual=presqu if presqu is not None else pre)   # relu(conv5(out) + presqu|pre)
+        return p["c6"](post, residual=out_residual), pre, post
+
+    def forward(self, x, presqu=None, postsqu=None):
+        if self.training:
+            raise NotImplementedError("engine Hourglass: training-mode BatchNorm is not built yet")
+        cl = lambda t: None if t is None else ops.to_cl(t)
+        out, pre, post = self.forward_cl(ops.to_cl(x), cl(presqu), cl(postsqu))
+        return ops.to_ncdhw(out), ops.to_ncdhw(pre), ops.to_ncdhw(post)
+
+
+class PSMAggregator(nn.Module):
+    """psmnet_cost_processor.py:135-221.  forward returns the reference's [cost3, cost2, cost1]
+    (full-resolution costs, drop-in); aggregate_cl returns the low-res costs the fused heads use."""
+
+    def __init__(self, max_disp, in_planes=64, batch_norm=True):
+        super().__init__()
+        self.max_disp, self.in_planes = max_disp, in_planes
+        self.dres0 = nn.Sequential(_c3(in_planes, 32, 3, 1, 1, True), _c3(32, 32, 3, 1, 1, True))
+        self.dres1 = nn.Sequential(_c3(32, 32, 3, 1, 1, True), _c3(32, 32, 3, 1, 1, False))
+        self.dres2, self.dres3, self.dres4 = Hourglass(32), Hourglass(32), Hourglass(32)
+        for i in (1, 2, 3):
+            setattr(self, f"classif{i}", nn.Sequential(_c3(32, 32, 3, 1, 1, True),
+                                                       nn.Conv3d(32, 1, kernel_size=3, stride=1, padding=1, bias=False)))
+        self._packed = None
+
+    def reset_engine(self):
+        self._packed = None
+        for h in (self.dres2, self.dres3, self.dres4):
+            h._packed = None
+
+    def _pack(self):
+        if self._packed is None:
+            P = PackedConv3d
+            d = dict(d00=P(self.dres0[0][0], self.dres0[0][1], ACT_RELU), d01=P(self.dres0[1][0], self.dres0[1][1], ACT_RELU),
+                     d10=P(self.dres1[0][0], self.dres1[0][1], ACT_RELU), d11=P(self.dres1[1][0], self.dres1[1][1], ACT_NONE))
+            for i in (1, 2, 3):
+                c = getattr(self, f"classif{i}")
+                d[f"k{i}a"], d[f"k{i}b"] = P(c[0][0], c[0][1], ACT_RELU), SmallCoConv3d(c[1])
+            self._packed = d
+        return self._packed
+
+    def aggregate_cl(self, raw_cost):
+        p = self._pack()
+        cost0 = p["d01"](p["d00"](raw_cost))
+        cost0 = p["d11"](p["d10"](cost0), residual=cost0)
+        out1, pre1, post1 = self.dres2.forward_cl(cost0, None, None, out_residual=cost0)
+        out2, pre2, post2 = self.dres3.forward_cl(out1, pre1, post1, out_residual=cost0)
+        out3, _, _ = self.dres4.forward_cl(out2, pre2, post2, out_residual=cost0)
+        cost1 = p["k1b"](p["k1a"](out1))
+        cost2 = p["k2b"](p["k2a"](out2), residual=cost1)
+        cost3 = p["k3b"](p["k3a"](out3), residual=cost2)
+        return cost3, cost2, cost1
+
+    def forward(self, raw_cost):
+        if self.training:
+            raise NotImplementedError("engine PSMAggregator: training mode is not built yet")
+        B, C, D, H, W = raw_cost.shape
+        lows = self.aggregate_cl(ops.to_cl(raw_cost))
+        # drop-in contract: full-resolution costs (psmnet_cost_processor.py:200-221); torch does the upsample
+        return [F.interpolate(c, [self.max_disp, H * 4, W * 4], mode="trilinear", align_corners=True).squeeze(1)
+                for c in lows]
+
+
+class PSMCostProcessor(nn.Module):
+    def __init__(self, max_disp=192, in_planes=64):
+        super().__init__()
+        self.max_disp = max_disp
+        self.aggregator = PSMAggregator(max_disp=max_disp, in_planes=in_planes)
+
+    def cat_func(self, left, right):
+        return ops.cat_fms(left, right, max_disp=int(self.max_disp // 4), start_disp=0, dilation=1)
+
+    def forward(self, inputs):
+        """Engine path: keeps the three costs at 1/4 resolution (the fused heads upsample on the fly)."""
+        l, r = inputs["ref_feature"], inputs["tgt_feature"]
+        vol = ops.build_cost_volume_cl(None, None, 0, l, r, maxdisp=int(self.max_disp // 4))
+        cost3, cost2, cost1 = self.aggregator.aggregate_cl(vol)
+        return {"cost1": cost1, "cost2": cost2, "cost3": cost3}
+
+    def input_output(self):
+        return {"inputs": ["ref_feature", "tgt_feature"], "outputs": ["cost1", "cost2", "cost3"]}
+
+
+class PSMDispProcessor(nn.Module):
+    """psmnet_disp_processor.py:93-118; accepts the reference's full-res costs [B,D,H,W] or the
+    engine's low-res costs [B,1,D/4,H/4,W/4] (then upsample+softmax+regression run fused)."""
+
+    def __init__(self, max_disp=192):
+        super().__init__()
+        self.max_disp = max_disp
+        self.disp_processor = ops.FasterSoftArgmin(max_disp=max_disp, start_disp=0, dilation=1, alpha=1.0, normalize=True)
+
+    def forward(self, inputs):
+        h, w = inputs["left"].shape[2:]
+        out = []
+        for k in ("cost1", "cost2", "cost3"):
+            c = inputs[k]
+            if c.dim() == 5:
+                out.append(ops.upsample_softargmin(c, self.max_disp, h, w, align_corners=True))
+            else:
+                out.append(self.disp_processor(c))
+        return out
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class PSMNet(nn.Module):
+    """models/psmnet/psmnet.py:11-30: forward(dict) -> {'disp_pred': disp3, 'train_preds': [disp1,disp2,disp3]}."""
+
+    def __init__(self, cfgs=_Cfg(MAX_DISP=192)):
+        super().__init__()
+        self.maxdisp = cfgs.MAX_DISP
+        self.Backbone = PSMBackbone()
+        self.CostProcessor = PSMCostProcessor(max_disp=self.maxdisp)
+        self.DispProcessor = PSMDispProcessor(max_disp=self.maxdisp)
+
+    def forward(self, inputs):
+        inputs.update(self.Backbone(inputs))
+        inputs.update(self.CostProcessor(inputs))
+        disp_out = self.DispProcessor(inputs)
+        return {"disp_pred": disp_out[-1], "train_preds": disp_out}

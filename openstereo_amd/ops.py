@@ -159,8 +159,12 @@ def build_cost_volume_cl(gwc_left, gwc_right, num_groups, cat_left=None, cat_rig
     """Fused gwc(+concat) volume written straight into one NDHWC buffer
     (replaces build_gwc_volume + build_concat_volume + torch.cat, gwcnet_cost_processor.py:55-68).
     Returns logical [B, G+2Cc (padded to 4), D, H, W] with channels_last_3d strides."""
-    lg, rg = _f32c(_chk(gwc_left, "gwc_left", 4)), _f32c(_chk(gwc_right, "gwc_right", 4))
-    assert lg.shape[1] % num_groups == 0
+    lg = rg = None
+    if gwc_left is not None:
+        lg, rg = _f32c(_chk(gwc_left, "gwc_left", 4)), _f32c(_chk(gwc_right, "gwc_right", 4))
+        assert lg.shape[1] % num_groups == 0
+    else:
+        num_groups = 0
     lc = rc = None
     Cc = 0
     if cat_left is not None:

@@ -50,6 +50,8 @@ def _is_residual_tail(name: str) -> bool:
     (BasicBlock.conv2, dres1's second conv, hourglass conv5/conv6 + redir*): scaled down so the
     un-normalised residual sums do not blow activations up layer after layer."""
     parts = name.split(".")
+    if "aggregator" in parts:      # PSMNet: dres1's 2nd conv, hourglass conv2/conv5/conv6 all feed un-normalised sums
+        return ".dres1.1." in name or any(p in ("conv2", "conv5", "conv6") for p in parts)
     return ("conv2" in parts and any(p.startswith("layer") for p in parts)) or ".dres1.2." in name \
         or any(p in ("conv5", "conv6", "redir1", "redir2") for p in parts)
 

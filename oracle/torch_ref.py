@@ -196,3 +196,152 @@ def gwc_hot_path(lg, rg, lc, rc, sd, maxdisp, h, w, num_groups=40):
     D4 = maxdisp // 4
     vol = torch.cat((gwc_volume(lg, rg, D4, num_groups), concat_volume(lc, rc, D4)), 1)
     return upsample_regression(gwc_aggregate(vol, sd), maxdisp, h, w, align_corners=False)
+
+
+# ============================================================================= PSMNet
+def _cbr2(x, sd, p, stride, pad, dil, relu=True):
+    """submodule.py:14-43,100-117 conv_bn[_relu] (2-D): keys p.0.(weight[,bias]), p.1.*"""
+    y = F.conv2d(x, sd[p + ".0.weight"], sd.get(p + ".0.bias"), stride, dil if dil > 1 else pad, dil)
+    y = _bn(y, sd, p + ".1")
+    return F.relu(y) if relu else y
+
+
+def _psm_block(x, sd, p, stride, pad, dil):
+    """submodule.py:219-245 BasicBlock (out += x, no ReLU after)."""
+    y = _cbr2(x, sd, p + ".conv1", stride, pad, dil, True)
+    y = _cbr2(y, sd, p + ".conv2", 1, pad, dil, False)
+    if (p + ".downsample.0.weight") in sd:
+        x = _cbr2(x, sd, p + ".downsample", stride, 0, 1, False)
+    return y + x
+
+
+def psm_features(img, sd, p="Backbone"):
+    """psmnet_backbone.py:84-116 (SPP)."""
+    x = img
+    for i, s in enumerate((2, 1, 1)):
+        x = _cbr2(x, sd, f"{p}.firstconv.{i}", s, 1, 1)
+    for i in range(3):
+        x = _psm_block(x, sd, f"{p}.layer1.{i}", 1, 1, 1)
+    o4 = x
+    for i in range(16):
+        o4 = _psm_block(o4, sd, f"{p}.layer2.{i}", 2 if i == 0 else 1, 1, 1)
+    o8 = o4
+    for i in range(3):
+        o8 = _psm_block(o8, sd, f"{p}.layer3.{i}", 1, 1, 1)
+    for i in range(3):
+        o8 = _psm_block(o8, sd, f"{p}.layer4.{i}", 1, 2, 2)
+    size = o8.shape[2:]
+    br = []
+    for i, k in zip((1, 2, 3, 4), (64, 32, 16, 8)):
+        b = _cbr2(F.avg_pool2d(o8, (k, k), (k, k)), sd, f"{p}.branch{i}.1", 1, 0, 1)
+        br.append(F.interpolate(b, size, mode="bilinear", align_corners=True))
+    f = torch.cat((o4, o8, br[3], br[2], br[1], br[0]), 1)
+    f = _cbr2(f, sd, p + ".lastconv.0", 1, 1, 1)
+    return F.conv2d(f, sd[p + ".lastconv.1.weight"])
+
+
+def _c3(x, sd, p, stride, relu):
+    y = _bn(F.conv3d(x, sd[p + ".0.weight"], None, stride, 1), sd, p + ".1")
+    return F.relu(y) if relu else y
+
+
+def _d3(x, sd, p):
+    return _bn(F.conv_transpose3d(x, sd[p + ".0.weight"], None, 2, 1, 1), sd, p + ".1")
+
+
+def psm_hourglass(x, sd, p, presqu=None, postsqu=None):
+    """psmnet_cost_processor.py:108-132."""
+    out = _c3(x, sd, p + ".conv1", 2, True)
+    pre = _c3(out, sd, p + ".conv2", 1, False)
+    pre = F.relu(pre + postsqu) if postsqu is not None else F.relu(pre)
+    out = _c3(_c3(pre, sd, p + ".conv3", 2, True), sd, p + ".conv4", 1, True)
+    post = F.relu(_d3(out, sd, p + ".conv5") + (presqu if presqu is not None else pre))
+    return _d3(post, sd, p + ".conv6"), pre, post
+
+
+def psm_aggregate(raw_cost, sd, p="CostProcessor.aggregator", taps=None):
+    """psmnet_cost_processor.py:182-198 -> low-res (cost3, cost2, cost1), each [B,1,D/4,H/4,W/4]."""
+    t = {} if taps is None else taps
+    c0 = _c3(_c3(raw_cost, sd, p + ".dres0.0", 1, True), sd, p + ".dres0.1", 1, True)
+    c0 = _c3(_c3(c0, sd, p + ".dres1.0", 1, True), sd, p + ".dres1.1", 1, False) + c0
+    t["cost0"] = c0
+    out1, pre1, post1 = psm_hourglass(c0, sd, p + ".dres2")
+    out1 = out1 + c0
+    out2, pre2, post2 = psm_hourglass(out1, sd, p + ".dres3", pre1, post1)
+    out2 = out2 + c0
+    out3, _, _ = psm_hourglass(out2, sd, p + ".dres4", pre2, post2)
+    out3 = out3 + c0
+    t["out1"], t["out3"] = out1, out3
+    head = lambda x, q: F.conv3d(_c3(x, sd, q + ".0", 1, True), sd[q + ".1.weight"], None, 1, 1)
+    cost1 = head(out1, p + ".classif1")
+    cost2 = head(out2, p + ".classif2") + cost1
+    cost3 = head(out3, p + ".classif3") + cost2
+    t["cost1"], t["cost3"] = cost1, cost3
+    return cost3, cost2, cost1
+
+
+def psmnet_forward(left, right, sd, maxdisp=192, taps=None):
+    """models/psmnet/psmnet.py:20-29 -> [disp1, disp2, disp3] (each [B,H,W]); trilinear align_corners=True."""
+    t = {} if taps is None else taps
+    lf, rf = psm_features(left, sd), psm_features(right, sd)
+    t["left_feature"], t["right_feature"] = lf, rf
+    vol = concat_volume(lf, rf, maxdisp // 4)
+    cost3, cost2, cost1 = psm_aggregate(vol, sd, taps=t)
+    h, w = left.shape[2:]
+    return [upsample_regression(c, maxdisp, h, w, align_corners=True) for c in (cost1, cost2, cost3)]
+
+
+# ============================================================================= StereoBase / IGEV aggregation (a8)
+def _sb_names(style):
+    """Parameter sub-keys of one conv unit: StereoBase BasicConv3d (`.block.0/.block.1`,
+    common/basic_block_3d.py:5-38) or IGEV BasicConv (`.conv/.bn`, models/igev/submodule.py:6-32)."""
+    return (".block.0", ".block.1") if style == "stereobase" else (".conv", ".bn")
+
+
+def _unit3d(x, sd, p, style, stride=1, pad=1, deconv=False, bn=True, act=True):
+    cw, cb = _sb_names(style)
+    if deconv:
+        y = F.conv_transpose3d(x, sd[p + cw + ".weight"], None, 2, 1)          # k4 s2 p1
+    else:
+        y = F.conv3d(x, sd[p + cw + ".weight"], None, stride, pad)
+    if bn:
+        y = _bn(y, sd, p + cb)
+    return F.leaky_relu(y, 0.01) if act else y
+
+
+def _feature_att(cv, feat, sd, p, style):
+    """stereobase/igev_blocks.py:35-48 / igev/submodule.py:237-250: cv * sigmoid(Conv2d(lrelu(bn(conv1x1(feat)))))."""
+    cw, cb = _sb_names(style)
+    a = F.leaky_relu(_bn(F.conv2d(feat, sd[p + ".feat_att.0" + cw + ".weight"]), sd, p + ".feat_att.0" + cb), 0.01)
+    a = F.conv2d(a, sd[p + ".feat_att.1.weight"], sd[p + ".feat_att.1.bias"])
+    return torch.sigmoid(a.unsqueeze(2)) * cv
+
+
+def igev_style_hourglass(x, features, sd, p, style="stereobase", return_multi=False):
+    """models/stereobase/hourglass.py:79-104 == models/igev/igev_stereo.py:51-76."""
+    u = lambda t, q, **kw: _unit3d(t, sd, p + q, style, **kw)
+    conv1 = u(u(x, ".conv1.0", stride=2), ".conv1.1")
+    conv1 = _feature_att(conv1, features[1], sd, p + ".feature_att_8", style)
+    conv2 = u(u(conv1, ".conv2.0", stride=2), ".conv2.1")
+    conv2 = _feature_att(conv2, features[2], sd, p + ".feature_att_16", style)
+    conv3 = u(u(conv2, ".conv3.0", stride=2), ".conv3.1")
+    conv3 = _feature_att(conv3, features[3], sd, p + ".feature_att_32", style)
+    conv3_up = u(conv3, ".conv3_up", deconv=True)
+    conv2 = torch.cat((conv3_up, conv2), dim=1)
+    conv2 = u(u(u(conv2, ".agg_0.0", pad=0), ".agg_0.1"), ".agg_0.2")
+    conv2 = _feature_att(conv2, features[2], sd, p + ".feature_att_up_16", style)
+    conv2_up = u(conv2, ".conv2_up", deconv=True)
+    conv1 = torch.cat((conv2_up, conv1), dim=1)
+    conv1 = u(u(u(conv1, ".agg_1.0", pad=0), ".agg_1.1"), ".agg_1.2")
+    conv1 = _feature_att(conv1, features[1], sd, p + ".feature_att_up_8", style)
+    conv = u(conv1, ".conv1_up", deconv=True, bn=False, act=False)
+    return [conv, conv1, conv2] if return_multi else conv
+
+
+def stereobase_cost_stage(match_l, match_r, cat_l, cat_r, features, sd, max_disp, num_groups=8):
+    """stereobase_gru.py:139-164: gwc + concat volume -> cost_agg -> classifier -> softmax -> regression."""
+    D4 = max_disp // 4
+    vol = torch.cat((gwc_volume(match_l, match_r, D4, num_groups), concat_volume(cat_l, cat_r, D4)), 1)
+    geo = igev_style_hourglass(vol, features, sd, "cost_agg", "stereobase")
+    prob = F.softmax(F.conv3d(geo, sd["classifier.weight"], None, 1, 1).squeeze(1), dim=1)
+    return disparity_regression(prob, D4, keepdim=True), prob, geo

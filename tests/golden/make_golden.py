@@ -137,6 +137,40 @@ def main():
     print("small GwcNet disp range", disp.min().item(), disp.max().item(), disp.std().item())
     save("gwcnet_small.npz", disp=disp, **taps)
 
+    # ------------------------------------------------------------------ StereoBase / IGEV hourglass (a8)
+    from stereo.modeling.models.stereobase.hourglass import Hourglass as SBHourglass
+    sys.modules.setdefault("timm", types.ModuleType("timm"))        # igev/extractor.py imports timm at module level only
+    from stereo.modeling.models.igev.igev_stereo import hourglass as IGEVHourglass
+    feats = [None, rnd((1, 64, 8, 16), 21), rnd((1, 192, 4, 8), 22), None]
+    sbh = SBHourglass(24, [96, 64, 192, 120]).eval()
+    sbh.load_state_dict(synth_state_dict(sbh, seed=6))
+    xs = rnd((1, 24, 8, 16, 32), 23)
+    fs = feats[:3] + [rnd((1, 120, 2, 4), 24)]
+    multi = sbh(xs, fs, return_multi=True)
+    save("stereobase_hourglass.npz", x=xs, f1=fs[1], f2=fs[2], f3=fs[3], y=multi[0], y1=multi[1], y2=multi[2])
+    igh = IGEVHourglass(8).eval()
+    igh.load_state_dict(synth_state_dict(igh, seed=7))
+    xi = rnd((1, 8, 8, 16, 32), 25)
+    fi = feats[:3] + [rnd((1, 160, 2, 4), 26)]
+    save("igev_hourglass.npz", x=xi, f1=fi[1], f2=fi[2], f3=fi[3], y=igh(xi, fi))
+
+    # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
+    from stereo.modeling.models.psmnet.psmnet import PSMNet
+    psm = PSMNet(Cfg(MAX_DISP=64)).eval()
+    psm.load_state_dict(synth_state_dict(psm, seed=0, head_gain=3.0), strict=False)   # keeps the frozen linspace kernel
+    ptaps = {}
+    psm.Backbone.register_forward_hook(lambda m, i, o: ptaps.update(
+        left_feature=o["ref_feature"].clone(), right_feature=o["tgt_feature"].clone()))
+    psm.CostProcessor.aggregator.dres4.register_forward_hook(      # subsampled tap of the last hourglass output
+        lambda m, i, o: ptaps.__setitem__("hg3_out_sub", o[0][:, :, ::2, ::4, ::4].clone()))
+    L, R = synth_images(1, 256, 512, seed=1, max_shift=16.0)
+    t = time.time()
+    out = psm({"left": L, "right": R})
+    print(f"PSMNet 256x512 D=64 reference forward: {time.time() - t:.1f} s; disp3 range "
+          f"{out['disp_pred'].min().item():.2f}..{out['disp_pred'].max().item():.2f} std {out['disp_pred'].std().item():.2f}")
+    save("psmnet_256x512.npz", disp1=out["train_preds"][0], disp2=out["train_preds"][1], disp3=out["train_preds"][2],
+         **ptaps)
+
     if args.full:
         L, R = synth_images(1, 544, 960, seed=1)
         t = time.time()

@@ -271,3 +271,105 @@ def test_gwcnet_full_size_vs_reference_golden():
     err = np.abs(d - g["disp"])
     print(f"full-size EPE {err.mean():.3e}, max {err.max():.3e}, >0.01px: {(err > 1e-2).mean() * 100:.4f}%")
     assert err.mean() < 1e-3, f"EPE {err.mean()}"
+
+
+# ----------------------------------------------------------------------------- PSMNet (BASELINE configs[0])
+def test_psmnet_256x512_vs_reference_golden():
+    from openstereo_amd.models.psmnet import PSMNet, _Cfg
+    g = golden("psmnet_256x512.npz")
+    net = PSMNet(_Cfg(MAX_DISP=64))
+    net.load_state_dict(synth_state_dict(net, seed=0, head_gain=3.0), strict=False)
+    net = net.to(DEV).eval()
+    L, R = synth_images(1, 256, 512, seed=1, max_shift=16.0)
+    with torch.no_grad():
+        inputs = {"left": L.to(DEV), "right": R.to(DEV)}
+        out = net(inputs)
+    close(inputs["ref_feature"], g["left_feature"], atol=2e-4, rtol=2e-4, what="PSM backbone feature")
+    assert out["disp_pred"].shape == (1, 256, 512) and len(out["train_preds"]) == 3
+    for d, k in zip(out["train_preds"], ("disp1", "disp2", "disp3")):
+        epe = np.abs(d.cpu().numpy() - g[k]).mean()
+        assert epe < 1e-3, (k, epe)
+
+
+def test_psmnet_engine_from_reference_features():
+    """Engine-only: reference feature maps in, aggregator tap + three disparities out."""
+    from openstereo_amd import ops
+    from openstereo_amd.models.psmnet import PSMNet, _Cfg
+    g = golden("psmnet_256x512.npz")
+    net = PSMNet(_Cfg(MAX_DISP=64))
+    net.load_state_dict(synth_state_dict(net, seed=0, head_gain=3.0), strict=False)
+    net = net.to(DEV).eval()
+    inputs = {"left": torch.zeros(1, 3, 256, 512, device=DEV), "ref_feature": g2(g["left_feature"]),
+              "tgt_feature": g2(g["right_feature"])}
+    inputs.update(net.CostProcessor(inputs))
+    for d, k in zip(net.DispProcessor(inputs), ("disp1", "disp2", "disp3")):
+        epe = np.abs(d.cpu().numpy() - g[k]).mean()
+        assert epe < 2e-4, (k, epe)
+
+
+def test_psm_hourglass_dropin_vs_oracle():
+    from openstereo_amd.models.psmnet import Hourglass
+    from oracle import torch_ref as O
+    hg = Hourglass(8)
+    sd = synth_state_dict(hg, seed=5)
+    hg.load_state_dict(sd)
+    x = T(np.random.default_rng(1).normal(0, 1, (1, 8, 8, 8, 12)).astype(np.float32))
+    pre_in = T(np.random.default_rng(2).normal(0, 1, (1, 16, 4, 4, 6)).astype(np.float32))
+    post_in = T(np.random.default_rng(3).normal(0, 1, (1, 16, 4, 4, 6)).astype(np.float32))
+    sdp = {"h." + k: v for k, v in sd.items()}
+    hg = hg.to(DEV).eval()
+    for (a, b) in ((None, None), (pre_in, post_in)):
+        ref = O.psm_hourglass(x, sdp, "h", a, b)
+        got = hg(x.to(DEV), None if a is None else a.to(DEV), None if b is None else b.to(DEV))
+        for r, o, nm in zip(ref, got, ("out", "pre", "post")):
+            close(o, r, atol=3e-5, rtol=3e-5, what=f"psm hourglass {nm}")
+
+
+# ----------------------------------------------------------------------------- StereoBase / IGEV aggregation (a8)
+def test_stereobase_hourglass_vs_reference_golden():
+    from openstereo_amd.models.igev_style import Hourglass
+    g = golden("stereobase_hourglass.npz")
+    hg = Hourglass(24, [96, 64, 192, 120])
+    hg.load_state_dict(synth_state_dict(hg, seed=6))
+    hg = hg.to(DEV).eval()
+    f = [None, g2(g["f1"]), g2(g["f2"]), g2(g["f3"])]
+    with torch.no_grad():
+        y, y1, y2 = hg(g2(g["x"]), f, return_multi=True)
+        y_single = hg(g2(g["x"]), f)
+    close(y2, g["y2"], atol=3e-5, rtol=3e-5, what="stereobase hourglass conv2 (1/16)")
+    close(y1, g["y1"], atol=3e-5, rtol=3e-5, what="stereobase hourglass conv1 (1/8)")
+    close(y, g["y"], atol=3e-5, rtol=3e-5, what="stereobase hourglass out")
+    close(y_single, g["y"], atol=3e-5, rtol=3e-5, what="stereobase hourglass out (single)")
+
+
+def test_igev_hourglass_vs_reference_golden():
+    from openstereo_amd.models.igev_style import hourglass
+    g = golden("igev_hourglass.npz")
+    hg = hourglass(8)
+    hg.load_state_dict(synth_state_dict(hg, seed=7))
+    hg = hg.to(DEV).eval()
+    f = [None, g2(g["f1"]), g2(g["f2"]), g2(g["f3"])]
+    with torch.no_grad():
+        y = hg(g2(g["x"]), f)
+    close(y, g["y"], atol=3e-5, rtol=3e-5, what="igev hourglass")
+
+
+def test_stereobase_cost_stage_vs_oracle():
+    """gwc(8 groups of 12) + concat(2x8) volume -> Hourglass(24) -> classifier -> softmax -> regression."""
+    from openstereo_amd.models.igev_style import StereoBaseCostStage
+    from oracle import torch_ref as O
+    st = StereoBaseCostStage(max_disp=64, num_groups=8, concat_channels=8, backbone_channels=[96, 64, 192, 120])
+    sd = synth_state_dict(st, seed=8, head_gain=20.0)
+    st.load_state_dict(sd)
+    r = np.random.default_rng(9)
+    mk = lambda *s: T(r.normal(0, 1, s).astype(np.float32))
+    ml, mr, cl, cr = mk(1, 96, 16, 40), mk(1, 96, 16, 40), mk(1, 8, 16, 40), mk(1, 8, 16, 40)
+    feats = [None, mk(1, 64, 8, 20), mk(1, 192, 4, 10), mk(1, 120, 2, 5)]
+    with torch.no_grad():
+        ref_disp, ref_prob, ref_geo = O.stereobase_cost_stage(ml, mr, cl, cr, feats, sd, 64, 8)
+        st = st.to(DEV).eval()
+        out = st(ml.to(DEV), mr.to(DEV), cl.to(DEV), cr.to(DEV), [None] + [f.to(DEV) for f in feats[1:]])
+    close(out["geo_encoding_volume"], ref_geo, atol=5e-5, rtol=5e-5, what="geo encoding volume")
+    close(out["prob"], ref_prob, atol=2e-5, rtol=1e-4, what="prob")
+    close(out["init_disp"], ref_disp, atol=5e-4, what="init disp")
+    assert float(ref_disp.std()) > 0.3        # not a degenerate (uniform-softmax) case

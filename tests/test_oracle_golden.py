@@ -78,3 +78,31 @@ def test_gwcnet_small_against_reference():
     close(taps["cost3"], g["cost3"], atol=1e-4, rtol=1e-4)
     epe = (disp.numpy() - g["disp"]).__abs__().mean()
     assert epe < 1e-4, epe
+
+
+def test_psmnet_256x512_against_reference():
+    """BASELINE configs[0]: PSMNet, one synthetic 256x512 pair, D=64, reference CPU path."""
+    from openstereo_amd.models.psmnet import PSMNet, _Cfg
+    g = golden("psmnet_256x512.npz")
+    sd = synth_state_dict(PSMNet(_Cfg(MAX_DISP=64)), seed=0, head_gain=3.0)
+    L, R = synth_images(1, 256, 512, seed=1, max_shift=16.0)
+    taps = {}
+    with torch.no_grad():
+        d1, d2, d3 = O.psmnet_forward(L, R, sd, maxdisp=64, taps=taps)
+    close(taps["left_feature"], g["left_feature"], atol=1e-5, rtol=1e-5)
+    for d, k in ((d1, "disp1"), (d2, "disp2"), (d3, "disp3")):
+        epe = np.abs(d.numpy() - g[k]).mean()
+        assert epe < 1e-4, (k, epe)
+
+
+def test_stereobase_and_igev_hourglass_against_reference():
+    from openstereo_amd.models.igev_style import Hourglass, hourglass
+    g = golden("stereobase_hourglass.npz")
+    sd = {"h." + k: v for k, v in synth_state_dict(Hourglass(24, [96, 64, 192, 120]), seed=6).items()}
+    f = [None, T(g["f1"]), T(g["f2"]), T(g["f3"])]
+    y, y1, y2 = O.igev_style_hourglass(T(g["x"]), f, sd, "h", "stereobase", return_multi=True)
+    close(y, g["y"], atol=2e-5, rtol=2e-5); close(y1, g["y1"], atol=2e-5, rtol=2e-5); close(y2, g["y2"], atol=2e-5, rtol=2e-5)
+    g = golden("igev_hourglass.npz")
+    sd = {"h." + k: v for k, v in synth_state_dict(hourglass(8), seed=7).items()}
+    f = [None, T(g["f1"]), T(g["f2"]), T(g["f3"])]
+    close(O.igev_style_hourglass(T(g["x"]), f, sd, "h", "igev"), g["y"], atol=2e-5, rtol=2e-5)
