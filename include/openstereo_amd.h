@@ -71,6 +71,13 @@ int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, i
                          int B, int H, int W, int maxdisp, int mask_left_concat,
                          void* stream);
 
+/* Same, for channels-last feature maps [B][H][W][stride] (what the engine's own 2-D backbone
+ * produces; *_stride = floats per pixel, >= channel count).  Always writes the NDHWC volume. */
+int osa_build_volume_nhwc_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
+                              const float* left_cat, const float* right_cat, int Cc, int cat_stride,
+                              float* vol, int vol_channels, int c_off,
+                              int B, int H, int W, int maxdisp, int mask_left_concat, void* stream);
+
 /* correlation layer: vol[b,d,h,w] = mean_c L[b,c,h,w]*R[b,c,h,w-d], 0 for w<d. vol is [B,D,H,W]. */
 int osa_corr_volume_f32(const float* left, const float* right, float* vol,
                         int B, int C, int H, int W, int maxdisp, void* stream);

@@ -29,6 +29,8 @@ SIGNATURES = {
     "osa_target_arch": (C.c_char_p, []),
     "osa_build_volume_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i,
                                    c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_build_volume_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i, c_i,
+                                        c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_corr_volume_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_ncdhw_to_ndhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_ll, c_i, c_i, c_st]),
     "osa_ndhwc_to_ncdhw_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_ll, c_i, c_i, c_st]),

@@ -248,6 +248,9 @@ static const KernelCfg g_cfgs[] = {
     OSA_CFG(2, 2, 2, 2, 8, 16),  // 9: 128 vox x 128 ch   brick 1x8x16
     OSA_CFG(4, 1, 4, 1, 8, 8),   // 10: 512 vox x 32 ch   brick 8x8x8
     OSA_CFG(1, 1, 1, 4, 4, 8),   // 11: 32 vox x 128 ch   brick 1x4x8   (tiny layers: more workgroups)
+    OSA_CFG(1, 1, 4, 1, 8, 16),  // 12: 128 vox x 32 ch   brick 1x8x16  (2-D layers, more workgroups)
+    OSA_CFG(1, 2, 4, 1, 8, 16),  // 13: 128 vox x 64 ch   brick 1x8x16
+    OSA_CFG(1, 1, 2, 2, 4, 16),  // 14:  64 vox x 64 ch   brick 1x4x16  (2-D stride-2 layers)
 };
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -260,9 +263,9 @@ static int pick_cfg(const ConvArgs& a, int stride) {
     const bool flat = (a.Ad == 1);
     const long long vox = (long long)a.B * a.Ad * a.Ah * a.Aw;
     if (flat) {
-        if (a.CoP % 128 == 0) return 9;
-        if (a.CoP % 64 == 0) return 8;
-        return 7;
+        if (stride == 2) return (a.CoP % 64 == 0) ? 14 : 12;
+        if (vox >= 200000) return (a.CoP % 64 == 0) ? 8 : 7;      // half-resolution maps: 256-pixel tiles
+        return (a.CoP % 64 == 0) ? 13 : 12;                        // quarter-resolution maps: 128-pixel tiles
     }
     if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 3);
     // measured on MI355X (tools/bench_layers.py): few-tap launches (1x1x1, transposed-conv parity

@@ -21,6 +21,7 @@ struct VolArgs {
     float* vol;
     int B, C, Cc, H, W, D, G, K;
     int VC, coff;          // volume channel count / first channel written
+    int gstride, cstride;  // >0: features are NHWC with this many floats per pixel (engine backbone); 0: NCHW
     int RS;                // LDS row stride (floats per pixel)
     int catbase;           // float offset of the concat channels inside an LDS row
     int nWt, nDch;         // tiles along w, chunks along d
@@ -55,8 +56,11 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
     // ---- stage: item = (quad, pixel), pixel fastest -> coalesced global reads along w
     auto stage = [&](float* dst, const float* fg, const float* fc, int npx, int wbase) {
         const int items = nq * npx;
+        const bool chan_fast = (p.gstride != 0);   // NHWC: consecutive lanes walk the channel quads of a pixel
         for (int it = tid; it < items; it += 256) {
-            const int qi = it / npx, px = it - qi * npx;
+            int qi, px;
+            if (chan_fast) { px = it / nq; qi = it - px * nq; }
+            else { qi = it / npx; px = it - qi * npx; }
             const int w = wbase + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const bool wok = (w >= 0) && (w < p.W);
@@ -65,19 +69,25 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
                 const int q = qi / p.G, g = qi - q * p.G;
                 lpos = qi * 4;
                 if (wok) {
-                    const float* src = fg + ((size_t)b * p.C + (size_t)g * p.K + q * 4) * plane + (size_t)h * p.W + w;
-                    v.x = src[0]; v.y = src[plane]; v.z = src[2 * plane]; v.w = src[3 * plane];
+                    if (p.gstride) {
+                        v = *reinterpret_cast<const float4*>(fg + (((size_t)b * p.H + h) * p.W + w) * p.gstride + g * p.K + q * 4);
+                    } else {
+                        const float* src = fg + ((size_t)b * p.C + (size_t)g * p.K + q * 4) * plane + (size_t)h * p.W + w;
+                        v.x = src[0]; v.y = src[plane]; v.z = src[2 * plane]; v.w = src[3 * plane];
+                    }
                 }
             } else {
                 const int qc = qi - nq_g;
                 lpos = p.catbase + qc * 4;
                 if (wok) {
-                    const float* src = fc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w;
                     const int rem = p.Cc - qc * 4;
+                    const float* src; size_t st;
+                    if (p.cstride) { src = fc + (((size_t)b * p.H + h) * p.W + w) * p.cstride + qc * 4; st = 1; }
+                    else { src = fc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w; st = plane; }
                     v.x = src[0];
-                    if (rem > 1) v.y = src[plane];
-                    if (rem > 2) v.z = src[2 * plane];
-                    if (rem > 3) v.w = src[3 * plane];
+                    if (rem > 1) v.y = src[st];
+                    if (rem > 2) v.z = src[2 * st];
+                    if (rem > 3) v.w = src[3 * st];
                 }
             }
             *reinterpret_cast<float4*>(dst + (size_t)px * p.RS + lpos) = v;
@@ -180,11 +190,37 @@ __global__ __launch_bounds__(256) void build_volume_ncdhw_kernel(const VolNArgs 
 
 using namespace osa;
 
+static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
+                             const float* left_cat, const float* right_cat, int Cc, int cat_stride,
+                             float* vol, int layout, int vol_channels, int c_off,
+                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream);
+
 extern "C" int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups,
                                     const float* left_cat, const float* right_cat, int Cc,
                                     float* vol, int layout, int vol_channels, int c_off,
                                     int B, int H, int W, int maxdisp, int mask_left_concat,
                                     void* stream) {
+    return build_volume_impl(left_gwc, right_gwc, C, num_groups, 0, left_cat, right_cat, Cc, 0, vol, layout,
+                             vol_channels, c_off, B, H, W, maxdisp, mask_left_concat, stream);
+}
+
+extern "C" int osa_build_volume_nhwc_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
+                                         const float* left_cat, const float* right_cat, int Cc, int cat_stride,
+                                         float* vol, int vol_channels, int c_off,
+                                         int B, int H, int W, int maxdisp, int mask_left_concat, void* stream) {
+    OSA_REQUIRE((C == 0 || (gwc_stride >= C && gwc_stride % 4 == 0 && ((size_t)left_gwc & 15) == 0 && ((size_t)right_gwc & 15) == 0)),
+                "build_volume_nhwc: gwc features need stride >= C, stride %% 4 == 0 and 16-byte alignment");
+    OSA_REQUIRE((Cc == 0 || cat_stride >= Cc), "build_volume_nhwc: concat stride %d < Cc %d", cat_stride, Cc);
+    OSA_REQUIRE(C == 0 || (C / (num_groups > 0 ? num_groups : 1)) % 4 == 0, "build_volume_nhwc: channels per group must be a multiple of 4");
+    return build_volume_impl(left_gwc, right_gwc, C, num_groups, gwc_stride ? gwc_stride : C, left_cat, right_cat, Cc,
+                             cat_stride ? cat_stride : Cc, vol, OSA_NDHWC, vol_channels, c_off, B, H, W, maxdisp,
+                             mask_left_concat, stream);
+}
+
+static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
+                             const float* left_cat, const float* right_cat, int Cc, int cat_stride,
+                             float* vol, int layout, int vol_channels, int c_off,
+                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream) {
     OSA_REQUIRE(vol != nullptr, "build_volume: vol is NULL");
     OSA_REQUIRE(B > 0 && H > 0 && W > 0 && maxdisp > 0, "build_volume: bad dims B=%d H=%d W=%d D=%d", B, H, W, maxdisp);
     OSA_REQUIRE(C >= 0 && Cc >= 0 && (C > 0 || Cc > 0), "build_volume: nothing to build (C=%d Cc=%d)", C, Cc);
@@ -213,6 +249,7 @@ extern "C" int osa_build_volume_f32(const float* left_gwc, const float* right_gw
         a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol;
         a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;
         a.VC = vol_channels; a.coff = c_off; a.mask_left = mask_left_concat;
+        a.gstride = gwc_stride; a.cstride = cat_stride;
         const int QG = (G > 0) ? K / 4 : 1;
         const int gfl = (G > 0) ? QG * G * 4 : 0;
         a.catbase = gfl;
@@ -242,6 +279,7 @@ extern "C" int osa_build_volume_f32(const float* left_gwc, const float* right_gw
         OSA_LAUNCH_CHECK("build_volume_ndhwc");
         return 0;
     }
+    OSA_REQUIRE(gwc_stride == 0 && cat_stride == 0, "build_volume: NHWC features need the NDHWC volume layout and K %% 4 == 0");
     VolNArgs a;
     a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol;
     a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;

@@ -41,17 +41,25 @@ class PackedConv3d:
             raise _lib.EngineError("PackedConv3d needs parameters on the GPU (no CPU path)")
         w = w.float().contiguous()
         self.transposed = isinstance(conv, nn.ConvTranspose3d)
-        self.k = tuple(conv.kernel_size)
-        self.stride = _t3(conv.stride)
-        self.pad = _t3(conv.padding)
-        self.dil = _t3(conv.dilation)
+        if isinstance(conv, nn.Conv2d):            # 2-D layer == 3-D layer with D = 1 and a 1 x kh x kw kernel
+            w = w[:, :, None].contiguous()
+            self.k = (1,) + tuple(conv.kernel_size)
+            self.stride = (1,) + tuple(conv.stride)
+            self.pad = (0,) + tuple(conv.padding)
+            self.dil = (1,) + tuple(conv.dilation)
+        else:
+            self.k = tuple(conv.kernel_size)
+            self.stride = _t3(conv.stride)
+            self.pad = _t3(conv.padding)
+            self.dil = _t3(conv.dilation)
         self.act, self.slope = act, float(slope)
-        if conv.bias is not None and bn is not None:
-            raise NotImplementedError("conv bias together with BN")
         self.scale, self.shift = bn_scale_shift(bn)
         if conv.bias is not None:
-            self.shift = conv.bias.detach().float().contiguous()
-            self.scale = torch.ones_like(self.shift)
+            bias = conv.bias.detach().float()
+            if bn is None:
+                self.shift, self.scale = bias.contiguous(), torch.ones_like(bias)
+            else:                                   # BN(conv + bias) = conv*s + (bias*s + t)
+                self.shift = (self.shift + bias * self.scale).contiguous()
         st = _stream()
         if self.transposed:
             self.Ci, self.Co = w.shape[0], w.shape[1]
@@ -80,7 +88,7 @@ class PackedConv3d:
         return (f(D, self.k[0], self.pad[0], self.dil[0], sd), f(H, self.k[1], self.pad[1], self.dil[1], s),
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
-    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0):
+    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0):
         """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
         Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
@@ -101,19 +109,21 @@ class PackedConv3d:
         if residual is not None:
             assert is_cl(residual) and tuple(residual.shape[2:]) == (Do, Ho, Wo)
             rCs = residual.shape[1]
+            assert rCs >= res_off + self.Co
         gCs = 0
         if gate is not None:
             assert gate.is_contiguous() and tuple(gate.shape[:3]) == (B, Ho, Wo) and gate.shape[3] >= self.Co
             gCs = gate.shape[3]
         xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
+        rp = None if residual is None else residual.data_ptr() + 4 * res_off
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
             if self.transposed:
                 _lib.call("osa_deconv3d_ndhwc_f32", xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
-                          _p(residual), yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
+                          rp, yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
                           self.k[0], self.pad[0], self.opad[0], _p(gate), gCs, self.act, self.slope, _stream())
             else:
                 _lib.call("osa_conv3d_ndhwc_f32", xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
-                          _p(residual), yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
+                          rp, yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
                           self.k[0], self.k[1], self.k[2], self.stride[1],
                           self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
                           _p(gate), gCs, self.act, self.slope, _stream())

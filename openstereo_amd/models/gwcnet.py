@@ -69,6 +69,50 @@ class _Features(nn.Module):
         blocks += [_ResBlock(cout, cout, 1, None, pad, dil) for _ in range(1, n)]
         return nn.Sequential(*blocks)
 
+    # ---- engine path: every conv+BN(+ReLU)(+residual) is one fused MFMA launch, NHWC activations,
+    # the l2|l3|l4 concat is written in place (channel slices of one 320-channel buffer).
+    def _pack(self):
+        if getattr(self, "_pk", None) is None:
+            P = lambda cb, act: PackedConv3d(cb[0], cb[1], act)
+            fc = self.firstconv
+            pk = {"first": [P(fc[0], ACT_RELU), P(fc[2], ACT_RELU), P(fc[4], ACT_RELU)], "layers": []}
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                pk["layers"].append([(P(b.conv1[0], ACT_RELU), P(b.conv2, ACT_NONE),
+                                      None if b.downsample is None else P(b.downsample, ACT_NONE)) for b in layer])
+            if self.concat_feature:
+                pk["last"] = (P(self.lastconv[0], ACT_RELU), PackedConv3d(self.lastconv[2]))
+            self._pk = pk
+        return self._pk
+
+    def forward_cl(self, img):
+        """img: [N,3,H,W] (NCHW, any float dtype).  Returns (gwc_feature [N,320,1,H/4,W/4] NDHWC,
+        concat_feature [N,12,1,H/4,W/4] NDHWC or None)."""
+        pk = self._pack()
+        x = ops.to_cl(img.unsqueeze(2))                 # [N,4,1,H,W], 4th channel zero
+        for conv in pk["first"]:
+            x = conv(x)
+        xoff, cat, slices = 0, None, {1: 0, 2: 64, 3: 192}
+        for li, blocks in enumerate(pk["layers"]):
+            for bi, (c1, c2, ds) in enumerate(blocks):
+                last = bi == len(blocks) - 1
+                y = c1(x, x_off=xoff)
+                if ds is not None:
+                    skip, soff = ds(x, x_off=xoff), 0
+                else:
+                    skip, soff = x, xoff
+                if last and li >= 1:
+                    if cat is None:
+                        N_, _, _, h4, w4 = y.shape
+                        cat = ops.empty_cl(N_, 320, 1, h4, w4, y.device)
+                    c2(y, residual=skip, res_off=soff, out=cat, out_off=slices[li])
+                    x, xoff = cat, slices[li]
+                else:
+                    x, xoff = c2(y, residual=skip, res_off=soff), 0
+        if not self.concat_feature:
+            return cat, None
+        l0, l2 = pk["last"]
+        return cat, l2(l0(cat))
+
     def forward(self, x):
         x = self.layer1(self.firstconv(x))
         l2 = self.layer2(x)
@@ -86,16 +130,29 @@ class GwcBackbone(nn.Module):
         self.use_concat_volume = use_concat_volume
         self.concat_channels = concat_channels if use_concat_volume else 0
         self.feature_extraction = _Features(use_concat_volume, self.concat_channels)
+        self.use_engine = True
 
     def forward(self, inputs):
-        # left and right go through the extractor as one batch of 2B images
+        """Reference contract: NCHW feature dicts.  engine=True (default on GPU in eval mode) runs the
+        extractor on the engine's conv kernel and converts at the boundary; GwcNet.forward skips
+        that conversion and hands the NHWC maps straight to the volume builder."""
         left, right = inputs["left"], inputs["right"]
         B = left.shape[0]
-        with timing.span("backbone2d", left.shape[2], left.shape[3]):
-            f = self.feature_extraction(torch.cat((left, right), 0))
+        if self.use_engine and not self.training and left.is_cuda:
+            gwc, catf = self.forward_cl(left, right)
+            f = {"gwc_feature": ops.to_ncdhw(gwc)[:, :, 0]}
+            if catf is not None:
+                f["concat_feature"] = ops.to_ncdhw(catf, self.concat_channels)[:, :, 0]
+        else:
+            with timing.span("backbone2d", left.shape[2], left.shape[3]):
+                f = self.feature_extraction(torch.cat((left, right), 0))
         ref = {k: v[:B] for k, v in f.items()}
         tgt = {k: v[B:] for k, v in f.items()}
         return {"ref_feature": ref, "tgt_feature": tgt}
+
+    def forward_cl(self, left, right):
+        with timing.span("backbone2d_engine", left.shape[2], left.shape[3]):
+            return self.feature_extraction.forward_cl(torch.cat((left, right), 0))
 
 
 # ----------------------------------------------------------------------------- cost volume
@@ -254,8 +311,23 @@ class GwcNet(nn.Module):
         self.CostProcessor = GwcVolumeCostProcessor(**kw)
         self.DispProcessor = GwcDispProcessor(concat_channels=cfgs.CONCAT_CHANNELS, **kw)
 
+    def reset_engine(self):
+        """Drop every packed weight (call after load_state_dict / parameter updates)."""
+        self.Backbone.feature_extraction._pk = None
+        self.DispProcessor.reset_engine()
+
     def forward(self, inputs):
-        inputs.update(self.Backbone(inputs))
-        inputs.update(self.CostProcessor(inputs))
+        if self.Backbone.use_engine and not self.training and inputs["left"].is_cuda:
+            # fused engine path: NHWC features never leave the engine layout
+            B = inputs["left"].shape[0]
+            gwc, catf = self.Backbone.forward_cl(inputs["left"], inputs["right"])
+            cp = self.CostProcessor
+            vol = ops.build_cost_volume_from_cl(gwc, cp.num_groups, catf if cp.use_concat_volume else None, B,
+                                                cp.maxdisp // cp.downsample,
+                                                cat_channels=self.Backbone.concat_channels or None)
+            inputs["cost_volume"] = vol
+        else:
+            inputs.update(self.Backbone(inputs))
+            inputs.update(self.CostProcessor(inputs))
         disp_out = self.DispProcessor(inputs)
         return {"disp_pred": disp_out["inference_disp"]["disp_est"]}

@@ -175,6 +175,33 @@ def build_cost_volume_cl(gwc_left, gwc_right, num_groups, cat_left=None, cat_rig
     return _build(lg, rg, num_groups, lc, rc, maxdisp, NDHWC, mask_left=mask_left, vol_channels=VC)
 
 
+def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_channels=None, cat_channels=None,
+                              gwc_off=0, mask_left=True):
+    """Volume from the engine backbone's channels-last feature maps.  gwc_feat / cat_feat: logical
+    [2B, Cs, 1, H, W] NDHWC tensors holding the left images first ([0:B]) and the right images last."""
+    assert is_cl(gwc_feat) and gwc_feat.shape[0] == 2 * B and gwc_feat.shape[2] == 1
+    _, Gs, _, H, W = gwc_feat.shape
+    C = Gs - gwc_off if gwc_channels is None else gwc_channels
+    img = H * W * Gs * 4
+    lg, rg = gwc_feat.data_ptr() + 4 * gwc_off, gwc_feat.data_ptr() + 4 * gwc_off + B * img
+    lc = rc = None
+    Cc = cs = 0
+    if cat_feat is not None:
+        assert is_cl(cat_feat) and cat_feat.shape[0] == 2 * B and tuple(cat_feat.shape[3:]) == (H, W)
+        cs = cat_feat.shape[1]
+        Cc = cs if cat_channels is None else cat_channels
+        lc, rc = cat_feat.data_ptr(), cat_feat.data_ptr() + B * H * W * cs * 4
+    nch = num_groups + 2 * Cc
+    VC = (nch + 3) // 4 * 4
+    out = empty_cl(B, VC, maxdisp, H, W, gwc_feat.device)
+    if VC != nch:
+        out.zero_()
+    with timing.span("build_volume", C, num_groups, Cc, NDHWC, maxdisp, H, W):
+        _lib.call("osa_build_volume_nhwc_f32", lg, rg, C, num_groups, Gs, lc, rc, Cc, cs, out.data_ptr(), VC, 0,
+                  B, H, W, maxdisp, 1 if mask_left else 0, _stream())
+    return out
+
+
 # --------------------------------------------------------------------------- regression
 def disparity_regression(x, maxdisp, keepdim=True):
     """disp_regression.py:8-12 (keepdim=True) / gwcnet_disp_processor.py:22-26 (keepdim=False)."""

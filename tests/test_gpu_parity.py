@@ -236,12 +236,19 @@ def test_gwcnet_small_vs_reference_golden():
     net = _gwcnet()
     L, R = synth_images(1, 64, 128, seed=1)
     with torch.no_grad():
-        inputs = {"left": L.to(DEV), "right": R.to(DEV)}
-        disp = net(inputs)["disp_pred"]
-    close(inputs["ref_feature"]["gwc_feature"], g["left_gwc"], atol=1e-4, rtol=1e-4, what="backbone gwc feature")
+        feats = net.Backbone({"left": L.to(DEV), "right": R.to(DEV)})          # engine backbone, NCHW contract
+        disp = net({"left": L.to(DEV), "right": R.to(DEV)})["disp_pred"]       # fused NHWC path
+    close(feats["ref_feature"]["gwc_feature"], g["left_gwc"], atol=1e-4, rtol=1e-4, what="engine backbone gwc feature (left)")
+    close(feats["tgt_feature"]["gwc_feature"], g["right_gwc"], atol=1e-4, rtol=1e-4, what="engine backbone gwc feature (right)")
+    close(feats["ref_feature"]["concat_feature"], g["left_cat"], atol=1e-4, rtol=1e-4, what="engine backbone concat feature")
     epe = (disp.cpu().numpy() - g["disp"]).__abs__().mean()
     assert disp.shape == (1, 64, 128)
     assert epe < 1e-3, f"EPE {epe}"
+    # the PyTorch-ROCm (MIOpen) backbone stays available and must agree too
+    net.Backbone.use_engine = False
+    with torch.no_grad():
+        disp2 = net({"left": L.to(DEV), "right": R.to(DEV)})["disp_pred"]
+    assert np.abs(disp2.cpu().numpy() - g["disp"]).mean() < 1e-3
 
 
 def test_gwcnet_engine_from_reference_features_small():
@@ -373,3 +380,15 @@ def test_stereobase_cost_stage_vs_oracle():
     close(out["prob"], ref_prob, atol=2e-5, rtol=1e-4, what="prob")
     close(out["init_disp"], ref_disp, atol=5e-4, what="init disp")
     assert float(ref_disp.std()) > 0.3        # not a degenerate (uniform-softmax) case
+
+
+def test_volume_from_channels_last_features():
+    """NHWC feature maps (engine backbone layout) -> same volume as the NCHW path."""
+    from openstereo_amd import ops
+    r = np.random.default_rng(11)
+    B, H, W = 2, 5, 37
+    gw = T(r.normal(0, 1, (2 * B, 320, H, W)).astype(np.float32)).to(DEV)
+    ct = T(r.normal(0, 1, (2 * B, 12, H, W)).astype(np.float32)).to(DEV)
+    ref = ops.build_cost_volume_cl(gw[:B], gw[B:], 40, ct[:B], ct[B:], maxdisp=24)
+    got = ops.build_cost_volume_from_cl(ops.to_cl(gw.unsqueeze(2)), 40, ops.to_cl(ct.unsqueeze(2)), B, 24)
+    assert torch.equal(ref, got)
