@@ -144,6 +144,37 @@ int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
                            const float* gate_logits, int gCs,
                            int act, float slope, void* stream);
 
+/*
+ * Split-precision mode ("f16x3"): every fp32 operand is split into two fp16 parts (hi + lo, 22
+ * significant bits) and each product is evaluated as Ahi*Bhi + Ahi*Blo + Alo*Bhi on the fp16
+ * matrix cores with fp32 accumulation -- fp32-class accuracy at a fraction of the fp32-MFMA time.
+ * Tensors in HBM stay fp32.  Weights are packed by the *_pack_f16x3 calls (same buffer size as the
+ * f32 packing) after multiplication by `wscale`, a power of two that moves them into the fp16
+ * normal range; pass out_scale = 1/wscale to the matching conv call.
+ */
+int osa_conv3d_pack_f16x3(const float* w_ref, float* w_packed,
+                          int Ci, int Co, int kd, int kh, int kw, float wscale, void* stream);
+int osa_deconv3d_pack_f16x3(const float* w_ref, float* w_packed,
+                            int Ci, int Co, int k, int pad, float wscale, void* stream);
+int osa_conv3d_ndhwc_f16x3(const float* x, const float* w_packed,
+                           const float* scale, const float* shift, const float* residual,
+                           float* y,
+                           int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                           int Co, int yCs, int rCs,
+                           int kd, int kh, int kw, int stride,
+                           int pad_d, int pad_h, int pad_w,
+                           int dil_d, int dil_h, int dil_w,
+                           const float* gate_logits, int gCs,
+                           int act, float slope, float out_scale, void* stream);
+int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
+                             const float* scale, const float* shift, const float* residual,
+                             float* y,
+                             int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                             int Co, int yCs, int rCs,
+                             int k, int pad, int opad,
+                             const float* gate_logits, int gCs,
+                             int act, float slope, float out_scale, void* stream);
+
 /* small-Cout 'same' convolution (Co <= 4, e.g. the 32->1 classifier heads). Reference weight
  * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer).
  * y = conv(x) + bias[co] + residual ; residual (or NULL) has y's layout (voxel stride yCs). */

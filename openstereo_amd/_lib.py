@@ -52,6 +52,22 @@ SIGNATURES = {
                                      c_i, c_i, c_i,
                                      c_fp, c_i,
                                      c_i, c_f, c_st]),
+    "osa_conv3d_pack_f16x3": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
+    "osa_deconv3d_pack_f16x3": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_st]),
+    "osa_conv3d_ndhwc_f16x3": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                     c_i, c_i, c_i, c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_i, c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_fp, c_i,
+                                     c_i, c_f, c_f, c_st]),
+    "osa_deconv3d_ndhwc_f16x3": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                       c_i, c_i, c_i, c_i, c_i, c_i,
+                                       c_i, c_i, c_i,
+                                       c_i, c_i, c_i,
+                                       c_fp, c_i,
+                                       c_i, c_f, c_f, c_st]),
     "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -24,6 +24,18 @@
 namespace osa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Arithmetic modes of the implicit GEMM:
+//   PREC_F32   v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak)
+//   PREC_F16X3 every fp32 operand x is split x = hi + lo (two fp16, 22 significant bits) and
+//              A.B ~= Ahi.Bhi + Ahi.Blo + Alo.Bhi on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//              3 MFMAs of 32 cycles per K=16 instead of 8 of 64 -> 5.3x less matrix-pipe time at
+//              fp32-class accuracy (dropped term Alo.Blo ~ 2^-22 relative).  Weights are pre-scaled
+//              by a power of two into the fp16 normal range (undone exactly in the epilogue);
+//              activations are saturated to +-65504 when split.
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 
 constexpr int CC = 16;        // input channels staged per pass (packed-weight format constant)
 constexpr int VS = CC + 4;    // LDS voxel stride in floats
@@ -46,6 +58,7 @@ struct ConvArgs {
     int tilesD, tilesH, tilesW;
     int nchunks, CoP;
     int act; float slope;
+    float oscale;                 // f16x3: 1 / (weight pre-scale), exact power of two; 1 for f32
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
     int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
@@ -53,7 +66,18 @@ struct ConvArgs {
 
 // Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
 // Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
-template <int NTHR>
+__device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) {
+    const float m = 65504.f;
+    const float x0 = fminf(fmaxf(v.x, -m), m), x1 = fminf(fmaxf(v.y, -m), m);
+    const float x2 = fminf(fmaxf(v.z, -m), m), x3 = fminf(fmaxf(v.w, -m), m);
+    f16x4 h = {(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
+    f16x4 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1]),
+               (_Float16)(x2 - (float)h[2]), (_Float16)(x3 - (float)h[3])};
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+template <int NTHR, int PREC>
 __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int b, int c0,
                                             int g0d, int g0h, int g0w, int tid) {
     constexpr int U = 4;
@@ -83,13 +107,27 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (lo[u] >= 0) smem[lo[u]] = v[u];
+            if (lo[u] >= 0) {
+                if constexpr (PREC == PREC_F32) {
+                    smem[lo[u]] = v[u];
+                } else {
+                    // voxel image: [16 x fp16 hi | 16 x fp16 lo | 16 B pad]; this quad's 4 channels -> 8 B each
+                    static_assert(NTHR % 4 == 0, "channel quad of an item must not depend on u");
+                    const int c4 = base & 3;        // == (base + u*NTHR) & 3
+                    uint2 h2, l2;
+                    split_f16(v[u], h2, l2);
+                    uint2* s2 = reinterpret_cast<uint2*>(smem);
+                    const int vbase = (lo[u] - c4) * 2;                 // voxel start in 8-byte units
+                    s2[vbase + c4] = h2;
+                    s2[vbase + 4 + c4] = l2;
+                }
+            }
     }
 }
 
 // CFG: MT m-tiles x NT n-tiles per wave, WM x WN waves, brick TD x TH x TW (TD derived)
-template <int MT, int NT, int WM, int WN, int TH, int TW>
-__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvArgs p) {
+template <int PREC, int MT, int NT, int WM, int WN, int TH, int TW>
+__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -140,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         if (ch) __syncthreads();
-        if (!(p.dbg & 1)) stage_brick<NW * 64>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
+        if (!(p.dbg & 1)) stage_brick<NW * 64, PREC>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
         __syncthreads();
         // A operands of tap 0 of this chunk
         float4 anx[JO][MT];
@@ -171,17 +209,32 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
                 for (int m = 0; m < MT; ++m)
                     anx[j][m] = smem[abase[m] + toffn + j * 2];
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PREC == PREC_F32) {
 #pragma unroll
-            for (int j = 0; j < JO; ++j)
+                for (int j = 0; j < JO; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].x, bcur[j][n].x, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].y, bcur[j][n].y, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].z, bcur[j][n].z, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].w, bcur[j][n].w, acc[m][n], 0, 0, 0);
+                        }
+            } else {
+                // [0] = hi halves, [1] = lo halves of the 16 channels of this chunk (K = 16 per MFMA);
+                // small cross terms first, then hi.hi
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].x, bcur[j][n].x, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].y, bcur[j][n].y, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].z, bcur[j][n].z, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].w, bcur[j][n].w, acc[m][n], 0, 0, 0);
+                        const f16x8 ah = __builtin_bit_cast(f16x8, av[0][m]), al = __builtin_bit_cast(f16x8, av[1][m]);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, bcur[0][n]), bl = __builtin_bit_cast(f16x8, bcur[1][n]);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m][n], 0, 0, 0);
                     }
+            }
             __builtin_amdgcn_sched_barrier(0);   // keep the ring rotation (and its waits) behind the MFMAs
 #pragma unroll
             for (int j = 0; j < JO; ++j)
@@ -196,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_f32_kernel(const ConvA
     for (int n = 0; n < NT; ++n) {
         const int co = n0 + (wn * NT + n) * 32 + col;
         const bool cok = co < p.Co;
-        const float sc = (cok && p.scale) ? p.scale[co] : 1.f;
+        const float sc = ((cok && p.scale) ? p.scale[co] : 1.f) * p.oscale;
         const float sh = (cok && p.shift) ? p.shift[co] : 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -228,12 +281,13 @@ struct KernelCfg {
     const char* name;
     int M, N;              // voxels / channels per workgroup
     int TD, TH, TW, threads;
-    void (*fn)(const ConvArgs);
+    void (*fn[2])(const ConvArgs);      // [PREC_F32], [PREC_F16X3]
 };
 
 #define OSA_CFG(MT, NT, WM, WN, TH, TW)                                                      \
     { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
-      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64, conv_mfma_f32_kernel<MT, NT, WM, WN, TH, TW> }
+      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
+      { conv_mfma_kernel<PREC_F32, MT, NT, WM, WN, TH, TW>, conv_mfma_kernel<PREC_F16X3, MT, NT, WM, WN, TH, TW> } }
 
 static const KernelCfg g_cfgs[] = {
     OSA_CFG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
@@ -307,7 +361,7 @@ static size_t brick_bytes(ConvArgs& a, const KernelCfg& k) {
     return (size_t)a.LD * a.LH * (a.LW * VS + 64) * sizeof(float);   // upper bound incl. row padding
 }
 
-static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what) {
+static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what) {
     int ci = pick_cfg(a, stride);
     if (brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
         // e.g. a stride-2 3x3x3 layer whose output depth collapses to 1: fall back to the small bricks
@@ -325,9 +379,9 @@ static int launch_conv(ConvArgs& a, int stride, hipStream_t st, const char* what
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k.fn[prec], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
-    hipLaunchKernelGGL(k.fn, grid, block, lds, st, a);
+    hipLaunchKernelGGL(k.fn[prec], grid, block, lds, st, a);
     OSA_LAUNCH_CHECK(what);
     return 0;
 }
@@ -358,6 +412,29 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs p) {
                          : p.src[((size_t)co * p.Ci + ci) * kvol + kidx];
     }
     p.dst[i] = v;
+}
+
+// f16x3 image of the same buffer: 16-byte unit index ((((ch*T + t)*2 + hl)*2 + kg)*CoP + co) holds the 8 fp16
+// hi (hl=0) or lo (hl=1) parts of  wscale * W_t[ci = ch*16 + 8*kg + e][co], e = 0..7.
+__global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const PackArgs p, float wscale) {
+    const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;      // fp16 elements
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = i & 7; size_t r = i >> 3;
+    const int co = r % p.CoP; r /= p.CoP;
+    const int kg = r & 1; r >>= 1;
+    const int hl = r & 1; r >>= 1;
+    const int t = r % p.T; const int ch = r / p.T;
+    const int ci = ch * CC + 8 * kg + e;
+    float v = 0.f;
+    if (ci < p.Ci && co < p.Co) {
+        const size_t kvol = (size_t)p.kd * p.kh * p.kw;
+        const size_t kidx = ((size_t)p.kz[t] * p.kh + p.ky[t]) * p.kw + p.kx[t];
+        v = wscale * (p.transposed ? p.src[((size_t)ci * p.Co + co) * kvol + kidx]
+                                   : p.src[((size_t)co * p.Ci + ci) * kvol + kidx]);
+    }
+    const _Float16 hi = (_Float16)v;
+    reinterpret_cast<_Float16*>(p.dst)[i] = hl ? (_Float16)(v - (float)hi) : hi;
 }
 
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
@@ -418,7 +495,7 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         if (ch) __syncthreads();
-        stage_brick<256>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
+        stage_brick<256, PREC_F32>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
         __syncthreads();
         for (int t = 0; t < p.T; ++t) {
             const float4* xp = smem + abase + p.toff[t];
@@ -453,8 +530,18 @@ extern "C" size_t osa_conv3d_packed_floats(int Ci, int Co, int kd, int kh, int k
     return packed_floats(Ci, Co, kd * kh * kw) + slack_floats(Co);
 }
 
-extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
-                                   int kd, int kh, int kw, void* stream) {
+static void launch_pack(const PackArgs& p, int prec, float wscale, hipStream_t st) {
+    if (prec == PREC_F32) {
+        const size_t total = (size_t)p.nchunks * p.T * JO * 2 * p.CoP * 4;
+        if (total) hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, p);
+    } else {
+        const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;
+        if (total) hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, p, wscale);
+    }
+}
+
+static int conv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
+                            int kd, int kh, int kw, int prec, float wscale, void* stream) {
     OSA_REQUIRE(w_ref && w_packed, "conv3d_pack: NULL pointer");
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= MAX_TAPS, "conv3d_pack: %dx%dx%d kernel has %d taps (max %d)", kd, kh, kw, T, MAX_TAPS);
@@ -466,10 +553,20 @@ extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, 
     for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int x = 0; x < kw; ++x, ++t) {
         p.kz[t] = (signed char)z; p.ky[t] = (signed char)y; p.kx[t] = (signed char)x;
     }
-    const size_t total = packed_floats(Ci, Co, T);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    launch_pack(p, prec, wscale, (hipStream_t)stream);
     OSA_LAUNCH_CHECK("conv3d_pack");
     return 0;
+}
+
+extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                   int kd, int kh, int kw, void* stream) {
+    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, PREC_F32, 1.f, stream);
+}
+
+extern "C" int osa_conv3d_pack_f16x3(const float* w_ref, float* w_packed, int Ci, int Co,
+                                     int kd, int kh, int kw, float wscale, void* stream) {
+    OSA_REQUIRE(wscale > 0.f, "conv3d_pack_f16x3: wscale must be a positive power of two");
+    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, PREC_F16X3, wscale, stream);
 }
 
 extern "C" size_t osa_deconv3d_packed_floats(int Ci, int Co, int k) {
@@ -477,8 +574,8 @@ extern "C" size_t osa_deconv3d_packed_floats(int Ci, int Co, int k) {
     return packed_floats(Ci, Co, k * k * k) + slack_floats(Co);
 }
 
-extern "C" int osa_deconv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
-                                     int k, int pad, void* stream) {
+static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
+                              int k, int pad, int prec, float wscale, void* stream) {
     OSA_REQUIRE(w_ref && w_packed, "deconv3d_pack: NULL pointer");
     OSA_REQUIRE(k == 3 || k == 4, "deconv3d_pack: kernel %d unsupported (3 or 4)", k);
     size_t off = 0;
@@ -494,14 +591,22 @@ extern "C" int osa_deconv3d_pack_f32(const float* w_ref, float* w_packed, int Ci
         for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c, ++t) {
             p.kz[t] = (signed char)kd_[a]; p.ky[t] = (signed char)kh_[b]; p.kx[t] = (signed char)kw_[c];
         }
-        const size_t total = packed_floats(Ci, Co, p.T);
-        if (total)
-            hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0,
-                               (hipStream_t)stream, p);
-        off += total;
+        launch_pack(p, prec, wscale, (hipStream_t)stream);
+        off += packed_floats(Ci, Co, p.T);
     }
     OSA_LAUNCH_CHECK("deconv3d_pack");
     return 0;
+}
+
+extern "C" int osa_deconv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                     int k, int pad, void* stream) {
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F32, 1.f, stream);
+}
+
+extern "C" int osa_deconv3d_pack_f16x3(const float* w_ref, float* w_packed, int Ci, int Co,
+                                       int k, int pad, float wscale, void* stream) {
+    OSA_REQUIRE(wscale > 0.f, "deconv3d_pack_f16x3: wscale must be a positive power of two");
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, wscale, stream);
 }
 
 static int check_common(const char* what, const float* x, const float* w, float* y,
@@ -517,16 +622,16 @@ static int check_common(const char* what, const float* x, const float* w, float*
     return 0;
 }
 
-extern "C" int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
-                                    const float* scale, const float* shift, const float* residual,
-                                    float* y,
-                                    int B, int Di, int Hi, int Wi, int Ci, int xCs,
-                                    int Co, int yCs, int rCs,
-                                    int kd, int kh, int kw, int stride,
-                                    int pad_d, int pad_h, int pad_w,
-                                    int dil_d, int dil_h, int dil_w,
-                                    const float* gate_logits, int gCs,
-                                    int act, float slope, void* stream) {
+static int conv3d_impl(const float* x, const float* w_packed,
+                       const float* scale, const float* shift, const float* residual,
+                       float* y,
+                       int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                       int Co, int yCs, int rCs,
+                       int kd, int kh, int kw, int stride,
+                       int pad_d, int pad_h, int pad_w,
+                       int dil_d, int dil_h, int dil_w,
+                       const float* gate_logits, int gCs,
+                       int act, float slope, int prec, float oscale, void* stream) {
     if (gate_logits) OSA_REQUIRE(gCs >= Co, "conv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("conv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     const int T = kd * kh * kw;
@@ -554,18 +659,35 @@ extern "C" int osa_conv3d_ndhwc_f32(const float* x, const float* w_packed,
         a.tw[t] = (signed char)(xx * dil_w - pad_w);
     }
     a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
-    a.act = act; a.slope = slope;
-    return launch_conv(a, stride, (hipStream_t)stream, "conv3d");
+    a.act = act; a.slope = slope; a.oscale = oscale;
+    return launch_conv(a, stride, prec, (hipStream_t)stream, "conv3d");
 }
 
-extern "C" int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
-                                      const float* scale, const float* shift, const float* residual,
-                                      float* y,
-                                      int B, int Di, int Hi, int Wi, int Ci, int xCs,
-                                      int Co, int yCs, int rCs,
-                                      int k, int pad, int opad,
-                                      const float* gate_logits, int gCs,
-                                      int act, float slope, void* stream) {
+#define OSA_CONV_PARAMS                                                                         \
+    const float* x, const float* w_packed, const float* scale, const float* shift,             \
+    const float* residual, float* y, int B, int Di, int Hi, int Wi, int Ci, int xCs,           \
+    int Co, int yCs, int rCs, int kd, int kh, int kw, int stride, int pad_d, int pad_h,        \
+    int pad_w, int dil_d, int dil_h, int dil_w, const float* gate_logits, int gCs, int act, float slope
+#define OSA_CONV_ARGS                                                                           \
+    x, w_packed, scale, shift, residual, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, kd, kh, kw,   \
+    stride, pad_d, pad_h, pad_w, dil_d, dil_h, dil_w, gate_logits, gCs, act, slope
+
+extern "C" int osa_conv3d_ndhwc_f32(OSA_CONV_PARAMS, void* stream) {
+    return conv3d_impl(OSA_CONV_ARGS, PREC_F32, 1.f, stream);
+}
+
+extern "C" int osa_conv3d_ndhwc_f16x3(OSA_CONV_PARAMS, float out_scale, void* stream) {
+    return conv3d_impl(OSA_CONV_ARGS, PREC_F16X3, out_scale, stream);
+}
+
+static int deconv3d_impl(const float* x, const float* w_packed,
+                         const float* scale, const float* shift, const float* residual,
+                         float* y,
+                         int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                         int Co, int yCs, int rCs,
+                         int k, int pad, int opad,
+                         const float* gate_logits, int gCs,
+                         int act, float slope, int prec, float oscale, void* stream) {
     if (gate_logits) OSA_REQUIRE(gCs >= Co, "deconv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     OSA_REQUIRE((k == 3 && pad == 1 && opad == 1) || (k == 4 && pad == 1 && opad == 0),
@@ -594,14 +716,30 @@ extern "C" int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
             a.td[t] = (signed char)dd[i]; a.th[t] = (signed char)dh[j]; a.tw[t] = (signed char)dw[l];
         }
         a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
-        a.act = act; a.slope = slope;
+        a.act = act; a.slope = slope; a.oscale = oscale;
         if (a.T > 0 && a.Ad > 0 && a.Ah > 0 && a.Aw > 0) {
-            const int rc = launch_conv(a, 1, (hipStream_t)stream, "deconv3d");
+            const int rc = launch_conv(a, 1, prec, (hipStream_t)stream, "deconv3d");
             if (rc) return rc;
         }
         off += packed_floats(Ci, Co, a.T);
     }
     return 0;
+}
+
+#define OSA_DECONV_PARAMS                                                                       \
+    const float* x, const float* w_packed, const float* scale, const float* shift,             \
+    const float* residual, float* y, int B, int Di, int Hi, int Wi, int Ci, int xCs,           \
+    int Co, int yCs, int rCs, int k, int pad, int opad, const float* gate_logits, int gCs, int act, float slope
+#define OSA_DECONV_ARGS                                                                         \
+    x, w_packed, scale, shift, residual, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, k, pad, opad, \
+    gate_logits, gCs, act, slope
+
+extern "C" int osa_deconv3d_ndhwc_f32(OSA_DECONV_PARAMS, void* stream) {
+    return deconv3d_impl(OSA_DECONV_ARGS, PREC_F32, 1.f, stream);
+}
+
+extern "C" int osa_deconv3d_ndhwc_f16x3(OSA_DECONV_PARAMS, float out_scale, void* stream) {
+    return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16X3, out_scale, stream);
 }
 
 extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,
@@ -617,7 +755,7 @@ extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref,
     OSA_REQUIRE(yCs >= Co, "conv3d_small_co: yCs < Co");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.y = y; a.res = residual;
+    a.x = x; a.y = y; a.res = residual; a.oscale = 1.f;
     a.B = B; a.Di = D; a.Hi = H; a.Wi = W; a.Ci = Ci; a.xCs = xCs;
     a.Do = D; a.Ho = H; a.Wo = W; a.Co = Co; a.yCs = yCs;
     a.Ad = D; a.Ah = H; a.Aw = W;

@@ -13,8 +13,29 @@ import torch.nn as nn
 from . import _lib, timing
 from .ops import _stream, _p, empty_cl, is_cl
 
+import math
+import os
+
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 enable_timing, collect_timing = timing.enable, timing.collect
+
+# Arithmetic mode of the MFMA convolutions:
+#   "f32"   exact fp32 products on v_mfma_f32_32x32x2_f32
+#   "f16x3" split precision: x = hi + lo (two fp16), Ahi.Bhi + Ahi.Blo + Alo.Bhi, fp32 accumulate
+PRECISIONS = ("f32", "f16x3")
+_precision = os.environ.get("OSA_PRECISION", "f32")
+assert _precision in PRECISIONS, f"OSA_PRECISION must be one of {PRECISIONS}"
+
+
+def set_precision(p: str):
+    """Default mode for PackedConv3d objects created afterwards (call model.reset_engine() to repack)."""
+    global _precision
+    assert p in PRECISIONS, p
+    _precision = p
+
+
+def get_precision() -> str:
+    return _precision
 
 
 def bn_scale_shift(bn):
@@ -35,7 +56,9 @@ def _t3(v):
 class PackedConv3d:
     """conv (or stride-2 transposed conv) + folded BN + activation, weights in MFMA operand order."""
 
-    def __init__(self, conv, bn=None, act=ACT_NONE, slope=0.01):
+    def __init__(self, conv, bn=None, act=ACT_NONE, slope=0.01, precision=None):
+        self.precision = precision or _precision
+        assert self.precision in PRECISIONS
         w = conv.weight.detach()
         if not w.is_cuda:
             raise _lib.EngineError("PackedConv3d needs parameters on the GPU (no CPU path)")
@@ -61,22 +84,38 @@ class PackedConv3d:
             else:                                   # BN(conv + bias) = conv*s + (bias*s + t)
                 self.shift = (self.shift + bias * self.scale).contiguous()
         st = _stream()
+        f16 = self.precision == "f16x3"
+        self.out_scale = 1.0
+        wscale = 1.0
+        if f16:
+            # power-of-two pre-scale: largest |w| lands in [2^13, 2^14) -> hi AND lo parts are fp16 normals
+            amax = float(w.abs().max())
+            k = 0 if amax == 0.0 or not math.isfinite(amax) else int(math.floor(math.log2(16384.0 / amax)))
+            wscale = 2.0 ** max(-14, min(k, 40))
+            self.out_scale = 1.0 / wscale
         if self.transposed:
             self.Ci, self.Co = w.shape[0], w.shape[1]
             assert self.k[0] == self.k[1] == self.k[2] and self.stride == (2, 2, 2)
             self.opad = _t3(conv.output_padding)
             n = _lib.load().osa_deconv3d_packed_floats(self.Ci, self.Co, self.k[0])
-            self.packed = torch.empty(n, device=w.device, dtype=torch.float32)
-            _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
-                      self.k[0], self.pad[0], st)
+            self.packed = torch.zeros(n, device=w.device, dtype=torch.float32)
+            if f16:
+                _lib.call("osa_deconv3d_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
+                          self.k[0], self.pad[0], wscale, st)
+            else:
+                _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
+                          self.k[0], self.pad[0], st)
         else:
             self.Co, self.Ci = w.shape[0], w.shape[1]
             assert conv.groups == 1
             s = self.stride
             assert s[1] == s[2] and (s[0] == s[1] or (self.k[0] == 1)), f"anisotropic stride {s}"
             n = _lib.load().osa_conv3d_packed_floats(self.Ci, self.Co, *self.k)
-            self.packed = torch.empty(n, device=w.device, dtype=torch.float32)
-            _lib.call("osa_conv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, st)
+            self.packed = torch.zeros(n, device=w.device, dtype=torch.float32)
+            if f16:
+                _lib.call("osa_conv3d_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, wscale, st)
+            else:
+                _lib.call("osa_conv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, st)
 
     def out_shape(self, D, H, W):
         if self.transposed:
@@ -117,16 +156,18 @@ class PackedConv3d:
         xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
         rp = None if residual is None else residual.data_ptr() + 4 * res_off
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
+            tail = (self.out_scale, _stream()) if self.precision == "f16x3" else (_stream(),)
+            sfx = "f16x3" if self.precision == "f16x3" else "f32"
             if self.transposed:
-                _lib.call("osa_deconv3d_ndhwc_f32", xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                _lib.call("osa_deconv3d_ndhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
                           rp, yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
-                          self.k[0], self.pad[0], self.opad[0], _p(gate), gCs, self.act, self.slope, _stream())
+                          self.k[0], self.pad[0], self.opad[0], _p(gate), gCs, self.act, self.slope, *tail)
             else:
-                _lib.call("osa_conv3d_ndhwc_f32", xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                _lib.call("osa_conv3d_ndhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
                           rp, yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
                           self.k[0], self.k[1], self.k[2], self.stride[1],
                           self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
-                          _p(gate), gCs, self.act, self.slope, _stream())
+                          _p(gate), gCs, self.act, self.slope, *tail)
         return out
 
 

@@ -123,8 +123,12 @@ CONV_CASES = [
 ]
 
 
+PRECS = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv3d_bn_act_vs_oracle(case):
+def test_conv3d_bn_act_vs_oracle(case, prec):
     from openstereo_amd import ops
     from openstereo_amd.engine import PackedConv3d
     name, Ci, Co, k, s, p, dil, (D, H, W), act, use_res = case
@@ -138,18 +142,19 @@ def test_conv3d_bn_act_vs_oracle(case):
         if res is not None:
             ref = ref + res
         ref = {"relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.01), "none": lambda t: t}[act](ref)
-    pc = PackedConv3d(conv.to(DEV), bn.to(DEV), {"none": 0, "relu": 1, "leaky": 2}[act], 0.01)
+    pc = PackedConv3d(conv.to(DEV), bn.to(DEV), {"none": 0, "relu": 1, "leaky": 2}[act], 0.01, precision=prec)
     y = pc(ops.to_cl(x.to(DEV)), residual=None if res is None else ops.to_cl(res.to(DEV)))
     assert ops.is_cl(y)
-    close(y[:, :Co], ref, atol=2e-5, rtol=2e-5, what=name)
+    close(y[:, :Co], ref, atol=2e-5, rtol=2e-5, what=f"{name} [{prec}]")
 
 
 DECONV_CASES = [("k3 128-64", 128, 64, 3, 1, 1, (3, 5, 7)), ("k3 64-32", 64, 32, 3, 1, 1, (4, 6, 9)),
                 ("k4 48-24", 48, 24, 4, 1, 0, (3, 4, 6)), ("k4 16-8", 16, 8, 4, 1, 0, (4, 5, 5))]
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
-def test_deconv3d_bn_residual_vs_oracle(case):
+def test_deconv3d_bn_residual_vs_oracle(case, prec):
     from openstereo_amd import ops
     from openstereo_amd.engine import PackedConv3d
     name, Ci, Co, k, p, op, (D, H, W) = case
@@ -161,9 +166,9 @@ def test_deconv3d_bn_residual_vs_oracle(case):
         up = bn(dc(x))
         res = torch.randn(up.shape, generator=torch.Generator().manual_seed(4))
         ref = F.relu(up + res)
-    pc = PackedConv3d(dc.to(DEV), bn.to(DEV), 1)
+    pc = PackedConv3d(dc.to(DEV), bn.to(DEV), 1, precision=prec)
     y = pc(ops.to_cl(x.to(DEV)), residual=ops.to_cl(res.to(DEV)))
-    close(y[:, :Co], ref, atol=2e-5, rtol=2e-5, what=name)
+    close(y[:, :Co], ref, atol=2e-5, rtol=2e-5, what=f"{name} [{prec}]")
 
 
 def test_conv2d_as_flat_conv3d_dilated():
@@ -264,10 +269,21 @@ def test_gwcnet_engine_from_reference_features_small():
     assert epe < 1e-3, f"EPE {epe}"
 
 
-def test_gwcnet_full_size_vs_reference_golden():
+@pytest.mark.parametrize("prec", PRECS)
+def test_gwcnet_full_size_vs_reference_golden(prec):
     """BASELINE configs[1]: 540x960 padded to 544x960, D=192; disparity within 1e-3 EPE of the
-    reference CPU path (golden produced by the real reference)."""
+    reference CPU path (golden produced by the real reference) -- in both arithmetic modes."""
+    from openstereo_amd import engine
     g = golden("gwcnet_full_disp.npz")
+    old = engine.get_precision()
+    engine.set_precision(prec)
+    try:
+        _full_size_check(g, prec)
+    finally:
+        engine.set_precision(old)
+
+
+def _full_size_check(g, prec):
     net = _gwcnet()
     L, R = synth_images(1, 544, 960, seed=1)
     with torch.no_grad():
@@ -276,7 +292,7 @@ def test_gwcnet_full_size_vs_reference_golden():
     d = disp.cpu().numpy()
     assert np.isfinite(d).all()
     err = np.abs(d - g["disp"])
-    print(f"full-size EPE {err.mean():.3e}, max {err.max():.3e}, >0.01px: {(err > 1e-2).mean() * 100:.4f}%")
+    print(f"[{prec}] full-size EPE {err.mean():.3e}, max {err.max():.3e}, >0.01px: {(err > 1e-2).mean() * 100:.4f}%")
     assert err.mean() < 1e-3, f"EPE {err.mean()}"
 
 
