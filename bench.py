@@ -26,7 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 H_IMG, W_IMG, H_PAD, W_PAD, MAXDISP = 540, 960, 544, 960, 192
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md dense peaks.  f16x3 executes 3 fp16 MFMAs per fp32-equivalent product, so the
+# roofline for ALGORITHMIC flops in that mode is 2500 / 3.
+PEAKS = {"f32": (157.3, "v_mfma_f32_32x32x2_f32 dense peak"),
+         "f16x3": (2500.0 / 3.0, "fp16 MFMA dense peak 2500 TF / 3 MFMAs per fp32-equivalent product")}
+DTYPES = {"f32": "f32", "f16x3": "f32 via f16x3 split-MFMA (hi/lo fp16 operands, f32 accumulate; HBM tensors f32)"}
 # algorithmic MACs per pair of one 3x3x3 32->32 layer at 48x136x240 (43.32 GMAC)
 DOM_GFLOP = 2 * 27 * 32 * 32 * 48 * 136 * 240 / 1e9
 
@@ -37,6 +41,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
+                    help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
+    ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -56,6 +63,7 @@ def main():
     from openstereo_amd.utils.weights import synth_state_dict, synth_images
     from openstereo_amd.parallel import reduce_step_time, whole_job_rate
     _lib.load()
+    engine.set_precision(args.precision)
 
     net = GwcNet()
     sd = synth_state_dict(net, seed=0)
@@ -89,23 +97,58 @@ def main():
     pairs_per_s = whole_job_rate(B, args.steps, world, dt)
 
     # ---- instrumented replay: per-layer HIP events on the launch stream ----
-    roofline = None
-    if rank == 0:
+    def measure_roofline(prec, nrep):
         rec = engine.enable_timing()
-        for _ in range(max(2, min(args.steps, 5))):
+        for _ in range(nrep):
             step()
         torch.cuda.synchronize()
         stats = engine.collect_timing(rec)
         dom = [v for k, v in stats.items() if k[0] == "conv3d" and k[1:] == (32, 32, 3, 1, 48, 136, 240)]
-        if dom:
-            ms = sum(sum(v) for v in dom) / sum(len(v) for v in dom) / B      # per pair
-            ach = DOM_GFLOP / ms                                               # GFLOP / ms = TFLOP/s
-            roofline = {"kernel": "conv_mfma_f32_kernel<2,1,4,1,8,8> 3x3x3 32->32 @48x136x240",
-                        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                        "avg_launch_ms": round(ms * B, 4),
-                        "stage_ms_per_step": {"/".join(map(str, k)): round(sum(v) / len(v), 4) for k, v in
-                                              sorted(stats.items(), key=lambda kv: -sum(kv[1]) / len(kv[1]))[:12]}}
+        if not dom:
+            return None, stats
+        ms = sum(sum(v) for v in dom) / sum(len(v) for v in dom) / B           # per pair
+        ach = DOM_GFLOP / ms                                                    # GFLOP / ms = TFLOP/s
+        peak, why = PEAKS[prec]
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")                    # PMC bytes per launch, measured offline
+        if os.path.exists(tj):
+            traffic = json.load(open(tj)).get(f"conv3d_32_32_V0_{prec}")
+        per_step = {"/".join(map(str, k)): round(sum(v) / nrep, 4) for k, v in
+                    sorted(stats.items(), key=lambda kv: -sum(kv[1]))}
+        return ({"kernel": f"conv_mfma_kernel<PREC_{prec.upper()},2,1,4,1,8,8> 3x3x3 32->32 @48x136x240 "
+                           f"(4 launches per pair, {DOM_GFLOP:.2f} algorithmic GFLOP each)",
+                 "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "peak_note": why,
+                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                 "avg_launch_ms": round(ms * B, 4),
+                 "stage_ms_per_step": dict(list(per_step.items())[:12])}, per_step)
+
+    roofline, alt = None, None
+    if rank == 0:
+        nrep = max(2, min(args.steps, 5))
+        roofline, per_step = measure_roofline(args.precision, nrep)
+        if args.stages:
+            json.dump(per_step, open(args.stages, "w"), indent=1)
+        if world == 1:
+            # the other arithmetic mode, same workload, for reference (short run)
+            other = "f32" if args.precision == "f16x3" else "f16x3"
+            engine.set_precision(other)
+            net.reset_engine()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nrep):
+                step()
+            torch.cuda.synchronize()
+            t_other = (time.perf_counter() - t1) / nrep
+            r_other, _ = measure_roofline(other, 2)
+            alt = {"precision": other, "dtype": DTYPES[other], "value": round(B / t_other, 3), "unit": "stereo-pairs/s",
+                   "ms_per_step": round(t_other * 1e3, 3),
+                   "roofline": None if r_other is None else {k: r_other[k] for k in ("kernel", "achieved", "peak", "frac")}}
+            engine.set_precision(args.precision)
+            net.reset_engine()
+            with torch.no_grad():
+                out = step()
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -125,12 +168,13 @@ def main():
             "metric": "stereo-pairs/s at 540x960 D=192 (GwcNet fwd)", "value": round(pairs_per_s, 3),
             "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "GwcNet-gc inference, SceneFlow-shaped 540x960 padded to 544x960, D=192, "
                                    "G=40 + 12ch concat (BASELINE configs[1])",
                        "pairs_per_gpu_per_step": B, "parallelism": f"independent pairs x{world}",
+                       "precision": args.precision,
                        "weights": "deterministic synthetic (sharpened), random-init architecture"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline}))
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precision": alt}))
     if dist is not None:
         dist.destroy_process_group()
 

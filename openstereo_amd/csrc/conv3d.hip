@@ -40,7 +40,7 @@ enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 constexpr int CC = 16;        // input channels staged per pass (packed-weight format constant)
 constexpr int VS = CC + 4;    // LDS voxel stride in floats
 constexpr int JO = CC / 8;    // k-octets per chunk
-constexpr int MAX_TAPS = 32;
+constexpr int MAX_TAPS = 64;   // 3x3x3 = 27; a fused k=4 transposed conv carries all 64 taps
 
 struct ConvArgs {
     const float* x; const float4* w; const float* scale; const float* shift; const float* res; float* y;
@@ -51,12 +51,14 @@ struct ConvArgs {
     int isd, ish, isw;            // input step per a (per dim)
     int os, ood, ooh, oow;        // output position = a*os + oo
     int T;                        // taps
+    int cls_end[8];               // fused transposed conv: taps [cls_end[c-1], cls_end[c]) belong to output-parity class c
     int dmin, hmin, wmin;         // min delta per dim
     int LD, LH, LW;               // LDS brick dims (voxels)
     int RowQ, PlaneQ;             // LDS float4s per brick row (padded) / per d-plane (16-byte units keep ds_read_b128)
     int dbg;                      // debug switch (OSA_DBG): 1 = skip staging (timing experiments only)
     int tilesD, tilesH, tilesW;
     int nchunks, CoP;
+    int cps;                      // channel chunks staged per pass (LDS holds cps bricks back to back)
     int act; float slope;
     float oscale;                 // f16x3: 1 / (weight pre-scale), exact power of two; 1 for f32
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
@@ -67,9 +69,9 @@ struct ConvArgs {
 // Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
 // Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
 __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) {
-    const float m = 65504.f;
-    const float x0 = fminf(fmaxf(v.x, -m), m), x1 = fminf(fmaxf(v.y, -m), m);
-    const float x2 = fminf(fmaxf(v.z, -m), m), x3 = fminf(fmaxf(v.w, -m), m);
+    const float m = 65504.f;      // saturate instead of producing inf (one v_med3_f32 per element)
+    const float x0 = __builtin_amdgcn_fmed3f(v.x, -m, m), x1 = __builtin_amdgcn_fmed3f(v.y, -m, m);
+    const float x2 = __builtin_amdgcn_fmed3f(v.z, -m, m), x3 = __builtin_amdgcn_fmed3f(v.w, -m, m);
     f16x4 h = {(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
     f16x4 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1]),
                (_Float16)(x2 - (float)h[2]), (_Float16)(x3 - (float)h[3])};
@@ -126,8 +128,12 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 }
 
 // CFG: MT m-tiles x NT n-tiles per wave, WM x WN waves, brick TD x TH x TW (TD derived)
-template <int PREC, int MT, int NT, int WM, int WN, int TH, int TW>
-__global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvArgs p) {
+// NCLS = 1: ordinary (strided / dilated / 1x1x1) convolution.
+// NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
+//           brick is staged once, every class has its own accumulator set and its own run of taps
+//           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW>
+__global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -156,120 +162,178 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_mfma_kernel(const ConvArgs 
         abase[m] = (td_ * p.isd) * p.PlaneQ + (th_ * p.ish) * p.RowQ + (tw_ * p.isw) * (VS / 4) + hh;
     }
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[NCLS][MT][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][m][n][r] = 0.f;
 
-    // One linear stream of B operands: [chunk][tap][octet] steps of 2*CoP float4 each.  The B
-    // operands of the NEXT tap are requested before the current tap's MFMAs start (register ring,
-    // one tap = JO steps deep), so their L2 latency hides behind 4*JO*MT*NT MFMAs; sched_barrier
-    // pins the issue order.  The packed buffer carries JO steps of slack for the last prefetch.
-    const size_t bstep = (size_t)2 * p.CoP;
+    // One linear stream of B operands: [chunk][tap][octet] "tap steps" of JO*2*CoP float4 each.
+    // Copy-free software pipeline: two static register sets (0/1) ping-pong.  Each half-iteration
+    // first requests the A (LDS) and B (global/L2) operands of the NEXT group of up to TU taps into
+    // the other set, then issues the MFMAs of the current set (sched_barrier pins that order).  A
+    // half-iteration with cnt == 0 only prefetches, so every tap run (chunk, parity class) ends with
+    // "set 0 holds the next group" and no register rotation is ever needed.  The packed buffer
+    // carries a few tap steps of slack for the last prefetch.
+    const size_t bstep = (size_t)2 * p.CoP;          // float4s per octet
+    const size_t tstep = (size_t)JO * bstep;         // float4s per tap
     const float4* wp = p.w + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
-    float4 bcur[JO][NT];
+    float4 B0[TU][JO][NT], B1[TU][JO][NT], A0[TU][JO][MT], A1[TU][JO][MT];
 #pragma unroll
-    for (int j = 0; j < JO; ++j)
+    for (int u = 0; u < TU; ++u)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bcur[j][n] = wp[j * bstep + n * 32];
+        for (int j = 0; j < JO; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) B0[u][j][n] = wp[u * tstep + j * bstep + n * 32];
 
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        if (ch) __syncthreads();
-        if (!(p.dbg & 1)) stage_brick<NW * 64, PREC>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
-        __syncthreads();
-        // A operands of tap 0 of this chunk
-        float4 anx[JO][MT];
-        {
-            const int toff0 = p.toff[0];
+    const int brickQ = p.LD * p.PlaneQ;          // float4s per staged chunk
+    const int Tm1 = p.T - 1;
+    const float4* sm = smem;
+    int t = 0;
+
+    // prefetch group starting at flat tap `tn` (B: `skip` tap steps ahead of wp) into (An, Bn)
+    auto prefetch = [&](float4 (&An)[TU][JO][MT], float4 (&Bn)[TU][JO][NT], int tn, int skip) {
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
 #pragma unroll
             for (int j = 0; j < JO; ++j)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    anx[j][m] = smem[abase[m] + toff0 + j * 2];
+                for (int n = 0; n < NT; ++n) Bn[u][j][n] = wp[(size_t)(skip + u) * tstep + j * bstep + n * 32];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int ti = tn + u;
+            const int to = p.toff[(ti < Tm1) ? ti : Tm1];
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) An[u][j][m] = sm[abase[m] + to + j * 2];
         }
-        for (int t = 0; t < p.T; ++t) {
-            // rotate: what was prefetched during the previous tap is consumed now
-            float4 av[JO][MT], bnx[JO][NT];
+    };
+    // MFMAs of the first `cnt` taps of (Ac, Bc) into accumulator set ac
+    auto compute = [&](const float4 (&Ac)[TU][JO][MT], const float4 (&Bc)[TU][JO][NT], f32x16 (&ac)[MT][NT], int cnt) {
 #pragma unroll
-            for (int j = 0; j < JO; ++j)
+        for (int u = 0; u < TU; ++u) {
+            if (u < cnt) {
+                if constexpr (PREC == PREC_F32) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[j][m] = anx[j][m];
-            // request the next tap's B (global, L2) and A (LDS) operands before this tap's MFMAs
-            const int toffn = p.toff[(t + 1 < p.T) ? t + 1 : t];
+                    for (int j = 0; j < JO; ++j)
 #pragma unroll
-            for (int j = 0; j < JO; ++j)
+                        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bnx[j][n] = wp[(JO + j) * bstep + n * 32];
-#pragma unroll
-            for (int j = 0; j < JO; ++j)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    anx[j][m] = smem[abase[m] + toffn + j * 2];
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PREC == PREC_F32) {
-#pragma unroll
-                for (int j = 0; j < JO; ++j)
+                            for (int n = 0; n < NT; ++n) {
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].x, Bc[u][j][n].x, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].y, Bc[u][j][n].y, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].z, Bc[u][j][n].z, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].w, Bc[u][j][n].w, ac[m][n], 0, 0, 0);
+                            }
+                } else {
+                    // [0] = hi halves, [1] = lo halves of the 16 channels of this chunk (K = 16 per MFMA);
+                    // small cross terms first, then hi.hi
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].x, bcur[j][n].x, acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].y, bcur[j][n].y, acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].z, bcur[j][n].z, acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][m].w, bcur[j][n].w, acc[m][n], 0, 0, 0);
+                            const f16x8 ah = __builtin_bit_cast(f16x8, Ac[u][0][m]), al = __builtin_bit_cast(f16x8, Ac[u][1][m]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, Bc[u][0][n]), bl = __builtin_bit_cast(f16x8, Bc[u][1][n]);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ac[m][n], 0, 0, 0);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, ac[m][n], 0, 0, 0);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, ac[m][n], 0, 0, 0);
                         }
-            } else {
-                // [0] = hi halves, [1] = lo halves of the 16 channels of this chunk (K = 16 per MFMA);
-                // small cross terms first, then hi.hi
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const f16x8 ah = __builtin_bit_cast(f16x8, av[0][m]), al = __builtin_bit_cast(f16x8, av[1][m]);
-                        const f16x8 bh = __builtin_bit_cast(f16x8, bcur[0][n]), bl = __builtin_bit_cast(f16x8, bcur[1][n]);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m][n], 0, 0, 0);
-                    }
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the ring rotation (and its waits) behind the MFMAs
+        }
+    };
+
+    for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
+        if (ch0) __syncthreads();
+        const int ncl = (p.nchunks - ch0 < p.cps) ? (p.nchunks - ch0) : p.cps;
+        if (!(p.dbg & 1))
+            for (int cl = 0; cl < ncl; ++cl)
+                stage_brick<NW * 64, PREC>(p, smem + cl * brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+        __syncthreads();
+        for (int cl = 0; cl < ncl; ++cl) {
+            sm = smem + cl * brickQ;
+            // A operands of the first TU taps of this chunk -> set 0 (B0 already holds their B operands)
 #pragma unroll
-            for (int j = 0; j < JO; ++j)
+            for (int u = 0; u < TU; ++u) {
+                const int to = p.toff[(u < Tm1) ? u : Tm1];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bcur[j][n] = bnx[j][n];
-            wp += JO * bstep;
+                for (int j = 0; j < JO; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) A0[u][j][m] = sm[abase[m] + to + j * 2];
+            }
+            t = 0;
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const int tend = (NCLS == 1) ? p.T : p.cls_end[c];
+                while (t < tend) {
+                    const int cnt0 = (tend - t < TU) ? (tend - t) : TU;
+                    prefetch(A1, B1, t + cnt0, cnt0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(A0, B0, acc[c], cnt0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wp += (size_t)cnt0 * tstep; t += cnt0;
+                    const int cnt1 = (tend - t < TU) ? (tend - t) : TU;     // 0 when the run had an odd number of groups
+                    prefetch(A0, B0, t + cnt1, cnt1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(A1, B1, acc[c], cnt1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wp += (size_t)cnt1 * tstep; t += cnt1;
+                }
+            }
         }
     }
 
-    // ---- epilogue: BN affine + residual + activation, NDHWC store ----
+    // ---- epilogue: BN affine + residual + activation (+ sigmoid gate), NDHWC store ----
+    // Voxel indices of the 16 accumulator rows are computed once per M tile; parity classes and N tiles
+    // only add a scalar offset.  All residual / gate loads of a 32x32 tile are issued before its stores.
+    const size_t bvox = (size_t)b * p.Do * p.Ho * p.Wo;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = n0 + (wn * NT + n) * 32 + col;
-        const bool cok = co < p.Co;
-        const float sc = ((cok && p.scale) ? p.scale[co] : 1.f) * p.oscale;
-        const float sh = (cok && p.shift) ? p.shift[co] : 0.f;
+    for (int m = 0; m < MT; ++m) {
+        unsigned v0[16], g0[16];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int q = (wm * MT + m) * 32 + row;
+            const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+            const bool ok = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+            v0[r] = ok ? (unsigned)((ad * p.os * p.Ho + ah * p.os) * p.Wo + aw * p.os) : 0xffffffffu;
+            g0[r] = (unsigned)(ah * p.os * p.Wo + aw * p.os);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const int q = (wm * MT + m) * 32 + row;
-                const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
-                if (cok && ad < p.Ad && ah < p.Ah && aw < p.Aw) {
-                    const size_t vox = (((size_t)b * p.Do + (ad * p.os + p.ood)) * p.Ho + (ah * p.os + p.ooh)) * p.Wo +
-                                       (aw * p.os + p.oow);
-                    float v = fmaf(acc[m][n][r], sc, sh);
-                    if (p.res) v += p.res[vox * p.rCs + co];
-                    if (p.act == OSA_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
-                    if (p.gate) {
-                        const float gl = p.gate[(((size_t)b * p.Ho + (ah * p.os + p.ooh)) * p.Wo + (aw * p.os + p.oow)) * p.gCs + co];
-                        v *= 1.0f / (1.0f + expf(-gl));
+        for (int c = 0; c < NCLS; ++c) {
+            const int ood = (NCLS == 1) ? p.ood : ((c >> 2) & 1), ooh = (NCLS == 1) ? p.ooh : ((c >> 1) & 1),
+                      oow = (NCLS == 1) ? p.oow : (c & 1);
+            const unsigned coff = (unsigned)((ood * p.Ho + ooh) * p.Wo + oow), goff = (unsigned)(ooh * p.Wo + oow);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n0 + (wn * NT + n) * 32 + col;
+                const bool cok = co < p.Co;
+                const float sc = ((cok && p.scale) ? p.scale[co] : 1.f) * p.oscale;
+                const float sh = (cok && p.shift) ? p.shift[co] : 0.f;
+                float rv[16], gv[16];
+                bool okr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = cok && (v0[r] != 0xffffffffu);   // supported transposed convs have Do == 2*Di: no ragged parity
+                    okr[r] = ok;
+                    rv[r] = 0.f; gv[r] = 0.f;
+                    if (ok && p.res) rv[r] = p.res[(bvox + v0[r] + coff) * p.rCs + co];
+                    if (ok && p.gate) gv[r] = p.gate[((size_t)b * p.Ho * p.Wo + g0[r] + goff) * p.gCs + co];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (okr[r]) {
+                        float v = fmaf(acc[c][m][n][r], sc, sh) + rv[r];
+                        if (p.act == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (p.act == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                        if (p.gate) v *= 1.0f / (1.0f + expf(-gv[r]));
+                        p.y[(bvox + v0[r] + coff) * p.yCs + co] = v;
                     }
-                    p.y[vox * p.yCs + co] = v;
                 }
             }
         }
@@ -284,10 +348,12 @@ struct KernelCfg {
     void (*fn[2])(const ConvArgs);      // [PREC_F32], [PREC_F16X3]
 };
 
+constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong pipeline
 #define OSA_CFG(MT, NT, WM, WN, TH, TW)                                                      \
     { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
       WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
-      { conv_mfma_kernel<PREC_F32, MT, NT, WM, WN, TH, TW>, conv_mfma_kernel<PREC_F16X3, MT, NT, WM, WN, TH, TW> } }
+      { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
+        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> } }
 
 static const KernelCfg g_cfgs[] = {
     OSA_CFG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
@@ -307,6 +373,11 @@ static const KernelCfg g_cfgs[] = {
     OSA_CFG(1, 1, 2, 2, 4, 16),  // 14:  64 vox x 64 ch   brick 1x4x16  (2-D stride-2 layers)
 };
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
+
+// fused transposed conv: 128 input-resolution positions x 32 channels x 8 parity classes per workgroup
+static const KernelCfg g_deconv_cfg = {
+    "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
+    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> } };
 
 static int pick_cfg(const ConvArgs& a, int stride) {
     const char* ov = getenv("OSA_CONV_CFG");
@@ -361,21 +432,31 @@ static size_t brick_bytes(ConvArgs& a, const KernelCfg& k) {
     return (size_t)a.LD * a.LH * (a.LW * VS + 64) * sizeof(float);   // upper bound incl. row padding
 }
 
-static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what) {
-    int ci = pick_cfg(a, stride);
-    if (brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
+static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what,
+                       const KernelCfg* forced = nullptr) {
+    int ci = forced ? 0 : pick_cfg(a, stride);
+    if (!forced && brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
         // e.g. a stride-2 3x3x3 layer whose output depth collapses to 1: fall back to the small bricks
         static const int fallback[] = {5, 3, 11};
         for (int f : fallback)
             if (a.CoP % g_cfgs[f].N == 0 && brick_bytes(a, g_cfgs[f]) <= 160 * 1024) { ci = f; break; }
     }
-    const KernelCfg& k = g_cfgs[ci];
+    const KernelCfg& k = forced ? *forced : g_cfgs[ci];
     a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
     (void)brick_bytes(a, k);
     OSA_REQUIRE((long long)a.LD * a.LH * a.LW < 65536, "%s: LDS brick too large", what);
     finish_geometry(a, k.TW);
-    const size_t lds = (size_t)a.LD * a.PlaneQ * sizeof(float4);
-    OSA_REQUIRE(lds <= 160 * 1024, "%s: LDS brick %dx%dx%d needs %zu B (> 160 KiB)", what, a.LD, a.LH, a.LW, lds);
+    const size_t brick = (size_t)a.LD * a.PlaneQ * sizeof(float4);
+    OSA_REQUIRE(brick <= 160 * 1024, "%s: LDS brick %dx%dx%d needs %zu B (> 160 KiB)", what, a.LD, a.LH, a.LW, brick);
+    // several channel chunks per staging pass (fewer barriers, more loads in flight) while the
+    // workgroup stays under ~40 KiB of LDS, i.e. as long as it does not cost residency
+    a.cps = 1;
+    {
+        const char* e = getenv("OSA_CPS");
+        const int want = e ? atoi(e) : 4;
+        while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= 40 * 1024) ++a.cps;
+    }
+    const size_t lds = brick * a.cps;
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
     if (lds > 64 * 1024)
@@ -442,7 +523,7 @@ static inline int nchunks_of(int ci) { return (ci + CC - 1) / CC; }
 static inline size_t packed_floats(int Ci, int Co, int T) {
     return (size_t)nchunks_of(Ci) * T * JO * 2 * pad32(Co) * 4;
 }
-static inline size_t slack_floats(int Co) { return (size_t)JO * 2 * pad32(Co) * 4; }   // one prefetched tap
+static inline size_t slack_floats(int Co) { return (size_t)4 * JO * 2 * pad32(Co) * 4; }   // up to 4 prefetched taps
 
 // transposed-conv parity class: taps of one dimension. o = 2a+par ; i = a + delta ; kernel index kk
 static int deconv_dim_taps(int k, int pad, int par, int* delta, int* kk) {
@@ -574,26 +655,39 @@ extern "C" size_t osa_deconv3d_packed_floats(int Ci, int Co, int k) {
     return packed_floats(Ci, Co, k * k * k) + slack_floats(Co);
 }
 
-static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
-                              int k, int pad, int prec, float wscale, void* stream) {
-    OSA_REQUIRE(w_ref && w_packed, "deconv3d_pack: NULL pointer");
-    OSA_REQUIRE(k == 3 || k == 4, "deconv3d_pack: kernel %d unsupported (3 or 4)", k);
-    size_t off = 0;
+// class-major tap list of a stride-2 transposed conv: for class c = (pd,ph,pw) all (kz,ky,kx) that hit
+// real inputs, with their input offsets delta.  Returns the total tap count (k^3).
+struct DeconvTaps {
+    int T; int cls_end[8];
+    signed char kz[MAX_TAPS], ky[MAX_TAPS], kx[MAX_TAPS], dz[MAX_TAPS], dy[MAX_TAPS], dx[MAX_TAPS];
+};
+static void deconv_taps(int k, int pad, DeconvTaps& d) {
+    int t = 0;
     for (int cls = 0; cls < 8; ++cls) {
         int dd[4], kd_[4], dh[4], kh_[4], dw[4], kw_[4];
         const int nd = deconv_dim_taps(k, pad, (cls >> 2) & 1, dd, kd_);
         const int nh = deconv_dim_taps(k, pad, (cls >> 1) & 1, dh, kh_);
         const int nw = deconv_dim_taps(k, pad, cls & 1, dw, kw_);
-        PackArgs p;
-        p.src = w_ref; p.dst = w_packed + off; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
-        p.kd = k; p.kh = k; p.kw = k; p.T = nd * nh * nw; p.nchunks = nchunks_of(Ci); p.transposed = 1;
-        int t = 0;
         for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c, ++t) {
-            p.kz[t] = (signed char)kd_[a]; p.ky[t] = (signed char)kh_[b]; p.kx[t] = (signed char)kw_[c];
+            d.kz[t] = (signed char)kd_[a]; d.ky[t] = (signed char)kh_[b]; d.kx[t] = (signed char)kw_[c];
+            d.dz[t] = (signed char)dd[a]; d.dy[t] = (signed char)dh[b]; d.dx[t] = (signed char)dw[c];
         }
-        launch_pack(p, prec, wscale, (hipStream_t)stream);
-        off += packed_floats(Ci, Co, p.T);
+        d.cls_end[cls] = t;
     }
+    d.T = t;
+}
+
+static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
+                              int k, int pad, int prec, float wscale, void* stream) {
+    OSA_REQUIRE(w_ref && w_packed, "deconv3d_pack: NULL pointer");
+    OSA_REQUIRE(k == 3 || k == 4, "deconv3d_pack: kernel %d unsupported (3 or 4)", k);
+    DeconvTaps d;
+    deconv_taps(k, pad, d);
+    PackArgs p;
+    p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
+    p.kd = k; p.kh = k; p.kw = k; p.T = d.T; p.nchunks = nchunks_of(Ci); p.transposed = 1;
+    for (int t = 0; t < d.T; ++t) { p.kz[t] = d.kz[t]; p.ky[t] = d.ky[t]; p.kx[t] = d.kx[t]; }
+    launch_pack(p, prec, wscale, (hipStream_t)stream);
     OSA_LAUNCH_CHECK("deconv3d_pack");
     return 0;
 }
@@ -692,38 +786,25 @@ static int deconv3d_impl(const float* x, const float* w_packed,
     if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     OSA_REQUIRE((k == 3 && pad == 1 && opad == 1) || (k == 4 && pad == 1 && opad == 0),
                 "deconv3d: only (k=3,p=1,op=1) and (k=4,p=1,op=0) with stride 2 are supported (got k=%d p=%d op=%d)", k, pad, opad);
-    const int Do = (Di - 1) * 2 - 2 * pad + k + opad, Ho = (Hi - 1) * 2 - 2 * pad + k + opad, Wo = (Wi - 1) * 2 - 2 * pad + k + opad;
-    size_t off = 0;
-    for (int cls = 0; cls < 8; ++cls) {
-        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-        int dd[4], kd_[4], dh[4], kh_[4], dw[4], kw_[4];
-        const int nd = deconv_dim_taps(k, pad, pd, dd, kd_);
-        const int nh = deconv_dim_taps(k, pad, ph, dh, kh_);
-        const int nw = deconv_dim_taps(k, pad, pw, dw, kw_);
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
-        a.x = x; a.w = reinterpret_cast<const float4*>(w_packed + off);
-        a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-        a.gate = gate_logits; a.gCs = gCs;
-        a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
-        a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.yCs = yCs; a.rCs = rCs;
-        a.Ad = (Do - pd + 1) / 2; a.Ah = (Ho - ph + 1) / 2; a.Aw = (Wo - pw + 1) / 2;
-        a.isd = a.ish = a.isw = 1;
-        a.os = 2; a.ood = pd; a.ooh = ph; a.oow = pw;
-        a.T = nd * nh * nw;
-        int t = 0;
-        for (int i = 0; i < nd; ++i) for (int j = 0; j < nh; ++j) for (int l = 0; l < nw; ++l, ++t) {
-            a.td[t] = (signed char)dd[i]; a.th[t] = (signed char)dh[j]; a.tw[t] = (signed char)dw[l];
-        }
-        a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
-        a.act = act; a.slope = slope; a.oscale = oscale;
-        if (a.T > 0 && a.Ad > 0 && a.Ah > 0 && a.Aw > 0) {
-            const int rc = launch_conv(a, 1, prec, (hipStream_t)stream, "deconv3d");
-            if (rc) return rc;
-        }
-        off += packed_floats(Ci, Co, a.T);
-    }
-    return 0;
+    DeconvTaps d;
+    deconv_taps(k, pad, d);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = reinterpret_cast<const float4*>(w_packed);
+    a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.gate = gate_logits; a.gCs = gCs;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
+    a.Do = (Di - 1) * 2 - 2 * pad + k + opad; a.Ho = (Hi - 1) * 2 - 2 * pad + k + opad; a.Wo = (Wi - 1) * 2 - 2 * pad + k + opad;
+    a.Co = Co; a.yCs = yCs; a.rCs = rCs;
+    a.Ad = (a.Do + 1) / 2; a.Ah = (a.Ho + 1) / 2; a.Aw = (a.Wo + 1) / 2;     // a-space covers every output parity
+    a.isd = a.ish = a.isw = 1;
+    a.os = 2;
+    a.T = d.T;
+    for (int t = 0; t < d.T; ++t) { a.td[t] = d.dz[t]; a.th[t] = d.dy[t]; a.tw[t] = d.dx[t]; }
+    for (int c = 0; c < 8; ++c) a.cls_end[c] = d.cls_end[c];
+    a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
+    a.act = act; a.slope = slope; a.oscale = oscale;
+    return launch_conv(a, 1, prec, (hipStream_t)stream, "deconv3d", &g_deconv_cfg);
 }
 
 #define OSA_DECONV_PARAMS                                                                       \
