@@ -194,6 +194,9 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
     const int Tm1 = p.T - 1;
     const float4* sm = smem;
     int t = 0;
+    // tap-offset table in one VGPR (lane i holds toff[i], T <= 64): v_readlane instead of a scalar
+    // memory load + lgkmcnt wait in front of every tap's LDS reads
+    const int toff_v = p.toff[(lane < p.T) ? lane : 0];
 
     // prefetch group starting at flat tap `tn` (B: `skip` tap steps ahead of wp) into (An, Bn)
     auto prefetch = [&](float4 (&An)[TU][JO][MT], float4 (&Bn)[TU][JO][NT], int tn, int skip) {
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
             const int ti = tn + u;
-            const int to = p.toff[(ti < Tm1) ? ti : Tm1];
+            const int to = __builtin_amdgcn_readlane(toff_v, (ti < Tm1) ? ti : Tm1);
 #pragma unroll
             for (int j = 0; j < JO; ++j)
 #pragma unroll
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
             // A operands of the first TU taps of this chunk -> set 0 (B0 already holds their B operands)
 #pragma unroll
             for (int u = 0; u < TU; ++u) {
-                const int to = p.toff[(u < Tm1) ? u : Tm1];
+                const int to = __builtin_amdgcn_readlane(toff_v, (u < Tm1) ? u : Tm1);
 #pragma unroll
                 for (int j = 0; j < JO; ++j)
 #pragma unroll
@@ -289,50 +292,99 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
     }
 
     // ---- epilogue: BN affine + residual + activation (+ sigmoid gate), NDHWC store ----
-    // Voxel indices of the 16 accumulator rows are computed once per M tile; parity classes and N tiles
-    // only add a scalar offset.  All residual / gate loads of a 32x32 tile are issued before its stores.
+    // MFMA result layout: lane -> output channel `col`, accumulator r -> voxel row (r&3)+8(r>>2)+4hh.
+    // Each 32x32 tile is transposed through a wave-private LDS buffer (row stride 36 floats, conflict
+    // free both ways) so that a lane ends up with 4 consecutive channels of one voxel: residual /
+    // gate loads and output stores are float4, 8 lanes cover one voxel's 128-byte channel row and a
+    // wave instruction covers 8 consecutive voxels (1 KB contiguous for a 32-channel tensor).
+    __syncthreads();                                   // everyone is done reading the input brick
+    float* tb = reinterpret_cast<float*>(smem) + wave * (32 * 36);
     const size_t bvox = (size_t)b * p.Do * p.Ho * p.Wo;
+    const bool vec4 = ((p.yCs & 3) == 0) && ((p.Co & 3) == 0) && (((size_t)p.y & 15) == 0) &&
+                      (!p.res || (((p.rCs & 3) == 0) && (((size_t)p.res & 15) == 0))) &&
+                      (!p.gate || (((p.gCs & 3) == 0) && (((size_t)p.gate & 15) == 0)));
+    const int vsub = lane >> 3, cq = (lane & 7) * 4;   // voxel within a group of 8, channel quad
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        unsigned v0[16], g0[16];
+        // the 4 voxels this lane finalises in M tile m: rows vsub + 8k
+        size_t v0[4], g0[4];
+        bool vok[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const int q = (wm * MT + m) * 32 + row;
+        for (int k = 0; k < 4; ++k) {
+            const int q = (wm * MT + m) * 32 + vsub + 8 * k;
             const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
-            const bool ok = ad < p.Ad && ah < p.Ah && aw < p.Aw;
-            v0[r] = ok ? (unsigned)((ad * p.os * p.Ho + ah * p.os) * p.Wo + aw * p.os) : 0xffffffffu;
-            g0[r] = (unsigned)(ah * p.os * p.Wo + aw * p.os);
+            vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+            v0[k] = bvox + ((size_t)(ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;
+            g0[k] = ((size_t)b * p.Ho + ah * p.os) * p.Wo + aw * p.os;
         }
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) {
             const int ood = (NCLS == 1) ? p.ood : ((c >> 2) & 1), ooh = (NCLS == 1) ? p.ooh : ((c >> 1) & 1),
                       oow = (NCLS == 1) ? p.oow : (c & 1);
-            const unsigned coff = (unsigned)((ood * p.Ho + ooh) * p.Wo + oow), goff = (unsigned)(ooh * p.Wo + oow);
+            const size_t coff = ((size_t)ood * p.Ho + ooh) * p.Wo + oow;     // supported transposed convs: Do == 2*Di
+            const size_t goff = (size_t)ooh * p.Wo + oow;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int co = n0 + (wn * NT + n) * 32 + col;
-                const bool cok = co < p.Co;
-                const float sc = ((cok && p.scale) ? p.scale[co] : 1.f) * p.oscale;
-                const float sh = (cok && p.shift) ? p.shift[co] : 0.f;
-                float rv[16], gv[16];
-                bool okr[16];
+                // registers -> LDS (tile[voxel row][channel])
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = cok && (v0[r] != 0xffffffffu);   // supported transposed convs have Do == 2*Di: no ragged parity
-                    okr[r] = ok;
-                    rv[r] = 0.f; gv[r] = 0.f;
-                    if (ok && p.res) rv[r] = p.res[(bvox + v0[r] + coff) * p.rCs + co];
-                    if (ok && p.gate) gv[r] = p.gate[((size_t)b * p.Ho * p.Wo + g0[r] + goff) * p.gCs + co];
+                for (int r = 0; r < 16; ++r)
+                    tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
+                const int co = n0 + (wn * NT + n) * 32 + cq;
+                const bool cok = co < p.Co;
+                float4 sc = make_float4(p.oscale, p.oscale, p.oscale, p.oscale), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cok && p.scale) {
+                    if (co + 3 < p.Co) { sc = *reinterpret_cast<const float4*>(p.scale + co); sh = *reinterpret_cast<const float4*>(p.shift + co); }
+                    else {
+                        sc.x = p.scale[co]; sh.x = p.shift[co];
+                        if (co + 1 < p.Co) { sc.y = p.scale[co + 1]; sh.y = p.shift[co + 1]; }
+                        if (co + 2 < p.Co) { sc.z = p.scale[co + 2]; sh.z = p.shift[co + 2]; }
+                    }
+                    sc.x *= p.oscale; sc.y *= p.oscale; sc.z *= p.oscale; sc.w *= p.oscale;
+                }
+                // LDS -> registers (4 voxels x 4 channels per lane), loads of residual / gate in flight together
+                float4 av[4], rv[4], gv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
+                    rv[k] = make_float4(0.f, 0.f, 0.f, 0.f); gv[k] = rv[k];
+                    if (vok[k] && cok) {
+                        const size_t vox = v0[k] + coff;
+                        if (vec4) {
+                            if (p.res) rv[k] = *reinterpret_cast<const float4*>(p.res + vox * p.rCs + co);
+                            if (p.gate) gv[k] = *reinterpret_cast<const float4*>(p.gate + (g0[k] + goff) * p.gCs + co);
+                        } else {
+                            float* rr = &rv[k].x; float* gg = &gv[k].x;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (co + e < p.Co) {
+                                    if (p.res) rr[e] = p.res[vox * p.rCs + co + e];
+                                    if (p.gate) gg[e] = p.gate[(g0[k] + goff) * p.gCs + co + e];
+                                }
+                        }
+                    }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (okr[r]) {
-                        float v = fmaf(acc[c][m][n][r], sc, sh) + rv[r];
+                for (int k = 0; k < 4; ++k) {
+                    float o[4];
+                    const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+                    const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+                    const float r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
                         if (p.act == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                         else if (p.act == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
-                        if (p.gate) v *= 1.0f / (1.0f + expf(-gv[r]));
-                        p.y[(bvox + v0[r] + coff) * p.yCs + co] = v;
+                        if (p.gate) v *= 1.0f / (1.0f + expf(-g4[e]));
+                        o[e] = v;
+                    }
+                    if (vok[k] && cok) {
+                        const size_t vox = v0[k] + coff;
+                        if (vec4) *reinterpret_cast<float4*>(p.y + vox * p.yCs + co) = make_float4(o[0], o[1], o[2], o[3]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (co + e < p.Co) p.y[vox * p.yCs + co + e] = o[e];
+                        }
                     }
                 }
             }
@@ -456,7 +508,9 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         const int want = e ? atoi(e) : 4;
         while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= 40 * 1024) ++a.cps;
     }
-    const size_t lds = brick * a.cps;
+    size_t lds = brick * a.cps;
+    const size_t epi = (size_t)(k.threads / 64) * 32 * 36 * sizeof(float);   // wave-private transpose tiles of the epilogue
+    if (lds < epi) lds = epi;
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
     if (lds > 64 * 1024)
