@@ -195,6 +195,15 @@ int osa_upsample_softargmin_f32(const float* cost_lowres, float* out,
                                 int B, int Dl, int Hl, int Wl, int D, int H, int W,
                                 int align_corners, void* stream);
 
+/* ---- disparity refinement ----------------------------- */
+/* convex 3x3 up-sampling: out[b,y,x] = sum_k W[b,k,y,x] * (gain*disp_low)[b, y/scale + k/3-1, x/scale + k%3-1]
+ * disp_low [B,1,h,w], weights [B,9,h*scale,w*scale], out [B,h*scale,w*scale].
+ * softmax_weights=1: `weights` are logits and softmax over the 9 taps is fused.
+ * (disp_refinement/disp_refinement.py:194-204, stereobase/igev_blocks.py:51-63, igev/submodule.py:253-265) */
+int osa_context_upsample_f32(const float* disp_low, const float* weights, float* out,
+                             int B, int h, int w, int scale, int softmax_weights, float gain,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

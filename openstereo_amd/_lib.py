@@ -71,6 +71,7 @@ SIGNATURES = {
     "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_context_upsample_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -249,6 +249,21 @@ def upsample_softargmin(cost_lowres, maxdisp, h, w, align_corners=False):
     return out
 
 
+def context_upsample(disp_low, up_weights, scale_factor=4, softmax_weights=False, gain=1.0):
+    """disp_refinement.py:194-204 / stereobase/igev_blocks.py:51-63 / igev/submodule.py:253-265:
+    disp_low [b,1,h,w], up_weights [b,9,s*h,s*w] -> [b,s*h,s*w].  softmax_weights / gain fuse the
+    F.softmax(spx_pred, 1) and `disp * 4.` the callers apply first (lightstereo.py:61-62)."""
+    _chk(disp_low, "disp_low", 4); _chk(up_weights, "up_weights", 4)
+    b, c, h, w = disp_low.shape
+    assert c == 1 and tuple(up_weights.shape) == (b, 9, h * scale_factor, w * scale_factor)
+    d, wt = _f32c(disp_low), _f32c(up_weights)
+    out = torch.empty((b, h * scale_factor, w * scale_factor), device=d.device, dtype=torch.float32)
+    with timing.span("context_upsample", h, w, scale_factor):
+        _lib.call("osa_context_upsample_f32", d.data_ptr(), wt.data_ptr(), out.data_ptr(), b, h, w, int(scale_factor),
+                  1 if softmax_weights else 0, float(gain), _stream())
+    return out if disp_low.dtype == torch.float32 else out.to(disp_low.dtype)
+
+
 class FasterSoftArgmin(torch.nn.Module):
     """psmnet_disp_processor.py:6-74: softmax over D + expectation; keeps the frozen
     `disp_regression.weight` buffer name so PSMNet checkpoints load."""

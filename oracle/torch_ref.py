@@ -345,3 +345,12 @@ def stereobase_cost_stage(match_l, match_r, cat_l, cat_r, features, sd, max_disp
     geo = igev_style_hourglass(vol, features, sd, "cost_agg", "stereobase")
     prob = F.softmax(F.conv3d(geo, sd["classifier.weight"], None, 1, 1).squeeze(1), dim=1)
     return disparity_regression(prob, D4, keepdim=True), prob, geo
+
+
+# ============================================================================= refinement (a13)
+def context_upsample(disp_low, up_weights, scale_factor=4):
+    """disp_refinement/disp_refinement.py:194-204 (== stereobase/igev_blocks.py:51-63, igev/submodule.py:253-265)."""
+    b, c, h, w = disp_low.shape
+    unf = F.unfold(disp_low, kernel_size=3, dilation=1, padding=1).reshape(b, -1, h, w)
+    unf = F.interpolate(unf, (h * scale_factor, w * scale_factor), mode="nearest")
+    return (unf * up_weights).sum(1)

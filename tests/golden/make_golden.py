@@ -103,6 +103,15 @@ def main():
          up_true=dr_nokeep(F.softmax(up_t.squeeze(1), dim=1), 24),
          low2=low2, up_odd=dr_nokeep(F.softmax(up_odd.squeeze(1), dim=1), 17))
 
+    # ------------------------------------------------------------------ context_upsample (a13)
+    from stereo.modeling.disp_refinement.disp_refinement import context_upsample as cu_shared
+    from stereo.modeling.models.stereobase.igev_blocks import context_upsample as cu_sb
+    dl, lg = rnd((2, 1, 6, 9), 31).abs() * 10, rnd((2, 9, 24, 36), 32)
+    wts = F.softmax(lg, 1)
+    assert torch.equal(cu_shared(dl * 4., wts), cu_sb(dl * 4., wts))
+    save("context_upsample.npz", disp_low=dl, logits=lg, weights=wts, out=cu_shared(dl * 4., wts),
+         out_s2=cu_shared(dl[:, :, :3, :4], wts[:, :, :6, :8], scale_factor=2))
+
     # ------------------------------------------------------------------ GwcNet hourglass + disp processor (a6, a10)
     from stereo.modeling.models.gwcnet.hourglass import Hourglass
     from stereo.modeling.models.gwcnet.gwcnet_disp_processor import GwcDispProcessor

@@ -1,0 +1,43 @@
+"""CPU: the patcher rebinds every copy of the hot-path helpers in an unmodified reference checkout
+(only runs where /root/reference is mounted) and restores them."""
+import os
+
+import pytest
+
+REF = os.environ.get("OPENSTEREO_REF", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not mounted")
+
+
+def test_patch_and_unpatch_reference():
+    import importlib
+    from openstereo_amd import attach, ops
+    attach.stub_reference_packages(REF)
+    cv = importlib.import_module("stereo.modeling.cost_volume.cost_volume")
+    sb = importlib.import_module("stereo.modeling.models.gwcnet.gwcnet_disp_processor")
+    orig = cv.build_gwc_volume
+    done = attach.patch_reference()
+    try:
+        assert cv.build_gwc_volume is ops.build_gwc_volume and cv.correlation_volume is ops.correlation_volume
+        assert "stereo.modeling.cost_volume.cost_volume.build_gwc_volume" in done
+        assert "stereo.modeling.models.psmnet.psmnet_cost_processor.cat_fms" in done
+        assert "GwcVolumeCostProcessor.build_gwc_volume" in done
+        assert sb.disparity_regression is not None and sb.disparity_regression.__name__ == "<lambda>"
+        assert len(done) >= 12
+    finally:
+        attach.unpatch_reference()
+    assert cv.build_gwc_volume is orig
+
+
+def test_attach_gwcnet_shares_parameters():
+    import importlib
+    import torch
+    from openstereo_amd import attach
+    attach.stub_reference_packages(REF)
+    RefGwc = importlib.import_module("stereo.modeling.models.gwcnet.gwcnet").GwcNet
+
+    class C(dict):
+        __getattr__ = dict.__getitem__
+    ref = RefGwc(C(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40)).eval()
+    eng = attach.attach_gwcnet(ref)
+    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), eng.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)

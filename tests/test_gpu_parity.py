@@ -408,3 +408,13 @@ def test_volume_from_channels_last_features():
     ref = ops.build_cost_volume_cl(gw[:B], gw[B:], 40, ct[:B], ct[B:], maxdisp=24)
     got = ops.build_cost_volume_from_cl(ops.to_cl(gw.unsqueeze(2)), 40, ops.to_cl(ct.unsqueeze(2)), B, 24)
     assert torch.equal(ref, got)
+
+
+def test_context_upsample_vs_reference_golden():
+    from openstereo_amd import ops
+    g = golden("context_upsample.npz")
+    dl, wt, lg = g2(g["disp_low"]), g2(g["weights"]), g2(g["logits"])
+    close(ops.context_upsample(dl * 4., wt), g["out"], atol=2e-5, what="context_upsample")
+    close(ops.context_upsample(dl, lg, softmax_weights=True, gain=4.0), g["out"], atol=2e-5, what="fused softmax+gain")
+    close(ops.context_upsample(dl[:, :, :3, :4].contiguous(), wt[:, :, :6, :8].contiguous(), scale_factor=2),
+          g["out_s2"], atol=2e-5, what="scale 2")

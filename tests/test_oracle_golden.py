@@ -106,3 +106,9 @@ def test_stereobase_and_igev_hourglass_against_reference():
     sd = {"h." + k: v for k, v in synth_state_dict(hourglass(8), seed=7).items()}
     f = [None, T(g["f1"]), T(g["f2"]), T(g["f3"])]
     close(O.igev_style_hourglass(T(g["x"]), f, sd, "h", "igev"), g["y"], atol=2e-5, rtol=2e-5)
+
+
+def test_context_upsample_against_reference():
+    g = golden("context_upsample.npz")
+    close(O.context_upsample(T(g["disp_low"]) * 4., T(g["weights"])), g["out"], atol=1e-6)
+    close(O.context_upsample(T(g["disp_low"])[:, :, :3, :4], T(g["weights"])[:, :, :6, :8], 2), g["out_s2"], atol=1e-6)
