@@ -175,6 +175,23 @@ int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
                              const float* gate_logits, int gCs,
                              int act, float slope, float out_scale, void* stream);
 
+/* Packing for backward passes.  Ci/Co are the roles of the convolution that will be EXECUTED with the
+ * packed buffer; src_transposed=1 reads w_ref as [Ci][Co][k] (instead of [Co][Ci][k]); flip=1 mirrors taps.
+ *   d(input) of a stride-1 Conv3d   : pack_ex(Ci'=Co, Co'=Ci, src_transposed=1, flip=1) + conv, pad' = dil*(k-1)-pad
+ *   d(input) of a stride-2 Conv3d   : osa_deconv3d_pack_*(w, Ci'=Co, Co'=Ci) + osa_deconv3d_ndhwc_* (k=3,p=1,op=1)
+ *   d(input) of a ConvTranspose3d   : pack_ex(Ci'=Co, Co'=Ci, 0, 0) + stride-2 conv */
+int osa_conv3d_pack_ex(const float* w_ref, float* w_packed, int Ci, int Co,
+                       int kd, int kh, int kw, int src_transposed, int flip,
+                       int f16x3, float wscale, void* stream);
+/* Weight gradient (fp32 matrix cores, exact): dw [Co][Ci][k] for a Conv3d, [Ci][Co][k] for a stride-2
+ * ConvTranspose3d (transposed=1).  x, dy NDHWC.  dw is zero-filled, then accumulated atomically. */
+int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
+                         int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                         int Do, int Ho, int Wo, int Co, int dyCs,
+                         int kd, int kh, int kw, int stride,
+                         int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                         int transposed, void* stream);
+
 /* small-Cout 'same' convolution (Co <= 4, e.g. the 32->1 classifier heads). Reference weight
  * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer).
  * y = conv(x) + bias[co] + residual ; residual (or NULL) has y's layout (voxel stride yCs). */
@@ -194,6 +211,25 @@ int osa_softmax_softargmin_f32(const float* cost, float* prob, float* out,
 int osa_upsample_softargmin_f32(const float* cost_lowres, float* out,
                                 int B, int Dl, int Hl, int Wl, int D, int H, int W,
                                 int align_corners, void* stream);
+
+/* ---- backward of the memory-bound ops (training) ------- */
+/* d(build_gwc_volume) (concat=0: left/right = forward features [B,C,H,W]) or d(build_concat_volume)
+ * (concat=1: C = channels per side).  dvol is NCDHW with vol_channels channels; this op's channels
+ * start at c_off.  Writes dleft/dright [B,C,H,W]. */
+int osa_build_volume_bwd_f32(const float* dvol, const float* left, const float* right,
+                             float* dleft, float* dright,
+                             int B, int C, int H, int W, int maxdisp, int num_groups,
+                             int concat, int mask_left_concat, int vol_channels, int c_off,
+                             void* stream);
+/* dprob[b,d,h,w] = d * dout[b,h,w] */
+int osa_softargmin_bwd_f32(const float* dout, float* dprob, int B, int D, int H, int W, void* stream);
+/* dcost = softmax(cost) * (d - disp) * dout */
+int osa_softmax_softargmin_bwd_f32(const float* cost, const float* dout, float* dcost,
+                                   int B, int D, int H, int W, void* stream);
+/* backward of osa_upsample_softargmin_f32 w.r.t. the low-res cost (zero-fills, then atomically accumulates) */
+int osa_upsample_softargmin_bwd_f32(const float* cost_lowres, const float* dout, float* dcost_lowres,
+                                    int B, int Dl, int Hl, int Wl, int D, int H, int W,
+                                    int align_corners, void* stream);
 
 /* ---- disparity refinement ----------------------------- */
 /* convex 3x3 up-sampling: out[b,y,x] = sum_k W[b,k,y,x] * (gain*disp_low)[b, y/scale + k/3-1, x/scale + k%3-1]

@@ -1,0 +1,312 @@
+"""Differentiable wrappers (training path, SURVEY 8b "Autograd / AMP", Appendix C).
+
+Every Function's forward AND backward run on the engine's HIP kernels:
+  * volume constructors  -> osa_build_volume_f32 / osa_build_volume_bwd_f32
+  * regression heads     -> osa_*softargmin*_f32 / *_bwd_f32
+  * Conv3d / ConvTranspose3d / Conv2d -> the MFMA implicit-GEMM kernel (forward), the SAME kernel with
+    role-swapped / flipped weight packing for the data gradient, and the fp32-MFMA wgrad kernel for the
+    weight gradient.
+BatchNorm (batch statistics, SyncBN), activations and residual adds stay ordinary torch modules in
+training mode, so their semantics (running-stat updates, DDP/SyncBN hooks) are exactly the reference's;
+fusion of BN/activation into the conv epilogue is an inference-only optimisation.
+Gradients flow to nn.Parameters as usual, so DistributedDataParallel's bucketed RCCL all-reduce works
+unchanged (one process per GPU).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib, engine, ops
+from .ops import _f32c, _p, _stream, empty_cl, is_cl, to_cl
+
+
+# ----------------------------------------------------------------------------- volumes
+class _GwcVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, maxdisp, num_groups):
+        l, r = _f32c(left), _f32c(right)
+        ctx.save_for_backward(l, r)
+        ctx.meta = (maxdisp, num_groups, left.dtype)
+        return ops._build(l, r, num_groups, None, None, maxdisp, ops.NCDHW)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        l, r = ctx.saved_tensors
+        maxdisp, G, dt = ctx.meta
+        B, C, H, W = l.shape
+        dv = _f32c(dvol)
+        dl, dr = torch.empty_like(l), torch.empty_like(r)
+        _lib.call("osa_build_volume_bwd_f32", dv.data_ptr(), l.data_ptr(), r.data_ptr(), dl.data_ptr(), dr.data_ptr(),
+                  B, C, H, W, maxdisp, G, 0, 1, G, 0, _stream())
+        return dl.to(dt), dr.to(dt), None, None
+
+
+class _ConcatVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, maxdisp, mask_left):
+        l, r = _f32c(left), _f32c(right)
+        ctx.meta = (maxdisp, mask_left, left.dtype, tuple(l.shape))
+        return ops._build(None, None, 0, l, r, maxdisp, ops.NCDHW, mask_left=mask_left)
+
+    @staticmethod
+    def backward(ctx, dvol):
+        maxdisp, mask_left, dt, (B, C, H, W) = ctx.meta
+        dv = _f32c(dvol)
+        dl = torch.empty((B, C, H, W), device=dv.device, dtype=torch.float32)
+        dr = torch.empty_like(dl)
+        _lib.call("osa_build_volume_bwd_f32", dv.data_ptr(), None, None, dl.data_ptr(), dr.data_ptr(),
+                  B, C, H, W, maxdisp, 0, 1, 1 if mask_left else 0, 2 * C, 0, _stream())
+        return dl.to(dt), dr.to(dt), None, None
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    assert refimg_fea.shape[1] % num_groups == 0
+    return _GwcVolume.apply(refimg_fea, targetimg_fea, maxdisp, num_groups)
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp, mask_left=True):
+    return _ConcatVolume.apply(refimg_fea, targetimg_fea, maxdisp, mask_left)
+
+
+def correlation_volume(left_feature, right_feature, max_disp):
+    return _GwcVolume.apply(left_feature, right_feature, max_disp, 1)[:, 0]
+
+
+# ----------------------------------------------------------------------------- regression
+class _SoftArgmin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob):
+        ctx.shape = tuple(prob.shape)
+        return ops.disparity_regression(prob, prob.shape[1], keepdim=False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, D, H, W = ctx.shape
+        g = _f32c(dout)
+        dp = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        _lib.call("osa_softargmin_bwd_f32", g.data_ptr(), dp.data_ptr(), B, D, H, W, _stream())
+        return dp
+
+
+class _SoftmaxSoftArgmin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost):
+        c = _f32c(cost)
+        ctx.save_for_backward(c)
+        return ops.softmax_disparity_regression(c, keepdim=False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (c,) = ctx.saved_tensors
+        B, D, H, W = c.shape
+        g = _f32c(dout)
+        dc = torch.empty_like(c)
+        _lib.call("osa_softmax_softargmin_bwd_f32", c.data_ptr(), g.data_ptr(), dc.data_ptr(), B, D, H, W, _stream())
+        return dc
+
+
+class _UpsampleSoftArgmin(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost_low, maxdisp, h, w, align_corners):
+        c = _f32c(cost_low)
+        ctx.save_for_backward(c)
+        ctx.meta = (maxdisp, h, w, align_corners)
+        return ops.upsample_softargmin(c, maxdisp, h, w, align_corners)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (c,) = ctx.saved_tensors
+        maxdisp, h, w, align = ctx.meta
+        B, Dl, Hl, Wl = c.shape
+        g = _f32c(dout)
+        dc = torch.empty_like(c)
+        _lib.call("osa_upsample_softargmin_bwd_f32", c.data_ptr(), g.data_ptr(), dc.data_ptr(), B, Dl, Hl, Wl,
+                  int(maxdisp), int(h), int(w), 1 if align else 0, _stream())
+        return dc, None, None, None, None
+
+
+def disparity_regression(prob, maxdisp, keepdim=True):
+    assert len(prob.shape) == 4 and prob.shape[1] == maxdisp
+    out = _SoftArgmin.apply(prob)
+    return out.unsqueeze(1) if keepdim else out
+
+
+def softmax_disparity_regression(cost, keepdim=True):
+    out = _SoftmaxSoftArgmin.apply(cost)
+    return out.unsqueeze(1) if keepdim else out
+
+
+def upsample_softargmin(cost_lowres, maxdisp, h, w, align_corners=False):
+    if cost_lowres.dim() == 5:
+        cost_lowres = cost_lowres[:, 0]
+    return _UpsampleSoftArgmin.apply(cost_lowres, maxdisp, h, w, align_corners)
+
+
+# ----------------------------------------------------------------------------- convolutions
+def _pow2_scale(w):
+    amax = float(w.abs().max())
+    k = 0 if amax == 0.0 or not math.isfinite(amax) else int(math.floor(math.log2(16384.0 / amax)))
+    return 2.0 ** max(-14, min(k, 40))
+
+
+def _pack(w, Ci, Co, k, mode, precision):
+    """mode: 'fwd' | 'dgrad_s1' (role swap + flip) | 'dgrad_of_deconv' (role swap) | 'deconv' (k^3 parity packing)."""
+    f16 = precision == "f16x3"
+    ws = _pow2_scale(w) if f16 else 1.0
+    lib = _lib.load()
+    if mode == "deconv":
+        n = lib.osa_deconv3d_packed_floats(Ci, Co, k[0])
+        buf = torch.zeros(n, device=w.device, dtype=torch.float32)
+        if f16:
+            _lib.call("osa_deconv3d_pack_f16x3", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, ws, _stream())
+        else:
+            _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
+    else:
+        n = lib.osa_conv3d_packed_floats(Ci, Co, *k)
+        buf = torch.zeros(n, device=w.device, dtype=torch.float32)
+        tr, fl = {"fwd": (0, 0), "dgrad_s1": (1, 1), "dgrad_of_deconv": (0, 0)}[mode]
+        _lib.call("osa_conv3d_pack_ex", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, 1 if f16 else 0, ws, _stream())
+    return buf, 1.0 / ws
+
+
+def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape):
+    """x NDHWC (channels padded to 4). plain conv, no epilogue extras."""
+    B, Cs, D, H, W = x.shape
+    CoS = (Co + 3) // 4 * 4
+    y = empty_cl(B, CoS, *out_shape, x.device)
+    if CoS != Co:
+        y.zero_()
+    Ci4 = (Ci + 3) // 4 * 4
+    sfx, tail = ("f16x3", (oscale, _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+              B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
+              None, 0, 0, 0.0, *tail)
+    return y
+
+
+def _run_deconv(x, packed, oscale, Ci, Co, k, pad, opad, precision):
+    B, Cs, D, H, W = x.shape
+    CoS = (Co + 3) // 4 * 4
+    od = lambda n: (n - 1) * 2 - 2 * pad + k + opad
+    y = empty_cl(B, CoS, od(D), od(H), od(W), x.device)
+    if CoS != Co:
+        y.zero_()
+    Ci4 = (Ci + 3) // 4 * 4
+    sfx, tail = ("f16x3", (oscale, _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+              B, D, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
+    return y
+
+
+def _out(n, k, p, d, s):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class _Conv3d(torch.autograd.Function):
+    """y = conv3d(x, w) (no bias).  x: logical [B,Ci,D,H,W] (any strides); y: NDHWC-strided [B,Co,...]."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, dil, precision):
+        xc = to_cl(x)                               # NDHWC, channels padded to a multiple of 4 with zeros
+        wf = _f32c(w)
+        Co, Ci = wf.shape[:2]
+        k = tuple(wf.shape[2:])
+        packed, osc = _pack(wf, Ci, Co, k, "fwd", precision)
+        B, _, D, H, W = xc.shape
+        sd = 1 if (D == 1 and k[0] == 1) else stride
+        oshape = (_out(D, k[0], pad[0], dil[0], sd), _out(H, k[1], pad[1], dil[1], stride), _out(W, k[2], pad[2], dil[2], stride))
+        y = _run_conv(xc, packed, osc, Ci, Co, k, stride, pad, dil, precision, oshape)
+        ctx.save_for_backward(xc, wf)
+        ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
+        return y[:, :Co]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wf = ctx.saved_tensors
+        stride, pad, dil, precision, xshape, xdt = ctx.meta
+        Co, Ci = wf.shape[:2]
+        k = tuple(wf.shape[2:])
+        dyc = to_cl(dy)
+        B, _, D, H, W = xc.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                packed, osc = _pack(wf, Co, Ci, k, "dgrad_s1", precision)
+                p2 = tuple(dil[i] * (k[i] - 1) - pad[i] for i in range(3))
+                dxc = _run_conv(dyc, packed, osc, Co, Ci, k, 1, p2, dil, precision, (D, H, W))
+            else:
+                assert k == (3, 3, 3) and pad == (1, 1, 1) and dil == (1, 1, 1) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0, \
+                    "stride-2 data gradient: 3x3x3, pad 1, even input dims (what the aggregation networks use)"
+                packed, osc = _pack(wf, Co, Ci, k, "deconv", precision)       # w [Co][Ci][k] == transposed-conv layout [Cin_t][Cout_t]
+                dxc = _run_deconv(dyc, packed, osc, Co, Ci, 3, 1, 1, precision)
+            dx = dxc[:, :Ci].to(xdt)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wf)
+            Do, Ho, Wo = dyc.shape[2:]
+            _lib.call("osa_conv3d_wgrad_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
+                      Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2],
+                      dil[0], dil[1], dil[2], 0, _stream())
+        return dx, dw, None, None, None, None
+
+
+class _ConvTranspose3d(torch.autograd.Function):
+    """y = conv_transpose3d(x, w[Ci][Co][k], stride 2); k3/p1/op1 or k4/p1/op0."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad, opad, precision):
+        xc = to_cl(x)
+        wf = _f32c(w)
+        Ci, Co, k = wf.shape[0], wf.shape[1], wf.shape[2]
+        packed, osc = _pack(wf, Ci, Co, (k, k, k), "deconv", precision)
+        y = _run_deconv(xc, packed, osc, Ci, Co, k, pad, opad, precision)
+        ctx.save_for_backward(xc, wf)
+        ctx.meta = (pad, opad, precision, x.dtype)
+        return y[:, :Co]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wf = ctx.saved_tensors
+        pad, opad, precision, xdt = ctx.meta
+        Ci, Co, k = wf.shape[0], wf.shape[1], wf.shape[2]
+        dyc = to_cl(dy)
+        B, _, D, H, W = xc.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dx = conv(dy, w) with stride 2: w read as [Cout'=Ci][Cin'=Co][k]
+            packed, osc = _pack(wf, Co, Ci, (k, k, k), "dgrad_of_deconv", precision)
+            dxc = _run_conv(dyc, packed, osc, Co, Ci, (k, k, k), 2, (pad,) * 3, (1, 1, 1), precision, (D, H, W))
+            dx = dxc[:, :Ci].to(xdt)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(wf)
+            Do, Ho, Wo = dyc.shape[2:]
+            _lib.call("osa_conv3d_wgrad_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
+                      Do, Ho, Wo, Co, dyc.shape[1], k, k, k, 2, pad, pad, pad, 1, 1, 1, 1, _stream())
+        return dx, dw, None, None, None
+
+
+def _t3(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None):
+    """Differentiable F.conv3d (groups=1, isotropic stride 1|2) on the engine; output is NDHWC-strided."""
+    s = _t3(stride)
+    assert s[0] == s[1] == s[2]
+    y = _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), precision or engine.get_precision())
+    return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+
+def conv_transpose3d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
+    assert _t3(stride) == (2, 2, 2)
+    p, op = _t3(padding)[0], _t3(output_padding)[0]
+    y = _ConvTranspose3d.apply(x, weight, p, op, precision or engine.get_precision())
+    return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+
+
+def conv_module(m, x):
+    """Run an nn.Conv3d / nn.ConvTranspose3d module's arithmetic on the engine (training path)."""
+    if isinstance(m, torch.nn.ConvTranspose3d):
+        return conv_transpose3d(x, m.weight, m.bias, m.stride, m.padding, m.output_padding)
+    return conv3d(x, m.weight, m.bias, m.stride, m.padding, m.dilation)

@@ -423,6 +423,7 @@ static const KernelCfg g_cfgs[] = {
     OSA_CFG(1, 1, 4, 1, 8, 16),  // 12: 128 vox x 32 ch   brick 1x8x16  (2-D layers, more workgroups)
     OSA_CFG(1, 2, 4, 1, 8, 16),  // 13: 128 vox x 64 ch   brick 1x8x16
     OSA_CFG(1, 1, 2, 2, 4, 16),  // 14:  64 vox x 64 ch   brick 1x4x16  (2-D stride-2 layers)
+    OSA_CFG(1, 1, 2, 1, 4, 8),   // 15:  64 vox x 32 ch   brick 2x4x8   (stride-2 layers with <= 32 outputs; 2 waves)
 };
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -444,7 +445,7 @@ static int pick_cfg(const ConvArgs& a, int stride) {
         if (vox >= 200000) return (a.CoP % 64 == 0) ? 8 : 7;      // half-resolution maps: 256-pixel tiles
         return (a.CoP % 64 == 0) ? 13 : 12;                        // quarter-resolution maps: 128-pixel tiles
     }
-    if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 3);
+    if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 15);
     // measured on MI355X (tools/bench_layers.py): few-tap launches (1x1x1, transposed-conv parity
     // classes) and sub-megavoxel volumes prefer the 128-voxel bricks (more workgroups in flight)
     if (a.T <= 8) return 3;
@@ -489,7 +490,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     int ci = forced ? 0 : pick_cfg(a, stride);
     if (!forced && brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
         // e.g. a stride-2 3x3x3 layer whose output depth collapses to 1: fall back to the small bricks
-        static const int fallback[] = {5, 3, 11};
+        static const int fallback[] = {5, 15, 3, 11};
         for (int f : fallback)
             if (a.CoP % g_cfgs[f].N == 0 && brick_bytes(a, g_cfgs[f]) <= 160 * 1024) { ci = f; break; }
     }
@@ -676,17 +677,19 @@ static void launch_pack(const PackArgs& p, int prec, float wscale, hipStream_t s
 }
 
 static int conv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
-                            int kd, int kh, int kw, int prec, float wscale, void* stream) {
+                            int kd, int kh, int kw, int prec, float wscale, void* stream,
+                            int src_transposed = 0, int flip = 0) {
     OSA_REQUIRE(w_ref && w_packed, "conv3d_pack: NULL pointer");
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= MAX_TAPS, "conv3d_pack: %dx%dx%d kernel has %d taps (max %d)", kd, kh, kw, T, MAX_TAPS);
     OSA_REQUIRE(Ci > 0 && Co > 0, "conv3d_pack: bad channels %d->%d", Ci, Co);
     PackArgs p;
     p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
-    p.kd = kd; p.kh = kh; p.kw = kw; p.T = T; p.nchunks = nchunks_of(Ci); p.transposed = 0;
+    p.kd = kd; p.kh = kh; p.kw = kw; p.T = T; p.nchunks = nchunks_of(Ci); p.transposed = src_transposed ? 1 : 0;
     int t = 0;
     for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int x = 0; x < kw; ++x, ++t) {
-        p.kz[t] = (signed char)z; p.ky[t] = (signed char)y; p.kx[t] = (signed char)x;
+        p.kz[t] = (signed char)(flip ? kd - 1 - z : z); p.ky[t] = (signed char)(flip ? kh - 1 - y : y);
+        p.kx[t] = (signed char)(flip ? kw - 1 - x : x);
     }
     launch_pack(p, prec, wscale, (hipStream_t)stream);
     OSA_LAUNCH_CHECK("conv3d_pack");
@@ -696,6 +699,20 @@ static int conv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
 extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
                                    int kd, int kh, int kw, void* stream) {
     return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, PREC_F32, 1.f, stream);
+}
+
+// Generic packing for backward passes: Ci/Co are the roles of the convolution that will be EXECUTED;
+// src_transposed=1 reads w_ref as [Ci][Co][k] instead of [Co][Ci][k]; flip=1 mirrors the taps.
+//   data-gradient of a stride-1 conv (weight [Co][Ci][k]) = conv with roles swapped:
+//       pack_ex(Ci' = Co, Co' = Ci, src_transposed = 1, flip = 1), padding' = dil*(k-1) - pad
+//   data-gradient of a ConvTranspose3d (weight [Ci][Co][k]) = strided conv:
+//       pack_ex(Ci' = Co, Co' = Ci, src_transposed = 0, flip = 0)
+extern "C" int osa_conv3d_pack_ex(const float* w_ref, float* w_packed, int Ci, int Co,
+                                  int kd, int kh, int kw, int src_transposed, int flip,
+                                  int f16x3, float wscale, void* stream) {
+    OSA_REQUIRE(wscale > 0.f, "conv3d_pack_ex: wscale must be a positive power of two");
+    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, f16x3 ? PREC_F16X3 : PREC_F32, wscale, stream,
+                            src_transposed, flip);
 }
 
 extern "C" int osa_conv3d_pack_f16x3(const float* w_ref, float* w_packed, int Ci, int Co,

@@ -1,0 +1,217 @@
+// Weight gradient of the 3-D convolutions on the fp32 matrix cores (training).
+//
+//   dW[a][b][t] = sum_{batch, pos}  P[pos][a] * Q[pos*s + off_t][b]
+//     Conv3d          (weight [Co][Ci][k]) : P = dy (a = co) at output positions, Q = x  (b = ci), off_t = t*dil - pad
+//     ConvTranspose3d (weight [Ci][Co][k]) : P = x  (a = ci) at input  positions, Q = dy (b = co), off_t = t - pad, s = 2
+// i.e. one kernel: for every tap a 32x32 (a x b) GEMM whose K dimension is the voxel axis.
+//
+// A workgroup owns one 32x32 (a,b) tile pair, a group of taps (one kd plane) and a strip of position
+// bricks.  Per brick it stages the P tile [pos][32] and the Q brick (halo included) [vox][32] into LDS;
+// each of the 4 waves takes a quarter of the positions, keeps its P operands in registers and streams
+// Q operands per tap: v_mfma_f32_32x32x2_f32 with K = 2 positions per instruction, one accumulator
+// tile per tap kept in registers across ALL bricks of the strip, so only one round of float atomics
+// per workgroup reaches the [a][b][t] gradient buffer.
+#include "osa_common.h"
+#include <cstring>
+
+namespace osa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_TAPS = 9;        // taps per workgroup (register accumulators: 9 x 16)
+constexpr int WG_PS = 36;         // LDS row stride (floats) of a 32-channel voxel: conflict-free column reads
+
+struct WgradArgs {
+    const float* P; const float* Q; float* dW;
+    int B;
+    int Pd, Ph, Pw, PC, PCs;      // P tensor dims (positions) / channels / voxel stride
+    int Qd, Qh, Qw, QC, QCs;      // Q tensor
+    int s;                        // Q position = pos*s + off
+    int T;                        // total taps (kd*kh*kw)
+    int kh, kw, kvol;
+    int tgroups;                  // ceil(T / WG_TAPS)
+    int tilesD, tilesH, tilesW, strip;   // position bricks; `strip` consecutive w-bricks per workgroup
+    int LD, LH, LW;               // Q brick dims
+    int dmin, hmin, wmin;
+    int A, Bc;                    // number of a / b channels (dW is [A][Bc][kvol])
+    signed char od[64], oh[64], ow[64];  // per-tap Q offsets (k = 4 transposed convs have 64 taps)
+};
+
+template <int TD, int TH, int TW>     // position brick, TD*TH*TW = 256 (64 per wave) or 64 (16 per wave)
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    constexpr int NPOS = TD * TH * TW;
+    constexpr int PER_WAVE = NPOS / 4;
+    constexpr int KSTEPS = PER_WAVE / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ps = smem;                          // [NPOS][WG_PS]
+    float* Qs = smem + NPOS * WG_PS;           // [LD*LH*LW][WG_PS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hh = lane >> 5;
+
+    // blockIdx.x -> (strip index over bricks, tap group); blockIdx.y -> (a tile, b tile)
+    const int tg = blockIdx.x % p.tgroups;
+    int sidx = blockIdx.x / p.tgroups;
+    const int atiles = (p.A + 31) / 32;
+    const int a0 = (blockIdx.y % atiles) * 32, b0 = (blockIdx.y / atiles) * 32;
+    const int t0 = tg * WG_TAPS;
+    const int nt = (p.T - t0 < WG_TAPS) ? (p.T - t0) : WG_TAPS;
+    const int nstripsW = (p.tilesW + p.strip - 1) / p.strip;
+    const int sw = sidx % nstripsW; sidx /= nstripsW;
+    const int thi = sidx % p.tilesH; sidx /= p.tilesH;
+    const int tdi = sidx % p.tilesD; const int b = sidx / p.tilesD;
+
+    f32x16 acc[WG_TAPS];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nQ = p.LD * p.LH * p.LW;
+    for (int twi = sw * p.strip; twi < (sw + 1) * p.strip && twi < p.tilesW; ++twi) {
+        const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
+        __syncthreads();
+        // ---- stage P tile: NPOS positions x 32 channels (zero outside the tensor / channel range)
+        for (int it = tid; it < NPOS * 8; it += 256) {
+            const int c4 = it & 7, q = it >> 3;
+            const int pw = q % TW, ph = (q / TW) % TH, pd = q / (TW * TH);
+            const int gd = p0d + pd, gh = p0h + ph, gw = p0w + pw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gd < p.Pd && gh < p.Ph && gw < p.Pw) {
+                const float* src = p.P + ((((size_t)b * p.Pd + gd) * p.Ph + gh) * p.Pw + gw) * p.PCs + a0 + c4 * 4;
+                if (a0 + c4 * 4 + 3 < p.PC) v = *reinterpret_cast<const float4*>(src);
+                else { if (a0 + c4 * 4 < p.PC) v.x = src[0]; if (a0 + c4 * 4 + 1 < p.PC) v.y = src[1]; if (a0 + c4 * 4 + 2 < p.PC) v.z = src[2]; }
+            }
+            *reinterpret_cast<float4*>(Ps + q * WG_PS + c4 * 4) = v;
+        }
+        // ---- stage Q brick
+        const int q0d = p0d * p.s + p.dmin, q0h = p0h * p.s + p.hmin, q0w = p0w * p.s + p.wmin;
+        for (int it = tid; it < nQ * 8; it += 256) {
+            const int c4 = it & 7, v_ = it >> 3;
+            const int lw = v_ % p.LW, lh = (v_ / p.LW) % p.LH, ld = v_ / (p.LW * p.LH);
+            const int gd = q0d + ld, gh = q0h + lh, gw = q0w + lw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh && (unsigned)gw < (unsigned)p.Qw) {
+                const float* src = p.Q + ((((size_t)b * p.Qd + gd) * p.Qh + gh) * p.Qw + gw) * p.QCs + b0 + c4 * 4;
+                if (b0 + c4 * 4 + 3 < p.QC) v = *reinterpret_cast<const float4*>(src);
+                else { if (b0 + c4 * 4 < p.QC) v.x = src[0]; if (b0 + c4 * 4 + 1 < p.QC) v.y = src[1]; if (b0 + c4 * 4 + 2 < p.QC) v.z = src[2]; }
+            }
+            *reinterpret_cast<float4*>(Qs + v_ * WG_PS + c4 * 4) = v;
+        }
+        __syncthreads();
+        // ---- this wave's positions: K steps of 2 positions (k = hh selects the position of the pair)
+        float areg[KSTEPS];
+        int qbase[KSTEPS];
+#pragma unroll
+        for (int k = 0; k < KSTEPS; ++k) {
+            const int q = wave * PER_WAVE + 2 * k + hh;
+            areg[k] = Ps[q * WG_PS + col];
+            const int pw = q % TW, ph = (q / TW) % TH, pd = q / (TW * TH);
+            qbase[k] = (((pd * p.s) * p.LH + ph * p.s) * p.LW + pw * p.s) * WG_PS + col;
+        }
+#pragma unroll
+        for (int t = 0; t < WG_TAPS; ++t) {
+            if (t < nt) {
+                const int tt = t0 + t;
+                const int toff = (((p.od[tt] - p.dmin) * p.LH + (p.oh[tt] - p.hmin)) * p.LW + (p.ow[tt] - p.wmin)) * WG_PS;
+#pragma unroll
+                for (int k = 0; k < KSTEPS; ++k)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[k], Qs[qbase[k] + toff], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- one round of atomics: dW[a][b][tap]
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t) {
+        if (t < nt) {
+            const int tt = t0 + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int a = a0 + (r & 3) + 8 * (r >> 2) + 4 * hh, bb = b0 + col;
+                if (a < p.A && bb < p.Bc) atomicAdd(p.dW + ((size_t)a * p.Bc + bb) * p.kvol + tt, acc[t][r]);
+            }
+        }
+    }
+}
+
+}  // namespace osa
+
+using namespace osa;
+
+// conv:   P = dy [B,Do,Ho,Wo,Co]  Q = x  [B,Di,Hi,Wi,Ci]  dW [Co][Ci][k]   (transposed = 0)
+// deconv: P = x  [B,Di,Hi,Wi,Ci]  Q = dy [B,Do,Ho,Wo,Co]  dW [Ci][Co][k]   (transposed = 1, stride 2, off = t - pad)
+extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
+                                    int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                    int Do, int Ho, int Wo, int Co, int dyCs,
+                                    int kd, int kh, int kw, int stride,
+                                    int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                                    int transposed, void* stream) {
+    OSA_REQUIRE(x && dy && dw, "conv3d_wgrad: NULL pointer");
+    const int T = kd * kh * kw;
+    OSA_REQUIRE(T >= 1 && T <= 64, "conv3d_wgrad: %d taps unsupported", T);
+    OSA_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride %d unsupported", stride);
+    OSA_REQUIRE(xCs % 4 == 0 && dyCs % 4 == 0 && (((size_t)x | (size_t)dy) & 15) == 0,
+                "conv3d_wgrad: tensors must be 16-byte aligned with voxel strides %% 4 == 0");
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.kh = kh; a.kw = kw; a.kvol = T;
+    a.s = (transposed ? 2 : stride);
+    const int sd = (!transposed && Di == 1 && kd == 1) ? 1 : a.s;
+    OSA_REQUIRE(sd == a.s, "conv3d_wgrad: flat (D=1) strided layers are not supported yet");
+    if (!transposed) {
+        a.P = dy; a.Pd = Do; a.Ph = Ho; a.Pw = Wo; a.PC = Co; a.PCs = dyCs;
+        a.Q = x; a.Qd = Di; a.Qh = Hi; a.Qw = Wi; a.QC = Ci; a.QCs = xCs;
+        a.A = Co; a.Bc = Ci;
+    } else {
+        OSA_REQUIRE(stride == 2, "conv3d_wgrad: transposed convs are stride 2");
+        a.P = x; a.Pd = Di; a.Ph = Hi; a.Pw = Wi; a.PC = Ci; a.PCs = xCs;
+        a.Q = dy; a.Qd = Do; a.Qh = Ho; a.Qw = Wo; a.QC = Co; a.QCs = dyCs;
+        a.A = Ci; a.Bc = Co;
+    }
+    a.dW = dw;
+    int t = 0, dmax = -128, hmax = -128, wmax = -128;
+    a.dmin = a.hmin = a.wmin = 127;
+    for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int xx = 0; xx < kw; ++xx, ++t) {
+        const int od = transposed ? z - pad_d : z * dil_d - pad_d;
+        const int oh = transposed ? y - pad_h : y * dil_h - pad_h;
+        const int ow = transposed ? xx - pad_w : xx * dil_w - pad_w;
+        a.od[t] = (signed char)od; a.oh[t] = (signed char)oh; a.ow[t] = (signed char)ow;
+        a.dmin = od < a.dmin ? od : a.dmin; dmax = od > dmax ? od : dmax;
+        a.hmin = oh < a.hmin ? oh : a.hmin; hmax = oh > hmax ? oh : hmax;
+        a.wmin = ow < a.wmin ? ow : a.wmin; wmax = ow > wmax ? ow : wmax;
+    }
+    a.tgroups = cdiv(T, WG_TAPS);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.A * a.Bc * T * sizeof(float), st);
+    OSA_REQUIRE(e == hipSuccess, "conv3d_wgrad: memset failed: %s", hipGetErrorString(e));
+    const bool small = (a.s == 2);
+    int TD = small ? 2 : 4, TH = small ? 4 : 8;
+    const int TW = 8;
+    // k = 4 transposed convs: the strided Q brick of a 2x4x8 position tile does not fit -> 2x2x8
+    const bool tiny = small && ((size_t)(TD * TH * TW + ((TD - 1) * 2 + (dmax - a.dmin) + 1) * ((TH - 1) * 2 + (hmax - a.hmin) + 1) *
+                                         ((TW - 1) * 2 + (wmax - a.wmin) + 1)) * WG_PS * sizeof(float) > 160 * 1024);
+    if (tiny) TH = 2;
+    a.LD = (TD - 1) * a.s + (dmax - a.dmin) + 1;
+    a.LH = (TH - 1) * a.s + (hmax - a.hmin) + 1;
+    a.LW = (TW - 1) * a.s + (wmax - a.wmin) + 1;
+    a.tilesD = cdiv(a.Pd, TD); a.tilesH = cdiv(a.Ph, TH); a.tilesW = cdiv(a.Pw, TW);
+    a.strip = a.tilesW;                                       // a whole row of bricks per workgroup
+    const size_t lds = ((size_t)TD * TH * TW + (size_t)a.LD * a.LH * a.LW) * WG_PS * sizeof(float);
+    OSA_REQUIRE(lds <= 160 * 1024, "conv3d_wgrad: %zu B of LDS needed", lds);
+    const long long gx = (long long)B * a.tilesD * a.tilesH * cdiv(a.tilesW, a.strip) * a.tgroups;
+    const int gy = cdiv(a.A, 32) * cdiv(a.Bc, 32);
+    OSA_REQUIRE(gx < (1ll << 31) && gy <= 65535, "conv3d_wgrad: grid too large");
+    dim3 grid((unsigned)gx, gy), block(256);
+    if (tiny) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<2, 2, 8>), grid, block, lds, st, a);
+    } else if (small) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<2, 4, 8>), grid, block, lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<4, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<4, 8, 8>), grid, block, lds, st, a);
+    }
+    OSA_LAUNCH_CHECK("conv3d_wgrad");
+    return 0;
+}

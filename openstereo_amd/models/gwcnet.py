@@ -17,8 +17,23 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+import torch.nn.functional as F
+
+from .. import autograd as AG
 from .. import ops, timing
 from ..engine import PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+
+
+def run_train(mod, x):
+    """Training-mode execution of a reference-shaped module tree: every Conv3d / ConvTranspose3d runs on
+    the engine through its autograd Function; BatchNorm (batch statistics), ReLU etc. stay torch modules."""
+    if isinstance(mod, (nn.Conv3d, nn.ConvTranspose3d)):
+        return AG.conv_module(mod, x)
+    if isinstance(mod, nn.Sequential):
+        for child in mod:
+            x = run_train(child, x)
+        return x
+    return mod(x)
 
 
 # ----------------------------------------------------------------------------- 2-D backbone
@@ -173,6 +188,12 @@ class GwcVolumeCostProcessor(nn.Module):
     def forward(self, inputs):
         l, r = inputs["ref_feature"], inputs["tgt_feature"]
         cat = self.use_concat_volume
+        if self.training or (torch.is_grad_enabled() and l["gwc_feature"].requires_grad):
+            D4 = self.maxdisp // self.downsample
+            vol = AG.build_gwc_volume(l["gwc_feature"], r["gwc_feature"], D4, self.num_groups)
+            if cat:
+                vol = torch.cat((vol, AG.build_concat_volume(l["concat_feature"], r["concat_feature"], D4)), 1)
+            return {"cost_volume": vol}
         vol = ops.build_cost_volume_cl(
             l["gwc_feature"], r["gwc_feature"], self.num_groups,
             l["concat_feature"] if cat else None, r["concat_feature"] if cat else None,
@@ -226,10 +247,18 @@ class Hourglass(nn.Module):
         c5 = p["c5"](c4, residual=p["r2"](c2))     # relu(conv5(c4) + redir2(c2))
         return p["c6"](c5, residual=p["r1"](x))    # relu(conv6(c5) + redir1(x))
 
+    def forward_train(self, x):
+        """hourglass.py:46-56 with autograd: convs on the engine, BN/ReLU/add in torch."""
+        c1 = run_train(self.conv1, x)
+        c2 = run_train(self.conv2, c1)
+        c4 = run_train(self.conv4, run_train(self.conv3, c2))
+        c5 = F.relu(run_train(self.conv5, c4) + run_train(self.redir2, c2))
+        return F.relu(run_train(self.conv6, c5) + run_train(self.redir1, x))
+
     def forward(self, x):
-        """Drop-in: NCDHW in -> NCDHW out (eval-mode BN)."""
-        if self.training:
-            raise NotImplementedError("engine Hourglass: training-mode BatchNorm is not built yet")
+        """Drop-in: NCDHW in -> NCDHW out.  Gradients required or training mode -> autograd path."""
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x)
         return ops.to_ncdhw(self.forward_cl(ops.to_cl(x)), channels=x.shape[1])
 
 
@@ -275,9 +304,24 @@ class GwcDispProcessor(nn.Module):
         out3 = self.dres4.forward_cl(self.dres3.forward_cl(self.dres2.forward_cl(cost0)))
         return p["k2"](p["k0"](out3))
 
+    def forward_train(self, inputs):
+        """gwcnet_disp_processor.py:83-126: four supervised outputs, everything differentiable."""
+        volume = inputs["cost_volume"]
+        h, w = inputs["left"].shape[2:]
+        cost0 = run_train(self.dres0, volume)
+        cost0 = run_train(self.dres1, cost0) + cost0
+        out1 = self.dres2.forward_train(cost0)
+        out2 = self.dres3.forward_train(out1)
+        out3 = self.dres4.forward_train(out2)
+        preds = []
+        for head, feat in ((self.classif0, cost0), (self.classif1, out1), (self.classif2, out2), (self.classif3, out3)):
+            cost = run_train(head, feat)                                  # [B,1,D/4,H/4,W/4]
+            preds.append(AG.upsample_softargmin(cost, self.maxdisp, h, w, align_corners=False))
+        return {"training_disp": {"disp": {"disp_ests": preds}}}
+
     def forward(self, inputs):
         if self.training:
-            raise NotImplementedError("engine GwcDispProcessor: training branch is not built yet")
+            return self.forward_train(inputs)
         volume = inputs["cost_volume"]
         h, w = inputs["left"].shape[2:]
         if not ops.is_cl(volume) or volume.shape[1] % 4:
@@ -330,4 +374,16 @@ class GwcNet(nn.Module):
             inputs.update(self.Backbone(inputs))
             inputs.update(self.CostProcessor(inputs))
         disp_out = self.DispProcessor(inputs)
+        if self.training:
+            ests = disp_out["training_disp"]["disp"]["disp_ests"]
+            return {"disp_preds": ests, "disp_pred": ests[-1]}
         return {"disp_pred": disp_out["inference_disp"]["disp_est"]}
+
+    def get_loss(self, model_preds, input_data):
+        """models/gwcnet/gwcnet.py:42-53."""
+        disp_gt = input_data["disp"]
+        mask = (disp_gt < self.maxdisp) & (disp_gt > 0)
+        loss = 0.0
+        for disp_est, weight in zip(model_preds["disp_preds"], [0.5, 0.5, 0.7, 1.0]):
+            loss = loss + weight * F.smooth_l1_loss(disp_est[mask], disp_gt[mask], reduction="mean")
+        return loss, {"scalar/train/loss_disp": loss.item()}

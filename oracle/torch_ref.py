@@ -354,3 +354,26 @@ def context_upsample(disp_low, up_weights, scale_factor=4):
     unf = F.unfold(disp_low, kernel_size=3, dilation=1, padding=1).reshape(b, -1, h, w)
     unf = F.interpolate(unf, (h * scale_factor, w * scale_factor), mode="nearest")
     return (unf * up_weights).sum(1)
+
+
+# ============================================================================= training branch (autograd oracle)
+def gwc_train_preds(volume, sd, maxdisp, h, w, p="DispProcessor"):
+    """gwcnet_disp_processor.py:93-126 with eval-mode (frozen) BatchNorm: the four supervised disparities.
+    Built from differentiable torch ops, so torch.autograd on it is the gradient oracle."""
+    x = F.relu(convbn3d(volume, sd, p + ".dres0.0"))
+    x = F.relu(convbn3d(x, sd, p + ".dres0.2"))
+    cost0 = convbn3d(F.relu(convbn3d(x, sd, p + ".dres1.0")), sd, p + ".dres1.2") + x
+    out1 = gwc_hourglass(cost0, sd, p + ".dres2")
+    out2 = gwc_hourglass(out1, sd, p + ".dres3")
+    out3 = gwc_hourglass(out2, sd, p + ".dres4")
+    preds = []
+    for i, feat in enumerate((cost0, out1, out2, out3)):
+        z = F.relu(convbn3d(feat, sd, f"{p}.classif{i}.0"))
+        preds.append(upsample_regression(F.conv3d(z, sd[f"{p}.classif{i}.2.weight"], None, 1, 1), maxdisp, h, w, False))
+    return preds
+
+
+def gwc_loss(preds, disp_gt, maxdisp):
+    """models/gwcnet/gwcnet.py:42-53 (smooth-L1, weights 0.5/0.5/0.7/1.0, mask 0 < gt < maxdisp)."""
+    mask = (disp_gt < maxdisp) & (disp_gt > 0)
+    return sum(wt * F.smooth_l1_loss(p_[mask], disp_gt[mask], reduction="mean") for p_, wt in zip(preds, [0.5, 0.5, 0.7, 1.0]))

@@ -1,0 +1,153 @@
+"""GPU: backward kernels (training path) against torch-CPU autograd of the oracle restatement."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from openstereo_amd.utils.weights import synth_state_dict, synth_images, synth_tensor
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def rn(shape, seed, scale=1.0):
+    return T((np.random.default_rng(seed).normal(0, 1, shape) * scale).astype(np.float32))
+
+
+def close(a, b, atol, rtol, what):
+    a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b); tol = atol + rtol * np.abs(b)
+    if not (err <= tol).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: max|err|={err.max():.3e} at {i}: got {a[i]} want {b[i]} ({(err > tol).mean() * 100:.2f}% out)")
+
+
+def test_volume_backward_vs_oracle_autograd():
+    from openstereo_amd import autograd as AG
+    from oracle import torch_ref as O
+    L, R = rn((2, 16, 5, 23), 1), rn((2, 16, 5, 23), 2)
+    for name, f_ref, f_eng in (
+            ("gwc", lambda l, r: O.gwc_volume(l, r, 9, 4), lambda l, r: AG.build_gwc_volume(l, r, 9, 4)),
+            ("concat", lambda l, r: O.concat_volume(l, r, 9), lambda l, r: AG.build_concat_volume(l, r, 9)),
+            ("concat-igev", lambda l, r: O.concat_volume(l, r, 9, False), lambda l, r: AG.build_concat_volume(l, r, 9, False)),
+            ("corr", lambda l, r: O.corr_volume(l, r, 9), lambda l, r: AG.correlation_volume(l, r, 9))):
+        lc, rc = L.clone().requires_grad_(), R.clone().requires_grad_()
+        v = f_ref(lc, rc)
+        gv = rn(tuple(v.shape), 3)
+        v.backward(gv)
+        lg, rg = L.to(DEV).requires_grad_(), R.to(DEV).requires_grad_()
+        ve = f_eng(lg, rg)
+        close(ve, v, 1e-6, 1e-6, name + " fwd")
+        ve.backward(gv.to(DEV))
+        close(lg.grad, lc.grad, 2e-6, 1e-5, name + " dL")
+        close(rg.grad, rc.grad, 2e-6, 1e-5, name + " dR")
+
+
+def test_regression_backward_vs_oracle_autograd():
+    from openstereo_amd import autograd as AG
+    from oracle import torch_ref as O
+    cost = rn((2, 12, 7, 9), 4, 2.0)
+    g = rn((2, 7, 9), 5)
+    c1 = cost.clone().requires_grad_(); O.softmax_regression(c1, keepdim=False).backward(g)
+    c2 = cost.to(DEV).requires_grad_(); AG.softmax_disparity_regression(c2, keepdim=False).backward(g.to(DEV))
+    close(c2.grad, c1.grad, 1e-6, 1e-5, "softmax+regression dcost")
+    prob = F.softmax(cost, 1)
+    p1 = prob.clone().requires_grad_(); O.disparity_regression(p1, 12, False).backward(g)
+    p2 = prob.to(DEV).requires_grad_(); AG.disparity_regression(p2, 12, False).backward(g.to(DEV))
+    close(p2.grad, p1.grad, 1e-6, 1e-6, "regression dprob")
+    low = rn((2, 1, 6, 5, 7), 6, 2.0)
+    for align, (D, H, W) in ((False, (24, 20, 28)), (True, (24, 20, 28)), (False, (17, 13, 21))):
+        gg = rn((2, H, W), 7)
+        l1 = low.clone().requires_grad_(); O.upsample_regression(l1, D, H, W, align).backward(gg)
+        l2 = low.to(DEV).requires_grad_(); AG.upsample_softargmin(l2, D, H, W, align).backward(gg.to(DEV))
+        close(l2.grad, l1.grad, 2e-5, 1e-4, f"upsample_softargmin dcost align={align} {D}x{H}x{W}")
+
+
+CONV_BWD = [  # name, Ci, Co, k, stride, pad, dil, dims
+    ("32-32 s1", 32, 32, 3, 1, 1, 1, (6, 9, 12)),
+    ("64-32 s1 ragged", 64, 32, 3, 1, 1, 1, (5, 7, 11)),
+    ("32-64 s2", 32, 64, 3, 2, 1, 1, (8, 12, 16)),
+    ("1x1 32-32", 32, 32, 1, 1, 0, 1, (4, 5, 9)),
+    ("24-8 s1", 24, 8, 3, 1, 1, 1, (4, 6, 10)),
+    ("32-1 head", 32, 1, 3, 1, 1, 1, (5, 6, 9)),
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", CONV_BWD, ids=[c[0] for c in CONV_BWD])
+def test_conv3d_backward_vs_torch_autograd(case, prec):
+    from openstereo_amd import autograd as AG
+    name, Ci, Co, k, s, p, dil, (D, H, W) = case
+    w = synth_tensor(name + ".w", (Co, Ci, k, k, k), 1) * 3.0
+    x = rn((2, Ci, D, H, W), 3)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = F.conv3d(xr, wr, None, s, p, dil)
+    gy = rn(tuple(y.shape), 4)
+    y.backward(gy)
+    xe, we = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    ye = AG.conv3d(xe, we, None, s, p, dil, precision=prec)
+    close(ye, y, 3e-5, 3e-5, f"{name} fwd [{prec}]")
+    ye.backward(gy.to(DEV))
+    close(xe.grad, xr.grad, 5e-5, 5e-5, f"{name} dx [{prec}]")
+    close(we.grad, wr.grad, 2e-4, 1e-4, f"{name} dw [{prec}]")
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("case", [("k3 64-32", 64, 32, 3, 1, 1, (3, 5, 7)), ("k4 16-8", 16, 8, 4, 1, 0, (4, 5, 6))], ids=["k3", "k4"])
+def test_conv_transpose3d_backward_vs_torch_autograd(case, prec):
+    from openstereo_amd import autograd as AG
+    name, Ci, Co, k, p, op, (D, H, W) = case
+    w = synth_tensor(name + ".w", (Ci, Co, k, k, k), 1) * 3.0
+    x = rn((2, Ci, D, H, W), 3)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = F.conv_transpose3d(xr, wr, None, 2, p, op)
+    gy = rn(tuple(y.shape), 4)
+    y.backward(gy)
+    xe, we = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    ye = AG.conv_transpose3d(xe, we, None, 2, p, op, precision=prec)
+    close(ye, y, 3e-5, 3e-5, f"{name} fwd [{prec}]")
+    ye.backward(gy.to(DEV))
+    close(xe.grad, xr.grad, 5e-5, 5e-5, f"{name} dx [{prec}]")
+    close(we.grad, wr.grad, 2e-4, 1e-4, f"{name} dw [{prec}]")
+
+
+def test_gwcnet_training_step_vs_oracle_autograd():
+    """One training step of GwcNet (frozen-BN semantics: BN modules in eval mode as common_utils.freeze_bn
+    does) on a 64x128 pair: loss and parameter gradients against torch-CPU autograd of the oracle."""
+    from openstereo_amd.models.gwcnet import GwcNet
+    from oracle import torch_ref as O
+    net = GwcNet()
+    sd = synth_state_dict(net, seed=0)
+    net.load_state_dict(sd)
+    L, R = synth_images(1, 64, 128, seed=1)
+    gt = T(np.random.default_rng(8).uniform(1.0, 100.0, (1, 64, 128)).astype(np.float32))
+    # ---- oracle (CPU autograd)
+    keys = ["DispProcessor.dres0.0.0.weight", "DispProcessor.dres1.2.0.weight", "DispProcessor.dres2.conv1.0.0.weight",
+            "DispProcessor.dres3.conv5.0.weight", "DispProcessor.dres4.redir1.0.weight", "DispProcessor.classif0.2.weight",
+            "DispProcessor.classif3.0.0.weight", "DispProcessor.dres2.conv2.0.1.weight", "Backbone.feature_extraction.lastconv.2.weight",
+            "Backbone.feature_extraction.layer4.2.conv2.0.weight"]
+    sdr = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_()
+    lg, lc = O.gwc_features(L, sdr); rg, rc = O.gwc_features(R, sdr)
+    vol = torch.cat((O.gwc_volume(lg, rg, 48, 40), O.concat_volume(lc, rc, 48)), 1)
+    loss_ref = O.gwc_loss(O.gwc_train_preds(vol, sdr, 192, 64, 128), gt, 192)
+    loss_ref.backward()
+    # ---- engine
+    net = net.to(DEV).train()
+    for m in net.modules():
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.eval()                                  # freeze_bn (common_utils.py:114-120)
+    out = net({"left": L.to(DEV), "right": R.to(DEV)})
+    assert len(out["disp_preds"]) == 4
+    loss, info = net.get_loss(out, {"disp": gt.to(DEV)})
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-3 * max(1.0, abs(float(loss_ref))), (float(loss), float(loss_ref))
+    params = dict(net.named_parameters())
+    for k in keys:
+        g, gr = params[k].grad, sdr[k].grad
+        scale = float(gr.abs().max()) + 1e-12
+        close(g, gr, 2e-3 * scale, 2e-3, f"grad {k}")
