@@ -151,3 +151,33 @@ def test_gwcnet_training_step_vs_oracle_autograd():
         g, gr = params[k].grad, sdr[k].grad
         scale = float(gr.abs().max()) + 1e-12
         close(g, gr, 2e-3 * scale, 2e-3, f"grad {k}")
+
+
+def test_ddp_wrapped_training_steps_reduce_loss():
+    """The autograd Functions under stock DistributedDataParallel (world_size 1, nccl == RCCL): DDP's
+    gradient hooks fire, an optimiser step lowers the loss."""
+    import os
+    import torch.distributed as dist
+    from openstereo_amd.models.gwcnet import GwcNet
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        net = GwcNet()
+        net.load_state_dict(synth_state_dict(net, seed=0))
+        net = net.to(DEV).train()
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        opt = torch.optim.SGD(ddp.parameters(), lr=1e-4)
+        L, R = synth_images(1, 64, 128, seed=1)
+        gt = T(np.random.default_rng(8).uniform(1.0, 100.0, (1, 64, 128)).astype(np.float32)).to(DEV)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            out = ddp({"left": L.to(DEV), "right": R.to(DEV)})
+            loss, _ = net.get_loss(out, {"disp": gt})
+            loss.backward()
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.DispProcessor.parameters())
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert losses[-1] < losses[0], losses
+    finally:
+        dist.destroy_process_group()
