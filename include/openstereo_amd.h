@@ -240,6 +240,32 @@ int osa_context_upsample_f32(const float* disp_low, const float* weights, float*
                              int B, int h, int w, int scale, int softmax_weights, float gain,
                              void* stream);
 
+/* ---- geometry-encoding volume of the GRU loop ---------- */
+/* models/stereobase/gru_blocks.py:170-229, models/igev/geometry.py:7-66 */
+/* corr[b,h,w1,w2] = sum_c fmap1[b,c,h,w1] * fmap2[b,c,h,w2]; fmaps NCHW, corr [B,H,W1,W2] */
+int osa_allpairs_corr_f32(const float* fmap1, const float* fmap2, float* corr,
+                          int B, int C, int H, int W1, int W2, void* stream);
+/* NDHWC geometry volume [B,D,H,W,Cs] (first C channels) -> per-pixel rows [B,H,W,C,D] */
+int osa_geo_rows_f32(const float* vol_ndhwc, float* rows, int B, int D, int H, int W, int C, int Cs, void* stream);
+/* y[r, j] = (x[r,2j] + x[r,2j+1]) / 2, j < n/2   (F.avg_pool2d(.,[1,2],stride=[1,2]) along the row axis) */
+int osa_avgpool_rows_f32(const float* x, float* y, long long rows, int n, void* stream);
+/* One GRU-iteration lookup: out [B,(C+1)*(2r+1)*levels,H,W]; geo_levels[l] rows [B,H,W,C,geo_len[l]],
+ * corr_levels[l] rows [B,H,W,corr_len[l]] (HOST arrays of device pointers / lengths); disp, coords_x [B,H,W]. */
+int osa_geo_lookup_f32(const float* const* geo_levels, const float* const* corr_levels,
+                       const int* geo_len, const int* corr_len, int levels,
+                       const float* disp, const float* coords_x, float* out,
+                       int B, int H, int W, int C, int radius, void* stream);
+
+/* ---- input pre-processing on device ------------------------- */
+/* RightTopPad(edge) + HWC->CHW + /255 + (x-mean)/std for the left and right image in one launch
+ * (stereo_trans.py:243-267, :22-29, :48-56).  left/right: device HWC images [H][W][3], uint8 (is_u8=1)
+ * or float32; mean3/std3: HOST pointers to 3 floats.  out: layout 0 = NCHW [2,3,Hp,Wp] (left first),
+ * layout 1 = NHWC4 [2,Hp,Wp,4] (4th channel zero; the engine backbone's input layout). */
+int osa_preprocess_pair_f32(const void* left_hwc, const void* right_hwc, int is_u8,
+                            int H, int W, int Hp, int Wp,
+                            const float* mean3, const float* std3,
+                            float* out, int layout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

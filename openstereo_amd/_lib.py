@@ -79,6 +79,12 @@ SIGNATURES = {
     "osa_softmax_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_context_upsample_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
+    "osa_allpairs_corr_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_geo_rows_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_avgpool_rows_f32": (c_i, [c_fp, c_fp, c_ll, c_i, c_st]),
+    "osa_geo_lookup_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
+                                 c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_preprocess_pair_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_fp, c_i, c_st]),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -1,0 +1,177 @@
+// Geometry-encoding volume of StereoBase / IGEV's GRU loop.
+//   reference: models/stereobase/gru_blocks.py:170-229 (CombinedGeoEncodingVolume),
+//              models/igev/geometry.py:7-66 (Combined_Geo_Encoding_Volume)
+//  * allpairs_corr : corr[b,h,w1,w2] = sum_c f1[b,c,h,w1] * f2[b,c,h,w2]          (einsum 'aijk,aijh->ajkh')
+//  * geo_rows      : NDHWC geometry volume -> per-pixel rows [B,H,W,C,D] (the reference's
+//                    permute(0,3,4,1,2).reshape(b*h*w, c, 1, d)), lookup-friendly: one row = D contiguous floats
+//  * avgpool_rows  : F.avg_pool2d(x, [1,2], stride=[1,2]) along the last axis -> pyramid level i+1
+//  * geo_lookup    : for every pixel, level and channel row: 2r+1 taps at x = pos/2^i + (k - r), 1-D linear
+//                    interpolation with zero padding (grid_sample, align_corners=True, H == 1), for the C geometry
+//                    rows (pos = disp) and the correlation row (pos = coords - disp); writes the reference's
+//                    [B, (C+1)*(2r+1)*levels, H, W] tensor in one pass instead of 4 grid_sample calls + cats per iteration.
+// All memory-bound; lanes run along w (outputs) or along the contiguous row axis (transposes).
+#include "osa_common.h"
+
+namespace osa {
+
+// ---- all-pairs correlation: block = (b, h, 16 left pixels); thread = right pixel
+__global__ __launch_bounds__(256) void allpairs_corr_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                            float* __restrict__ corr, int C, int H, int W1, int W2) {
+    extern __shared__ float f1s[];                 // [C][16]
+    const int tiles = (W1 + 15) / 16;
+    int bid = blockIdx.x;
+    const int t = bid % tiles; bid /= tiles;
+    const int h = bid % H; const int b = bid / H;
+    const int w10 = t * 16;
+    const size_t plane1 = (size_t)H * W1, plane2 = (size_t)H * W2;
+    for (int i = threadIdx.x; i < C * 16; i += 256) {
+        const int c = i >> 4, j = i & 15;
+        f1s[i] = (w10 + j < W1) ? f1[((size_t)b * C + c) * plane1 + (size_t)h * W1 + w10 + j] : 0.f;
+    }
+    __syncthreads();
+    for (int w2 = threadIdx.x; w2 < W2; w2 += 256) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        const float* r = f2 + (size_t)b * C * plane2 + (size_t)h * W2 + w2;
+        for (int c = 0; c < C; ++c) {
+            const float v = r[(size_t)c * plane2];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(f1s[c * 16 + j], v, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (w10 + j < W1) corr[(((size_t)b * H + h) * W1 + w10 + j) * W2 + w2] = acc[j];
+    }
+}
+
+// ---- NDHWC volume [B,D,H,W,Cs] -> rows [B,H,W,C,D]; block = (b, h, 8 pixels)
+__global__ __launch_bounds__(256) void geo_rows_kernel(const float* __restrict__ vol, float* __restrict__ rows,
+                                                       int D, int H, int W, int C, int Cs) {
+    extern __shared__ float tile[];                // [8][D][C+1]
+    const int tiles = (W + 7) / 8;
+    int bid = blockIdx.x;
+    const int t = bid % tiles; bid /= tiles;
+    const int h = bid % H; const int b = bid / H;
+    const int w0 = t * 8, CP = C + 1;
+    const int n_in = 8 * D * C;
+    for (int i = threadIdx.x; i < n_in; i += 256) {       // c fastest: coalesced C-vectors
+        const int c = i % C; int r = i / C;
+        const int px = r % 8; const int d = r / 8;
+        float v = 0.f;
+        if (w0 + px < W) v = vol[((((size_t)b * D + d) * H + h) * W + w0 + px) * Cs + c];
+        tile[(px * D + d) * CP + c] = v;
+    }
+    __syncthreads();
+    const int n_out = 8 * C * D;
+    for (int i = threadIdx.x; i < n_out; i += 256) {      // d fastest: one pixel's [C][D] block is contiguous
+        const int d = i % D; int r = i / D;
+        const int c = r % C; const int px = r / C;
+        if (w0 + px < W) rows[((((size_t)b * H + h) * W + w0 + px) * C + c) * D + d] = tile[(px * D + d) * CP + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long long rows, int n) {
+    const int no = n / 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * no) return;
+    const long long r = i / no; const int j = (int)(i - r * no);
+    const float* p = x + r * n + 2 * j;
+    y[i] = (p[0] + p[1]) * 0.5f;
+}
+
+struct LookupArgs {
+    const float* geo[4]; const float* corr[4];      // per level: rows [B,H,W,C,Dl] / [B,H,W,W2l]
+    const float* disp; const float* coords; float* out;
+    int B, H, W, C, levels, radius;
+    int Dl[4], Wl[4];
+};
+
+__device__ __forceinline__ float sample_row(const float* __restrict__ row, int n, float x) {
+    const float xf = floorf(x);
+    const int x0 = (int)xf;
+    const float w1 = x - xf;
+    const float a = (x0 >= 0 && x0 < n) ? row[x0] : 0.f;
+    const float b = (x0 + 1 >= 0 && x0 + 1 < n) ? row[x0 + 1] : 0.f;
+    return a * (1.f - w1) + b * w1;
+}
+
+__global__ __launch_bounds__(256) void geo_lookup_kernel(const LookupArgs p) {
+    const long long HW = (long long)p.H * p.W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // pixel
+    if (i >= (long long)p.B * HW) return;
+    const long long b = i / HW, hw = i - b * HW;
+    const int taps = 2 * p.radius + 1;
+    const int per_level = (p.C + 1) * taps;
+    const float d = p.disp[i], cx = p.coords[i];
+    float* o = p.out + (size_t)b * per_level * p.levels * HW + hw;
+    float scale = 1.f;
+    for (int l = 0; l < p.levels; ++l, scale *= 0.5f) {
+        const float* g = p.geo[l] + (size_t)i * p.C * p.Dl[l];
+        const float xg = d * scale, xc = cx * scale - d * scale;
+        for (int c = 0; c < p.C; ++c) {
+            const float* row = g + (size_t)c * p.Dl[l];
+            for (int k = 0; k < taps; ++k)
+                o[((size_t)l * per_level + c * taps + k) * HW] = sample_row(row, p.Dl[l], xg + (float)(k - p.radius));
+        }
+        const float* crow = p.corr[l] + (size_t)i * p.Wl[l];
+        for (int k = 0; k < taps; ++k)
+            o[((size_t)l * per_level + p.C * taps + k) * HW] = sample_row(crow, p.Wl[l], xc + (float)(k - p.radius));
+    }
+}
+
+}  // namespace osa
+
+using namespace osa;
+
+extern "C" int osa_allpairs_corr_f32(const float* fmap1, const float* fmap2, float* corr,
+                                     int B, int C, int H, int W1, int W2, void* stream) {
+    OSA_REQUIRE(fmap1 && fmap2 && corr, "allpairs_corr: NULL pointer");
+    OSA_REQUIRE(B > 0 && C > 0 && H > 0 && W1 > 0 && W2 > 0, "allpairs_corr: bad dims");
+    const size_t lds = (size_t)C * 16 * sizeof(float);
+    OSA_REQUIRE(lds <= 64 * 1024, "allpairs_corr: C=%d too large", C);
+    const long long nblk = (long long)B * H * cdiv(W1, 16);
+    hipLaunchKernelGGL(allpairs_corr_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, fmap1, fmap2, corr, C, H, W1, W2);
+    OSA_LAUNCH_CHECK("allpairs_corr");
+    return 0;
+}
+
+extern "C" int osa_geo_rows_f32(const float* vol_ndhwc, float* rows, int B, int D, int H, int W, int C, int Cs, void* stream) {
+    OSA_REQUIRE(vol_ndhwc && rows, "geo_rows: NULL pointer");
+    OSA_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && Cs >= C, "geo_rows: bad dims");
+    const size_t lds = (size_t)8 * D * (C + 1) * sizeof(float);
+    OSA_REQUIRE(lds <= 160 * 1024, "geo_rows: D*C too large for LDS (%zu B)", lds);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)geo_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long long nblk = (long long)B * H * cdiv(W, 8);
+    hipLaunchKernelGGL(geo_rows_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, vol_ndhwc, rows, D, H, W, C, Cs);
+    OSA_LAUNCH_CHECK("geo_rows");
+    return 0;
+}
+
+extern "C" int osa_avgpool_rows_f32(const float* x, float* y, long long rows, int n, void* stream) {
+    OSA_REQUIRE(x && y && rows > 0 && n >= 2, "avgpool_rows: bad arguments");
+    const long long total = rows * (n / 2);
+    hipLaunchKernelGGL(avgpool_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, rows, n);
+    OSA_LAUNCH_CHECK("avgpool_rows");
+    return 0;
+}
+
+extern "C" int osa_geo_lookup_f32(const float* const* geo_levels, const float* const* corr_levels,
+                                  const int* geo_len, const int* corr_len, int levels,
+                                  const float* disp, const float* coords_x, float* out,
+                                  int B, int H, int W, int C, int radius, void* stream) {
+    OSA_REQUIRE(geo_levels && corr_levels && geo_len && corr_len && disp && coords_x && out, "geo_lookup: NULL pointer");
+    OSA_REQUIRE(levels >= 1 && levels <= 4, "geo_lookup: %d levels unsupported (1..4)", levels);
+    LookupArgs a;
+    for (int l = 0; l < levels; ++l) {
+        OSA_REQUIRE(geo_levels[l] && corr_levels[l] && geo_len[l] > 0 && corr_len[l] > 0, "geo_lookup: level %d missing", l);
+        a.geo[l] = geo_levels[l]; a.corr[l] = corr_levels[l]; a.Dl[l] = geo_len[l]; a.Wl[l] = corr_len[l];
+    }
+    a.disp = disp; a.coords = coords_x; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.levels = levels; a.radius = radius;
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(geo_lookup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("geo_lookup");
+    return 0;
+}

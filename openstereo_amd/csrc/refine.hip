@@ -69,3 +69,60 @@ extern "C" int osa_context_upsample_f32(const float* disp_low, const float* weig
     OSA_LAUNCH_CHECK("context_upsample");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Input pre-processing on device: RightTopPad(edge) + HWC->CHW + /255 + normalise,
+// the EVALUATING transform chain of cfgs/gwcnet/gwcnet_sceneflow_uniform.yaml (stereo/datasets/
+// dataset_utils/stereo_trans.py:243-267 RightTopPad, :22-29 TransposeImage, :48-56 NormalizeImage),
+// for the left and the right image in one launch.  out[i, c, y, x] = ((img_i[ys, xs, c] / 255) - mean[c]) / std[c]
+// with ys = clamp(y - pad_top, 0, H-1), xs = min(x, W-1).  layout 0: NCHW [2,3,Hp,Wp];
+// layout 1: NHWC4 [2,Hp,Wp,4] (4th channel 0) -- what the engine's first conv consumes directly.
+namespace osa {
+struct PreArgs {
+    const void* img[2]; float* out;
+    int u8, H, W, Hp, Wp, layout;
+    float mean[3], stdv[3];
+};
+
+__global__ __launch_bounds__(256) void preprocess_pair_kernel(const PreArgs p) {
+    const long long n = (long long)2 * p.Hp * p.Wp;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % p.Wp); const long long r = i / p.Wp;
+    const int y = (int)(r % p.Hp); const int im = (int)(r / p.Hp);
+    int ys = y - (p.Hp - p.H); ys = ys < 0 ? 0 : ys;
+    const int xs = x < p.W ? x : p.W - 1;
+    const size_t src = ((size_t)ys * p.W + xs) * 3;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float raw = p.u8 ? (float)reinterpret_cast<const unsigned char*>(p.img[im])[src + c]
+                               : reinterpret_cast<const float*>(p.img[im])[src + c];
+        v[c] = (raw / 255.0f - p.mean[c]) / p.stdv[c];
+    }
+    if (p.layout == 0) {
+        const size_t plane = (size_t)p.Hp * p.Wp;
+        float* o = p.out + (size_t)im * 3 * plane + (size_t)y * p.Wp + x;
+        o[0] = v[0]; o[plane] = v[1]; o[2 * plane] = v[2];
+    } else {
+        reinterpret_cast<float4*>(p.out)[i] = make_float4(v[0], v[1], v[2], 0.f);
+    }
+}
+}  // namespace osa
+
+extern "C" int osa_preprocess_pair_f32(const void* left_hwc, const void* right_hwc, int is_u8,
+                                       int H, int W, int Hp, int Wp,
+                                       const float* mean3, const float* std3,
+                                       float* out, int layout, void* stream) {
+    OSA_REQUIRE(left_hwc && right_hwc && out && mean3 && std3, "preprocess_pair: NULL pointer");
+    OSA_REQUIRE(H > 0 && W > 0 && Hp >= H && Wp >= W, "preprocess_pair: padded size %dx%d smaller than image %dx%d", Hp, Wp, H, W);
+    OSA_REQUIRE(layout == 0 || layout == 1, "preprocess_pair: bad layout");
+    osa::PreArgs a;
+    a.img[0] = left_hwc; a.img[1] = right_hwc; a.out = out; a.u8 = is_u8 ? 1 : 0;
+    a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp; a.layout = layout;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }   // host pointers (3 floats each)
+    const long long n = (long long)2 * Hp * Wp;
+    hipLaunchKernelGGL(osa::preprocess_pair_kernel, dim3(osa::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("preprocess_pair");
+    return 0;
+}

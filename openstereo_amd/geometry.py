@@ -1,0 +1,73 @@
+"""CombinedGeoEncodingVolume on the engine.
+
+Same constructor / call contract as models/stereobase/gru_blocks.py:170-229 and
+models/igev/geometry.py:7-66: built once per forward from the matching features and the aggregated
+geometry volume, then called once per GRU iteration with the current disparity.  The engine keeps the
+volume as per-pixel rows ([B,H,W,C,D], D contiguous) plus an averaged pyramid, and one fused kernel per
+iteration produces the reference's [B,(C+1)*(2r+1)*levels,H,W] tensor (replacing 2*levels grid_sample
+calls, their coordinate tensors and the concatenations)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib, ops, timing
+from .ops import _f32c, _stream, is_cl
+
+
+class CombinedGeoEncodingVolume:
+    def __init__(self, init_fmap1, init_fmap2, geo_volume, num_levels=2, radius=4):
+        assert 1 <= num_levels <= 4
+        self.num_levels, self.radius = num_levels, radius
+        f1, f2 = _f32c(init_fmap1), _f32c(init_fmap2)
+        B, Cf, H, W1 = f1.shape
+        W2 = f2.shape[3]
+        dev = f1.device
+        corr = torch.empty((B, H, W1, W2), device=dev, dtype=torch.float32)
+        _lib.call("osa_allpairs_corr_f32", f1.data_ptr(), f2.data_ptr(), corr.data_ptr(), B, Cf, H, W1, W2, _stream())
+        gv = geo_volume if is_cl(geo_volume) and geo_volume.dtype == torch.float32 else ops.to_cl(geo_volume.float(), pad_to=1)
+        _, Cs, D, Hg, Wg = gv.shape
+        C = geo_volume.shape[1] if not is_cl(geo_volume) else Cs
+        self.C = C
+        assert (Hg, Wg) == (H, W1)
+        rows = torch.empty((B, H, W1, C, D), device=dev, dtype=torch.float32)
+        _lib.call("osa_geo_rows_f32", gv.data_ptr(), rows.data_ptr(), B, D, H, W1, C, Cs, _stream())
+        self.geo_volume_pyramid, self.init_corr_pyramid = [rows], [corr]
+        for _ in range(num_levels - 1):
+            g, c = self.geo_volume_pyramid[-1], self.init_corr_pyramid[-1]
+            g2 = torch.empty(g.shape[:-1] + (g.shape[-1] // 2,), device=dev, dtype=torch.float32)
+            c2 = torch.empty(c.shape[:-1] + (c.shape[-1] // 2,), device=dev, dtype=torch.float32)
+            _lib.call("osa_avgpool_rows_f32", g.data_ptr(), g2.data_ptr(), g.numel() // g.shape[-1], g.shape[-1], _stream())
+            _lib.call("osa_avgpool_rows_f32", c.data_ptr(), c2.data_ptr(), c.numel() // c.shape[-1], c.shape[-1], _stream())
+            self.geo_volume_pyramid.append(g2); self.init_corr_pyramid.append(c2)
+        L = num_levels
+        self._gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in self.geo_volume_pyramid])
+        self._cp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in self.init_corr_pyramid])
+        self._gl = (ctypes.c_int * L)(*[t.shape[-1] for t in self.geo_volume_pyramid])
+        self._cl = (ctypes.c_int * L)(*[t.shape[-1] for t in self.init_corr_pyramid])
+        self.shape = (B, H, W1)
+
+    def __call__(self, disp, coords):
+        """disp [B,1,H,W] (quarter-res disparity), coords [B,H,W,1] (x coordinate grid) ->
+        [B,(C+1)*(2r+1)*levels,H,W] float32."""
+        B, H, W = self.shape
+        d, cx = _f32c(disp).reshape(B, H, W), _f32c(coords).reshape(B, H, W)
+        out = torch.empty((B, (self.C + 1) * (2 * self.radius + 1) * self.num_levels, H, W), device=d.device, dtype=torch.float32)
+        with timing.span("geo_lookup", self.C, self.num_levels, self.radius, H, W):
+            _lib.call("osa_geo_lookup_f32", self._gp, self._cp, self._gl, self._cl, self.num_levels,
+                      d.data_ptr(), cx.data_ptr(), out.data_ptr(), B, H, W, self.C, self.radius, _stream())
+        return out
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """einsum('aijk,aijh->ajkh') -> [B,H,W1,1,W2] (gru_blocks.py:221-229)."""
+        f1, f2 = _f32c(fmap1), _f32c(fmap2)
+        B, Cf, H, W1 = f1.shape
+        W2 = f2.shape[3]
+        out = torch.empty((B, H, W1, 1, W2), device=f1.device, dtype=torch.float32)
+        _lib.call("osa_allpairs_corr_f32", f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cf, H, W1, W2, _stream())
+        return out
+
+
+Combined_Geo_Encoding_Volume = CombinedGeoEncodingVolume      # IGEV's name (models/igev/geometry.py:7)

@@ -264,6 +264,32 @@ def context_upsample(disp_low, up_weights, scale_factor=4, softmax_weights=False
     return out if disp_low.dtype == torch.float32 else out.to(disp_low.dtype)
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def preprocess_pair(left_hwc, right_hwc, pad_size, mean=IMAGENET_MEAN, std=IMAGENET_STD, channels_last=False):
+    """RightTopPad(SIZE=pad_size, edge) -> TransposeImage -> ToTensor -> NormalizeImage for a stereo pair,
+    fused on the GPU (stereo_trans.py:243-267,22-29,48-56).  left/right: [H,W,3] uint8 or float32 CUDA tensors.
+    Returns (left, right) [1,3,Hp,Wp]; channels_last=True returns the engine's NHWC4 pair tensor [2,4,1,Hp,Wp]."""
+    import ctypes
+    _chk(left_hwc, "left_hwc", 3); _chk(right_hwc, "right_hwc", 3)
+    assert left_hwc.shape == right_hwc.shape and left_hwc.shape[2] == 3 and left_hwc.dtype == right_hwc.dtype
+    assert left_hwc.dtype in (torch.uint8, torch.float32)
+    H, W = left_hwc.shape[:2]
+    Hp, Wp = max(pad_size[0], H), max(pad_size[1], W)        # RightTopPad never crops (h = min(h, th))
+    l, r = left_hwc.contiguous(), right_hwc.contiguous()
+    m3 = (ctypes.c_float * 3)(*mean); s3 = (ctypes.c_float * 3)(*std)
+    if channels_last:
+        out = torch.empty((2, 1, Hp, Wp, 4), device=l.device, dtype=torch.float32)
+    else:
+        out = torch.empty((2, 3, Hp, Wp), device=l.device, dtype=torch.float32)
+    _lib.call("osa_preprocess_pair_f32", l.data_ptr(), r.data_ptr(), 1 if l.dtype == torch.uint8 else 0, H, W, Hp, Wp,
+              m3, s3, out.data_ptr(), 1 if channels_last else 0, _stream())
+    if channels_last:
+        return out.permute(0, 4, 1, 2, 3)
+    return out[0:1], out[1:2]
+
+
 class FasterSoftArgmin(torch.nn.Module):
     """psmnet_disp_processor.py:6-74: softmax over D + expectation; keeps the frozen
     `disp_regression.weight` buffer name so PSMNet checkpoints load."""

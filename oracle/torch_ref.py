@@ -377,3 +377,53 @@ def gwc_loss(preds, disp_gt, maxdisp):
     """models/gwcnet/gwcnet.py:42-53 (smooth-L1, weights 0.5/0.5/0.7/1.0, mask 0 < gt < maxdisp)."""
     mask = (disp_gt < maxdisp) & (disp_gt > 0)
     return sum(wt * F.smooth_l1_loss(p_[mask], disp_gt[mask], reduction="mean") for p_, wt in zip(preds, [0.5, 0.5, 0.7, 1.0]))
+
+
+# ============================================================================= pre-processing (8f #3)
+def preprocess_image(img_hwc, pad_size, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """stereo_trans.py:243-267 (RightTopPad, np.pad 'edge' on top/right), :22-29 (HWC->CHW), :32-44 (float32),
+    :48-56 (x/255 then (x-mean)/std, torchvision normalize semantics).  img_hwc: numpy [H,W,3]."""
+    import numpy as np
+    h, w = img_hwc.shape[:2]
+    th, tw = pad_size
+    h, w = min(h, th), min(w, tw)
+    img = np.pad(img_hwc, np.array([[th - h, 0], [0, tw - w], [0, 0]]), "edge")
+    t = torch.from_numpy(img.transpose((2, 0, 1)).copy()).to(torch.float32) / 255.0
+    m = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+    return (t - m) / s
+
+
+# ============================================================================= geometry-encoding volume (a5)
+class GeoEncodingVolume:
+    """models/stereobase/gru_blocks.py:170-229 == models/igev/geometry.py:7-66: all-pairs correlation, per-pixel
+    rows, avg-pooled pyramid, and per-iteration lookups through F.grid_sample (align_corners=True, zero padding)."""
+
+    def __init__(self, fmap1, fmap2, geo_volume, num_levels=2, radius=4):
+        self.num_levels, self.radius = num_levels, radius
+        corr = torch.einsum("aijk,aijh->ajkh", fmap1, fmap2)                  # [B,H,W1,W2]
+        b, c, d, h, w = geo_volume.shape
+        g = geo_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, c, 1, d)
+        cr = corr.reshape(b * h * w, 1, 1, corr.shape[-1])
+        self.geo, self.corr = [g], [cr]
+        for _ in range(num_levels - 1):
+            self.geo.append(F.avg_pool2d(self.geo[-1], [1, 2], stride=[1, 2]))
+            self.corr.append(F.avg_pool2d(self.corr[-1], [1, 2], stride=[1, 2]))
+
+    @staticmethod
+    def _sample(img, x):
+        W = img.shape[-1]
+        grid = torch.cat([2 * x / (W - 1) - 1, torch.zeros_like(x)], dim=-1)
+        return F.grid_sample(img, grid, align_corners=True)
+
+    def __call__(self, disp, coords):
+        r = self.radius
+        b, _, h, w = disp.shape
+        dx = torch.linspace(-r, r, 2 * r + 1).view(1, 1, 2 * r + 1, 1)
+        out = []
+        for i in range(self.num_levels):
+            x0 = dx + disp.reshape(b * h * w, 1, 1, 1) / 2 ** i
+            out.append(self._sample(self.geo[i], x0).view(b, h, w, -1))
+            xc = coords.reshape(b * h * w, 1, 1, 1) / 2 ** i - disp.reshape(b * h * w, 1, 1, 1) / 2 ** i + dx
+            out.append(self._sample(self.corr[i], xc).view(b, h, w, -1))
+        return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().float()

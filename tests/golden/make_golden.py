@@ -103,6 +103,19 @@ def main():
          up_true=dr_nokeep(F.softmax(up_t.squeeze(1), dim=1), 24),
          low2=low2, up_odd=dr_nokeep(F.softmax(up_odd.squeeze(1), dim=1), 17))
 
+    # ------------------------------------------------------------------ geometry-encoding volume (a5)
+    from stereo.modeling.models.stereobase.gru_blocks import CombinedGeoEncodingVolume
+    from stereo.modeling.models.igev.geometry import Combined_Geo_Encoding_Volume
+    f1, f2 = rnd((2, 12, 5, 14), 41), rnd((2, 12, 5, 14), 42)
+    gvol = rnd((2, 6, 10, 5, 14), 43)
+    dsp = (rnd((2, 1, 5, 14), 44).abs() * 3.0)
+    crd = torch.arange(14, dtype=torch.float32).view(1, 1, 14, 1).repeat(2, 5, 1, 1)
+    gev = CombinedGeoEncodingVolume(f1, f2, gvol, num_levels=2, radius=4)
+    lk = gev(dsp, crd)
+    assert torch.equal(lk, Combined_Geo_Encoding_Volume(f1, f2, gvol, num_levels=2, radius=4)(dsp, crd))
+    save("geo_encoding.npz", f1=f1, f2=f2, geo=gvol, disp=dsp, coords=crd, lookup=lk,
+         corr=CombinedGeoEncodingVolume.corr(f1, f2), lookup2=gev(dsp * 2.5 + 1.0, crd))
+
     # ------------------------------------------------------------------ context_upsample (a13)
     from stereo.modeling.disp_refinement.disp_refinement import context_upsample as cu_shared
     from stereo.modeling.models.stereobase.igev_blocks import context_upsample as cu_sb

@@ -418,3 +418,32 @@ def test_context_upsample_vs_reference_golden():
     close(ops.context_upsample(dl, lg, softmax_weights=True, gain=4.0), g["out"], atol=2e-5, what="fused softmax+gain")
     close(ops.context_upsample(dl[:, :, :3, :4].contiguous(), wt[:, :, :6, :8].contiguous(), scale_factor=2),
           g["out_s2"], atol=2e-5, what="scale 2")
+
+
+def test_preprocess_pair_vs_oracle():
+    """RightTopPad + transpose + normalise fused on device vs the numpy/torch restatement of the transform chain."""
+    from openstereo_amd import ops
+    from oracle import torch_ref as O
+    r = np.random.default_rng(12)
+    for dt in (np.uint8, np.float32):
+        L = r.integers(0, 256, (27, 45, 3)).astype(dt)
+        R = r.integers(0, 256, (27, 45, 3)).astype(dt)
+        l, rr = ops.preprocess_pair(T(L).to(DEV), T(R).to(DEV), (32, 48))
+        close(l[0], O.preprocess_image(L, (32, 48)), atol=1e-6, rtol=1e-6, what=f"left {dt.__name__}")
+        close(rr[0], O.preprocess_image(R, (32, 48)), atol=1e-6, rtol=1e-6, what=f"right {dt.__name__}")
+        cl = ops.preprocess_pair(T(L).to(DEV), T(R).to(DEV), (32, 48), channels_last=True)
+        assert ops.is_cl(cl) and cl.shape == (2, 4, 1, 32, 48)
+        close(cl[0, :3, 0], O.preprocess_image(L, (32, 48)), atol=1e-6, rtol=1e-6, what="NHWC4 left")
+        assert float(cl[:, 3].abs().max()) == 0.0
+
+
+def test_geo_encoding_volume_vs_reference_golden():
+    """All-pairs correlation, pyramid and the fused per-iteration lookup (a5) vs the reference class."""
+    from openstereo_amd.geometry import CombinedGeoEncodingVolume
+    g = golden("geo_encoding.npz")
+    close(CombinedGeoEncodingVolume.corr(g2(g["f1"]), g2(g["f2"])), g["corr"], atol=2e-6, rtol=1e-5, what="all-pairs corr")
+    gev = CombinedGeoEncodingVolume(g2(g["f1"]), g2(g["f2"]), g2(g["geo"]), num_levels=2, radius=4)
+    out = gev(g2(g["disp"]), g2(g["coords"]))
+    assert out.shape == g["lookup"].shape
+    close(out, g["lookup"], atol=2e-5, rtol=1e-5, what="lookup")
+    close(gev(g2(g["disp"]) * 2.5 + 1.0, g2(g["coords"])), g["lookup2"], atol=2e-5, rtol=1e-5, what="lookup (large disp, out-of-range taps)")

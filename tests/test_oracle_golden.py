@@ -112,3 +112,10 @@ def test_context_upsample_against_reference():
     g = golden("context_upsample.npz")
     close(O.context_upsample(T(g["disp_low"]) * 4., T(g["weights"])), g["out"], atol=1e-6)
     close(O.context_upsample(T(g["disp_low"])[:, :, :3, :4], T(g["weights"])[:, :, :6, :8], 2), g["out_s2"], atol=1e-6)
+
+
+def test_geo_encoding_volume_against_reference():
+    g = golden("geo_encoding.npz")
+    gev = O.GeoEncodingVolume(T(g["f1"]), T(g["f2"]), T(g["geo"]), 2, 4)
+    close(gev(T(g["disp"]), T(g["coords"])), g["lookup"], atol=1e-6)
+    close(gev(T(g["disp"]) * 2.5 + 1.0, T(g["coords"])), g["lookup2"], atol=1e-6)
