@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=2, help="pairs per GPU per step")
     ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")

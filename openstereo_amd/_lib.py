@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libopenstereo_amd.so")
+LIB_PATH = os.environ.get("OSA_LIB_PATH") or os.path.join(_HERE, "lib", "libopenstereo_amd.so")   # override: A/B experiments only
 
 _lock = threading.Lock()
 _lib = None

@@ -68,14 +68,20 @@ struct ConvArgs {
 
 // Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
 // Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with hi, lo fp16.  hi uses the packed round-toward-zero convert (2 floats per
+// instruction): any rounding is fine for hi because lo = x - float(hi) is exact in fp32 and carries
+// the remainder; lo is rounded to nearest, error <= 2^-12 |lo| <= 2^-22 |x|.
 __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) {
     const float m = 65504.f;      // saturate instead of producing inf (one v_med3_f32 per element)
     const float x0 = __builtin_amdgcn_fmed3f(v.x, -m, m), x1 = __builtin_amdgcn_fmed3f(v.y, -m, m);
     const float x2 = __builtin_amdgcn_fmed3f(v.z, -m, m), x3 = __builtin_amdgcn_fmed3f(v.w, -m, m);
-    f16x4 h = {(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
-    f16x4 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1]),
-               (_Float16)(x2 - (float)h[2]), (_Float16)(x3 - (float)h[3])};
-    hi = __builtin_bit_cast(uint2, h);
+    const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    // lo is rounded to nearest (unbiased): its error is what remains of the split
+    const f16x4 l = {(_Float16)(x0 - (float)h01[0]), (_Float16)(x1 - (float)h01[1]),
+                     (_Float16)(x2 - (float)h23[0]), (_Float16)(x3 - (float)h23[1])};
+    hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
     lo = __builtin_bit_cast(uint2, l);
 }
 
