@@ -85,6 +85,9 @@ __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) 
     lo = __builtin_bit_cast(uint2, l);
 }
 
+// Thread-linear item order (every lane busy on every load).  A row-wise variant with wave-uniform
+// row arithmetic (2x fewer VALU instructions) was measured slower overall on MI355X: rows of 10-18
+// voxels leave 40-45 % of the lanes idle, which costs more than the index arithmetic saves.
 template <int NTHR, int PREC>
 __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int b, int c0,
                                             int g0d, int g0h, int g0w, int tid) {
@@ -186,15 +189,21 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
     // "set 0 holds the next group" and no register rotation is ever needed.  The packed buffer
     // carries a few tap steps of slack for the last prefetch.
     const size_t bstep = (size_t)2 * p.CoP;          // float4s per octet
-    const size_t tstep = (size_t)JO * bstep;         // float4s per tap
+    const size_t tstep = (p.dbg & 4) ? 0 : (size_t)JO * bstep;   // float4s per tap (dbg 4: stationary B stream, timing only)
     const float4* wp = p.w + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
-    float4 B0[TU][JO][NT], B1[TU][JO][NT], A0[TU][JO][MT], A1[TU][JO][MT];
+    constexpr bool RING3 = (TU == 3);     // TU == 3 selects the 3-deep B ring (taps % 3 == 0, NCLS == 1)
+    constexpr int TUA = RING3 ? 1 : TU;
+    static_assert(!RING3 || NCLS == 1, "the B ring needs tap runs that are multiples of 3");
+    float4 B0[TUA][JO][NT], B1[TUA][JO][NT], B2[TUA][JO][NT], A0[TUA][JO][MT], A1[TUA][JO][MT];
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int u = 0; u < TUA; ++u)
 #pragma unroll
         for (int j = 0; j < JO; ++j)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) B0[u][j][n] = wp[u * tstep + j * bstep + n * 32];
+            for (int n = 0; n < NT; ++n) {
+                B0[u][j][n] = wp[u * tstep + j * bstep + n * 32];
+                if constexpr (RING3) B1[u][j][n] = wp[tstep + j * bstep + n * 32];
+            }
 
     const int brickQ = p.LD * p.PlaneQ;          // float4s per staged chunk
     const int Tm1 = p.T - 1;
@@ -205,15 +214,15 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
     const int toff_v = p.toff[(lane < p.T) ? lane : 0];
 
     // prefetch group starting at flat tap `tn` (B: `skip` tap steps ahead of wp) into (An, Bn)
-    auto prefetch = [&](float4 (&An)[TU][JO][MT], float4 (&Bn)[TU][JO][NT], int tn, int skip) {
+    auto prefetch = [&](float4 (&An)[TUA][JO][MT], float4 (&Bn)[TUA][JO][NT], int tn, int skip) {
 #pragma unroll
-        for (int u = 0; u < TU; ++u)
+        for (int u = 0; u < TUA; ++u)
 #pragma unroll
             for (int j = 0; j < JO; ++j)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) Bn[u][j][n] = wp[(size_t)(skip + u) * tstep + j * bstep + n * 32];
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
+        for (int u = 0; u < TUA; ++u) {
             const int ti = tn + u;
             const int to = __builtin_amdgcn_readlane(toff_v, (ti < Tm1) ? ti : Tm1);
 #pragma unroll
@@ -223,9 +232,9 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
         }
     };
     // MFMAs of the first `cnt` taps of (Ac, Bc) into accumulator set ac
-    auto compute = [&](const float4 (&Ac)[TU][JO][MT], const float4 (&Bc)[TU][JO][NT], f32x16 (&ac)[MT][NT], int cnt) {
+    auto compute = [&](const float4 (&Ac)[TUA][JO][MT], const float4 (&Bc)[TUA][JO][NT], f32x16 (&ac)[MT][NT], int cnt) {
 #pragma unroll
-        for (int u = 0; u < TU; ++u) {
+        for (int u = 0; u < TUA; ++u) {
             if (u < cnt) {
                 if constexpr (PREC == PREC_F32) {
 #pragma unroll
@@ -256,6 +265,16 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
             }
         }
     };
+    // B ring step: request A of tap `ta` into An and B of stream position wp + sb tap steps into Bn,
+    // then issue the MFMAs of (Ac, Bc).  B operands are requested two taps ahead of their use (the
+    // L2 round trip is longer than one tap's MFMAs), A operands (LDS) one tap ahead.
+    auto ring_step = [&](float4 (&An)[TUA][JO][MT], int ta, float4 (&Bn)[TUA][JO][NT], int sb,
+                         const float4 (&Ac)[TUA][JO][MT], const float4 (&Bc)[TUA][JO][NT]) {
+        prefetch(An, Bn, ta, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(Ac, Bc, acc[0], 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
         if (ch0) __syncthreads();
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
             sm = smem + cl * brickQ;
             // A operands of the first TU taps of this chunk -> set 0 (B0 already holds their B operands)
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
+            for (int u = 0; u < TUA; ++u) {
                 const int to = __builtin_amdgcn_readlane(toff_v, (u < Tm1) ? u : Tm1);
 #pragma unroll
                 for (int j = 0; j < JO; ++j)
@@ -276,6 +295,21 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
                     for (int m = 0; m < MT; ++m) A0[u][j][m] = sm[abase[m] + to + j * 2];
             }
             t = 0;
+            if constexpr (RING3) {
+                // invariant at the top: A0 = tap t, B0 = tap t, B1 = tap t+1 (stream positions wp, wp+1).
+                // Three steps are one full turn of the B ring, so leaving after the first triple keeps
+                // the invariant for the next chunk (whose A0 is reloaded anyway).
+                for (; t < p.T; t += 6) {
+                    ring_step(A1, t + 1, B2, 2, A0, B0);
+                    ring_step(A0, t + 2, B0, 3, A1, B1);
+                    ring_step(A1, t + 3, B1, 4, A0, B2);
+                    if (t + 3 >= p.T) { wp += (size_t)3 * tstep; break; }
+                    ring_step(A0, t + 4, B2, 5, A1, B0);
+                    ring_step(A1, t + 5, B0, 6, A0, B1);
+                    ring_step(A0, t + 6, B1, 7, A1, B2);
+                    wp += (size_t)6 * tstep;
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) {
                 const int tend = (NCLS == 1) ? p.T : p.cls_end[c];
@@ -294,6 +328,7 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
                     wp += (size_t)cnt1 * tstep; t += cnt1;
                 }
             }
+            }
         }
     }
 
@@ -304,6 +339,19 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
     // gate loads and output stores are float4, 8 lanes cover one voxel's 128-byte channel row and a
     // wave instruction covers 8 consecutive voxels (1 KB contiguous for a 32-channel tensor).
     __syncthreads();                                   // everyone is done reading the input brick
+    if (p.dbg & 8) {                                   // timing only: no epilogue (keeps the accumulators live)
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc[c][m][n][r];
+        if (s == 12345.678f) p.y[0] = s;
+        return;
+    }
     float* tb = reinterpret_cast<float*>(smem) + wave * (32 * 36);
     const size_t bvox = (size_t)b * p.Do * p.Ho * p.Wo;
     const bool vec4 = ((p.yCs & 3) == 0) && ((p.Co & 3) == 0) && (((size_t)p.y & 15) == 0) &&
@@ -404,6 +452,7 @@ struct KernelCfg {
     int M, N;              // voxels / channels per workgroup
     int TD, TH, TW, threads;
     void (*fn[2])(const ConvArgs);      // [PREC_F32], [PREC_F16X3]
+    void (*fn3[2])(const ConvArgs);     // same, B-ring pipeline (tap count a multiple of 3); may be null
 };
 
 constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong pipeline
@@ -411,7 +460,9 @@ constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong p
     { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
       WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
       { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
-        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> } }
+        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
+      { conv_mfma_kernel<PREC_F32, 1, 3, MT, NT, WM, WN, TH, TW>,                             \
+        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW> } }
 
 static const KernelCfg g_cfgs[] = {
     OSA_CFG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
@@ -436,7 +487,8 @@ constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 // fused transposed conv: 128 input-resolution positions x 32 channels x 8 parity classes per workgroup
 static const KernelCfg g_deconv_cfg = {
     "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
-    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> } };
+    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> },
+    { nullptr, nullptr } };
 
 static int pick_cfg(const ConvArgs& a, int stride) {
     const char* ov = getenv("OSA_CONV_CFG");
@@ -520,10 +572,13 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     if (lds < epi) lds = epi;
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
+    // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
+    const bool no_ring = getenv("OSA_NORING") != nullptr;
+    void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)k.fn[prec], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
-    hipLaunchKernelGGL(k.fn[prec], grid, block, lds, st, a);
+    hipLaunchKernelGGL(fn, grid, block, lds, st, a);
     OSA_LAUNCH_CHECK(what);
     return 0;
 }

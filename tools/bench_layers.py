@@ -36,9 +36,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--dbgs", default="", help="comma list of OSA_DBG masks to sweep (timing-only kernel ablations)")
     args = ap.parse_args()
     dev = "cuda:0"
     cfgs = [None] + [int(c) for c in args.cfgs.split(",") if c != ""]
+    if args.dbgs:       # ablation sweep: reuse the cfg loop, value = -(mask) - 1
+        cfgs = [None] + [-int(c) - 1 for c in args.dbgs.split(",")]
     total = {}
     for name, kind, Ci, Co, k, s, dims, count in LAYERS:
         if args.only and args.only not in name:
@@ -55,9 +58,11 @@ def main():
         macs = args.batch * Ci * Co * (k ** 3) * (od[0] * od[1] * od[2]) / (8 if kind == "deconv" else 1)
         line = f"{name:26s} {macs / 1e9:7.2f} GMAC x{count}"
         for cfg in cfgs:
-            if cfg is None:
-                os.environ.pop("OSA_CONV_CFG", None)
-            else:
+            os.environ.pop("OSA_CONV_CFG", None)
+            os.environ.pop("OSA_DBG", None)
+            if cfg is not None and cfg < 0:
+                os.environ["OSA_DBG"] = str(-cfg - 1)
+            elif cfg is not None:
                 os.environ["OSA_CONV_CFG"] = str(cfg)
             try:
                 for _ in range(3):
@@ -77,6 +82,7 @@ def main():
                 line += f" | cfg {cfg}: n/a ({str(ex)[:40]})"
         print(line, flush=True)
     os.environ.pop("OSA_CONV_CFG", None)
+    os.environ.pop("OSA_DBG", None)
     print(f"sum over one forward (auto cfg): {total.get('auto', 0):.3f} ms")
 
 
