@@ -499,14 +499,16 @@ static int pick_cfg(const ConvArgs& a, int stride) {
     const bool flat = (a.Ad == 1);
     const long long vox = (long long)a.B * a.Ad * a.Ah * a.Aw;
     if (flat) {
+        // measured on MI355X (tools/bench_layers.py --set 2d, 1 and 2 pairs per step)
         if (stride == 2) return (a.CoP % 64 == 0) ? 14 : 12;
-        if (vox >= 200000) return (a.CoP % 64 == 0) ? 8 : 7;      // half-resolution maps: 256-pixel tiles
-        return (a.CoP % 64 == 0) ? 13 : 12;                        // quarter-resolution maps: 128-pixel tiles
+        if (a.CoP % 128 == 0) return 9;                            // 128 pixels x 128 channels, 2x2 waves
+        return (a.CoP % 64 == 0) ? 13 : 12;                        // 128-pixel tiles
     }
     if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 15);
     // measured on MI355X (tools/bench_layers.py): few-tap launches (1x1x1, transposed-conv parity
     // classes) and sub-megavoxel volumes prefer the 128-voxel bricks (more workgroups in flight)
-    if (a.T <= 8) return 3;
+    if (a.T <= 8) return (a.CoP % 64 == 0) ? 4 : 3;
+    if (a.CoP % 128 == 0) return 2;                                // 128 voxels x 128 channels, 2x2 waves
     if (vox < (1ll << 20)) return (a.CoP % 64 == 0) ? 4 : 3;
     return (a.CoP % 64 == 0) ? 1 : 0;
 }

@@ -150,6 +150,170 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
     }
 }
 
+// ---- NDHWC, quad lanes: every lane produces 4 consecutive output channels of one voxel ----
+// Needs G % 4 == 0, Cc % 4 == 0 and (G + 2Cc) / 4 = NQ a power of two <= 64 (GwcNet: 16).  A wave
+// covers 64 / NQ consecutive pixels, so one store instruction writes 64 x 16 B = 1 KB of contiguous
+// NDHWC volume (4 voxels for GwcNet) instead of one 256-byte voxel.  The left features of a lane
+// (its 4 groups x K channels) live in registers for the whole disparity chunk; only the sliding
+// right window goes through LDS, permuted so that the NQ lanes of a voxel read consecutive 16-byte
+// slots.  Same k-ordered fmaf chain and the same division by K as the per-channel kernel.
+struct VolQArgs {
+    VolArgs v;
+    int NQ, lgNQ, DCH, RSq;
+    int dbg;               // timing experiments only (OSA_VOL_DBG): 1 = no stores, 2 = no dot products, 4 = no window staging
+};
+
+template <int QG>
+__global__ __launch_bounds__(256) void build_volume_quads_kernel(const VolQArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float4 smq[];
+    const VolArgs& p = q.v;
+    const int vpw = 64 >> q.lgNQ, WT = 4 * vpw;
+    const int NPXR = WT + q.DCH - 1;
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int dch = bid % p.nDch; bid /= p.nDch;
+    const int wt = bid % p.nWt;   bid /= p.nWt;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    const int w0 = wt * WT, d0 = dch * q.DCH;
+    const int wr0 = w0 - (d0 + q.DCH - 1);            // first right pixel of the window
+
+    const int tid = threadIdx.x;
+    const size_t plane = (size_t)p.H * p.W;
+    const int G4 = p.G >> 2;
+    const int nq_g = QG * p.G, nq_c = p.Cc >> 2, nq = nq_g + nq_c;
+    const size_t rowpix = ((size_t)b * p.H + h) * p.W;
+
+    // ---- right window -> LDS.  Source quad (g, kq) goes to slot (g&3)*QG*G4 + kq*G4 + (g>>2).
+    // Item = (pixel, quad); the fast index follows the feature layout (NHWC: quads of a pixel, NCHW:
+    // pixels of a quad).  A thread walks its items with a carry instead of dividing, and keeps 4
+    // loads in flight before the first LDS store.
+    {
+        const int items = (q.dbg & 4) ? 0 : nq * NPXR;
+        const bool chan_fast = (p.gstride != 0);
+        const int inner = chan_fast ? nq : NPXR;      // extent of the fast index
+        const int step_hi = 256 / inner, step_lo = 256 - step_hi * inner;
+        int hi = tid / inner, lo = tid - hi * inner;
+        for (int it0 = tid; it0 < items; it0 += 4 * 256) {
+            float4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qi = chan_fast ? lo : hi, px = chan_fast ? hi : lo;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[u] = -1;
+                if (it0 + u * 256 < items) {
+                    const int w = wr0 + px;
+                    const bool wok = (w >= 0) && (w < p.W);
+                    int pos;
+                    if (qi < nq_g) {
+                        const int g = qi / QG, kq = qi - g * QG;
+                        pos = ((g & 3) * QG + kq) * G4 + (g >> 2);
+                        if (wok) {
+                            if (p.gstride) v[u] = *reinterpret_cast<const float4*>(p.rg + (rowpix + w) * p.gstride + g * p.K + kq * 4);
+                            else {
+                                const float* src = p.rg + ((size_t)b * p.C + (size_t)g * p.K + kq * 4) * plane + (size_t)h * p.W + w;
+                                v[u] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+                            }
+                        }
+                    } else {
+                        const int qc = qi - nq_g;
+                        pos = qi;
+                        if (wok) {
+                            if (p.cstride) {
+                                const float* src = p.rc + (rowpix + w) * p.cstride + qc * 4;
+                                v[u] = make_float4(src[0], src[1], src[2], src[3]);
+                            } else {
+                                const float* src = p.rc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w;
+                                v[u] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+                            }
+                        }
+                    }
+                    dst[u] = px * q.RSq + pos;
+                }
+                lo += step_lo; hi += step_hi;
+                if (lo >= inner) { lo -= inner; ++hi; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) smq[dst[u]] = v[u];
+        }
+    }
+
+    // ---- this lane's voxel column and role
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cq = lane & (q.NQ - 1), wsub = lane >> q.lgNQ;
+    const int w = w0 + wave * vpw + wsub;
+    const bool wlive = w < p.W;
+    const int role = (cq < G4) ? 0 : ((cq < G4 + nq_c) ? 1 : 2);   // gwc quad / left concat quad / right concat quad
+    float4 Lr[4 * QG];
+    float4 lcat = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4 * QG; ++i) Lr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wlive && role == 0) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int kq = 0; kq < QG; ++kq) {
+                const int g = cq * 4 + gi;
+                if (p.gstride) Lr[gi * QG + kq] = *reinterpret_cast<const float4*>(p.lg + (rowpix + w) * p.gstride + g * p.K + kq * 4);
+                else {
+                    const float* src = p.lg + ((size_t)b * p.C + (size_t)g * p.K + kq * 4) * plane + (size_t)h * p.W + w;
+                    Lr[gi * QG + kq] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+                }
+            }
+    } else if (wlive && role == 1) {
+        const int qc = cq - G4;
+        if (p.cstride) {
+            const float* src = p.lc + (rowpix + w) * p.cstride + qc * 4;
+            lcat = make_float4(src[0], src[1], src[2], src[3]);
+        } else {
+            const float* src = p.lc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w;
+            lcat = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+        }
+    }
+    __syncthreads();
+
+    const float Kf = (float)p.K;
+    // mean over K channels: for K a power of two the multiply by 1/K is exact (== the division)
+    const bool kpow2 = (p.K & (p.K - 1)) == 0;
+    const float Kinv = 1.0f / Kf;
+    const int rq = nq_g + (cq - G4 - nq_c);           // right-concat slot of this lane (role 2)
+    float* vout = p.vol + p.coff + cq * 4;
+#pragma unroll 4
+    for (int dd = 0; dd < q.DCH; ++dd) {
+        const int d = d0 + dd;
+        if (d >= p.D) break;
+        const bool valid = (w >= d);
+        const float4* rrow = smq + (size_t)(wave * vpw + wsub + q.DCH - 1 - dd) * q.RSq;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (role == 0 && !(q.dbg & 2)) {
+            float sv[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                float s = 0.f;
+#pragma unroll
+                for (int kq = 0; kq < QG; ++kq) {
+                    const float4 r = rrow[(gi * QG + kq) * G4 + cq];
+                    const float4 l = Lr[gi * QG + kq];
+                    s = fmaf(l.x, r.x, s); s = fmaf(l.y, r.y, s);
+                    s = fmaf(l.z, r.z, s); s = fmaf(l.w, r.w, s);
+                }
+                sv[gi] = valid ? (kpow2 ? s * Kinv : s / Kf) : 0.f;
+            }
+            o = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        } else if (role == 1) {
+            if (valid || !p.mask_left) o = lcat;
+        } else {
+            if (valid) o = rrow[rq];
+        }
+        if (wlive && (!(q.dbg & 1) || o.x == 12345.678f)) {
+            const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
+            *reinterpret_cast<float4*>(vout + vox * p.VC) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ NCDHW ----
 // One thread per output element, w fastest. grid.y = channel, grid.z = b*D+d.
 struct VolNArgs {
@@ -245,6 +409,54 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
         return -1;
     }
     if (fast) {
+        const int nq4 = nch / 4;
+        const bool quads = (G % 4 == 0) && (Cc % 4 == 0) && nq4 >= 1 && nq4 <= 64 && (nq4 & (nq4 - 1)) == 0 &&
+                           (vol_channels % 4 == 0) && (c_off % 4 == 0) && (((size_t)vol & 15) == 0) &&
+                           !getenv("OSA_VOL_PERCHANNEL");
+        if (quads) {
+            VolQArgs qa;
+            VolArgs& a = qa.v;
+            a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol;
+            a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;
+            a.VC = vol_channels; a.coff = c_off; a.mask_left = mask_left_concat;
+            a.gstride = gwc_stride; a.cstride = cat_stride;
+            a.RS = 0; a.catbase = 0;
+            const int QG = (G > 0) ? K / 4 : 1;
+            qa.NQ = nq4; qa.lgNQ = 0;
+            while ((1 << qa.lgNQ) < nq4) ++qa.lgNQ;
+            const int WT = 4 * (64 / nq4);
+            qa.RSq = ((G > 0) ? QG * G : 0) + Cc / 4;
+            if (qa.RSq % 16 > 6) qa.RSq += 16 - qa.RSq % 16;     // keeps the lanes of two neighbouring voxels on distinct 16-byte slots
+            // disparity chunk: D split evenly into the fewest chunks whose right window fits ~52 KiB of
+            // LDS (3 workgroups per CU); very wide feature vectors may use up to the whole 160 KiB
+            int nchunk = 1;
+            while (nchunk < maxdisp && (size_t)(WT + cdiv(maxdisp, nchunk) - 1) * qa.RSq * 16 > 52 * 1024) ++nchunk;
+            const int dch = cdiv(maxdisp, nchunk);
+            qa.DCH = dch;
+            { const char* e = getenv("OSA_VOL_DBG"); qa.dbg = e ? atoi(e) : 0; }
+            a.nWt = cdiv(W, WT); a.nDch = cdiv(maxdisp, dch);
+            const size_t lds = (size_t)(WT + dch - 1) * qa.RSq * 16;
+            OSA_REQUIRE(lds <= 160 * 1024, "build_volume: %zu B of LDS needed (> 160 KiB); too many channels", lds);
+            const long long nblk = (long long)B * H * a.nWt * a.nDch;
+            OSA_REQUIRE(nblk < (1ll << 31), "build_volume: grid too large");
+            dim3 grid((unsigned)nblk), block(256);
+#define OSA_VOLQ_LAUNCH(Q)                                                                          \
+            do {                                                                                    \
+                if (lds > 64 * 1024)                                                                \
+                    (void)hipFuncSetAttribute((const void*)build_volume_quads_kernel<Q>,            \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
+                hipLaunchKernelGGL(build_volume_quads_kernel<Q>, grid, block, lds, st, qa);         \
+            } while (0)
+            switch (QG) {
+                case 1: OSA_VOLQ_LAUNCH(1); break;
+                case 2: OSA_VOLQ_LAUNCH(2); break;
+                case 3: OSA_VOLQ_LAUNCH(3); break;
+                default: OSA_VOLQ_LAUNCH(4); break;
+            }
+#undef OSA_VOLQ_LAUNCH
+            OSA_LAUNCH_CHECK("build_volume_quads");
+            return 0;
+        }
         VolArgs a;
         a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol;
         a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;

@@ -30,12 +30,27 @@ LAYERS = [  # name, kind, Ci, Co, k, stride, input dims, count per forward
 ]
 
 
+# GwcNet feature extractor (2 images per pair, D = 1): name, kind, Ci, Co, k, stride, dims, count, dilation
+F2, F4 = (1, 272, 480), (1, 136, 240)
+LAYERS_2D = [
+    ("first 32->32 half", "conv2d", 32, 32, 3, 1, F2, 2 + 6, 1),
+    ("l2.0 32->64 s2", "conv2d", 32, 64, 3, 2, F2, 1, 1),
+    ("l2 64->64 quarter", "conv2d", 64, 64, 3, 1, F4, 31, 1),
+    ("l3.0 64->128 quarter", "conv2d", 64, 128, 3, 1, F4, 1, 1),
+    ("l3 128->128 quarter", "conv2d", 128, 128, 3, 1, F4, 5, 1),
+    ("l4 128->128 dil2", "conv2d", 128, 128, 3, 1, F4, 6, 2),
+    ("last 320->128", "conv2d", 320, 128, 3, 1, F4, 1, 1),
+    ("last 128->12 1x1", "conv2d", 128, 12, 1, 1, F4, 1, 1),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfgs", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--set", default="3d", choices=["3d", "2d"], help="2d: the feature extractor's layers (batch = 2 x --batch images)")
     ap.add_argument("--dbgs", default="", help="comma list of OSA_DBG masks to sweep (timing-only kernel ablations)")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -43,19 +58,23 @@ def main():
     if args.dbgs:       # ablation sweep: reuse the cfg loop, value = -(mask) - 1
         cfgs = [None] + [-int(c) - 1 for c in args.dbgs.split(",")]
     total = {}
-    for name, kind, Ci, Co, k, s, dims, count in LAYERS:
+    layers = [l + (1,) for l in LAYERS] if args.set == "3d" else LAYERS_2D
+    nb = args.batch * (2 if args.set == "2d" else 1)
+    for name, kind, Ci, Co, k, s, dims, count, dil in layers:
         if args.only and args.only not in name:
             continue
-        if kind == "deconv":
+        if kind == "conv2d":
+            m = nn.Conv2d(Ci, Co, k, s, dil * (k // 2), dilation=dil, bias=False)
+        elif kind == "deconv":
             m = nn.ConvTranspose3d(Ci, Co, k, stride=2, padding=1, output_padding=1, bias=False)
         else:
             m = nn.Conv3d(Ci, Co, k, s, k // 2, bias=False)
         m = m.to(dev)
-        x = ops.empty_cl(args.batch, Ci, *dims, dev)
+        x = ops.empty_cl(nb, Ci, *dims, dev)
         x.normal_()
-        layer = SmallCoConv3d(m) if kind == "small" else PackedConv3d(m, nn.BatchNorm3d(Co).to(dev).eval(), 1)
+        layer = SmallCoConv3d(m) if kind == "small" else PackedConv3d(m, (nn.BatchNorm2d(Co) if kind == "conv2d" else nn.BatchNorm3d(Co)).to(dev).eval(), 1)
         od = layer.out_shape(*dims) if kind != "small" else dims
-        macs = args.batch * Ci * Co * (k ** 3) * (od[0] * od[1] * od[2]) / (8 if kind == "deconv" else 1)
+        macs = nb * Ci * Co * (k ** (2 if kind == "conv2d" else 3)) * (od[0] * od[1] * od[2]) / (8 if kind == "deconv" else 1)
         line = f"{name:26s} {macs / 1e9:7.2f} GMAC x{count}"
         for cfg in cfgs:
             os.environ.pop("OSA_CONV_CFG", None)

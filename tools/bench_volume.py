@@ -1,0 +1,27 @@
+"""Micro-benchmark of the NDHWC volume builder (GwcNet shape): quad-lane kernel vs the per-channel
+kernel and timing-only ablations (OSA_VOL_DBG).  GPU only.
+"""
+import os, sys, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from openstereo_amd import ops
+dev = "cuda:0"
+B, H, W, D = 1, 136, 240, 48
+gf = ops.empty_cl(2 * B, 320, 1, H, W, dev); gf.normal_()
+cf = ops.empty_cl(2 * B, 12, 1, H, W, dev); cf.normal_()
+def run():
+    return ops.build_cost_volume_from_cl(gf, 40, cf, B, D)
+outs = {}
+for mode in ("quads", "perchannel", "quads", "dbg1", "dbg2", "dbg4", "dbg3", "dbg6", "dbg7"):
+    os.environ.pop("OSA_VOL_PERCHANNEL", None); os.environ.pop("OSA_VOL_DBG", None)
+    if mode == "perchannel": os.environ["OSA_VOL_PERCHANNEL"] = "1"
+    if mode.startswith("dbg"): os.environ["OSA_VOL_DBG"] = mode[3:]
+    for _ in range(3): v = run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): v = run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    outs[mode] = v.clone()
+    print(f"{mode}: {ms:.3f} ms  {(487.8e6 / ms / 1e9):.2f} TB/s (algorithmic 487.8 MB)")
+print("bit-identical:", torch.equal(outs["quads"], outs["perchannel"]))
