@@ -45,7 +45,10 @@ extern "C" {
 #define OSA_ABI_VERSION 1
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
-enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2 };
+enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3 };
+/* OR'ed into `act`: the gate tensor is a plain multiplier (LightStereo AttentionModule, attn * cost,
+ * models/lightstereo/aggregation.py:134) instead of logits passed through a sigmoid */
+enum { OSA_GATE_RAW = 16 };
 
 /* ---- misc ------------------------------------------------------------- */
 int         osa_abi_version(void);
@@ -174,6 +177,49 @@ int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
                              int k, int pad, int opad,
                              const float* gate_logits, int gCs,
                              int act, float slope, float out_scale, void* stream);
+
+/*
+ * 2-D transposed convolution (nn.ConvTranspose2d, stride 2) on an NHWC map: the D = 1 case of the
+ * fused parity-class kernel (4 classes).  LightStereo Aggregation.conv5 / conv6
+ * (stereo/modeling/models/lightstereo/aggregation.py:29-35): k = 3, pad 1, opad 1, + BatchNorm2d,
+ * with the redir residual and ReLU of :57-58 fused.  Weight layout of the reference: [Ci][Co][kh][kw].
+ */
+size_t osa_deconv2d_packed_floats(int Ci, int Co, int k);
+int    osa_deconv2d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad, void* stream);
+int    osa_deconv2d_pack_f16x3(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad,
+                               float wscale, void* stream);
+int osa_deconv2d_nhwc_f32(const float* x, const float* w_packed,
+                          const float* scale, const float* shift, const float* residual,
+                          float* y,
+                          int B, int Hi, int Wi, int Ci, int xCs,
+                          int Co, int yCs, int rCs,
+                          int k, int pad, int opad,
+                          const float* gate_logits, int gCs,
+                          int act, float slope, void* stream);
+int osa_deconv2d_nhwc_f16x3(const float* x, const float* w_packed,
+                            const float* scale, const float* shift, const float* residual,
+                            float* y,
+                            int B, int Hi, int Wi, int Ci, int xCs,
+                            int Co, int yCs, int rCs,
+                            int k, int pad, int opad,
+                            const float* gate_logits, int gCs,
+                            int act, float slope, float out_scale, void* stream);
+
+/*
+ * Depthwise 2-D convolution on an NHWC map (groups == channels): LightStereo MobileV2Residual.dwconv
+ * (aggregation.py:79-83, 3x3, stride 1/2, + BatchNorm2d + ReLU6) and the strip convolutions of
+ * AttentionModule (aggregation.py:105-113: 1x7, 7x1, 1x11, 11x1, 1x21, 21x1, with bias).
+ *   y = act( dwconv(x, w) * scale[c] + shift[c] ) + add
+ *   w_packed: [kh*kw][C], made by osa_dwconv2d_pack_f32 from the reference layout [C][1][kh][kw]
+ *   scale/shift: folded eval BatchNorm or (1, bias); NULL = 1 / 0.   add: NHWC addend (stride aCs) or NULL
+ *   act: OSA_ACT_NONE / OSA_ACT_RELU / OSA_ACT_RELU6.   C and all strides multiples of 4, fp32 exact (fmaf per tap).
+ */
+int osa_dwconv2d_pack_f32(const float* w_ref, float* w_packed, int C, int kh, int kw, void* stream);
+int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
+                          const float* scale, const float* shift, const float* add, float* y,
+                          int B, int Hi, int Wi, int C, int xCs, int yCs, int aCs,
+                          int kh, int kw, int stride, int pad_h, int pad_w, int dil_h, int dil_w,
+                          int act, void* stream);
 
 /* Packing for backward passes.  Ci/Co are the roles of the convolution that will be EXECUTED with the
  * packed buffer; src_transposed=1 reads w_ref as [Ci][Co][k] (instead of [Co][Ci][k]); flip=1 mirrors taps.

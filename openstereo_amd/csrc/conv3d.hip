@@ -142,7 +142,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
 template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW>
-__global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (NCLS >= 4) ? 2 : 1) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -358,6 +358,8 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
                       (!p.res || (((p.rCs & 3) == 0) && (((size_t)p.res & 15) == 0))) &&
                       (!p.gate || (((p.gCs & 3) == 0) && (((size_t)p.gate & 15) == 0)));
     const int vsub = lane >> 3, cq = (lane & 7) * 4;   // voxel within a group of 8, channel quad
+    const int actk = p.act & 15;
+    const bool gate_raw = (p.act & OSA_GATE_RAW) != 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         // the 4 voxels this lane finalises in M tile m: rows vsub + 8k
@@ -426,9 +428,10 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS == 8) ? 2 : 1) void conv_mfma_k
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
-                        if (p.act == OSA_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (p.act == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
-                        if (p.gate) v *= 1.0f / (1.0f + expf(-g4[e]));
+                        if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                        else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                        if (p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
                         o[e] = v;
                     }
                     if (vok[k] && cok) {
@@ -488,6 +491,11 @@ constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 static const KernelCfg g_deconv_cfg = {
     "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
     { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> },
+    { nullptr, nullptr } };
+// fused 2-D transposed conv (D = 1): 128 input-resolution pixels x 32 channels x 4 parity classes
+static const KernelCfg g_deconv_flat_cfg = {
+    "deconv4_1x1_4x1_8x16", 128, 32, 1, 8, 16, 256,
+    { conv_mfma_kernel<PREC_F32, 4, 1, 1, 1, 4, 1, 8, 16>, conv_mfma_kernel<PREC_F16X3, 4, 1, 1, 1, 4, 1, 8, 16> },
     { nullptr, nullptr } };
 
 static int pick_cfg(const ConvArgs& a, int stride) {
@@ -795,11 +803,13 @@ struct DeconvTaps {
     int T; int cls_end[8];
     signed char kz[MAX_TAPS], ky[MAX_TAPS], kx[MAX_TAPS], dz[MAX_TAPS], dy[MAX_TAPS], dx[MAX_TAPS];
 };
-static void deconv_taps(int k, int pad, DeconvTaps& d) {
+static void deconv_taps(int k, int pad, DeconvTaps& d, bool flat = false) {
     int t = 0;
     for (int cls = 0; cls < 8; ++cls) {
         int dd[4], kd_[4], dh[4], kh_[4], dw[4], kw_[4];
-        const int nd = deconv_dim_taps(k, pad, (cls >> 2) & 1, dd, kd_);
+        // flat: a 1 x k x k kernel on a D = 1 tensor -- only the 4 classes with even d parity exist
+        int nd = flat ? (((cls >> 2) & 1) ? 0 : 1) : deconv_dim_taps(k, pad, (cls >> 2) & 1, dd, kd_);
+        if (flat) { dd[0] = 0; kd_[0] = 0; }
         const int nh = deconv_dim_taps(k, pad, (cls >> 1) & 1, dh, kh_);
         const int nw = deconv_dim_taps(k, pad, cls & 1, dw, kw_);
         for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c, ++t) {
@@ -812,14 +822,14 @@ static void deconv_taps(int k, int pad, DeconvTaps& d) {
 }
 
 static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
-                              int k, int pad, int prec, float wscale, void* stream) {
+                              int k, int pad, int prec, float wscale, void* stream, bool flat = false) {
     OSA_REQUIRE(w_ref && w_packed, "deconv3d_pack: NULL pointer");
     OSA_REQUIRE(k == 3 || k == 4, "deconv3d_pack: kernel %d unsupported (3 or 4)", k);
     DeconvTaps d;
-    deconv_taps(k, pad, d);
+    deconv_taps(k, pad, d, flat);
     PackArgs p;
     p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
-    p.kd = k; p.kh = k; p.kw = k; p.T = d.T; p.nchunks = nchunks_of(Ci); p.transposed = 1;
+    p.kd = flat ? 1 : k; p.kh = k; p.kw = k; p.T = d.T; p.nchunks = nchunks_of(Ci); p.transposed = 1;
     for (int t = 0; t < d.T; ++t) { p.kz[t] = d.kz[t]; p.ky[t] = d.ky[t]; p.kx[t] = d.kx[t]; }
     launch_pack(p, prec, wscale, (hipStream_t)stream);
     OSA_LAUNCH_CHECK("deconv3d_pack");
@@ -835,6 +845,22 @@ extern "C" int osa_deconv3d_pack_f16x3(const float* w_ref, float* w_packed, int 
                                        int k, int pad, float wscale, void* stream) {
     OSA_REQUIRE(wscale > 0.f, "deconv3d_pack_f16x3: wscale must be a positive power of two");
     return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, wscale, stream);
+}
+
+// ---- 2-D transposed conv (nn.ConvTranspose2d, stride 2): the D = 1 case, 4 parity classes
+extern "C" size_t osa_deconv2d_packed_floats(int Ci, int Co, int k) {
+    return packed_floats(Ci, Co, k * k) + slack_floats(Co);
+}
+
+extern "C" int osa_deconv2d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                     int k, int pad, void* stream) {
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F32, 1.f, stream, true);
+}
+
+extern "C" int osa_deconv2d_pack_f16x3(const float* w_ref, float* w_packed, int Ci, int Co,
+                                       int k, int pad, float wscale, void* stream) {
+    OSA_REQUIRE(wscale > 0.f, "deconv2d_pack_f16x3: wscale must be a positive power of two");
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, wscale, stream, true);
 }
 
 static int check_common(const char* what, const float* x, const float* w, float* y,
@@ -915,20 +941,21 @@ static int deconv3d_impl(const float* x, const float* w_packed,
                          int Co, int yCs, int rCs,
                          int k, int pad, int opad,
                          const float* gate_logits, int gCs,
-                         int act, float slope, int prec, float oscale, void* stream) {
+                         int act, float slope, int prec, float oscale, void* stream, bool flat = false) {
     if (gate_logits) OSA_REQUIRE(gCs >= Co, "deconv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
+    if (flat) OSA_REQUIRE(Di == 1, "deconv2d: the tensor must have D == 1 (got %d)", Di);
     OSA_REQUIRE((k == 3 && pad == 1 && opad == 1) || (k == 4 && pad == 1 && opad == 0),
                 "deconv3d: only (k=3,p=1,op=1) and (k=4,p=1,op=0) with stride 2 are supported (got k=%d p=%d op=%d)", k, pad, opad);
     DeconvTaps d;
-    deconv_taps(k, pad, d);
+    deconv_taps(k, pad, d, flat);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = reinterpret_cast<const float4*>(w_packed);
     a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.gate = gate_logits; a.gCs = gCs;
     a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.xCs = xCs;
-    a.Do = (Di - 1) * 2 - 2 * pad + k + opad; a.Ho = (Hi - 1) * 2 - 2 * pad + k + opad; a.Wo = (Wi - 1) * 2 - 2 * pad + k + opad;
+    a.Do = flat ? 1 : (Di - 1) * 2 - 2 * pad + k + opad; a.Ho = (Hi - 1) * 2 - 2 * pad + k + opad; a.Wo = (Wi - 1) * 2 - 2 * pad + k + opad;
     a.Co = Co; a.yCs = yCs; a.rCs = rCs;
     a.Ad = (a.Do + 1) / 2; a.Ah = (a.Ho + 1) / 2; a.Aw = (a.Wo + 1) / 2;     // a-space covers every output parity
     a.isd = a.ish = a.isw = 1;
@@ -938,7 +965,7 @@ static int deconv3d_impl(const float* x, const float* w_packed,
     for (int c = 0; c < 8; ++c) a.cls_end[c] = d.cls_end[c];
     a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
     a.act = act; a.slope = slope; a.oscale = oscale;
-    return launch_conv(a, 1, prec, (hipStream_t)stream, "deconv3d", &g_deconv_cfg);
+    return launch_conv(a, 1, prec, (hipStream_t)stream, flat ? "deconv2d" : "deconv3d", flat ? &g_deconv_flat_cfg : &g_deconv_cfg);
 }
 
 #define OSA_DECONV_PARAMS                                                                       \
@@ -955,6 +982,22 @@ extern "C" int osa_deconv3d_ndhwc_f32(OSA_DECONV_PARAMS, void* stream) {
 
 extern "C" int osa_deconv3d_ndhwc_f16x3(OSA_DECONV_PARAMS, float out_scale, void* stream) {
     return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16X3, out_scale, stream);
+}
+
+#define OSA_DECONV2D_PARAMS                                                                     \
+    const float* x, const float* w_packed, const float* scale, const float* shift,             \
+    const float* residual, float* y, int B, int Hi, int Wi, int Ci, int xCs,                   \
+    int Co, int yCs, int rCs, int k, int pad, int opad, const float* gate_logits, int gCs, int act, float slope
+#define OSA_DECONV2D_ARGS                                                                       \
+    x, w_packed, scale, shift, residual, y, B, 1, Hi, Wi, Ci, xCs, Co, yCs, rCs, k, pad, opad, \
+    gate_logits, gCs, act, slope
+
+extern "C" int osa_deconv2d_nhwc_f32(OSA_DECONV2D_PARAMS, void* stream) {
+    return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F32, 1.f, stream, true);
+}
+
+extern "C" int osa_deconv2d_nhwc_f16x3(OSA_DECONV2D_PARAMS, float out_scale, void* stream) {
+    return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F16X3, out_scale, stream, true);
 }
 
 extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,

@@ -1,0 +1,113 @@
+// Depthwise 2-D convolution, NHWC (LightStereo's MobileV2Residual depthwise
+// 3x3 convs and the strip convolutions 1x7 / 7x1 / 1x11 / 11x1 / 1x21 / 21x1 of AttentionModule,
+// stereo/modeling/models/lightstereo/aggregation.py:63-134).
+//
+// One multiply-add per output element and tap: HBM/L2 bound, no matrix work.  A thread owns 4
+// consecutive channels of one output pixel (float4 everywhere), neighbouring threads neighbouring
+// channel quads, so every load and store of a wave is a run of full 256-byte channel rows; the
+// kh*kw taps of a pixel re-read rows that other pixels of the workgroup just touched (L1/L2).
+// Weights are repacked once to [tap][C] so a tap's 4 weights are one float4.
+// Epilogue: y = act(acc * scale[c] + shift[c]) + add   (folded eval BatchNorm or bias; optional addend).
+#include "osa_common.h"
+
+namespace osa {
+
+struct DwArgs {
+    const float* x; const float* w; const float* scale; const float* shift; const float* add; float* y;
+    int B, Hi, Wi, Ho, Wo, C, xCs, yCs, aCs;
+    int kh, kw, stride, pad_h, pad_w, dil_h, dil_w, act;
+    long long total;     // B*Ho*Wo*(C/4)
+};
+
+__global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.total) return;
+    const int nq = p.C >> 2;
+    const int q = (int)(idx % nq);
+    long long pix = idx / nq;
+    const int ox = (int)(pix % p.Wo); pix /= p.Wo;
+    const int oy = (int)(pix % p.Ho);
+    const int b = (int)(pix / p.Ho);
+    const int c = q * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.xCs + c;
+    const int iy0 = oy * p.stride - p.pad_h, ix0 = ox * p.stride - p.pad_w;
+    for (int ky = 0; ky < p.kh; ++ky) {
+        const int iy = iy0 + ky * p.dil_h;
+        if ((unsigned)iy >= (unsigned)p.Hi) continue;
+        for (int kx = 0; kx < p.kw; ++kx) {
+            const int ix = ix0 + kx * p.dil_w;
+            if ((unsigned)ix >= (unsigned)p.Wi) continue;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * p.Wi + ix) * p.xCs);
+            const float4 w = *reinterpret_cast<const float4*>(p.w + (size_t)(ky * p.kw + kx) * p.C + c);
+            acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
+            acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+        }
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c);
+    if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + c);
+    float o[4] = {fmaf(acc.x, sc.x, sh.x), fmaf(acc.y, sc.y, sh.y), fmaf(acc.z, sc.z, sh.z), fmaf(acc.w, sc.w, sh.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.act == OSA_ACT_RELU) o[e] = fmaxf(o[e], 0.f);
+        else if (p.act == OSA_ACT_RELU6) o[e] = fminf(fmaxf(o[e], 0.f), 6.f);
+    }
+    const size_t opix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+    if (p.add) {
+        const float4 a = *reinterpret_cast<const float4*>(p.add + opix * p.aCs + c);
+        o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+    }
+    *reinterpret_cast<float4*>(p.y + opix * p.yCs + c) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void dwconv2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // dst index t*C + c
+    if (i >= C * T) return;
+    const int t = i / C, c = i - t * C;
+    dst[i] = src[(size_t)c * T + t];
+}
+
+}  // namespace osa
+
+using namespace osa;
+
+extern "C" int osa_dwconv2d_pack_f32(const float* w_ref, float* w_packed, int C, int kh, int kw, void* stream) {
+    OSA_REQUIRE(w_ref && w_packed, "dwconv2d_pack: NULL pointer");
+    OSA_REQUIRE(C > 0 && kh > 0 && kw > 0, "dwconv2d_pack: bad dims C=%d k=%dx%d", C, kh, kw);
+    const int n = C * kh * kw;
+    hipLaunchKernelGGL(dwconv2d_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w_ref, w_packed, C, kh * kw);
+    OSA_LAUNCH_CHECK("dwconv2d_pack");
+    return 0;
+}
+
+extern "C" int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
+                                     const float* scale, const float* shift, const float* add, float* y,
+                                     int B, int Hi, int Wi, int C, int xCs, int yCs, int aCs,
+                                     int kh, int kw, int stride, int pad_h, int pad_w, int dil_h, int dil_w,
+                                     int act, void* stream) {
+    OSA_REQUIRE(x && w_packed && y, "dwconv2d: NULL pointer");
+    OSA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0, "dwconv2d: bad dims B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
+    OSA_REQUIRE(C % 4 == 0 && xCs % 4 == 0 && yCs % 4 == 0 && xCs >= C && yCs >= C,
+                "dwconv2d: C=%d, strides %d/%d must be multiples of 4 with stride >= C", C, xCs, yCs);
+    OSA_REQUIRE((((size_t)x | (size_t)y | (size_t)w_packed) & 15) == 0, "dwconv2d: pointers must be 16-byte aligned");
+    if (add) OSA_REQUIRE(aCs % 4 == 0 && aCs >= C && ((size_t)add & 15) == 0, "dwconv2d: addend stride %d / alignment", aCs);
+    if (scale) OSA_REQUIRE(((size_t)scale & 15) == 0, "dwconv2d: scale must be 16-byte aligned");
+    if (shift) OSA_REQUIRE(((size_t)shift & 15) == 0, "dwconv2d: shift must be 16-byte aligned");
+    OSA_REQUIRE(stride == 1 || stride == 2, "dwconv2d: stride %d unsupported", stride);
+    OSA_REQUIRE(kh > 0 && kw > 0 && dil_h > 0 && dil_w > 0 && pad_h >= 0 && pad_w >= 0, "dwconv2d: bad kernel geometry");
+    OSA_REQUIRE(act == OSA_ACT_NONE || act == OSA_ACT_RELU || act == OSA_ACT_RELU6, "dwconv2d: act %d unsupported", act);
+    DwArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.add = add; a.y = y;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.C = C; a.xCs = xCs; a.yCs = yCs; a.aCs = aCs;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil_h = dil_h; a.dil_w = dil_w; a.act = act;
+    a.Ho = (Hi + 2 * pad_h - dil_h * (kh - 1) - 1) / stride + 1;
+    a.Wo = (Wi + 2 * pad_w - dil_w * (kw - 1) - 1) / stride + 1;
+    OSA_REQUIRE(a.Ho > 0 && a.Wo > 0, "dwconv2d: empty output");
+    a.total = (long long)B * a.Ho * a.Wo * (C / 4);
+    const long long nblk = (a.total + 255) / 256;
+    OSA_REQUIRE(nblk < (1ll << 31), "dwconv2d: grid too large");
+    hipLaunchKernelGGL(dwconv2d_nhwc_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("dwconv2d");
+    return 0;
+}

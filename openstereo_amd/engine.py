@@ -16,7 +16,8 @@ from .ops import _stream, _p, empty_cl, is_cl
 import math
 import os
 
-ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6 = 0, 1, 2, 3
+GATE_RAW = 16          # OR'ed into act: the gate is a plain multiplier, not sigmoid logits
 enable_timing, collect_timing = timing.enable, timing.collect
 
 # Arithmetic mode of the MFMA convolutions:
@@ -63,8 +64,9 @@ class PackedConv3d:
         if not w.is_cuda:
             raise _lib.EngineError("PackedConv3d needs parameters on the GPU (no CPU path)")
         w = w.float().contiguous()
-        self.transposed = isinstance(conv, nn.ConvTranspose3d)
-        if isinstance(conv, nn.Conv2d):            # 2-D layer == 3-D layer with D = 1 and a 1 x kh x kw kernel
+        self.transposed = isinstance(conv, (nn.ConvTranspose3d, nn.ConvTranspose2d))
+        self.flat_deconv = isinstance(conv, nn.ConvTranspose2d)    # D = 1 map, 4 parity classes
+        if isinstance(conv, (nn.Conv2d, nn.ConvTranspose2d)):            # 2-D layer == 3-D layer with D = 1 and a 1 x kh x kw kernel
             w = w[:, :, None].contiguous()
             self.k = (1,) + tuple(conv.kernel_size)
             self.stride = (1,) + tuple(conv.stride)
@@ -95,16 +97,23 @@ class PackedConv3d:
             self.out_scale = 1.0 / wscale
         if self.transposed:
             self.Ci, self.Co = w.shape[0], w.shape[1]
-            assert self.k[0] == self.k[1] == self.k[2] and self.stride == (2, 2, 2)
-            self.opad = _t3(conv.output_padding)
-            n = _lib.load().osa_deconv3d_packed_floats(self.Ci, self.Co, self.k[0])
+            assert conv.groups == 1
+            if self.flat_deconv:
+                assert self.k[1] == self.k[2] and self.stride == (1, 2, 2)
+                self.opad = (0,) + tuple(conv.output_padding)
+                fam = "osa_deconv2d"
+            else:
+                assert self.k[0] == self.k[1] == self.k[2] and self.stride == (2, 2, 2)
+                self.opad = _t3(conv.output_padding)
+                fam = "osa_deconv3d"
+            n = getattr(_lib.load(), fam + "_packed_floats")(self.Ci, self.Co, self.k[1])
             self.packed = torch.zeros(n, device=w.device, dtype=torch.float32)
             if f16:
-                _lib.call("osa_deconv3d_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
-                          self.k[0], self.pad[0], wscale, st)
+                _lib.call(fam + "_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
+                          self.k[1], self.pad[1], wscale, st)
             else:
-                _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
-                          self.k[0], self.pad[0], st)
+                _lib.call(fam + "_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
+                          self.k[1], self.pad[1], st)
         else:
             self.Co, self.Ci = w.shape[0], w.shape[1]
             assert conv.groups == 1
@@ -119,19 +128,21 @@ class PackedConv3d:
 
     def out_shape(self, D, H, W):
         if self.transposed:
-            k, p, op = self.k[0], self.pad[0], self.opad[0]
-            return tuple((n - 1) * 2 - 2 * p + k + op for n in (D, H, W))
+            k, p, op = self.k[1], self.pad[1], self.opad[1]
+            up = lambda n: (n - 1) * 2 - 2 * p + k + op
+            return (1, up(H), up(W)) if self.flat_deconv else (up(D), up(H), up(W))
         s = self.stride[1]
         sd = 1 if (D == 1 and self.k[0] == 1) else s
         f = lambda n, k, p, d, st: (n + 2 * p - d * (k - 1) - 1) // st + 1
         return (f(D, self.k[0], self.pad[0], self.dil[0], sd), f(H, self.k[1], self.pad[1], self.dil[1], s),
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
-    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0):
+    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False):
         """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
         Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
-        multiplied by sigmoid(gate) broadcast over D (FeatureAtt)."""
+        multiplied by sigmoid(gate) broadcast over D (FeatureAtt); gate_raw=True multiplies by the
+        gate itself (LightStereo AttentionModule: attn * cost)."""
         assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
         B, Cs, D, H, W = x.shape
         assert Cs >= x_off + self.Ci and Cs % 4 == 0 and x_off % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
@@ -155,19 +166,70 @@ class PackedConv3d:
             gCs = gate.shape[3]
         xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
         rp = None if residual is None else residual.data_ptr() + 4 * res_off
+        act = self.act | (GATE_RAW if (gate is not None and gate_raw) else 0)
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
             tail = (self.out_scale, _stream()) if self.precision == "f16x3" else (_stream(),)
             sfx = "f16x3" if self.precision == "f16x3" else "f32"
-            if self.transposed:
+            if self.flat_deconv:
+                assert D == 1
+                _lib.call("osa_deconv2d_nhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                          rp, yp, B, H, W, Ci, Cs, self.Co, yCs, rCs,
+                          self.k[1], self.pad[1], self.opad[1], _p(gate), gCs, act, self.slope, *tail)
+            elif self.transposed:
                 _lib.call("osa_deconv3d_ndhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
                           rp, yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
-                          self.k[0], self.pad[0], self.opad[0], _p(gate), gCs, self.act, self.slope, *tail)
+                          self.k[0], self.pad[0], self.opad[0], _p(gate), gCs, act, self.slope, *tail)
             else:
                 _lib.call("osa_conv3d_ndhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
                           rp, yp, B, D, H, W, Ci, Cs, self.Co, yCs, rCs,
                           self.k[0], self.k[1], self.k[2], self.stride[1],
                           self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
-                          _p(gate), gCs, self.act, self.slope, *tail)
+                          _p(gate), gCs, act, self.slope, *tail)
+        return out
+
+
+class DepthwiseConv2d:
+    """Depthwise nn.Conv2d (groups == channels) + folded BN / bias + activation on an NHWC map
+    (logical [B,C,1,H,W] NDHWC tensor).  LightStereo MobileV2Residual.dwconv and the AttentionModule
+    strip convolutions (aggregation.py:79-83, 105-113).  fp32 fmaf per tap in both precision modes."""
+
+    def __init__(self, conv, bn=None, act=ACT_NONE):
+        assert isinstance(conv, nn.Conv2d) and conv.groups == conv.in_channels == conv.out_channels
+        w = conv.weight.detach()
+        if not w.is_cuda:
+            raise _lib.EngineError("DepthwiseConv2d needs parameters on the GPU (no CPU path)")
+        w = w.float().contiguous()
+        self.C = conv.in_channels
+        assert self.C % 4 == 0, "depthwise engine layers need a channel count divisible by 4"
+        self.k, self.stride, self.pad, self.dil = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding), tuple(conv.dilation)
+        assert self.stride[0] == self.stride[1]
+        self.act = act
+        self.scale, self.shift = bn_scale_shift(bn)
+        if conv.bias is not None:
+            bias = conv.bias.detach().float()
+            if bn is None:
+                self.shift, self.scale = bias.contiguous(), None
+            else:
+                self.shift = (self.shift + bias * self.scale).contiguous()
+        self.packed = torch.empty(self.k[0] * self.k[1] * self.C, device=w.device, dtype=torch.float32)
+        _lib.call("osa_dwconv2d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.C, self.k[0], self.k[1], _stream())
+
+    def __call__(self, x, add=None):
+        assert is_cl(x) and x.dtype == torch.float32 and x.shape[2] == 1
+        B, Cs, _, H, W = x.shape
+        assert Cs >= self.C
+        f = lambda n, k, p, d, st: (n + 2 * p - d * (k - 1) - 1) // st + 1
+        Ho, Wo = f(H, self.k[0], self.pad[0], self.dil[0], self.stride[0]), f(W, self.k[1], self.pad[1], self.dil[1], self.stride[1])
+        out = empty_cl(B, self.C, 1, Ho, Wo, x.device)
+        aCs = 0
+        if add is not None:
+            assert is_cl(add) and tuple(add.shape[2:]) == (1, Ho, Wo) and add.shape[1] >= self.C
+            aCs = add.shape[1]
+        with timing.span("dwconv2d", self.C, self.C, self.k[0] * self.k[1], self.stride[0], 1, H, W):
+            _lib.call("osa_dwconv2d_nhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                      _p(add), out.data_ptr(), B, H, W, self.C, Cs, self.C, aCs,
+                      self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1], self.dil[0], self.dil[1],
+                      self.act, _stream())
         return out
 
 

@@ -1,0 +1,173 @@
+"""LightStereo 2-D cost aggregation on the gfx950 engine.
+
+Mirror of stereo/modeling/models/lightstereo/aggregation.py:7-134 -- same class names, constructor
+arguments and state_dict keys (`conv0.N.pwconv.0.weight`, `att0.conv0_1.weight`, ...) -- with the
+forward pass on the engine.  The correlation volume is treated as a [B, D/4, H/4, W/4] feature map
+(disparity = channel); every tensor is NHWC between layers:
+
+  * 1x1 expand / project convs (+BN +ReLU6, + the residual of MobileV2Residual) and the two stride-2
+    ConvTranspose2d (+BN + redir residual + ReLU): MFMA implicit GEMM (PackedConv3d, D = 1),
+  * depthwise 3x3 (stride 1/2) + BN + ReLU6 and the strip convolutions of AttentionModule:
+    DepthwiseConv2d (fp32 VALU, HBM/L2 bound); the `attn + attn_0 + attn_1 + attn_2` sum is folded
+    into the addend of the second strip conv of each branch (same left-to-right order),
+  * `attn * cost` is the raw-gate epilogue of AttentionModule.conv3.
+
+forward() accepts the reference's NCHW tensors and returns `[conv6]` NCHW like the reference;
+forward_cl() is the channels-last entry used inside engine chains.  No CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..engine import PackedConv3d, DepthwiseConv2d, ACT_NONE, ACT_RELU, ACT_RELU6
+from ..ops import empty_cl, is_cl
+
+
+def nchw_to_cl(x):
+    """[B,C,H,W] (any strides) -> logical [B,Cpad4,1,H,W] NDHWC engine tensor (padded channels zero)."""
+    B, C, H, W = x.shape
+    Cp = (C + 3) // 4 * 4
+    out = empty_cl(B, Cp, 1, H, W, x.device)
+    if Cp != C:
+        out.zero_()
+    out[:, :C, 0] = x.float()
+    return out
+
+
+def cl_to_nchw(x, C=None):
+    C = x.shape[1] if C is None else C
+    return x[:, :C, 0].contiguous()
+
+
+class MobileV2Residual(nn.Module):
+    """aggregation.py:63-98"""
+
+    def __init__(self, inp, oup, stride, expanse_ratio, dilation=1):
+        super().__init__()
+        self.stride = stride
+        assert stride in [1, 2]
+        hidden_dim = int(inp * expanse_ratio)
+        self.use_res_connect = self.stride == 1 and inp == oup
+        pad = dilation
+        self.pwconv = nn.Sequential(nn.Conv2d(inp, hidden_dim, 1, 1, 0, bias=False), nn.BatchNorm2d(hidden_dim), nn.ReLU6(inplace=True))
+        self.dwconv = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim, 3, stride, pad, dilation=dilation, groups=hidden_dim, bias=False),
+                                    nn.BatchNorm2d(hidden_dim), nn.ReLU6(inplace=True))
+        self.pwliner = nn.Sequential(nn.Conv2d(hidden_dim, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup))
+        self._eng = None
+
+    def _pack(self):
+        if self._eng is None:
+            self._eng = (PackedConv3d(self.pwconv[0], self.pwconv[1], ACT_RELU6),
+                         DepthwiseConv2d(self.dwconv[0], self.dwconv[1], ACT_RELU6),
+                         PackedConv3d(self.pwliner[0], self.pwliner[1], ACT_NONE))
+        return self._eng
+
+    def forward_cl(self, x):
+        pw, dw, pl = self._pack()
+        return pl(dw(pw(x)), residual=x if self.use_res_connect else None)     # x + feat fused in the epilogue
+
+    def forward(self, x):
+        return cl_to_nchw(self.forward_cl(nchw_to_cl(x)), self.pwliner[0].out_channels)
+
+
+class AttentionModule(nn.Module):
+    """aggregation.py:101-134"""
+
+    def __init__(self, dim, img_feat_dim):
+        super().__init__()
+        self.conv0 = nn.Conv2d(img_feat_dim, dim, 1)
+        self.conv0_1 = nn.Conv2d(dim, dim, (1, 7), padding=(0, 3), groups=dim)
+        self.conv0_2 = nn.Conv2d(dim, dim, (7, 1), padding=(3, 0), groups=dim)
+        self.conv1_1 = nn.Conv2d(dim, dim, (1, 11), padding=(0, 5), groups=dim)
+        self.conv1_2 = nn.Conv2d(dim, dim, (11, 1), padding=(5, 0), groups=dim)
+        self.conv2_1 = nn.Conv2d(dim, dim, (1, 21), padding=(0, 10), groups=dim)
+        self.conv2_2 = nn.Conv2d(dim, dim, (21, 1), padding=(10, 0), groups=dim)
+        self.conv3 = nn.Conv2d(dim, dim, 1)
+        self._eng = None
+
+    def _pack(self):
+        if self._eng is None:
+            self._eng = dict(conv0=PackedConv3d(self.conv0), conv3=PackedConv3d(self.conv3),
+                             **{n: DepthwiseConv2d(getattr(self, n)) for n in
+                                ("conv0_1", "conv0_2", "conv1_1", "conv1_2", "conv2_1", "conv2_2")})
+        return self._eng
+
+    def forward_cl(self, cost, x):
+        e = self._pack()
+        attn = e["conv0"](x)
+        s = e["conv0_2"](e["conv0_1"](attn), add=attn)        # attn + attn_0
+        s = e["conv1_2"](e["conv1_1"](attn), add=s)           # ... + attn_1
+        s = e["conv2_2"](e["conv2_1"](attn), add=s)           # ... + attn_2
+        B, C, _, H, W = cost.shape
+        gate = cost.permute(0, 2, 3, 4, 1).reshape(B, H, W, C)  # NHWC view of the same memory
+        return e["conv3"](s, gate=gate, gate_raw=True)         # conv3(attn) * cost
+
+    def forward(self, cost, x):
+        return cl_to_nchw(self.forward_cl(nchw_to_cl(cost), nchw_to_cl(x)), self.conv3.out_channels)
+
+
+class Aggregation(nn.Module):
+    """aggregation.py:7-60"""
+
+    def __init__(self, in_channels, left_att, blocks, expanse_ratio, backbone_channels):
+        super().__init__()
+        self.left_att = left_att
+        self.expanse_ratio = expanse_ratio
+        c = in_channels
+        self.conv0 = nn.Sequential(*[MobileV2Residual(c, c, stride=1, expanse_ratio=expanse_ratio) for _ in range(blocks[0])])
+        self.conv1 = MobileV2Residual(c, c * 2, stride=2, expanse_ratio=expanse_ratio)
+        self.conv2 = nn.Sequential(*[MobileV2Residual(c * 2, c * 2, stride=1, expanse_ratio=expanse_ratio) for _ in range(blocks[1] - 1)])
+        self.conv3 = MobileV2Residual(c * 2, c * 4, stride=2, expanse_ratio=expanse_ratio)
+        self.conv4 = nn.Sequential(*[MobileV2Residual(c * 4, c * 4, stride=1, expanse_ratio=expanse_ratio) for _ in range(blocks[2] - 1)])
+        self.conv5 = nn.Sequential(nn.ConvTranspose2d(c * 4, c * 2, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm2d(c * 2))
+        self.conv6 = nn.Sequential(nn.ConvTranspose2d(c * 2, c, 3, padding=1, output_padding=1, stride=2, bias=False),
+                                   nn.BatchNorm2d(c))
+        self.redir1 = MobileV2Residual(c, c, stride=1, expanse_ratio=expanse_ratio)
+        self.redir2 = MobileV2Residual(c * 2, c * 2, stride=1, expanse_ratio=expanse_ratio)
+        if self.left_att:
+            self.att0 = AttentionModule(c, backbone_channels[0])
+            self.att2 = AttentionModule(c * 2, backbone_channels[1])
+            self.att4 = AttentionModule(c * 4, backbone_channels[2])
+        self._eng = None
+
+    def reset_engine(self):
+        """Drop packed weights (call after loading a checkpoint)."""
+        self._eng = None
+        for m in self.modules():
+            if m is not self and hasattr(m, "_eng"):
+                m._eng = None
+
+    def _pack(self):
+        if self._eng is None:
+            self._eng = (PackedConv3d(self.conv5[0], self.conv5[1], ACT_RELU), PackedConv3d(self.conv6[0], self.conv6[1], ACT_RELU))
+        return self._eng
+
+    def forward_cl(self, x, features_left):
+        """x: NHWC volume (logical [B,D4,1,H4,W4]); features_left: NHWC maps at 1/4, 1/8, 1/16."""
+        assert is_cl(x)
+        d5, d6 = self._pack()
+        for blk in self.conv0:
+            x = blk.forward_cl(x)
+        if self.left_att:
+            x = self.att0.forward_cl(x, features_left[0])
+        conv2 = self.conv1.forward_cl(x)
+        for blk in self.conv2:
+            conv2 = blk.forward_cl(conv2)
+        if self.left_att:
+            conv2 = self.att2.forward_cl(conv2, features_left[1])
+        conv4 = self.conv3.forward_cl(conv2)
+        for blk in self.conv4:
+            conv4 = blk.forward_cl(conv4)
+        if self.left_att:
+            conv4 = self.att4.forward_cl(conv4, features_left[2])
+        conv5 = d5(conv4, residual=self.redir2.forward_cl(conv2))     # relu(conv5(conv4) + redir2(conv2))
+        conv6 = d6(conv5, residual=self.redir1.forward_cl(x))         # relu(conv6(conv5) + redir1(x))
+        return conv6
+
+    def forward(self, x, features_left):
+        if not x.is_cuda:
+            raise RuntimeError("openstereo_amd Aggregation runs on the GPU engine only (no CPU path)")
+        out = self.forward_cl(nchw_to_cl(x), [nchw_to_cl(f) for f in features_left[:3]])
+        return [cl_to_nchw(out, self.conv6[0].out_channels)]

@@ -427,3 +427,54 @@ class GeoEncodingVolume:
             xc = coords.reshape(b * h * w, 1, 1, 1) / 2 ** i - disp.reshape(b * h * w, 1, 1, 1) / 2 ** i + dx
             out.append(self._sample(self.corr[i], xc).view(b, h, w, -1))
         return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+# ----------------------------------------------------------------------------- LightStereo 2-D aggregation (a9)
+def _mobile_v2_residual(x, sd, p, stride):
+    """MobileV2Residual.forward, stereo/modeling/models/lightstereo/aggregation.py:88-98 (dilation 1)."""
+    inp, oup = sd[p + ".pwconv.0.weight"].shape[1], sd[p + ".pwliner.0.weight"].shape[0]
+    hid = sd[p + ".dwconv.0.weight"].shape[0]
+    f = F.relu6(_bn(F.conv2d(x, sd[p + ".pwconv.0.weight"]), sd, p + ".pwconv.1"))
+    f = F.relu6(_bn(F.conv2d(f, sd[p + ".dwconv.0.weight"], None, stride, 1, 1, hid), sd, p + ".dwconv.1"))
+    f = _bn(F.conv2d(f, sd[p + ".pwliner.0.weight"]), sd, p + ".pwliner.1")
+    return x + f if (stride == 1 and inp == oup) else f
+
+
+def _ls_attention(cost, x, sd, p):
+    """AttentionModule.forward, aggregation.py:118-134."""
+    dim = sd[p + ".conv3.weight"].shape[0]
+    c = lambda t, n, pad: F.conv2d(t, sd[f"{p}.{n}.weight"], sd[f"{p}.{n}.bias"], 1, pad, 1, dim)
+    attn = F.conv2d(x, sd[p + ".conv0.weight"], sd[p + ".conv0.bias"])
+    a0 = c(c(attn, "conv0_1", (0, 3)), "conv0_2", (3, 0))
+    a1 = c(c(attn, "conv1_1", (0, 5)), "conv1_2", (5, 0))
+    a2 = c(c(attn, "conv2_1", (0, 10)), "conv2_2", (10, 0))
+    attn = attn + a0 + a1 + a2
+    attn = F.conv2d(attn, sd[p + ".conv3.weight"], sd[p + ".conv3.bias"])
+    return attn * cost
+
+
+def lightstereo_aggregation(x, features_left, sd, p="", blocks=(1, 2, 4), left_att=True, taps=None):
+    """Aggregation.forward, aggregation.py:42-60.  sd: the reference module's state_dict (prefix p)."""
+    q = (p + ".") if p else ""
+    for i in range(blocks[0]):
+        x = _mobile_v2_residual(x, sd, f"{q}conv0.{i}", 1)
+    if left_att:
+        x = _ls_attention(x, features_left[0], sd, q + "att0")
+        if taps is not None:
+            taps["att0"] = x
+    conv2 = _mobile_v2_residual(x, sd, q + "conv1", 2)
+    for i in range(blocks[1] - 1):
+        conv2 = _mobile_v2_residual(conv2, sd, f"{q}conv2.{i}", 1)
+    if left_att:
+        conv2 = _ls_attention(conv2, features_left[1], sd, q + "att2")
+    conv4 = _mobile_v2_residual(conv2, sd, q + "conv3", 2)
+    for i in range(blocks[2] - 1):
+        conv4 = _mobile_v2_residual(conv4, sd, f"{q}conv4.{i}", 1)
+    if left_att:
+        conv4 = _ls_attention(conv4, features_left[2], sd, q + "att4")
+        if taps is not None:
+            taps["att4"] = conv4
+    up = lambda t, n: _bn(F.conv_transpose2d(t, sd[f"{q}{n}.0.weight"], None, 2, 1, 1), sd, f"{q}{n}.1")
+    conv5 = F.relu(up(conv4, "conv5") + _mobile_v2_residual(conv2, sd, q + "redir2", 1))
+    conv6 = F.relu(up(conv5, "conv6") + _mobile_v2_residual(x, sd, q + "redir1", 1))
+    return conv6

@@ -50,13 +50,35 @@ class Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
+def gen_lightstereo():
+    """LightStereo-S aggregation (a9): cfgs/lightstereo/lightstereo_s_sceneflow.yaml -- in_channels 48,
+    AGGREGATION_BLOCKS [1, 2, 4], EXPANSE_RATIO 4, LEFT_ATT true, MobileNetv2 channels [24, 32, 96, 160]."""
+    from openstereo_amd.utils.weights import synth_state_dict
+    from stereo.modeling.models.lightstereo.aggregation import Aggregation
+    agg = Aggregation(in_channels=48, left_att=True, blocks=[1, 2, 4], expanse_ratio=4,
+                      backbone_channels=[24, 32, 96, 160]).eval()
+    agg.load_state_dict(synth_state_dict(agg, seed=9))
+    x = rnd((1, 48, 32, 64), 51)
+    feats = [rnd((1, 24, 32, 64), 52), rnd((1, 32, 16, 32), 53), rnd((1, 96, 8, 16), 54), rnd((1, 160, 4, 8), 55)]
+    taps = {}
+    agg.att0.register_forward_hook(lambda m, i, o: taps.__setitem__("att0", o.clone()))
+    agg.att4.register_forward_hook(lambda m, i, o: taps.__setitem__("att4", o.clone()))
+    y = agg(x, feats)[0]
+    print("LightStereo aggregation out range", y.min().item(), y.max().item(), y.std().item())
+    save("lightstereo_agg.npz", y=y, **taps)      # inputs: rnd(shape, 51..54), see tests/conftest.py lightstereo_inputs()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
     from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    if args.only == "lightstereo":
+        gen_lightstereo()
+        return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
     from stereo.modeling.cost_volume import cost_volume as cv
@@ -175,6 +197,9 @@ def main():
     xi = rnd((1, 8, 8, 16, 32), 25)
     fi = feats[:3] + [rnd((1, 160, 2, 4), 26)]
     save("igev_hourglass.npz", x=xi, f1=fi[1], f2=fi[2], f3=fi[3], y=igh(xi, fi))
+
+    # ------------------------------------------------------------------ LightStereo 2-D aggregation (a9)
+    gen_lightstereo()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

@@ -447,3 +447,124 @@ def test_geo_encoding_volume_vs_reference_golden():
     assert out.shape == g["lookup"].shape
     close(out, g["lookup"], atol=2e-5, rtol=1e-5, what="lookup")
     close(gev(g2(g["disp"]) * 2.5 + 1.0, g2(g["coords"])), g["lookup2"], atol=2e-5, rtol=1e-5, what="lookup (large disp, out-of-range taps)")
+
+
+# ----------------------------------------------------------------------------- LightStereo 2-D aggregation (a9)
+DW_CASES = [
+    # name, C, (kh, kw), stride, (ph, pw), (H, W), bias, bn, act, add
+    ("dw3x3 s1 bn relu6", 192, (3, 3), 1, (1, 1), (13, 22), False, True, "relu6", False),
+    ("dw3x3 s2 bn relu6", 96, (3, 3), 2, (1, 1), (14, 21), False, True, "relu6", False),
+    ("strip 1x7 bias", 48, (1, 7), 1, (0, 3), (9, 30), True, False, "none", False),
+    ("strip 21x1 bias add", 48, (21, 1), 1, (10, 0), (25, 11), True, False, "none", True),
+    ("strip 1x11 bias add", 96, (1, 11), 1, (0, 5), (6, 17), True, False, "none", True),
+]
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=[c[0] for c in DW_CASES])
+def test_depthwise_conv2d_vs_torch(case):
+    from openstereo_amd.engine import DepthwiseConv2d
+    from openstereo_amd.models.lightstereo import nchw_to_cl, cl_to_nchw
+    name, C, k, s, p, (H, W), bias, use_bn, act, use_add = case
+    conv = nn.Conv2d(C, C, k, s, p, groups=C, bias=bias)
+    conv.weight.data = synth_tensor(name + ".w", conv.weight.shape, 1)
+    if bias:
+        conv.bias.data = synth_tensor(name + ".bias", conv.bias.shape, 1)
+    bn = None
+    if use_bn:
+        bn = nn.BatchNorm2d(C)
+        bn.load_state_dict({k_: synth_tensor(f"{name}.{k_}", v.shape, 2) for k_, v in bn.state_dict().items()})
+        bn.eval()
+    x = T(np.random.default_rng(3).normal(0, 2, (2, C, H, W)).astype(np.float32))
+    with torch.no_grad():
+        ref = conv(x)
+        if bn is not None:
+            ref = bn(ref)
+        ref = {"relu6": F.relu6, "none": lambda t: t}[act](ref)
+        add = torch.randn(ref.shape, generator=torch.Generator().manual_seed(4)) if use_add else None
+        if add is not None:
+            ref = ref + add
+    layer = DepthwiseConv2d(conv.to(DEV), None if bn is None else bn.to(DEV), {"none": 0, "relu6": 3}[act])
+    y = layer(nchw_to_cl(x.to(DEV)), add=None if add is None else nchw_to_cl(add.to(DEV)))
+    close(cl_to_nchw(y), ref, atol=1e-5, rtol=1e-5, what=name)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("case", [("192-96", 192, 96, (5, 9)), ("96-48", 96, 48, (8, 16)), ("24-12 ragged", 24, 12, (7, 19))],
+                         ids=lambda c: c[0])
+def test_deconv2d_bn_residual_vs_torch(case, prec):
+    """nn.ConvTranspose2d(k=3, s=2, p=1, op=1) + BN + residual + ReLU: the D = 1 parity-class kernel."""
+    from openstereo_amd.engine import PackedConv3d
+    from openstereo_amd.models.lightstereo import nchw_to_cl, cl_to_nchw
+    name, Ci, Co, (H, W) = case
+    dc = nn.ConvTranspose2d(Ci, Co, 3, padding=1, output_padding=1, stride=2, bias=False)
+    dc.weight.data = synth_tensor(name + ".w", dc.weight.shape, 1)
+    bn = nn.BatchNorm2d(Co)
+    bn.load_state_dict({k: synth_tensor(f"{name}.{k}", v.shape, 2) for k, v in bn.state_dict().items()})
+    bn.eval()
+    x = T(np.random.default_rng(3).normal(0, 1, (2, Ci, H, W)).astype(np.float32))
+    with torch.no_grad():
+        up = bn(dc(x))
+        res = torch.randn(up.shape, generator=torch.Generator().manual_seed(4))
+        ref = F.relu(up + res)
+    pc = PackedConv3d(dc.to(DEV), bn.to(DEV), 1, precision=prec)
+    y = pc(nchw_to_cl(x.to(DEV)), residual=nchw_to_cl(res.to(DEV)))
+    close(cl_to_nchw(y, Co), ref, atol=2e-5, rtol=2e-5, what=f"deconv2d {name} [{prec}]")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_pointwise_relu6_and_raw_gate(prec):
+    """1x1 Conv2d + BN + ReLU6 (MobileV2Residual.pwconv) and conv3(attn) * cost (AttentionModule)."""
+    from openstereo_amd.engine import PackedConv3d, ACT_RELU6
+    from openstereo_amd.models.lightstereo import nchw_to_cl, cl_to_nchw
+    conv = nn.Conv2d(48, 192, 1, bias=False)
+    conv.weight.data = synth_tensor("pw.w", conv.weight.shape, 1) * 4.0     # push part of the outputs beyond 6
+    bn = nn.BatchNorm2d(192)
+    bn.load_state_dict({k: synth_tensor(f"pw.{k}", v.shape, 2) for k, v in bn.state_dict().items()})
+    bn.eval()
+    x = T(np.random.default_rng(3).normal(0, 1, (2, 48, 9, 14)).astype(np.float32))
+    with torch.no_grad():
+        ref = F.relu6(bn(conv(x)))
+    assert (ref == 6).any() and (ref == 0).any()
+    y = PackedConv3d(conv.to(DEV), bn.to(DEV), ACT_RELU6, precision=prec)(nchw_to_cl(x.to(DEV)))
+    close(cl_to_nchw(y), ref, atol=2e-5, rtol=2e-5, what=f"pw relu6 [{prec}]")
+
+    c3 = nn.Conv2d(48, 48, 1)
+    c3.weight.data = synth_tensor("c3.w", c3.weight.shape, 1)
+    c3.bias.data = synth_tensor("c3.bias", c3.bias.shape, 1)
+    cost = T(np.random.default_rng(5).normal(0, 2, (2, 48, 9, 14)).astype(np.float32))
+    with torch.no_grad():
+        ref = c3(x) * cost
+    cc = nchw_to_cl(cost.to(DEV))
+    gate = cc.permute(0, 2, 3, 4, 1).reshape(2, 9, 14, 48)
+    y = PackedConv3d(c3.to(DEV), precision=prec)(nchw_to_cl(x.to(DEV)), gate=gate, gate_raw=True)
+    close(cl_to_nchw(y), ref, atol=4e-5, rtol=2e-5, what=f"raw gate [{prec}]")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_lightstereo_aggregation_vs_reference_golden(prec):
+    """a9 end to end: engine Aggregation (drop-in forward, NCHW in/out) vs the real reference's output."""
+    from conftest import lightstereo_case
+    from openstereo_amd import engine
+    g = golden("lightstereo_agg.npz")
+    agg, sd, x, feats = lightstereo_case()
+    old = engine.get_precision()
+    engine.set_precision(prec)
+    try:
+        agg = agg.to(DEV)
+        with torch.no_grad():
+            y = agg(x.to(DEV), [f.to(DEV) for f in feats])[0]
+            a0 = agg.att0(_ls_conv0(agg, x.to(DEV)), feats[0].to(DEV))
+    finally:
+        engine.set_precision(old)
+    ref = g["y"]
+    tol = 2e-4 * max(1.0, float(np.abs(ref).max()))
+    close(a0, g["att0"], atol=2e-4 * max(1.0, float(np.abs(g["att0"]).max())), rtol=1e-4, what=f"att0 [{prec}]")
+    close(y, ref, atol=tol, rtol=1e-4, what=f"LightStereo aggregation [{prec}]")
+
+
+def _ls_conv0(agg, x):
+    from openstereo_amd.models.lightstereo import nchw_to_cl, cl_to_nchw
+    t = nchw_to_cl(x)
+    for blk in agg.conv0:
+        t = blk.forward_cl(t)
+    return cl_to_nchw(t, 48)

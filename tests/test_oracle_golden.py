@@ -119,3 +119,20 @@ def test_geo_encoding_volume_against_reference():
     gev = O.GeoEncodingVolume(T(g["f1"]), T(g["f2"]), T(g["geo"]), 2, 4)
     close(gev(T(g["disp"]), T(g["coords"])), g["lookup"], atol=1e-6)
     close(gev(T(g["disp"]) * 2.5 + 1.0, T(g["coords"])), g["lookup2"], atol=1e-6)
+
+
+def test_lightstereo_aggregation_against_reference():
+    """a9: oracle restatement of LightStereo's Aggregation vs the real reference module's output."""
+    from conftest import lightstereo_case
+    agg, sd, x, feats = lightstereo_case()
+    g = golden("lightstereo_agg.npz")
+    # state_dict keys of the engine-side mirror are the reference's (checked when the fixture was made:
+    # load_state_dict of the reference module with the same synth dict is strict)
+    taps = {}
+    with torch.no_grad():
+        y = O.lightstereo_aggregation(x, feats, sd, taps=taps)
+    for k, v in (("y", y), ("att0", taps["att0"]), ("att4", taps["att4"])):
+        ref = torch.from_numpy(g[k])
+        assert v.shape == ref.shape
+        err = (v - ref).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
