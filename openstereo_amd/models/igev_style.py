@@ -155,10 +155,36 @@ class Hourglass(nn.Module):
     def forward_cl(self, x, features, return_multi=False):
         return hourglass_forward_cl(self._pack(), x, self.gate_logits(features), return_multi)
 
+    @staticmethod
+    def _unit_train(m, x):
+        """BasicConv3d / BasicDeconv3d in training mode: the convolution (forward, dgrad, wgrad) on the
+        engine through autograd, BatchNorm3d / LeakyReLU as the reference's own torch modules."""
+        from .. import autograd as A
+        x = A.conv_module(m.block[0], x)
+        for layer in list(m.block)[1:]:
+            x = layer(x)
+        return x
+
+    def forward_train(self, x, features, return_multi=False):
+        """hourglass.py:79-104 with differentiable engine convolutions (BASELINE configs[2]: StereoBase
+        training).  FeatureAtt gates, concatenations, BatchNorm and activations are torch ops so that
+        batch statistics, SyncBN and DDP behave exactly like the reference."""
+        seq = lambda mods, t: [t := self._unit_train(m, t) for m in mods][-1]
+        att = lambda fa, cv, feat: torch.sigmoid(fa.feat_att(feat).unsqueeze(2)) * cv
+        conv1 = att(self.feature_att_8, seq(self.conv1, x), features[1])
+        conv2 = att(self.feature_att_16, seq(self.conv2, conv1), features[2])
+        conv3 = att(self.feature_att_32, seq(self.conv3, conv2), features[3])
+        conv2 = torch.cat((self._unit_train(self.conv3_up, conv3), conv2), dim=1)
+        conv2 = att(self.feature_att_up_16, seq(self.agg_0, conv2), features[2])
+        conv1 = torch.cat((self._unit_train(self.conv2_up, conv2), conv1), dim=1)
+        conv1 = att(self.feature_att_up_8, seq(self.agg_1, conv1), features[1])
+        conv = self._unit_train(self.conv1_up, conv1)
+        return [conv, conv1, conv2] if return_multi else conv
+
     def forward(self, x, features, return_multi=False):
-        """Drop-in: NCDHW in -> NCDHW out."""
-        if self.training:
-            raise NotImplementedError("engine Hourglass: training-mode BatchNorm is not built yet")
+        """Drop-in: NCDHW in -> NCDHW out.  Training mode (or grad-requiring inputs) takes the autograd path."""
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(x, features, return_multi)
         out = self.forward_cl(ops.to_cl(x), features, return_multi)
         if return_multi:
             return [ops.to_ncdhw(t) for t in out]

@@ -153,6 +153,46 @@ def test_gwcnet_training_step_vs_oracle_autograd():
         close(g, gr, 2e-3 * scale, 2e-3, f"grad {k}")
 
 
+def test_stereobase_hourglass_training_step_vs_oracle_autograd():
+    """BASELINE configs[2] (StereoBase training, FREEZE_BN: true): forward + backward of the engine
+    Hourglass(24) autograd path against torch-CPU autograd of the oracle -- outputs, d(input) and
+    weight gradients of strided / plain / 1x1x1 convolutions, k4 transposed convs and a gate branch."""
+    from conftest import golden
+    from openstereo_amd.models.igev_style import Hourglass
+    from oracle import torch_ref as O
+    g = golden("stereobase_hourglass.npz")
+    hg = Hourglass(24, [96, 64, 192, 120])
+    sd = synth_state_dict(hg, seed=6)
+    hg.load_state_dict(sd)
+    x = T(g["x"])
+    feats = [None, T(g["f1"]), T(g["f2"]), T(g["f3"])]
+    gy = [rn(tuple(g[k].shape), 30 + i) for i, k in enumerate(("y", "y1", "y2"))]
+    keys = ["conv1.0.block.0.weight", "conv2.1.block.0.weight", "conv3.0.block.0.weight", "conv3_up.block.0.weight",
+            "conv1_up.block.0.weight", "agg_0.0.block.0.weight", "agg_1.2.block.0.weight", "feature_att_16.feat_att.1.weight"]
+    # ---- oracle, CPU autograd
+    sdr = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_()
+    xr = x.clone().requires_grad_()
+    outs = O.igev_style_hourglass(xr, feats, {"hg." + k: v for k, v in sdr.items()}, "hg", return_multi=True)
+    sum((o * w).sum() for o, w in zip(outs, gy)).backward()
+    # ---- engine autograd path (BatchNorm frozen in eval mode, module in train mode)
+    hg = hg.to(DEV).train()
+    for m in hg.modules():
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.eval()
+    xe = x.to(DEV).requires_grad_()
+    oe = hg(xe, [None] + [f.to(DEV) for f in feats[1:]], return_multi=True)
+    for o, ref, name in zip(oe, outs, ("out", "conv1", "conv2")):
+        close(o, ref, 5e-5, 5e-5, f"train fwd {name}")
+    sum((o * w.to(DEV)).sum() for o, w in zip(oe, gy)).backward()
+    close(xe.grad, xr.grad, 2e-3 * float(xr.grad.abs().max()), 2e-3, "d(input)")
+    params = dict(hg.named_parameters())
+    for k in keys:
+        gr = sdr[k].grad
+        close(params[k].grad, gr, 2e-3 * (float(gr.abs().max()) + 1e-12), 2e-3, f"grad {k}")
+
+
 def test_ddp_wrapped_training_steps_reduce_loss():
     """The autograd Functions under stock DistributedDataParallel (world_size 1, nccl == RCCL): DDP's
     gradient hooks fire, an optimiser step lowers the loss."""

@@ -568,3 +568,25 @@ def _ls_conv0(agg, x):
     for blk in agg.conv0:
         t = blk.forward_cl(t)
     return cl_to_nchw(t, 48)
+
+
+def test_lightstereo_aggregation_kitti15_size_vs_oracle():
+    """BASELINE configs[3]: LightStereo 2-D aggregation at KITTI15 size (375x1242 padded to 384x1248,
+    quarter resolution 96x312, D/4 = 48) -- engine (f16x3) vs the CPU oracle on the same seeded inputs."""
+    from conftest import lightstereo_case, rnd
+    from oracle import torch_ref as O
+    from openstereo_amd import engine
+    agg, sd, _, _ = lightstereo_case()
+    x = rnd((1, 48, 96, 312), 61).abs()
+    feats = [rnd((1, 24, 96, 312), 62), rnd((1, 32, 48, 156), 63), rnd((1, 96, 24, 78), 64)]
+    with torch.no_grad():
+        ref = O.lightstereo_aggregation(x, feats, sd)
+    old = engine.get_precision()
+    engine.set_precision("f16x3")
+    try:
+        agg = agg.to(DEV)
+        with torch.no_grad():
+            y = agg(x.to(DEV), [f.to(DEV) for f in feats])[0]
+    finally:
+        engine.set_precision(old)
+    close(y, ref, atol=2e-4 * max(1.0, ref.abs().max().item()), rtol=1e-4, what="LightStereo aggregation @96x312")
