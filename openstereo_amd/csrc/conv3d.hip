@@ -91,7 +91,10 @@ __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) 
 template <int NTHR, int PREC>
 __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int b, int c0,
                                             int g0d, int g0h, int g0w, int tid) {
-    constexpr int U = 4;
+#ifndef OSA_STAGE_U
+#define OSA_STAGE_U 4
+#endif
+    constexpr int U = OSA_STAGE_U;
     const int total = p.LD * p.LH * p.LW * (CC / 4);
     const int LHW = p.LH * p.LW;
     for (int base = tid; base < total; base += NTHR * U) {
@@ -338,6 +341,24 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS >= 4) ? 2 : 1) void conv_mfma_k
     // free both ways) so that a lane ends up with 4 consecutive channels of one voxel: residual /
     // gate loads and output stores are float4, 8 lanes cover one voxel's 128-byte channel row and a
     // wave instruction covers 8 consecutive voxels (1 KB contiguous for a 32-channel tensor).
+    // folded-BN scale / shift of this lane's channel quads: requested before the barrier so the loads
+    // overlap the tail of the tap loop instead of stalling the first tile of the epilogue
+    float4 scv[NT], shv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n0 + (wn * NT + n) * 32 + (lane & 7) * 4;
+        float4 sc = make_float4(p.oscale, p.oscale, p.oscale, p.oscale), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < p.Co && p.scale) {
+            if (co + 3 < p.Co) { sc = *reinterpret_cast<const float4*>(p.scale + co); sh = *reinterpret_cast<const float4*>(p.shift + co); }
+            else {
+                sc.x = p.scale[co]; sh.x = p.shift[co];
+                if (co + 1 < p.Co) { sc.y = p.scale[co + 1]; sh.y = p.shift[co + 1]; }
+                if (co + 2 < p.Co) { sc.z = p.scale[co + 2]; sh.z = p.shift[co + 2]; }
+            }
+            sc.x *= p.oscale; sc.y *= p.oscale; sc.z *= p.oscale; sc.w *= p.oscale;
+        }
+        scv[n] = sc; shv[n] = sh;
+    }
     __syncthreads();                                   // everyone is done reading the input brick
     if (p.dbg & 8) {                                   // timing only: no epilogue (keeps the accumulators live)
         float s = 0.f;
@@ -353,99 +374,125 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS >= 4) ? 2 : 1) void conv_mfma_k
         return;
     }
     float* tb = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+    // per-batch-item base pointers (wave-uniform, 64-bit); everything per lane is a 32-bit element offset
     const size_t bvox = (size_t)b * p.Do * p.Ho * p.Wo;
+    float* yb = p.y + bvox * p.yCs;
+    const float* resb = p.res ? p.res + bvox * p.rCs : nullptr;
+    const float* gateb = p.gate ? p.gate + (size_t)b * p.Ho * p.Wo * p.gCs : nullptr;
     const bool vec4 = ((p.yCs & 3) == 0) && ((p.Co & 3) == 0) && (((size_t)p.y & 15) == 0) &&
                       (!p.res || (((p.rCs & 3) == 0) && (((size_t)p.res & 15) == 0))) &&
                       (!p.gate || (((p.gCs & 3) == 0) && (((size_t)p.gate & 15) == 0)));
     const int vsub = lane >> 3, cq = (lane & 7) * 4;   // voxel within a group of 8, channel quad
     const int actk = p.act & 15;
     const bool gate_raw = (p.act & OSA_GATE_RAW) != 0;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        // the 4 voxels this lane finalises in M tile m: rows vsub + 8k
-        size_t v0[4], g0[4];
-        bool vok[4];
+    // A wave finalises NI = MT*NCLS*NT tiles of 32 voxels x 32 channels one after the other.  The
+    // residual rows of tile i+PD are requested before tile i is processed (rolling window of PD
+    // tiles, static register sets), so the HBM round trip of a residual overlaps the LDS transposes,
+    // arithmetic and stores of the PD-1 tiles in front of it -- the fused transposed conv has 8 tiles
+    // per wave and spent half of its time waiting for them one by one.
+    constexpr int NI = MT * NCLS * NT;
+    constexpr int PD = (NCLS >= 4) ? 3 : ((NI < 2) ? NI : 2);
+    // voxel bookkeeping of the 4 rows (vsub + 8k) this lane finalises in M tile m
+    auto rows_of = [&](int m, int (&v0)[4], int (&g0)[4], bool (&vok)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int q = (wm * MT + m) * 32 + vsub + 8 * k;
             const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
             vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
-            v0[k] = bvox + ((size_t)(ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;
-            g0[k] = ((size_t)b * p.Ho + ah * p.os) * p.Wo + aw * p.os;
+            v0[k] = ((ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;      // voxel index inside batch item b (host: < 2^31 elements)
+            g0[k] = (ah * p.os) * p.Wo + aw * p.os;
         }
+    };
+    auto class_off = [&](int c, int& coff, int& goff) {
+        const int ood = (NCLS == 1) ? p.ood : ((c >> 2) & 1), ooh = (NCLS == 1) ? p.ooh : ((c >> 1) & 1),
+                  oow = (NCLS == 1) ? p.oow : (c & 1);
+        coff = (ood * p.Ho + ooh) * p.Wo + oow;              // supported transposed convs: Do == 2*Di
+        goff = ooh * p.Wo + oow;
+    };
+    // tile order: m outer, class, n inner
+    auto load_res = [&](int i, float4 (&rv)[4]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[4], g0[4], coff, goff; bool vok[4];
+        rows_of(m, v0, g0, vok);
+        class_off(c, coff, goff);
+        const int co = n0 + (wn * NT + n) * 32 + cq;
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) {
-            const int ood = (NCLS == 1) ? p.ood : ((c >> 2) & 1), ooh = (NCLS == 1) ? p.ooh : ((c >> 1) & 1),
-                      oow = (NCLS == 1) ? p.oow : (c & 1);
-            const size_t coff = ((size_t)ood * p.Ho + ooh) * p.Wo + oow;     // supported transposed convs: Do == 2*Di
-            const size_t goff = (size_t)ooh * p.Wo + oow;
+        for (int k = 0; k < 4; ++k) {
+            rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.res && vok[k] && co < p.Co) {
+                const float* rp = resb + (v0[k] + coff) * p.rCs + co;
+                if (vec4) rv[k] = *reinterpret_cast<const float4*>(rp);
+                else {
+                    float* rr = &rv[k].x;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                // registers -> LDS (tile[voxel row][channel])
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
-                const int co = n0 + (wn * NT + n) * 32 + cq;
-                const bool cok = co < p.Co;
-                float4 sc = make_float4(p.oscale, p.oscale, p.oscale, p.oscale), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cok && p.scale) {
-                    if (co + 3 < p.Co) { sc = *reinterpret_cast<const float4*>(p.scale + co); sh = *reinterpret_cast<const float4*>(p.shift + co); }
-                    else {
-                        sc.x = p.scale[co]; sh.x = p.shift[co];
-                        if (co + 1 < p.Co) { sc.y = p.scale[co + 1]; sh.y = p.shift[co + 1]; }
-                        if (co + 2 < p.Co) { sc.z = p.scale[co + 2]; sh.z = p.shift[co + 2]; }
-                    }
-                    sc.x *= p.oscale; sc.y *= p.oscale; sc.z *= p.oscale; sc.w *= p.oscale;
-                }
-                // LDS -> registers (4 voxels x 4 channels per lane), loads of residual / gate in flight together
-                float4 av[4], rv[4], gv[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
-                    rv[k] = make_float4(0.f, 0.f, 0.f, 0.f); gv[k] = rv[k];
-                    if (vok[k] && cok) {
-                        const size_t vox = v0[k] + coff;
-                        if (vec4) {
-                            if (p.res) rv[k] = *reinterpret_cast<const float4*>(p.res + vox * p.rCs + co);
-                            if (p.gate) gv[k] = *reinterpret_cast<const float4*>(p.gate + (g0[k] + goff) * p.gCs + co);
-                        } else {
-                            float* rr = &rv[k].x; float* gg = &gv[k].x;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (co + e < p.Co) {
-                                    if (p.res) rr[e] = p.res[vox * p.rCs + co + e];
-                                    if (p.gate) gg[e] = p.gate[(g0[k] + goff) * p.gCs + co + e];
-                                }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float o[4];
-                    const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
-                    const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-                    const float r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
-                        if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
-                        else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-                        if (p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
-                        o[e] = v;
-                    }
-                    if (vok[k] && cok) {
-                        const size_t vox = v0[k] + coff;
-                        if (vec4) *reinterpret_cast<float4*>(p.y + vox * p.yCs + co) = make_float4(o[0], o[1], o[2], o[3]);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (co + e < p.Co) p.y[vox * p.yCs + co + e] = o[e];
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Co) rr[e] = rp[e];
                 }
             }
         }
+    };
+    auto finish = [&](int i, const float4 (&rv)[4]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[4], g0[4], coff, goff; bool vok[4];
+        rows_of(m, v0, g0, vok);
+        class_off(c, coff, goff);
+        // registers -> LDS (tile[voxel row][channel])
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
+        const int co = n0 + (wn * NT + n) * 32 + cq;
+        const bool cok = co < p.Co;
+        const float4 sc = scv[n], sh = shv[n];
+        // LDS -> registers (4 voxels x 4 channels per lane); gate rows requested together
+        float4 av[4], gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
+            gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.gate && vok[k] && cok) {
+                const float* gp = gateb + (g0[k] + goff) * p.gCs + co;
+                if (vec4) gv[k] = *reinterpret_cast<const float4*>(gp);
+                else {
+                    float* gg = &gv[k].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Co) gg[e] = gp[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[4];
+            const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+            const float r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
+                if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                if (p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
+                o[e] = v;
+            }
+            if (vok[k] && cok) {
+                float* yp = yb + (v0[k] + coff) * p.yCs + co;
+                if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Co) yp[e] = o[e];
+                }
+            }
+        }
+    };
+    float4 rvb[PD][4];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) load_res(i, rvb[i]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        finish(i, rvb[i % PD]);
+        if (i + PD < NI) load_res(i + PD, rvb[i % PD]);
     }
 }
 
@@ -582,6 +629,11 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     if (lds < epi) lds = epi;
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
+    {   // the epilogue addresses one batch item with 32-bit element offsets
+        const long long ovox = (long long)a.Do * a.Ho * a.Wo;
+        const int cs = a.yCs > a.rCs ? (a.yCs > a.gCs ? a.yCs : a.gCs) : (a.rCs > a.gCs ? a.rCs : a.gCs);
+        OSA_REQUIRE(ovox * cs < (1ll << 31), "%s: one batch item of the output exceeds 2^31 elements", what);
+    }
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = getenv("OSA_NORING") != nullptr;
     void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];
