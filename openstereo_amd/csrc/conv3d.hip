@@ -97,6 +97,8 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
     constexpr int U = OSA_STAGE_U;
     const int total = p.LD * p.LH * p.LW * (CC / 4);
     const int LHW = p.LH * p.LW;
+    // wave-uniform 64-bit base of batch item b / chunk c0; per-lane offsets are 32-bit (host checks < 2^31 elements)
+    const float* xb = p.x + (size_t)b * p.Di * p.Hi * p.Wi * p.xCs + c0;
     for (int base = tid; base < total; base += NTHR * U) {
         float4 v[U];
         int lo[U];
@@ -115,8 +117,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                 lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * (VS / 4) + c4;
                 if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) &&
                     ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
-                    v[u] = *reinterpret_cast<const float4*>(
-                        p.x + ((((size_t)b * p.Di + gd) * p.Hi + gh) * (size_t)p.Wi + gw) * p.xCs + c0 + c4 * 4);
+                    v[u] = *reinterpret_cast<const float4*>(xb + ((gd * p.Hi + gh) * p.Wi + gw) * p.xCs + c4 * 4);
             }
         }
 #pragma unroll
@@ -633,6 +634,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         const long long ovox = (long long)a.Do * a.Ho * a.Wo;
         const int cs = a.yCs > a.rCs ? (a.yCs > a.gCs ? a.yCs : a.gCs) : (a.rCs > a.gCs ? a.rCs : a.gCs);
         OSA_REQUIRE(ovox * cs < (1ll << 31), "%s: one batch item of the output exceeds 2^31 elements", what);
+        OSA_REQUIRE((long long)a.Di * a.Hi * a.Wi * a.xCs < (1ll << 31), "%s: one batch item of the input exceeds 2^31 elements", what);
     }
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = getenv("OSA_NORING") != nullptr;
