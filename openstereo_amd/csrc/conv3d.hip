@@ -61,6 +61,7 @@ struct ConvArgs {
     int cps;                      // channel chunks staged per pass (LDS holds cps bricks back to back)
     int act; float slope;
     float oscale;                 // f16x3: 1 / (weight pre-scale), exact power of two; 1 for f32
+    int VQ;                       // LDS voxel stride in 16-byte slots: 4 (compact) or 5 (padded), see finish_geometry
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
     int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
@@ -114,7 +115,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                 const int lh = __umulhi((unsigned)r, p.magicW);
                 const int lw = r - lh * p.LW;
                 const int gd = g0d + ld, gh = g0h + lh, gw = g0w + lw;
-                lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * (VS / 4) + c4;
+                lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * p.VQ + c4;
                 if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) &&
                     ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
                     v[u] = *reinterpret_cast<const float4*>(xb + ((gd * p.Hi + gh) * p.Wi + gw) * p.xCs + c4 * 4);
@@ -146,7 +147,12 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
 template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW>
-__global__ __launch_bounds__(WM * WN * 64, (NCLS >= 4) ? 2 : 1) void conv_mfma_kernel(const ConvArgs p) {
+// Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
+// (MT = 2, NT = 1: the dominant 32 -> 32 layers) are held to 128 registers so that 4 workgroups
+// share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
+// limit costs the 64-channel tiles 5 %, so they keep the default).
+#define OSA_MIN_BLOCKS ((NCLS >= 4) ? 2 : ((MT == 2 && NT == 1 && WM * WN == 4) ? 4 : 1))
+__global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64, (NCLS >= 4) ? 2 : 1) void conv_mfma_k
     for (int m = 0; m < MT; ++m) {
         const int q = (wm * MT + m) * 32 + col;
         const int tw_ = q % TW, th_ = (q / TW) % TH, td_ = q / (TW * TH);
-        abase[m] = (td_ * p.isd) * p.PlaneQ + (th_ * p.ish) * p.RowQ + (tw_ * p.isw) * (VS / 4) + hh;
+        abase[m] = (td_ * p.isd) * p.PlaneQ + (th_ * p.ish) * p.RowQ + (tw_ * p.isw) * p.VQ + hh;
     }
 
     f32x16 acc[NCLS][MT][NT];
@@ -569,18 +575,31 @@ static int pick_cfg(const ConvArgs& a, int stride) {
     return (a.CoP % 64 == 0) ? 1 : 0;
 }
 
-// LDS row padding: consecutive w voxels sit 5 16-byte slots apart (conflict free within a row); an
-// M tile of 32 voxels spans 4 rows (TW=8) or 2 rows (TW=16).  ds_read_b128 is serviced in 16-lane
-// groups that mix rows, so the row stride is padded to 8 (mod 16) slots for TW=8 and to 0 (mod 16)
-// for TW=16: each group then touches 16 distinct slots.
-static void finish_geometry(ConvArgs& a, int TW) {
-    const int want = (TW == 8) ? 32 : 0;                 // floats mod 64
-    int rowf = a.LW * VS;
-    while ((rowf & 63) != want) rowf += 4;
-    if (getenv("OSA_NOPAD")) rowf = a.LW * VS;
-    a.RowQ = rowf / 4; a.PlaneQ = a.LH * a.RowQ;
+// LDS image of a staged chunk: one voxel = 64 B of operands (16 fp32, or 16 hi + 16 lo fp16).
+// ds_read_b128 is serviced in 16-lane groups that mix the rows of an M tile (4 rows of 8 voxels for
+// TW = 8, 2 rows of 16 for TW = 16); a group is conflict free when its 16 addresses fall into 16
+// distinct 16-byte slots (mod 256 B).
+//  * compact (TW = 8, unit w stride): voxels 4 slots apart -> a row's 4 lanes of a group sit on slots
+//    {0,4,8,12} + const, and an ODD row stride moves the 4 rows of the tile onto the 4 residues mod 4:
+//    16 distinct slots with one slot of padding per row (39 KB for the 6x10x10 brick -> 4 per CU).
+//  * padded (TW = 16, strided or dilated taps): voxels 5 slots apart (conflict free within a row of
+//    16), row stride a multiple of 16 slots for TW = 16 and 8 (mod 16) for TW = 8.
+static void finish_geometry(ConvArgs& a, int TW, bool compact) {
+    if (getenv("OSA_NOCOMPACT")) compact = false;
+    int rowq;
+    if (compact) {
+        a.VQ = 4;
+        rowq = a.LW * 4 + 1;
+    } else {
+        a.VQ = 5;
+        const int want = (TW == 8) ? 8 : 0;              // slots mod 16
+        rowq = a.LW * 5;
+        while ((rowq & 15) != want) ++rowq;
+        if (getenv("OSA_NOPAD")) rowq = a.LW * 5;
+    }
+    a.RowQ = rowq; a.PlaneQ = a.LH * a.RowQ;
     for (int t = 0; t < a.T; ++t)
-        a.toff[t] = (a.td[t] - a.dmin) * a.PlaneQ + (a.th[t] - a.hmin) * a.RowQ + (a.tw[t] - a.wmin) * (VS / 4);
+        a.toff[t] = (a.td[t] - a.dmin) * a.PlaneQ + (a.th[t] - a.hmin) * a.RowQ + (a.tw[t] - a.wmin) * a.VQ;
     a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
     a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
     const char* dbg = getenv("OSA_DBG");
@@ -614,7 +633,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
     (void)brick_bytes(a, k);
     OSA_REQUIRE((long long)a.LD * a.LH * a.LW < 65536, "%s: LDS brick too large", what);
-    finish_geometry(a, k.TW);
+    finish_geometry(a, k.TW, k.TW == 8 && a.isw == 1);
     const size_t brick = (size_t)a.LD * a.PlaneQ * sizeof(float4);
     OSA_REQUIRE(brick <= 160 * 1024, "%s: LDS brick %dx%dx%d needs %zu B (> 160 KiB)", what, a.LD, a.LH, a.LW, brick);
     // several channel chunks per staging pass (fewer barriers, more loads in flight) while the
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
         wl[i] = (ci < p.Ci) ? wref[((size_t)co * p.Ci + ci) * p.T + t] : 0.f;
     }
     const int tw_ = tid % TW, th_ = (tid / TW) % TH, td_ = tid / (TW * TH);
-    const int abase = td_ * p.PlaneQ + th_ * p.RowQ + tw_ * (VS / 4);
+    const int abase = td_ * p.PlaneQ + th_ * p.RowQ + tw_ * p.VQ;
     float acc[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) acc[o] = bias ? bias[o] : 0.f;
@@ -1081,7 +1100,7 @@ extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref,
     a.dmin = -pad_d; a.hmin = -pad_h; a.wmin = -pad_w;
     a.LD = 4 + 2 * pad_d; a.LH = 8 + 2 * pad_h; a.LW = 8 + 2 * pad_w;
     a.tilesD = cdiv(D, 4); a.tilesH = cdiv(H, 8); a.tilesW = cdiv(W, 8);
-    finish_geometry(a, 8);
+    finish_geometry(a, 8, false);      // thread-per-voxel reads: the padded image is the conflict-free one
     const size_t lds = ((size_t)a.LD * a.PlaneQ * 4 + (size_t)a.nchunks * a.T * Co * 16) * sizeof(float);
     OSA_REQUIRE(lds <= 160 * 1024, "conv3d_small_co: %zu B of LDS needed", lds);
     const long long nblk = (long long)B * a.tilesD * a.tilesH * a.tilesW;
