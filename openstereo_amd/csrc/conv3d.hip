@@ -521,15 +521,24 @@ constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong p
       { conv_mfma_kernel<PREC_F32, 1, 3, MT, NT, WM, WN, TH, TW>,                             \
         conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW> } }
 
+// same tile without the B ring: at 4 waves per SIMD (128 registers) the ring version of the
+// 256-voxel x 32-channel tile spills, the ping-pong version (116 registers) does not
+#define OSA_CFG_PINGPONG(MT, NT, WM, WN, TH, TW)                                             \
+    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
+      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
+      { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
+        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
+      { nullptr, nullptr } }
+
 static const KernelCfg g_cfgs[] = {
-    OSA_CFG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
+    OSA_CFG_PINGPONG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
     OSA_CFG(2, 2, 4, 1, 8, 8),   // 1: 256 vox x  64 ch   brick 4x8x8
     OSA_CFG(2, 2, 2, 2, 8, 8),   // 2: 128 vox x 128 ch   brick 2x8x8
     OSA_CFG(1, 1, 4, 1, 4, 8),   // 3: 128 vox x  32 ch   brick 4x4x8
     OSA_CFG(1, 2, 4, 1, 4, 8),   // 4: 128 vox x  64 ch   brick 4x4x8
     OSA_CFG(1, 1, 2, 2, 4, 8),   // 5:  64 vox x  64 ch   brick 2x4x8   (stride-2 layers)
     OSA_CFG(1, 2, 2, 2, 4, 8),   // 6:  64 vox x 128 ch   brick 2x4x8
-    OSA_CFG(2, 1, 4, 1, 16, 16), // 7: 256 vox x  32 ch   brick 1x16x16 (2-D layers)
+    OSA_CFG_PINGPONG(2, 1, 4, 1, 16, 16), // 7: 256 vox x  32 ch   brick 1x16x16 (2-D layers)
     OSA_CFG(2, 2, 4, 1, 16, 16), // 8: 256 vox x  64 ch   brick 1x16x16
     OSA_CFG(2, 2, 2, 2, 8, 16),  // 9: 128 vox x 128 ch   brick 1x8x16
     OSA_CFG(4, 1, 4, 1, 8, 8),   // 10: 512 vox x 32 ch   brick 8x8x8
