@@ -179,6 +179,29 @@ int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
                              int act, float slope, float out_scale, void* stream);
 
 /*
+ * Transposed conv with a fused 1x1x1 "redir" branch: GwcNet Hourglass,
+ *   conv6 = relu(conv6(conv5) + redir1(x))        models/gwcnet/hourglass.py:54 (redir1 = Conv3d 1x1x1 + BN, :43)
+ *   y = act( BN(deconv3d(x, w)) + BN_r(conv1x1x1(rx, rw)) )
+ * rx is an NDHWC tensor at OUTPUT resolution with rCi <= 32 channels (stride rxCs); rw_packed comes from
+ * osa_conv3d_pack_{f32,f16x3}(w_r, ..., Ci = rCi, Co, 1, 1, 1); rscale / rshift are its folded BN.  The 1x1x1
+ * product runs on the MFMA inside the epilogue (x rows loaded straight into A-operand order), so the redir
+ * tensor is never written or read back: 400 MB of HBM traffic less per GwcNet hourglass at 544x960.  Same
+ * arithmetic in the same order as the two separate launches (bit-identical results).
+ */
+int osa_deconv3d_redir_ndhwc_f32(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                                 int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs,
+                                 int k, int pad, int opad,
+                                 const float* rx, int rxCs, int rCi, const float* rw_packed,
+                                 const float* rscale, const float* rshift,
+                                 int act, float slope, void* stream);
+int osa_deconv3d_redir_ndhwc_f16x3(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                                   int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs,
+                                   int k, int pad, int opad,
+                                   const float* rx, int rxCs, int rCi, const float* rw_packed,
+                                   const float* rscale, const float* rshift, float r_out_scale,
+                                   int act, float slope, float out_scale, void* stream);
+
+/*
  * 2-D transposed convolution (nn.ConvTranspose2d, stride 2) on an NHWC map: the D = 1 case of the
  * fused parity-class kernel (4 classes).  LightStereo Aggregation.conv5 / conv6
  * (stereo/modeling/models/lightstereo/aggregation.py:29-35): k = 3, pad 1, opad 1, + BatchNorm2d,

@@ -78,6 +78,16 @@ SIGNATURES = {
     "osa_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_deconv3d_redir_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
+                                           c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                           c_i, c_i, c_i,
+                                           c_fp, c_i, c_i, c_fp, c_fp, c_fp,
+                                           c_i, c_f, c_st]),
+    "osa_deconv3d_redir_ndhwc_f16x3": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
+                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                             c_i, c_i, c_i,
+                                             c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_f,
+                                             c_i, c_f, c_f, c_st]),
     "osa_deconv2d_packed_floats": (C.c_size_t, [c_i, c_i, c_i]),
     "osa_deconv2d_pack_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_deconv2d_pack_f16x3": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_st]),

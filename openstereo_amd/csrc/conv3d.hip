@@ -62,6 +62,10 @@ struct ConvArgs {
     int act; float slope;
     float oscale;                 // f16x3: 1 / (weight pre-scale), exact power of two; 1 for f32
     int VQ;                       // LDS voxel stride in 16-byte slots: 4 (compact) or 5 (padded), see finish_geometry
+    // fused 1x1x1 "redir" branch of a transposed conv (GwcNet hourglass: relu(conv6(c5) + redir1(x))):
+    // rx = NDHWC tensor at OUTPUT resolution (<= 32 channels), rw = its packed 1x1x1 weights (same packing,
+    // T = 1), rscale / rshift = its folded BN, roscale = its f16x3 output scale.  NULL rx = not fused.
+    const float* rx; const float4* rw; const float* rscale; const float* rshift; float roscale; int rxCs, rCi;
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
     int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
@@ -146,7 +150,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 // NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
-template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW>
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, bool REDIR = false>
 // Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
 // (MT = 2, NT = 1: the dominant 32 -> 32 layers) are held to 128 registers so that 4 workgroups
 // share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
     // arithmetic and stores of the PD-1 tiles in front of it -- the fused transposed conv has 8 tiles
     // per wave and spent half of its time waiting for them one by one.
     constexpr int NI = MT * NCLS * NT;
-    constexpr int PD = (NCLS >= 4) ? 3 : ((NI < 2) ? NI : 2);
+    constexpr int PD = REDIR ? 2 : ((NCLS >= 4) ? 3 : ((NI < 2) ? NI : 2));
     // voxel bookkeeping of the 4 rows (vsub + 8k) this lane finalises in M tile m
     auto rows_of = [&](int m, int (&v0)[4], int (&g0)[4], bool (&vok)[4]) {
 #pragma unroll
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
         for (int k = 0; k < 4; ++k) {
             av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
             gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.gate && vok[k] && cok) {
+            if (!REDIR && p.gate && vok[k] && cok) {
                 const float* gp = gateb + (g0[k] + goff) * p.gCs + co;
                 if (vec4) gv[k] = *reinterpret_cast<const float4*>(gp);
                 else {
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                 if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
                 else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-                if (p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
+                if (!REDIR && p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
                 o[e] = v;
             }
             if (vok[k] && cok) {
@@ -494,12 +498,96 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
         }
     };
     float4 rvb[PD][4];
+    if constexpr (REDIR) {
+        {
+            // ---- fused redir branch: R = BN_r(W_r . x) for the 32 output voxels of every tile, on the
+            // MFMA in accumulator layout (lane = channel, register = voxel row), then
+            // z = fma(acc, s, t) + fma(R, s_r, t_r) replaces the accumulator and the common path below
+            // runs with unit scale and no residual -- the same arithmetic, in the same order, as the
+            // separate 1x1x1 launch whose output used to be read back as the residual.
+            const float* rxb = p.rx + bvox * p.rxCs;
+            const size_t rbstep = (size_t)2 * p.CoP, rtstep = (size_t)JO * rbstep;
+            const int rch = (p.rCi + CC - 1) / CC;                 // 1 or 2 chunks
+            // x rows of tile i in MFMA A-operand order: lane (col, hh) -> voxel row `col`
+            auto load_x = [&](int i, float4 (&rv)[4]) {
+                const int c = (i / NT) % NCLS, m = i / (NT * NCLS);
+                const int q = (wm * MT + m) * 32 + col;
+                const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+                const bool ok = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+                const int vox = ((ad * 2 + ((c >> 2) & 1)) * p.Ho + ah * 2 + ((c >> 1) & 1)) * p.Wo + aw * 2 + (c & 1);
 #pragma unroll
-    for (int i = 0; i < PD; ++i) load_res(i, rvb[i]);
+                for (int k = 0; k < 4; ++k) {
+                    rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int ch = k >> 1, j = k & 1;
+                    // f16x3: 8 consecutive channels 8hh..8hh+7 of the chunk (two float4s); f32: channels 8j+4hh..+3
+                    const int cin = ch * CC + ((PREC == PREC_F32) ? (8 * j + 4 * hh) : (8 * hh + 4 * j));
+                    if (ok && ch < rch && cin < p.rCi) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
+                }
+            };
+            auto add_redir = [&](int i, const float4 (&rv)[4]) {
+                const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+                const float4* rwp = p.rw + (size_t)hh * p.CoP + n0 + (wn * NT + n) * 32 + col;
+                f32x16 r;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        finish(i, rvb[i % PD]);
-        if (i + PD < NI) load_res(i + PD, rvb[i % PD]);
+                for (int e = 0; e < 16; ++e) r[e] = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    if (ch < rch) {
+                        const float4 b0 = rwp[ch * rtstep], b1 = rwp[ch * rtstep + rbstep];
+                        if constexpr (PREC == PREC_F32) {
+                            const float4 a0 = rv[2 * ch], a1 = rv[2 * ch + 1];
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, r, 0, 0, 0);
+                        } else {
+                            uint2 h0, l0, h1, l1;
+                            split_f16(rv[2 * ch], h0, l0);
+                            split_f16(rv[2 * ch + 1], h1, l1);
+                            const f16x8 ah = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                            const f16x8 al = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                            const f16x8 bh = __builtin_bit_cast(f16x8, b0), bl = __builtin_bit_cast(f16x8, b1);
+                            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, r, 0, 0, 0);
+                        }
+                    }
+                }
+                // per-lane (channel `col`) BN factors of both branches
+                const int cl = n0 + (wn * NT + n) * 32 + col;
+                const bool lok = cl < p.Co;
+                const float s6 = (lok && p.scale) ? p.scale[cl] * p.oscale : p.oscale, t6 = (lok && p.shift) ? p.shift[cl] : 0.f;
+                const float sr = (lok && p.rscale) ? p.rscale[cl] * p.roscale : p.roscale, tr = (lok && p.rshift) ? p.rshift[cl] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][m][n][e] = fmaf(acc[c][m][n][e], s6, t6) + fmaf(r[e], sr, tr);
+            };
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { scv[n] = make_float4(1.f, 1.f, 1.f, 1.f); shv[n] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            const float4 zero4[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                                     make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+            for (int i = 0; i < PD; ++i) load_x(i, rvb[i]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                add_redir(i, rvb[i % PD]);
+                if (i + PD < NI) load_x(i + PD, rvb[i % PD]);
+                finish(i, zero4);
+            }
+            return;
+        }
+    }
+    if constexpr (!REDIR) {
+#pragma unroll
+        for (int i = 0; i < PD; ++i) load_res(i, rvb[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            finish(i, rvb[i % PD]);
+            if (i + PD < NI) load_res(i + PD, rvb[i % PD]);
+        }
     }
 }
 
@@ -551,6 +639,10 @@ static const KernelCfg g_cfgs[] = {
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 // fused transposed conv: 128 input-resolution positions x 32 channels x 8 parity classes per workgroup
+static const KernelCfg g_deconv_redir_cfg = {
+    "deconv8_redir_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
+    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, true>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, true> },
+    { nullptr, nullptr } };
 static const KernelCfg g_deconv_cfg = {
     "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
     { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> },
@@ -1023,7 +1115,9 @@ static int deconv3d_impl(const float* x, const float* w_packed,
                          int Co, int yCs, int rCs,
                          int k, int pad, int opad,
                          const float* gate_logits, int gCs,
-                         int act, float slope, int prec, float oscale, void* stream, bool flat = false) {
+                         int act, float slope, int prec, float oscale, void* stream, bool flat = false,
+                         const float* rx = nullptr, int rxCs = 0, int rCi = 0, const float* rw_packed = nullptr,
+                         const float* rscale = nullptr, const float* rshift = nullptr, float roscale = 1.f) {
     if (gate_logits) OSA_REQUIRE(gCs >= Co, "deconv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     if (flat) OSA_REQUIRE(Di == 1, "deconv2d: the tensor must have D == 1 (got %d)", Di);
@@ -1047,7 +1141,16 @@ static int deconv3d_impl(const float* x, const float* w_packed,
     for (int c = 0; c < 8; ++c) a.cls_end[c] = d.cls_end[c];
     a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
     a.act = act; a.slope = slope; a.oscale = oscale;
-    return launch_conv(a, 1, prec, (hipStream_t)stream, flat ? "deconv2d" : "deconv3d", flat ? &g_deconv_flat_cfg : &g_deconv_cfg);
+    if (rx) {
+        OSA_REQUIRE(!flat && !residual && !gate_logits, "deconv3d_redir: residual / gate cannot be combined with the fused redir branch");
+        OSA_REQUIRE(rw_packed && rCi > 0 && rCi <= 32 && rCi % 4 == 0 && rxCs >= rCi && rxCs % 4 == 0 && ((size_t)rx & 15) == 0,
+                    "deconv3d_redir: redir input needs <= 32 channels (multiple of 4), stride >= channels, 16-byte alignment (Ci=%d stride=%d)", rCi, rxCs);
+        OSA_REQUIRE((long long)a.Do * a.Ho * a.Wo * rxCs < (1ll << 31), "deconv3d_redir: redir input too large");
+        a.rx = rx; a.rxCs = rxCs; a.rCi = rCi; a.rw = reinterpret_cast<const float4*>(rw_packed);
+        a.rscale = rscale; a.rshift = rshift; a.roscale = roscale;
+    }
+    return launch_conv(a, 1, prec, (hipStream_t)stream, flat ? "deconv2d" : "deconv3d",
+                       flat ? &g_deconv_flat_cfg : (rx ? &g_deconv_redir_cfg : &g_deconv_cfg));
 }
 
 #define OSA_DECONV_PARAMS                                                                       \
@@ -1064,6 +1167,23 @@ extern "C" int osa_deconv3d_ndhwc_f32(OSA_DECONV_PARAMS, void* stream) {
 
 extern "C" int osa_deconv3d_ndhwc_f16x3(OSA_DECONV_PARAMS, float out_scale, void* stream) {
     return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16X3, out_scale, stream);
+}
+
+// transposed conv with the 1x1x1 redir branch computed in its epilogue (see ConvArgs::rx)
+#define OSA_REDIR_PARAMS const float* rx, int rxCs, int rCi, const float* rw_packed, const float* rscale, const float* rshift
+extern "C" int osa_deconv3d_redir_ndhwc_f32(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                                            int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs,
+                                            int k, int pad, int opad, OSA_REDIR_PARAMS, int act, float slope, void* stream) {
+    return deconv3d_impl(x, w_packed, scale, shift, nullptr, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, 0, k, pad, opad, nullptr, 0,
+                         act, slope, PREC_F32, 1.f, stream, false, rx, rxCs, rCi, rw_packed, rscale, rshift, 1.f);
+}
+
+extern "C" int osa_deconv3d_redir_ndhwc_f16x3(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                                              int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs,
+                                              int k, int pad, int opad, OSA_REDIR_PARAMS, float r_out_scale,
+                                              int act, float slope, float out_scale, void* stream) {
+    return deconv3d_impl(x, w_packed, scale, shift, nullptr, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, 0, k, pad, opad, nullptr, 0,
+                         act, slope, PREC_F16X3, out_scale, stream, false, rx, rxCs, rCi, rw_packed, rscale, rshift, r_out_scale);
 }
 
 #define OSA_DECONV2D_PARAMS                                                                     \

@@ -137,12 +137,14 @@ class PackedConv3d:
         return (f(D, self.k[0], self.pad[0], self.dil[0], sd), f(H, self.k[1], self.pad[1], self.dil[1], s),
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
-    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False):
+    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False, redir=None):
         """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
         Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
         multiplied by sigmoid(gate) broadcast over D (FeatureAtt); gate_raw=True multiplies by the
-        gate itself (LightStereo AttentionModule: attn * cost)."""
+        gate itself (LightStereo AttentionModule: attn * cost).  redir=(layer, t): a transposed conv adds
+        layer(t) -- a 1x1x1 PackedConv3d (+BN) on the output-resolution tensor t (<= 32 channels) -- inside
+        its epilogue (GwcNet hourglass conv6 + redir1); replaces `residual`."""
         assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
         B, Cs, D, H, W = x.shape
         assert Cs >= x_off + self.Ci and Cs % 4 == 0 and x_off % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
@@ -170,7 +172,17 @@ class PackedConv3d:
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
             tail = (self.out_scale, _stream()) if self.precision == "f16x3" else (_stream(),)
             sfx = "f16x3" if self.precision == "f16x3" else "f32"
-            if self.flat_deconv:
+            if redir is not None:
+                rl, rt = redir
+                assert self.transposed and not self.flat_deconv and residual is None and gate is None
+                assert rl.precision == self.precision and rl.k == (1, 1, 1) and rl.Co == self.Co and rl.act == ACT_NONE
+                assert is_cl(rt) and tuple(rt.shape[2:]) == (Do, Ho, Wo) and rt.shape[1] >= rl.Ci and rl.Ci <= 32
+                rtail = (rl.out_scale,) if self.precision == "f16x3" else ()
+                _lib.call("osa_deconv3d_redir_ndhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                          yp, B, D, H, W, Ci, Cs, self.Co, yCs, self.k[0], self.pad[0], self.opad[0],
+                          rt.data_ptr(), rt.shape[1], (rl.Ci + 3) // 4 * 4, rl.packed.data_ptr(), _p(rl.scale), _p(rl.shift), *rtail,
+                          act, self.slope, *tail)
+            elif self.flat_deconv:
                 assert D == 1
                 _lib.call("osa_deconv2d_nhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
                           rp, yp, B, H, W, Ci, Cs, self.Co, yCs, rCs,

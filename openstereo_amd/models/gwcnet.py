@@ -14,6 +14,8 @@ PyTorch-ROCm modules.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -42,6 +44,8 @@ def _cb2(cin, cout, k, stride, pad, dil):
         nn.Conv2d(cin, cout, k, stride, dil if dil > 1 else pad, dil, bias=False),
         nn.BatchNorm2d(cout))
 
+
+_FUSE_REDIR = os.environ.get("OSA_FUSE_REDIR", "1") != "0"
 
 class _ResBlock(nn.Module):
     def __init__(self, cin, cout, stride, shortcut, pad, dil):
@@ -245,6 +249,8 @@ class Hourglass(nn.Module):
         c2 = p["c2"](c1)
         c4 = p["c4"](p["c3"](c2))
         c5 = p["c5"](c4, residual=p["r2"](c2))     # relu(conv5(c4) + redir2(c2))
+        if _FUSE_REDIR and p["r1"].Ci <= 32:
+            return p["c6"](c5, redir=(p["r1"], x))  # relu(conv6(c5) + redir1(x)), redir1 inside conv6's epilogue
         return p["c6"](c5, residual=p["r1"](x))    # relu(conv6(c5) + redir1(x))
 
     def forward_train(self, x):

@@ -590,3 +590,29 @@ def test_lightstereo_aggregation_kitti15_size_vs_oracle():
     finally:
         engine.set_precision(old)
     close(y, ref, atol=2e-4 * max(1.0, ref.abs().max().item()), rtol=1e-4, what="LightStereo aggregation @96x312")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(3, 5, 7), (4, 6, 9)], ids=["3x5x7", "4x6x9"])
+def test_deconv3d_fused_redir_matches_two_launches(shape, prec):
+    """relu(BN(deconv(c5)) + BN_r(conv1x1x1(x))) with the redir branch computed inside the transposed
+    conv's epilogue: bit-identical to deconv + separate 1x1x1 launch, and within tolerance of torch."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d
+    D, H, W = shape
+    dc = nn.ConvTranspose3d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False)
+    dc.weight.data = synth_tensor("fr.dc.w", dc.weight.shape, 1)
+    rc = nn.Conv3d(32, 32, 1, bias=False)
+    rc.weight.data = synth_tensor("fr.rc.w", rc.weight.shape, 1)
+    bn, bnr = _bn_for(32, 2, "fr.bn"), _bn_for(32, 3, "fr.bnr")
+    c5 = T(np.random.default_rng(3).normal(0, 1, (2, 64, D, H, W)).astype(np.float32))
+    x = T(np.random.default_rng(4).normal(0, 1, (2, 32, 2 * D, 2 * H, 2 * W)).astype(np.float32))
+    with torch.no_grad():
+        ref = F.relu(bn(dc(c5)) + bnr(rc(x)))
+    pd = PackedConv3d(dc.to(DEV), bn.to(DEV), 1, precision=prec)
+    pr = PackedConv3d(rc.to(DEV), bnr.to(DEV), 0, precision=prec)
+    c5c, xc = ops.to_cl(c5.to(DEV)), ops.to_cl(x.to(DEV))
+    two = pd(c5c, residual=pr(xc))
+    fused = pd(c5c, redir=(pr, xc))
+    assert torch.equal(two, fused), f"fused redir differs from two launches: {(two - fused).abs().max().item():.3e}"
+    close(fused[:, :32], ref, atol=3e-5, rtol=3e-5, what=f"fused redir [{prec}]")
