@@ -182,7 +182,7 @@ int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
  * Transposed conv with a fused 1x1x1 "redir" branch: GwcNet Hourglass,
  *   conv6 = relu(conv6(conv5) + redir1(x))        models/gwcnet/hourglass.py:54 (redir1 = Conv3d 1x1x1 + BN, :43)
  *   y = act( BN(deconv3d(x, w)) + BN_r(conv1x1x1(rx, rw)) )
- * rx is an NDHWC tensor at OUTPUT resolution with rCi <= 32 channels (stride rxCs); rw_packed comes from
+ * rx is an NDHWC tensor at OUTPUT resolution with rCi <= 64 channels (stride rxCs); rw_packed comes from
  * osa_conv3d_pack_{f32,f16x3}(w_r, ..., Ci = rCi, Co, 1, 1, 1); rscale / rshift are its folded BN.  The 1x1x1
  * product runs on the MFMA inside the epilogue (x rows loaded straight into A-operand order), so the redir
  * tensor is never written or read back: 400 MB of HBM traffic less per GwcNet hourglass at 544x960.  Same

@@ -150,7 +150,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 // NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
-template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, bool REDIR = false>
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0>
 // Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
 // (MT = 2, NT = 1: the dominant 32 -> 32 layers) are held to 128 registers so that 4 workgroups
 // share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
@@ -497,7 +497,8 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             }
         }
     };
-    float4 rvb[PD][4];
+    constexpr int RV = (REDIR == 2) ? 8 : 4;      // float4 rows held per prefetched tile
+    float4 rvb[PD][RV];
     if constexpr (REDIR) {
         {
             // ---- fused redir branch: R = BN_r(W_r . x) for the 32 output voxels of every tile, on the
@@ -507,16 +508,17 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             // separate 1x1x1 launch whose output used to be read back as the residual.
             const float* rxb = p.rx + bvox * p.rxCs;
             const size_t rbstep = (size_t)2 * p.CoP, rtstep = (size_t)JO * rbstep;
-            const int rch = (p.rCi + CC - 1) / CC;                 // 1 or 2 chunks
+            constexpr int RCH = RV / 2;                            // chunks of 16 redir input channels held per tile
+            const int rch = (p.rCi + CC - 1) / CC;
             // x rows of tile i in MFMA A-operand order: lane (col, hh) -> voxel row `col`
-            auto load_x = [&](int i, float4 (&rv)[4]) {
+            auto load_x = [&](int i, float4 (&rv)[RV]) {
                 const int c = (i / NT) % NCLS, m = i / (NT * NCLS);
                 const int q = (wm * MT + m) * 32 + col;
                 const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
                 const bool ok = ad < p.Ad && ah < p.Ah && aw < p.Aw;
                 const int vox = ((ad * 2 + ((c >> 2) & 1)) * p.Ho + ah * 2 + ((c >> 1) & 1)) * p.Wo + aw * 2 + (c & 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < RV; ++k) {
                     rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int ch = k >> 1, j = k & 1;
                     // f16x3: 8 consecutive channels 8hh..8hh+7 of the chunk (two float4s); f32: channels 8j+4hh..+3
@@ -524,14 +526,14 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                     if (ok && ch < rch && cin < p.rCi) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
                 }
             };
-            auto add_redir = [&](int i, const float4 (&rv)[4]) {
+            auto add_redir = [&](int i, const float4 (&rv)[RV]) {
                 const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
                 const float4* rwp = p.rw + (size_t)hh * p.CoP + n0 + (wn * NT + n) * 32 + col;
                 f32x16 r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) r[e] = 0.f;
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
+                for (int ch = 0; ch < RCH; ++ch) {
                     if (ch < rch) {
                         const float4 b0 = rwp[ch * rtstep], b1 = rwp[ch * rtstep + rbstep];
                         if constexpr (PREC == PREC_F32) {
@@ -641,7 +643,11 @@ constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 // fused transposed conv: 128 input-resolution positions x 32 channels x 8 parity classes per workgroup
 static const KernelCfg g_deconv_redir_cfg = {
     "deconv8_redir_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
-    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, true>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, true> },
+    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, 1>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 1> },
+    { nullptr, nullptr } };
+static const KernelCfg g_deconv_redir64_cfg = {
+    "deconv8_redir64_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
+    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, 2>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 2> },
     { nullptr, nullptr } };
 static const KernelCfg g_deconv_cfg = {
     "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
@@ -1143,14 +1149,14 @@ static int deconv3d_impl(const float* x, const float* w_packed,
     a.act = act; a.slope = slope; a.oscale = oscale;
     if (rx) {
         OSA_REQUIRE(!flat && !residual && !gate_logits, "deconv3d_redir: residual / gate cannot be combined with the fused redir branch");
-        OSA_REQUIRE(rw_packed && rCi > 0 && rCi <= 32 && rCi % 4 == 0 && rxCs >= rCi && rxCs % 4 == 0 && ((size_t)rx & 15) == 0,
-                    "deconv3d_redir: redir input needs <= 32 channels (multiple of 4), stride >= channels, 16-byte alignment (Ci=%d stride=%d)", rCi, rxCs);
+        OSA_REQUIRE(rw_packed && rCi > 0 && rCi <= 64 && rCi % 4 == 0 && rxCs >= rCi && rxCs % 4 == 0 && ((size_t)rx & 15) == 0,
+                    "deconv3d_redir: redir input needs <= 64 channels (multiple of 4), stride >= channels, 16-byte alignment (Ci=%d stride=%d)", rCi, rxCs);
         OSA_REQUIRE((long long)a.Do * a.Ho * a.Wo * rxCs < (1ll << 31), "deconv3d_redir: redir input too large");
         a.rx = rx; a.rxCs = rxCs; a.rCi = rCi; a.rw = reinterpret_cast<const float4*>(rw_packed);
         a.rscale = rscale; a.rshift = rshift; a.roscale = roscale;
     }
     return launch_conv(a, 1, prec, (hipStream_t)stream, flat ? "deconv2d" : "deconv3d",
-                       flat ? &g_deconv_flat_cfg : (rx ? &g_deconv_redir_cfg : &g_deconv_cfg));
+                       flat ? &g_deconv_flat_cfg : (rx ? (rCi > 32 ? &g_deconv_redir64_cfg : &g_deconv_redir_cfg) : &g_deconv_cfg));
 }
 
 #define OSA_DECONV_PARAMS                                                                       \

@@ -143,7 +143,7 @@ class PackedConv3d:
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
         multiplied by sigmoid(gate) broadcast over D (FeatureAtt); gate_raw=True multiplies by the
         gate itself (LightStereo AttentionModule: attn * cost).  redir=(layer, t): a transposed conv adds
-        layer(t) -- a 1x1x1 PackedConv3d (+BN) on the output-resolution tensor t (<= 32 channels) -- inside
+        layer(t) -- a 1x1x1 PackedConv3d (+BN) on the output-resolution tensor t (<= 64 channels) -- inside
         its epilogue (GwcNet hourglass conv6 + redir1); replaces `residual`."""
         assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
         B, Cs, D, H, W = x.shape
@@ -176,7 +176,7 @@ class PackedConv3d:
                 rl, rt = redir
                 assert self.transposed and not self.flat_deconv and residual is None and gate is None
                 assert rl.precision == self.precision and rl.k == (1, 1, 1) and rl.Co == self.Co and rl.act == ACT_NONE
-                assert is_cl(rt) and tuple(rt.shape[2:]) == (Do, Ho, Wo) and rt.shape[1] >= rl.Ci and rl.Ci <= 32
+                assert is_cl(rt) and tuple(rt.shape[2:]) == (Do, Ho, Wo) and rt.shape[1] >= rl.Ci and rl.Ci <= 64
                 rtail = (rl.out_scale,) if self.precision == "f16x3" else ()
                 _lib.call("osa_deconv3d_redir_ndhwc_" + sfx, xp, self.packed.data_ptr(), _p(self.scale), _p(self.shift),
                           yp, B, D, H, W, Ci, Cs, self.Co, yCs, self.k[0], self.pad[0], self.opad[0],

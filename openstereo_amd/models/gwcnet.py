@@ -248,7 +248,10 @@ class Hourglass(nn.Module):
         c1 = p["c1"](x)
         c2 = p["c2"](c1)
         c4 = p["c4"](p["c3"](c2))
-        c5 = p["c5"](c4, residual=p["r2"](c2))     # relu(conv5(c4) + redir2(c2))
+        if _FUSE_REDIR and p["r2"].Ci <= 64:
+            c5 = p["c5"](c4, redir=(p["r2"], c2))  # relu(conv5(c4) + redir2(c2)), redir2 inside conv5's epilogue
+        else:
+            c5 = p["c5"](c4, residual=p["r2"](c2))
         if _FUSE_REDIR and p["r1"].Ci <= 32:
             return p["c6"](c5, redir=(p["r1"], x))  # relu(conv6(c5) + redir1(x)), redir1 inside conv6's epilogue
         return p["c6"](c5, residual=p["r1"](x))    # relu(conv6(c5) + redir1(x))

@@ -593,20 +593,22 @@ def test_lightstereo_aggregation_kitti15_size_vs_oracle():
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("chans", [(64, 32), (128, 64)], ids=["conv6+redir1", "conv5+redir2"])
 @pytest.mark.parametrize("shape", [(3, 5, 7), (4, 6, 9)], ids=["3x5x7", "4x6x9"])
-def test_deconv3d_fused_redir_matches_two_launches(shape, prec):
+def test_deconv3d_fused_redir_matches_two_launches(shape, chans, prec):
     """relu(BN(deconv(c5)) + BN_r(conv1x1x1(x))) with the redir branch computed inside the transposed
     conv's epilogue: bit-identical to deconv + separate 1x1x1 launch, and within tolerance of torch."""
     from openstereo_amd import ops
     from openstereo_amd.engine import PackedConv3d
     D, H, W = shape
-    dc = nn.ConvTranspose3d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False)
+    Ci, Co = chans
+    dc = nn.ConvTranspose3d(Ci, Co, 3, stride=2, padding=1, output_padding=1, bias=False)
     dc.weight.data = synth_tensor("fr.dc.w", dc.weight.shape, 1)
-    rc = nn.Conv3d(32, 32, 1, bias=False)
+    rc = nn.Conv3d(Co, Co, 1, bias=False)
     rc.weight.data = synth_tensor("fr.rc.w", rc.weight.shape, 1)
-    bn, bnr = _bn_for(32, 2, "fr.bn"), _bn_for(32, 3, "fr.bnr")
-    c5 = T(np.random.default_rng(3).normal(0, 1, (2, 64, D, H, W)).astype(np.float32))
-    x = T(np.random.default_rng(4).normal(0, 1, (2, 32, 2 * D, 2 * H, 2 * W)).astype(np.float32))
+    bn, bnr = _bn_for(Co, 2, "fr.bn"), _bn_for(Co, 3, "fr.bnr")
+    c5 = T(np.random.default_rng(3).normal(0, 1, (2, Ci, D, H, W)).astype(np.float32))
+    x = T(np.random.default_rng(4).normal(0, 1, (2, Co, 2 * D, 2 * H, 2 * W)).astype(np.float32))
     with torch.no_grad():
         ref = F.relu(bn(dc(c5)) + bnr(rc(x)))
     pd = PackedConv3d(dc.to(DEV), bn.to(DEV), 1, precision=prec)
@@ -615,4 +617,4 @@ def test_deconv3d_fused_redir_matches_two_launches(shape, prec):
     two = pd(c5c, residual=pr(xc))
     fused = pd(c5c, redir=(pr, xc))
     assert torch.equal(two, fused), f"fused redir differs from two launches: {(two - fused).abs().max().item():.3e}"
-    close(fused[:, :32], ref, atol=3e-5, rtol=3e-5, what=f"fused redir [{prec}]")
+    close(fused[:, :Co], ref, atol=3e-5, rtol=3e-5, what=f"fused redir [{prec}]")
