@@ -754,6 +754,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     size_t lds = brick * a.cps;
     const size_t epi = (size_t)(k.threads / 64) * 32 * 36 * sizeof(float);   // wave-private transpose tiles of the epilogue
     if (lds < epi) lds = epi;
+    { const char* e = getenv("OSA_LDS_MIN"); if (e && (size_t)atoi(e) > lds) lds = (size_t)atoi(e); }   // experiments: cap residency
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
     {   // the epilogue addresses one batch item with 32-bit element offsets
