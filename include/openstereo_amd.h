@@ -45,7 +45,7 @@ extern "C" {
 #define OSA_ABI_VERSION 1
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
-enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3 };
+enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3, OSA_ACT_SIGMOID = 4, OSA_ACT_TANH = 5 };
 /* OR'ed into `act`: the gate tensor is a plain multiplier (LightStereo AttentionModule, attn * cost,
  * models/lightstereo/aggregation.py:134) instead of logits passed through a sigmoid */
 enum { OSA_GATE_RAW = 16 };
@@ -243,6 +243,15 @@ int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
                           int B, int Hi, int Wi, int C, int xCs, int yCs, int aCs,
                           int kh, int kw, int stride, int pad_h, int pad_w, int dil_h, int dil_w,
                           int act, void* stream);
+
+/*
+ * ConvGRU state update (models/igev/update.py:42, models/stereobase/gru_blocks.py ConvGRU):
+ *   out[p][c] = (1 - z[p][c]) * h[p][c] + z[p][c] * q[p][c]       for npix pixels x C channels, NHWC with
+ * per-tensor channel strides.  z = sigmoid(convz(hx) + cz) and q = tanh(convq([r*h, x]) + cq) come out of
+ * the conv epilogues (OSA_ACT_SIGMOID / OSA_ACT_TANH, residual = cz / cq, r*h = sigmoid(...) with h as raw gate).
+ */
+int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
+                        long long npix, int C, int zCs, int qCs, int hCs, int oCs, void* stream);
 
 /* Packing for backward passes.  Ci/Co are the roles of the convolution that will be EXECUTED with the
  * packed buffer; src_transposed=1 reads w_ref as [Ci][Co][k] (instead of [Co][Ci][k]); flip=1 mirrors taps.

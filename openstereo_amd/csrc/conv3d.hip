@@ -483,6 +483,8 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                 if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
                 else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                else if (actk == OSA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                else if (actk == OSA_ACT_TANH) v = tanhf(v);
                 if (!REDIR && p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
                 o[e] = v;
             }

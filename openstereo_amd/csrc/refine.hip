@@ -126,3 +126,37 @@ extern "C" int osa_preprocess_pair_f32(const void* left_hwc, const void* right_h
     OSA_LAUNCH_CHECK("preprocess_pair");
     return 0;
 }
+
+
+// ------------------------------------------------------------------ ConvGRU state update --
+namespace osa {
+__global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restrict__ z, const float* __restrict__ q,
+                                                          const float* __restrict__ h, float* __restrict__ out,
+                                                          long long total, int nq, int zCs, int qCs, int hCs, int oCs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long px = i / nq;
+    const int c = (int)(i - px * nq) * 4;
+    const float4 zv = *reinterpret_cast<const float4*>(z + px * zCs + c);
+    const float4 qv = *reinterpret_cast<const float4*>(q + px * qCs + c);
+    const float4 hv = *reinterpret_cast<const float4*>(h + px * hCs + c);
+    float4 o;
+    o.x = (1.f - zv.x) * hv.x + zv.x * qv.x; o.y = (1.f - zv.y) * hv.y + zv.y * qv.y;
+    o.z = (1.f - zv.z) * hv.z + zv.z * qv.z; o.w = (1.f - zv.w) * hv.w + zv.w * qv.w;
+    *reinterpret_cast<float4*>(out + px * oCs + c) = o;
+}
+}  // namespace osa
+
+extern "C" int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
+                                   long long npix, int C, int zCs, int qCs, int hCs, int oCs, void* stream) {
+    OSA_REQUIRE(z && q && h && out, "gru_combine: NULL pointer");
+    OSA_REQUIRE(npix > 0 && C > 0 && C % 4 == 0, "gru_combine: bad dims npix=%lld C=%d (C must be a multiple of 4)", npix, C);
+    OSA_REQUIRE(zCs >= C && qCs >= C && hCs >= C && oCs >= C && ((zCs | qCs | hCs | oCs) & 3) == 0, "gru_combine: bad channel strides");
+    OSA_REQUIRE((((size_t)z | (size_t)q | (size_t)h | (size_t)out) & 15) == 0, "gru_combine: pointers must be 16-byte aligned");
+    const long long total = npix * (C / 4);
+    OSA_REQUIRE((total + 255) / 256 < (1ll << 31), "gru_combine: grid too large");
+    hipLaunchKernelGGL(osa::gru_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       z, q, h, out, total, C / 4, zCs, qCs, hCs, oCs);
+    OSA_LAUNCH_CHECK("gru_combine");
+    return 0;
+}

@@ -16,7 +16,7 @@ from .ops import _stream, _p, empty_cl, is_cl
 import math
 import os
 
-ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6 = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4, 5
 GATE_RAW = 16          # OR'ed into act: the gate is a plain multiplier, not sigmoid logits
 enable_timing, collect_timing = timing.enable, timing.collect
 

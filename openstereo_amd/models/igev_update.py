@@ -1,0 +1,210 @@
+"""IGEV / StereoBase iterative-refinement update block on the gfx950 engine (BASELINE
+configs[4] "IGEV iterative GRU refinement").
+
+Mirror of stereo/modeling/models/igev/update.py:17-144 (stereobase/gru_blocks.py:233-328 is the same
+block with a configurable correlation-plane count): same class names, constructor arguments and
+state_dict keys; forward on the engine with NHWC tensors:
+
+  * every Conv2d (3x3, 1x1, 7x7, with bias) is the MFMA conv kernel with D = 1; inputs that the
+    reference concatenates (`torch.cat([h, x...])`) are channel slices of one buffer,
+  * ConvGRU: z = sigmoid(convz(hx) + cz) and q = tanh(convq([r*h, x]) + cq) are fused epilogues
+    (residual = cz / cq, OSA_ACT_SIGMOID / OSA_ACT_TANH); r*h = sigmoid(convr(hx) + cr) * h comes out of
+    convr's epilogue with h as a raw gate, written straight into the [r*h | x] buffer;
+    h' = (1-z)*h + z*q is `osa_gru_combine_f32`,
+  * pool2x / interp (avg_pool2d, bilinear align_corners=True) stay PyTorch-ROCm ops on NHWC views
+    (tiny maps, feature side).
+
+forward() takes and returns the reference's NCHW tensors; forward_cl() is the channels-last entry.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from ..engine import PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from ..ops import empty_cl, is_cl, _stream
+from .lightstereo import nchw_to_cl, cl_to_nchw
+
+
+def _nhwc(x):
+    """NHWC 4-D view [B,H,W,C] of an engine tensor (logical [B,C,1,H,W])."""
+    B, C, _, H, W = x.shape
+    return x.permute(0, 2, 3, 4, 1).reshape(B, H, W, C)
+
+
+def _as_cl(t4):
+    """4-D logical NCHW tensor (any strides) -> engine tensor, without a copy when it already is NHWC."""
+    B, C, H, W = t4.shape
+    if C % 4 == 0 and t4.dtype == torch.float32 and t4.stride() == (H * W * C, 1, W * C, C):
+        return t4.unsqueeze(2)
+    return nchw_to_cl(t4)
+
+
+def pool2x(x):
+    """update.py:99-100 on an engine tensor."""
+    return _as_cl(F.avg_pool2d(x[:, :, 0], 3, stride=2, padding=1))
+
+
+def interp(x, dest):
+    """update.py:107-109 (bilinear, align_corners=True) on engine tensors."""
+    return _as_cl(F.interpolate(x[:, :, 0], dest.shape[3:], mode="bilinear", align_corners=True))
+
+
+def _cat_cl(parts, dev):
+    """Channel concatenation into one NHWC buffer (what torch.cat does for the reference)."""
+    B, _, _, H, W = parts[0].shape
+    C = sum(p.shape[1] for p in parts)
+    out = empty_cl(B, C, 1, H, W, dev)
+    o = 0
+    for p in parts:
+        out[:, o:o + p.shape[1]] = p
+        o += p.shape[1]
+    return out
+
+
+class DispHead(nn.Module):
+    """update.py:17-26"""
+
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self._eng = None
+
+    def forward_cl(self, x):
+        if self._eng is None:
+            self._eng = (PackedConv3d(self.conv1, None, ACT_RELU), PackedConv3d(self.conv2))
+        return self._eng[1](self._eng[0](x))
+
+    def forward(self, x):
+        return cl_to_nchw(self.forward_cl(nchw_to_cl(x)), self.conv2.out_channels)
+
+
+class ConvGRU(nn.Module):
+    """update.py:29-45"""
+
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__()
+        k, p = kernel_size, kernel_size // 2
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, k, padding=p)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, k, padding=p)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, k, padding=p)
+        self.hidden_dim = hidden_dim
+        self._eng = None
+
+    def forward_cl(self, h, cz, cr, cq, *x_list):
+        if self._eng is None:
+            self._eng = (PackedConv3d(self.convz, None, ACT_SIGMOID), PackedConv3d(self.convr, None, ACT_SIGMOID),
+                         PackedConv3d(self.convq, None, ACT_TANH))
+        pz, pr, pq = self._eng
+        hd = self.hidden_dim
+        assert hd % 4 == 0 and h.shape[1] == hd
+        hx = _cat_cl([h, *x_list], h.device)                   # [h | x]
+        z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
+        rhx = hx.clone()                                       # [r*h | x]: the x part is shared, r*h overwrites the h slice
+        pr(hx, residual=cr, gate=_nhwc(h), gate_raw=True, out=rhx, out_off=0)   # sigmoid(convr(hx) + cr) * h
+        q = pq(rhx, residual=cq)                               # tanh(convq([r*h, x]) + cq)
+        out = empty_cl(*h.shape, h.device)
+        B, _, _, H, W = h.shape
+        _lib.call("osa_gru_combine_f32", z.data_ptr(), q.data_ptr(), h.data_ptr(), out.data_ptr(),
+                  B * H * W, hd, z.shape[1], q.shape[1], h.shape[1], out.shape[1], _stream())
+        return out
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        c = nchw_to_cl
+        return cl_to_nchw(self.forward_cl(c(h), c(cz), c(cr), c(cq), *[c(x) for x in x_list]), self.hidden_dim)
+
+
+class BasicMotionEncoder(nn.Module):
+    """update.py:72-92; `cor_planes` overrides the IGEV formula for StereoBase (gru_blocks.py:236)."""
+
+    def __init__(self, args, cor_planes=None):
+        super().__init__()
+        self.args = args
+        if cor_planes is None:
+            cor_planes = args.CORR_LEVELS * (2 * args.CORR_RADIUS + 1) * (8 + 1)
+        self.convc1 = nn.Conv2d(cor_planes, 64, 1, padding=0)
+        self.convc2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.convd1 = nn.Conv2d(1, 64, 7, padding=3)
+        self.convd2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 64, 128 - 1, 3, padding=1)
+        self._eng = None
+
+    def forward_cl(self, disp, corr):
+        """disp: engine tensor with the disparity in channel 0 (channels 1..3 zero); corr: engine tensor."""
+        if self._eng is None:
+            R = lambda m: PackedConv3d(m, None, ACT_RELU)
+            self._eng = dict(c1=R(self.convc1), c2=R(self.convc2), d1=R(self.convd1), d2=R(self.convd2), conv=R(self.conv))
+        e = self._eng
+        B, _, _, H, W = disp.shape
+        cor_disp = empty_cl(B, 128, 1, H, W, disp.device)      # [cor | disp_]
+        e["c2"](e["c1"](corr), out=cor_disp, out_off=0)
+        e["d2"](e["d1"](disp), out=cor_disp, out_off=64)
+        out = empty_cl(B, 128, 1, H, W, disp.device)           # [conv(cor_disp) (127) | disp]
+        e["conv"](cor_disp, out=out, out_off=0)
+        out[:, 127] = disp[:, 0]
+        return out
+
+    def forward(self, disp, corr):
+        return cl_to_nchw(self.forward_cl(nchw_to_cl(disp), nchw_to_cl(corr)), 128)
+
+
+class BasicMultiUpdateBlock(nn.Module):
+    """update.py:112-144"""
+
+    def __init__(self, args, hidden_dims=[], cor_planes=None):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args, cor_planes)
+        encoder_output_dim = 128
+        self.gru04 = ConvGRU(hidden_dims[2], encoder_output_dim + hidden_dims[1] * (args.N_GRU_LAYERS > 1))
+        self.gru08 = ConvGRU(hidden_dims[1], hidden_dims[0] * (args.N_GRU_LAYERS == 3) + hidden_dims[2])
+        self.gru16 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.disp_head = DispHead(hidden_dims[2], hidden_dim=256, output_dim=1)
+        self.mask_feat_4 = nn.Sequential(nn.Conv2d(hidden_dims[2], 32, 3, padding=1), nn.ReLU(inplace=True))
+        self._mask = None
+
+    def reset_engine(self):
+        self._mask = None
+        for m in self.modules():
+            if hasattr(m, "_eng"):
+                m._eng = None
+
+    def forward_cl(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+        """Engine tensors everywhere; `net` (list) is updated in place like the reference does."""
+        if iter16:
+            net[2] = self.gru16.forward_cl(net[2], *(inp[2]), pool2x(net[1]))
+        if iter08:
+            if self.args.N_GRU_LAYERS > 2:
+                net[1] = self.gru08.forward_cl(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            else:
+                net[1] = self.gru08.forward_cl(net[1], *(inp[1]), pool2x(net[0]))
+        if iter04:
+            motion_features = self.encoder.forward_cl(disp, corr)
+            if self.args.N_GRU_LAYERS > 1:
+                net[0] = self.gru04.forward_cl(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
+            else:
+                net[0] = self.gru04.forward_cl(net[0], *(inp[0]), motion_features)
+        if not update:
+            return net
+        delta_disp = self.disp_head.forward_cl(net[0])
+        if self._mask is None:
+            self._mask = PackedConv3d(self.mask_feat_4[0], None, ACT_RELU)
+        return net, self._mask(net[0]), delta_disp
+
+    def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+        if not net[0].is_cuda:
+            raise RuntimeError("openstereo_amd BasicMultiUpdateBlock runs on the GPU engine only (no CPU path)")
+        c = nchw_to_cl
+        net_cl = [c(t) for t in net]
+        inp_cl = [[c(t) for t in ts] for ts in inp]
+        res = self.forward_cl(net_cl, inp_cl, None if corr is None else c(corr), None if disp is None else c(disp),
+                              iter04, iter08, iter16, update)
+        back = lambda lst: [cl_to_nchw(t, r.shape[1]) for t, r in zip(lst, net)]
+        if not update:
+            return back(res)
+        n, mask, delta = res
+        return back(n), cl_to_nchw(mask, 32), cl_to_nchw(delta, 1)

@@ -478,3 +478,50 @@ def lightstereo_aggregation(x, features_left, sd, p="", blocks=(1, 2, 4), left_a
     conv5 = F.relu(up(conv4, "conv5") + _mobile_v2_residual(conv2, sd, q + "redir2", 1))
     conv6 = F.relu(up(conv5, "conv6") + _mobile_v2_residual(x, sd, q + "redir1", 1))
     return conv6
+
+
+# ----------------------------------------------------------------------------- IGEV / StereoBase update block (8f #4)
+def _conv_b(x, sd, p, pad):
+    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], 1, pad)
+
+
+def _conv_gru(h, cz, cr, cq, xs, sd, p):
+    """ConvGRU.forward, stereo/modeling/models/igev/update.py:36-45."""
+    x = torch.cat(xs, dim=1)
+    hx = torch.cat([h, x], dim=1)
+    z = torch.sigmoid(_conv_b(hx, sd, p + ".convz", 1) + cz)
+    r = torch.sigmoid(_conv_b(hx, sd, p + ".convr", 1) + cr)
+    q = torch.tanh(_conv_b(torch.cat([r * h, x], dim=1), sd, p + ".convq", 1) + cq)
+    return (1 - z) * h + z * q
+
+
+def _motion_encoder(disp, corr, sd, p):
+    """BasicMotionEncoder.forward, update.py:83-92."""
+    cor = F.relu(_conv_b(corr, sd, p + ".convc1", 0))
+    cor = F.relu(_conv_b(cor, sd, p + ".convc2", 1))
+    d = F.relu(_conv_b(disp, sd, p + ".convd1", 3))
+    d = F.relu(_conv_b(d, sd, p + ".convd2", 1))
+    out = F.relu(_conv_b(torch.cat([cor, d], dim=1), sd, p + ".conv", 1))
+    return torch.cat([out, disp], dim=1)
+
+
+def igev_update_block(net, inp, corr, disp, sd, p="", n_gru_layers=3, iter04=True, iter08=True, iter16=True, update=True):
+    """BasicMultiUpdateBlock.forward, update.py:129-150 (net is a list of 3 hidden states, finest first)."""
+    q = (p + ".") if p else ""
+    net = list(net)
+    pool2x = lambda t: F.avg_pool2d(t, 3, stride=2, padding=1)
+    interp = lambda t, dest: F.interpolate(t, dest.shape[2:], mode="bilinear", align_corners=True)
+    if iter16:
+        net[2] = _conv_gru(net[2], *inp[2], [pool2x(net[1])], sd, q + "gru16")
+    if iter08:
+        xs = [pool2x(net[0]), interp(net[2], net[1])] if n_gru_layers > 2 else [pool2x(net[0])]
+        net[1] = _conv_gru(net[1], *inp[1], xs, sd, q + "gru08")
+    if iter04:
+        mf = _motion_encoder(disp, corr, sd, q + "encoder")
+        xs = [mf, interp(net[1], net[0])] if n_gru_layers > 1 else [mf]
+        net[0] = _conv_gru(net[0], *inp[0], xs, sd, q + "gru04")
+    if not update:
+        return net
+    delta = _conv_b(F.relu(_conv_b(net[0], sd, q + "disp_head.conv1", 1)), sd, q + "disp_head.conv2", 1)
+    mask = F.relu(_conv_b(net[0], sd, q + "mask_feat_4.0", 1))
+    return net, mask, delta

@@ -51,3 +51,23 @@ def lightstereo_case():
     x = rnd((1, 48, 32, 64), 51)
     feats = [rnd((1, 24, 32, 64), 52), rnd((1, 32, 16, 32), 53), rnd((1, 96, 8, 16), 54), rnd((1, 160, 4, 8), 55)]
     return agg, sd, x, feats
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def igev_update_case():
+    """IGEV update-block fixture (make_golden.gen_igev_update): module, seeded weights, inputs."""
+    import torch
+    from openstereo_amd.utils.weights import synth_state_dict
+    from openstereo_amd.models.igev_update import BasicMultiUpdateBlock
+    args = _Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2)
+    blk = BasicMultiUpdateBlock(args, hidden_dims=[128, 128, 128]).eval()
+    sd = synth_state_dict(blk, seed=11)
+    blk.load_state_dict(sd)
+    H, W = 16, 32
+    net = [torch.tanh(rnd((1, 128, H >> i, W >> i), 70 + i)) for i in range(3)]
+    inp = [[rnd((1, 128, H >> i, W >> i), 80 + 3 * i + j) * 0.5 for j in range(3)] for i in range(3)]
+    corr, disp = rnd((1, 162, H, W), 90), rnd((1, 1, H, W), 91).abs() * 10
+    return blk, sd, net, inp, corr, disp

@@ -68,16 +68,39 @@ def gen_lightstereo():
     save("lightstereo_agg.npz", y=y, **taps)      # inputs: rnd(shape, 51..54), see tests/conftest.py lightstereo_inputs()
 
 
+def gen_igev_update():
+    """IGEV BasicMultiUpdateBlock (8f #4): cfgs/igev defaults -- CORR_LEVELS 2, CORR_RADIUS 4, N_GRU_LAYERS 3,
+    N_DOWNSAMPLE 2, HIDDEN_DIMS [128, 128, 128]; one full iteration (all three GRUs + heads)."""
+    import importlib.util
+    from openstereo_amd.utils.weights import synth_state_dict
+    spec = importlib.util.spec_from_file_location("ref_igev_update", os.path.join(REF, "stereo/modeling/models/igev/update.py"))
+    upd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(upd)
+    args = Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2)
+    blk = upd.BasicMultiUpdateBlock(args, hidden_dims=[128, 128, 128]).eval()
+    blk.load_state_dict(synth_state_dict(blk, seed=11))
+    H, W = 16, 32
+    net = [torch.tanh(rnd((1, 128, H >> i, W >> i), 70 + i)) for i in range(3)]
+    inp = [[rnd((1, 128, H >> i, W >> i), 80 + 3 * i + j) * 0.5 for j in range(3)] for i in range(3)]
+    corr, disp = rnd((1, 162, H, W), 90), rnd((1, 1, H, W), 91).abs() * 10
+    n, mask, delta = blk([t.clone() for t in net], inp, corr, disp)
+    print("IGEV update block: delta range", delta.min().item(), delta.max().item())
+    save("igev_update.npz", net0=n[0], net1=n[1], net2=n[2], mask=mask, delta=delta)   # inputs: rnd(...) as in tests/conftest.py igev_update_case()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
     from openstereo_amd.utils.weights import synth_state_dict, synth_images
     if args.only == "lightstereo":
         gen_lightstereo()
+        return
+    if args.only == "igev_update":
+        gen_igev_update()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -200,6 +223,7 @@ def main():
 
     # ------------------------------------------------------------------ LightStereo 2-D aggregation (a9)
     gen_lightstereo()
+    gen_igev_update()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

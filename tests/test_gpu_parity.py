@@ -618,3 +618,56 @@ def test_deconv3d_fused_redir_matches_two_launches(shape, chans, prec):
     fused = pd(c5c, redir=(pr, xc))
     assert torch.equal(two, fused), f"fused redir differs from two launches: {(two - fused).abs().max().item():.3e}"
     close(fused[:, :Co], ref, atol=3e-5, rtol=3e-5, what=f"fused redir [{prec}]")
+
+
+# ----------------------------------------------------------------------------- IGEV / StereoBase update block (8f #4)
+def test_gru_combine_and_sigmoid_tanh_epilogues():
+    from openstereo_amd import _lib, ops
+    from openstereo_amd.engine import PackedConv3d, ACT_SIGMOID, ACT_TANH
+    from openstereo_amd.models.lightstereo import nchw_to_cl, cl_to_nchw
+    conv = nn.Conv2d(64, 32, 3, padding=1)
+    conv.weight.data = synth_tensor("gru.w", conv.weight.shape, 1) * 3.0
+    conv.bias.data = synth_tensor("gru.bias", conv.bias.shape, 1)
+    x = T(np.random.default_rng(3).normal(0, 1, (2, 64, 9, 14)).astype(np.float32))
+    c = T(np.random.default_rng(4).normal(0, 1, (2, 32, 9, 14)).astype(np.float32))
+    with torch.no_grad():
+        pre = conv(x) + c
+    conv = conv.to(DEV)
+    for act, fn in ((ACT_SIGMOID, torch.sigmoid), (ACT_TANH, torch.tanh)):
+        y = PackedConv3d(conv, None, act, precision="f32")(nchw_to_cl(x.to(DEV)), residual=nchw_to_cl(c.to(DEV)))
+        close(cl_to_nchw(y), fn(pre), atol=2e-5, rtol=2e-5, what=f"act {act}")
+    z, q, h = (T(np.random.default_rng(s).uniform(-1, 1, (2, 32, 9, 14)).astype(np.float32)) for s in (5, 6, 7))
+    zc, qc, hc = (nchw_to_cl(t.to(DEV)) for t in (z, q, h))
+    out = ops.empty_cl(2, 32, 1, 9, 14, DEV)
+    _lib.call("osa_gru_combine_f32", zc.data_ptr(), qc.data_ptr(), hc.data_ptr(), out.data_ptr(), 2 * 9 * 14, 32, 32, 32, 32, 32, ops._stream())
+    close(cl_to_nchw(out), (1 - z) * h + z * q, 0, 0, "gru combine")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_igev_update_block_vs_reference_golden(prec):
+    """One full iteration of BasicMultiUpdateBlock (3 ConvGRUs, motion encoder, disp head, mask head) on the
+    engine vs the real reference's outputs; then two more iterations vs the oracle (state fed back)."""
+    from conftest import igev_update_case
+    from oracle import torch_ref as O
+    from openstereo_amd import engine
+    g = golden("igev_update.npz")
+    blk, sd, net, inp, corr, disp = igev_update_case()
+    old = engine.get_precision()
+    engine.set_precision(prec)
+    try:
+        blk = blk.to(DEV)
+        dv = lambda ts: [t.to(DEV) for t in ts]
+        with torch.no_grad():
+            n, mask, delta = blk(dv(net), [dv(ts) for ts in inp], corr.to(DEV), disp.to(DEV))
+            for k, v in (("net0", n[0]), ("net1", n[1]), ("net2", n[2]), ("mask", mask), ("delta", delta)):
+                close(v, g[k], atol=3e-5, rtol=3e-5, what=f"update block {k} [{prec}]")
+            # slow-fast schedule of igev_stereo.py:194-201: low-res GRUs only, then a full update
+            rn, rm, rd = O.igev_update_block(net, inp, corr, disp, sd)
+            rn = O.igev_update_block(rn, inp, None, None, sd, iter16=True, iter08=False, iter04=False, update=False)
+            rn, rm, rd = O.igev_update_block(rn, inp, corr, disp + rd, sd)
+            n = blk(n, [dv(ts) for ts in inp], iter16=True, iter08=False, iter04=False, update=False)
+            n, mask, d2 = blk(n, [dv(ts) for ts in inp], corr.to(DEV), disp.to(DEV) + delta)
+    finally:
+        engine.set_precision(old)
+    close(n[0], rn[0], atol=1e-4, rtol=1e-4, what=f"iteration 2 net0 [{prec}]")
+    close(d2, rd, atol=2e-4, rtol=2e-4, what=f"iteration 2 delta [{prec}]")

@@ -136,3 +136,16 @@ def test_lightstereo_aggregation_against_reference():
         assert v.shape == ref.shape
         err = (v - ref).abs().max().item()
         assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
+
+
+def test_igev_update_block_against_reference():
+    """8f #4: oracle restatement of BasicMultiUpdateBlock (ConvGRUs, motion encoder, heads) vs the real reference."""
+    from conftest import igev_update_case
+    blk, sd, net, inp, corr, disp = igev_update_case()
+    g = golden("igev_update.npz")
+    with torch.no_grad():
+        n, mask, delta = O.igev_update_block(net, inp, corr, disp, sd)
+    for k, v in (("net0", n[0]), ("net1", n[1]), ("net2", n[2]), ("mask", mask), ("delta", delta)):
+        ref = torch.from_numpy(g[k])
+        assert v.shape == ref.shape
+        assert (v - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), k
