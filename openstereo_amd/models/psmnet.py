@@ -78,11 +78,68 @@ class PSMBackbone(nn.Module):
               for i in (1, 2, 3, 4)]
         return self.lastconv(torch.cat((o4, o8, br[3], br[2], br[1], br[0]), 1))
 
+    # ---- engine path: every conv+BN(+ReLU)(+residual) is one fused MFMA launch on NHWC
+    # maps; layer2 / layer4 write their outputs straight into the 320-channel SPP concat buffer
+    # [o4 | o8 | branch4 | branch3 | branch2 | branch1]; only the four average pools and the bilinear
+    # resampling of the 32-channel branch maps (a few hundred pixels each) stay PyTorch-ROCm ops.
+    use_engine = True
+
+    def reset_engine(self):
+        self._pk = None
+
+    def _pack(self):
+        if getattr(self, "_pk", None) is None:
+            P = lambda cb, act: PackedConv3d(cb[0], cb[1], act)
+            pk = {"first": [P(m, ACT_RELU) for m in self.firstconv], "layers": []}
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                pk["layers"].append([(P(b.conv1, ACT_RELU), P(b.conv2, ACT_NONE),
+                                      None if b.downsample is None else P(b.downsample, ACT_NONE)) for b in layer])
+            pk["branch"] = [P(getattr(self, f"branch{i}")[1], ACT_RELU) for i in (1, 2, 3, 4)]
+            pk["last"] = (P(self.lastconv[0], ACT_RELU), PackedConv3d(self.lastconv[1]))
+            self._pk = pk
+        return self._pk
+
+    def forward_cl(self, img):
+        """img [N,3,H,W] -> NHWC feature map (logical [N,32,1,H/4,W/4])."""
+        pk = self._pack()
+        x = ops.to_cl(img.unsqueeze(2))                 # [N,4,1,H,W], 4th channel zero
+        for conv in pk["first"]:
+            x = conv(x)
+        xoff, cat = 0, None
+        slices = {1: 0, 3: 64}                          # layer2 -> cat[0:64] (o4), layer4 -> cat[64:192] (o8)
+        for li, blocks in enumerate(pk["layers"]):
+            for bi, (c1, c2, ds) in enumerate(blocks):
+                y = c1(x, x_off=xoff)
+                skip, soff = (ds(x, x_off=xoff), 0) if ds is not None else (x, xoff)
+                if bi == len(blocks) - 1 and li in slices:
+                    if cat is None:
+                        N_, _, _, h4, w4 = y.shape
+                        cat = ops.empty_cl(N_, 320, 1, h4, w4, y.device)
+                    c2(y, residual=skip, res_off=soff, out=cat, out_off=slices[li])
+                    x, xoff = cat, slices[li]
+                else:
+                    x, xoff = c2(y, residual=skip, res_off=soff), 0
+        h4, w4 = cat.shape[3], cat.shape[4]
+        o8 = cat[:, 64:192, 0]                          # NCHW-logical view of the NHWC slice
+        for slot, (i, k) in enumerate(((4, 8), (3, 16), (2, 32), (1, 64))):      # concat order branch4..branch1 (psmnet_backbone.py:127)
+            pooled = F.avg_pool2d(o8, (k, k), stride=(k, k))
+            N_, C_, ph, pw = pooled.shape
+            pcl = ops.empty_cl(N_, C_, 1, ph, pw, pooled.device)
+            pcl[:, :, 0] = pooled
+            br = pk["branch"][i - 1](pcl)                                      # 1x1 conv + BN + ReLU
+            cat[:, 192 + 32 * slot:224 + 32 * slot, 0] = F.interpolate(br[:, :, 0], (h4, w4), mode="bilinear", align_corners=True)
+        l0, l1 = pk["last"]
+        return l1(l0(cat))
+
     def forward(self, inputs):
         left, right = inputs["left"], inputs["right"]
         B = left.shape[0]
         with timing.span("backbone2d", left.shape[2], left.shape[3]):
-            f = self._forward(torch.cat((left, right), 0))
+            x = torch.cat((left, right), 0)
+            if self.use_engine and x.is_cuda and not self.training:
+                f = self.forward_cl(x)[:, :32, 0].contiguous()
+            else:
+                f = self._forward(x)
         return {"ref_feature": f[:B], "tgt_feature": f[B:]}
 
 

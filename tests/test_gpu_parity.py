@@ -671,3 +671,24 @@ def test_igev_update_block_vs_reference_golden(prec):
         engine.set_precision(old)
     close(n[0], rn[0], atol=1e-4, rtol=1e-4, what=f"iteration 2 net0 [{prec}]")
     close(d2, rd, atol=2e-4, rtol=2e-4, what=f"iteration 2 delta [{prec}]")
+
+
+def test_psmnet_spp_backbone_engine_vs_reference_golden_and_torch_path():
+    """PSMNet's SPP feature extractor on the engine (8f #4) vs the real reference's feature map and vs the
+    PyTorch-ROCm module path of the same parameters."""
+    from openstereo_amd.models.psmnet import PSMNet, _Cfg
+    g = golden("psmnet_256x512.npz")
+    net = PSMNet(_Cfg(MAX_DISP=64))
+    net.load_state_dict(synth_state_dict(net, seed=0, head_gain=3.0), strict=False)
+    net = net.to(DEV).eval()
+    L, R = synth_images(1, 256, 512, seed=1, max_shift=16.0)
+    bb = net.Backbone
+    with torch.no_grad():
+        assert bb.use_engine
+        fe = bb({"left": L.to(DEV), "right": R.to(DEV)})
+        bb.use_engine = False
+        ft = bb({"left": L.to(DEV), "right": R.to(DEV)})
+        bb.use_engine = True
+    close(fe["ref_feature"], g["left_feature"], atol=2e-4, rtol=2e-4, what="engine SPP backbone (left)")
+    close(fe["tgt_feature"], g["right_feature"], atol=2e-4, rtol=2e-4, what="engine SPP backbone (right)")
+    close(fe["ref_feature"], ft["ref_feature"], atol=2e-4, rtol=2e-4, what="engine vs torch SPP backbone")
