@@ -163,11 +163,12 @@ struct VolQArgs {
     int dbg;               // timing experiments only (OSA_VOL_DBG): 1 = no stores, 2 = no dot products, 4 = no window staging
 };
 
-template <int QG>
-__global__ __launch_bounds__(256) void build_volume_quads_kernel(const VolQArgs q) {
+template <int QG, int NWV>     // NWV waves per workgroup (4 or 8): a wider pixel tile amortises the right window
+__global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQArgs q) {
     extern __shared__ __attribute__((aligned(16))) float4 smq[];
     const VolArgs& p = q.v;
-    const int vpw = 64 >> q.lgNQ, WT = 4 * vpw;
+    constexpr int NTHR = NWV * 64;
+    const int vpw = 64 >> q.lgNQ, WT = NWV * vpw;
     const int NPXR = WT + q.DCH - 1;
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -184,6 +185,39 @@ __global__ __launch_bounds__(256) void build_volume_quads_kernel(const VolQArgs 
     const int nq_g = QG * p.G, nq_c = p.Cc >> 2, nq = nq_g + nq_c;
     const size_t rowpix = ((size_t)b * p.H + h) * p.W;
 
+    // ---- this lane's voxel column and role; its left features are requested first so that their
+    // latency overlaps the staging of the right window
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cq = lane & (q.NQ - 1), wsub = lane >> q.lgNQ;
+    const int w = w0 + wave * vpw + wsub;
+    const bool wlive = w < p.W;
+    const int role = (cq < G4) ? 0 : ((cq < G4 + nq_c) ? 1 : 2);   // gwc quad / left concat quad / right concat quad
+    float4 Lr[4 * QG];
+    float4 lcat = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4 * QG; ++i) Lr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wlive && role == 0) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int kq = 0; kq < QG; ++kq) {
+                const int g = cq * 4 + gi;
+                if (p.gstride) Lr[gi * QG + kq] = *reinterpret_cast<const float4*>(p.lg + (rowpix + w) * p.gstride + g * p.K + kq * 4);
+                else {
+                    const float* src = p.lg + ((size_t)b * p.C + (size_t)g * p.K + kq * 4) * plane + (size_t)h * p.W + w;
+                    Lr[gi * QG + kq] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+                }
+            }
+    } else if (wlive && role == 1) {
+        const int qc = cq - G4;
+        if (p.cstride) {
+            const float* src = p.lc + (rowpix + w) * p.cstride + qc * 4;
+            lcat = make_float4(src[0], src[1], src[2], src[3]);
+        } else {
+            const float* src = p.lc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w;
+            lcat = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+        }
+    }
     // ---- right window -> LDS.  Source quad (g, kq) goes to slot (g&3)*QG*G4 + kq*G4 + (g>>2).
     // Item = (pixel, quad); the fast index follows the feature layout (NHWC: quads of a pixel, NCHW:
     // pixels of a quad).  A thread walks its items with a carry instead of dividing, and keeps 4
@@ -192,9 +226,9 @@ __global__ __launch_bounds__(256) void build_volume_quads_kernel(const VolQArgs 
         const int items = (q.dbg & 4) ? 0 : nq * NPXR;
         const bool chan_fast = (p.gstride != 0);
         const int inner = chan_fast ? nq : NPXR;      // extent of the fast index
-        const int step_hi = 256 / inner, step_lo = 256 - step_hi * inner;
+        const int step_hi = NTHR / inner, step_lo = NTHR - step_hi * inner;
         int hi = tid / inner, lo = tid - hi * inner;
-        for (int it0 = tid; it0 < items; it0 += 4 * 256) {
+        for (int it0 = tid; it0 < items; it0 += 4 * NTHR) {
             float4 v[4];
             int dst[4];
 #pragma unroll
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(256) void build_volume_quads_kernel(const VolQArgs 
                 const int qi = chan_fast ? lo : hi, px = chan_fast ? hi : lo;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[u] = -1;
-                if (it0 + u * 256 < items) {
+                if (it0 + u * NTHR < items) {
                     const int w = wr0 + px;
                     const bool wok = (w >= 0) && (w < p.W);
                     int pos;
@@ -240,38 +274,6 @@ __global__ __launch_bounds__(256) void build_volume_quads_kernel(const VolQArgs 
         }
     }
 
-    // ---- this lane's voxel column and role
-    const int lane = tid & 63, wave = tid >> 6;
-    const int cq = lane & (q.NQ - 1), wsub = lane >> q.lgNQ;
-    const int w = w0 + wave * vpw + wsub;
-    const bool wlive = w < p.W;
-    const int role = (cq < G4) ? 0 : ((cq < G4 + nq_c) ? 1 : 2);   // gwc quad / left concat quad / right concat quad
-    float4 Lr[4 * QG];
-    float4 lcat = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 4 * QG; ++i) Lr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wlive && role == 0) {
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-            for (int kq = 0; kq < QG; ++kq) {
-                const int g = cq * 4 + gi;
-                if (p.gstride) Lr[gi * QG + kq] = *reinterpret_cast<const float4*>(p.lg + (rowpix + w) * p.gstride + g * p.K + kq * 4);
-                else {
-                    const float* src = p.lg + ((size_t)b * p.C + (size_t)g * p.K + kq * 4) * plane + (size_t)h * p.W + w;
-                    Lr[gi * QG + kq] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
-                }
-            }
-    } else if (wlive && role == 1) {
-        const int qc = cq - G4;
-        if (p.cstride) {
-            const float* src = p.lc + (rowpix + w) * p.cstride + qc * 4;
-            lcat = make_float4(src[0], src[1], src[2], src[3]);
-        } else {
-            const float* src = p.lc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w;
-            lcat = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
-        }
-    }
     __syncthreads();
 
     const float Kf = (float)p.K;
@@ -424,13 +426,18 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             const int QG = (G > 0) ? K / 4 : 1;
             qa.NQ = nq4; qa.lgNQ = 0;
             while ((1 << qa.lgNQ) < nq4) ++qa.lgNQ;
-            const int WT = 4 * (64 / nq4);
+            // 8 waves per workgroup when the map is wide enough (amortises the right window over 2x the pixels)
+            int nwv = (W >= 8 * (64 / nq4) * 2) ? 8 : 4;
+            { const char* e = getenv("OSA_VOL_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) nwv = atoi(e); }
+            const int WT = nwv * (64 / nq4);
             qa.RSq = ((G > 0) ? QG * G : 0) + Cc / 4;
             if (qa.RSq % 16 > 6) qa.RSq += 16 - qa.RSq % 16;     // keeps the lanes of two neighbouring voxels on distinct 16-byte slots
             // disparity chunk: D split evenly into the fewest chunks whose right window fits ~52 KiB of
             // LDS (3 workgroups per CU); very wide feature vectors may use up to the whole 160 KiB
+            size_t budget = (nwv == 8) ? 78 * 1024 : 52 * 1024;   // 2 x 8 waves or 3 x 4 waves per CU
+            { const char* e = getenv("OSA_VOL_LDS"); if (e && atoi(e) > 0) budget = (size_t)atoi(e); }
             int nchunk = 1;
-            while (nchunk < maxdisp && (size_t)(WT + cdiv(maxdisp, nchunk) - 1) * qa.RSq * 16 > 52 * 1024) ++nchunk;
+            while (nchunk < maxdisp && (size_t)(WT + cdiv(maxdisp, nchunk) - 1) * qa.RSq * 16 > budget) ++nchunk;
             const int dch = cdiv(maxdisp, nchunk);
             qa.DCH = dch;
             { const char* e = getenv("OSA_VOL_DBG"); qa.dbg = e ? atoi(e) : 0; }
@@ -439,20 +446,22 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             OSA_REQUIRE(lds <= 160 * 1024, "build_volume: %zu B of LDS needed (> 160 KiB); too many channels", lds);
             const long long nblk = (long long)B * H * a.nWt * a.nDch;
             OSA_REQUIRE(nblk < (1ll << 31), "build_volume: grid too large");
-            dim3 grid((unsigned)nblk), block(256);
-#define OSA_VOLQ_LAUNCH(Q)                                                                          \
+            dim3 grid((unsigned)nblk), block(nwv * 64);
+#define OSA_VOLQ_LAUNCH1(Q, NWV)                                                                    \
             do {                                                                                    \
                 if (lds > 64 * 1024)                                                                \
-                    (void)hipFuncSetAttribute((const void*)build_volume_quads_kernel<Q>,            \
+                    (void)hipFuncSetAttribute((const void*)build_volume_quads_kernel<Q, NWV>,       \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
-                hipLaunchKernelGGL(build_volume_quads_kernel<Q>, grid, block, lds, st, qa);         \
+                hipLaunchKernelGGL((build_volume_quads_kernel<Q, NWV>), grid, block, lds, st, qa);  \
             } while (0)
+#define OSA_VOLQ_LAUNCH(Q) do { if (nwv == 8) OSA_VOLQ_LAUNCH1(Q, 8); else OSA_VOLQ_LAUNCH1(Q, 4); } while (0)
             switch (QG) {
                 case 1: OSA_VOLQ_LAUNCH(1); break;
                 case 2: OSA_VOLQ_LAUNCH(2); break;
                 case 3: OSA_VOLQ_LAUNCH(3); break;
                 default: OSA_VOLQ_LAUNCH(4); break;
             }
+#undef OSA_VOLQ_LAUNCH1
 #undef OSA_VOLQ_LAUNCH
             OSA_LAUNCH_CHECK("build_volume_quads");
             return 0;

@@ -11,8 +11,12 @@ cf = ops.empty_cl(2 * B, 12, 1, H, W, dev); cf.normal_()
 def run():
     return ops.build_cost_volume_from_cl(gf, 40, cf, B, D)
 outs = {}
-for mode in ("quads", "perchannel", "quads", "dbg1", "dbg2", "dbg4", "dbg3", "dbg6", "dbg7"):
-    os.environ.pop("OSA_VOL_PERCHANNEL", None); os.environ.pop("OSA_VOL_DBG", None)
+for mode in ("quads", "perchannel", "quads", "w4", "w8", "w4", "w8", "w8lds160", "dbg1", "dbg2", "dbg4", "dbg7"):
+    for k in ("OSA_VOL_PERCHANNEL", "OSA_VOL_DBG", "OSA_VOL_WAVES", "OSA_VOL_LDS"):
+        os.environ.pop(k, None)
+    if mode.startswith("w"):
+        os.environ["OSA_VOL_WAVES"] = mode[1]
+        if "lds" in mode: os.environ["OSA_VOL_LDS"] = str(int(mode.split("lds")[1]) * 1024)
     if mode == "perchannel": os.environ["OSA_VOL_PERCHANNEL"] = "1"
     if mode.startswith("dbg"): os.environ["OSA_VOL_DBG"] = mode[3:]
     for _ in range(3): v = run()
