@@ -93,25 +93,29 @@ __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) 
 // Thread-linear item order (every lane busy on every load).  A row-wise variant with wave-uniform
 // row arithmetic (2x fewer VALU instructions) was measured slower overall on MI355X: rows of 10-18
 // voxels leave 40-45 % of the lanes idle, which costs more than the index arithmetic saves.
-template <int NTHR, int PREC>
-__device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int b, int c0,
+// NCL consecutive 16-channel chunks are staged in one pass (bricks back to back in LDS, brickQ apart):
+// the index arithmetic of an item is shared by its NCL loads, and the two 64-byte halves of a voxel's
+// 128-byte line are requested together.
+template <int NTHR, int PREC, int NCL>
+__device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
                                             int g0d, int g0h, int g0w, int tid) {
 #ifndef OSA_STAGE_U
 #define OSA_STAGE_U 4
 #endif
-    constexpr int U = OSA_STAGE_U;
+    constexpr int U = (NCL == 1) ? OSA_STAGE_U : OSA_STAGE_U / 2;
     const int total = p.LD * p.LH * p.LW * (CC / 4);
     const int LHW = p.LH * p.LW;
     // wave-uniform 64-bit base of batch item b / chunk c0; per-lane offsets are 32-bit (host checks < 2^31 elements)
     const float* xb = p.x + (size_t)b * p.Di * p.Hi * p.Wi * p.xCs + c0;
     for (int base = tid; base < total; base += NTHR * U) {
-        float4 v[U];
+        float4 v[U][NCL];
         int lo[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int it = base + u * NTHR;
             lo[u] = -1;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int cl = 0; cl < NCL; ++cl) v[u][cl] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (it < total) {
                 const int c4 = it & 3, vx = it >> 2;
                 const int ld = __umulhi((unsigned)vx, p.magicHW);
@@ -120,26 +124,33 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                 const int lw = r - lh * p.LW;
                 const int gd = g0d + ld, gh = g0h + lh, gw = g0w + lw;
                 lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * p.VQ + c4;
-                if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) &&
-                    ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci))
-                    v[u] = *reinterpret_cast<const float4*>(xb + ((gd * p.Hi + gh) * p.Wi + gw) * p.xCs + c4 * 4);
+                if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) && ((unsigned)gw < (unsigned)p.Wi)) {
+                    const float* src = xb + ((gd * p.Hi + gh) * p.Wi + gw) * p.xCs + c4 * 4;
+#pragma unroll
+                    for (int cl = 0; cl < NCL; ++cl)
+                        if (c0 + cl * CC + c4 * 4 < p.Ci) v[u][cl] = *reinterpret_cast<const float4*>(src + cl * CC);
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (lo[u] >= 0) {
-                if constexpr (PREC == PREC_F32) {
-                    smem[lo[u]] = v[u];
-                } else {
-                    // voxel image: [16 x fp16 hi | 16 x fp16 lo | 16 B pad]; this quad's 4 channels -> 8 B each
-                    static_assert(NTHR % 4 == 0, "channel quad of an item must not depend on u");
-                    const int c4 = base & 3;        // == (base + u*NTHR) & 3
-                    uint2 h2, l2;
-                    split_f16(v[u], h2, l2);
-                    uint2* s2 = reinterpret_cast<uint2*>(smem);
-                    const int vbase = (lo[u] - c4) * 2;                 // voxel start in 8-byte units
-                    s2[vbase + c4] = h2;
-                    s2[vbase + 4 + c4] = l2;
+#pragma unroll
+                for (int cl = 0; cl < NCL; ++cl) {
+                    float4* dst = smem + cl * brickQ;
+                    if constexpr (PREC == PREC_F32) {
+                        dst[lo[u]] = v[u][cl];
+                    } else {
+                        // voxel image: [16 x fp16 hi | 16 x fp16 lo]; this quad's 4 channels -> 8 B each
+                        static_assert(NTHR % 4 == 0, "channel quad of an item must not depend on u");
+                        const int c4 = base & 3;        // == (base + u*NTHR) & 3
+                        uint2 h2, l2;
+                        split_f16(v[u][cl], h2, l2);
+                        uint2* s2 = reinterpret_cast<uint2*>(dst);
+                        const int vbase = (lo[u] - c4) * 2;                 // voxel start in 8-byte units
+                        s2[vbase + c4] = h2;
+                        s2[vbase + 4 + c4] = l2;
+                    }
                 }
             }
     }
@@ -293,9 +304,13 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
     for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
         if (ch0) __syncthreads();
         const int ncl = (p.nchunks - ch0 < p.cps) ? (p.nchunks - ch0) : p.cps;
-        if (!(p.dbg & 1))
-            for (int cl = 0; cl < ncl; ++cl)
-                stage_brick<NW * 64, PREC>(p, smem + cl * brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+        if (!(p.dbg & 1)) {
+            int cl = 0;
+            for (; cl + 2 <= ncl; cl += 2)
+                stage_brick<NW * 64, PREC, 2>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+            if (cl < ncl)
+                stage_brick<NW * 64, PREC, 1>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+        }
         __syncthreads();
         for (int cl = 0; cl < ncl; ++cl) {
             sm = smem + cl * brickQ;
@@ -751,7 +766,9 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     {
         const char* e = getenv("OSA_CPS");
         const int want = e ? atoi(e) : 4;
-        while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= 40 * 1024) ++a.cps;
+        size_t cap = 40 * 1024;
+        { const char* c = getenv("OSA_CPS_LDS"); if (c && atoi(c) > 0) cap = (size_t)atoi(c); }
+        while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= cap) ++a.cps;
     }
     size_t lds = brick * a.cps;
     const size_t epi = (size_t)(k.threads / 64) * 32 * 36 * sizeof(float);   // wave-private transpose tiles of the epilogue
@@ -885,7 +902,7 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         if (ch) __syncthreads();
-        stage_brick<256, PREC_F32>(p, smem, b, ch * CC, g0d, g0h, g0w, tid);
+        stage_brick<256, PREC_F32, 1>(p, smem, 0, b, ch * CC, g0d, g0h, g0w, tid);
         __syncthreads();
         for (int t = 0; t < p.T; ++t) {
             const float4* xp = smem + abase + p.toff[t];
