@@ -85,3 +85,23 @@ def test_state_dict_layout_matches_reference_names():
     assert len(sd) == 533
     assert sd["DispProcessor.dres0.0.0.weight"].shape == (32, 64, 3, 3, 3)
     assert sd["DispProcessor.dres2.conv5.0.weight"].shape == (128, 64, 3, 3, 3)
+
+
+def test_argument_validation_of_round1_additions(lib):
+    """Depthwise conv, 2-D transposed conv, fused redir branch, GRU combine: argument errors are reported
+    (non-zero return + message) before anything is launched."""
+    f = 16                                                      # any non-NULL, 16-byte aligned "pointer"
+    rc = lib.osa_dwconv2d_nhwc_f32(f, f, None, None, None, f, 1, 8, 8, 6, 8, 8, 0, 3, 3, 1, 1, 1, 1, 1, 0, None)
+    assert rc != 0 and b"multiples of 4" in lib.osa_last_error()         # C = 6
+    rc = lib.osa_dwconv2d_nhwc_f32(f, f, None, None, None, f, 1, 8, 8, 8, 8, 8, 0, 3, 3, 3, 1, 1, 1, 1, 0, None)
+    assert rc != 0 and b"stride" in lib.osa_last_error()
+    rc = lib.osa_dwconv2d_nhwc_f32(None, f, None, None, None, f, 1, 8, 8, 8, 8, 8, 0, 3, 3, 1, 1, 1, 1, 1, 0, None)
+    assert rc != 0 and b"NULL" in lib.osa_last_error()
+    rc = lib.osa_deconv2d_nhwc_f32(f, f, None, None, None, f, 1, 4, 4, 8, 8, 8, 8, 0, 5, 1, 1, None, 0, 0, 0.0, None)
+    assert rc != 0 and b"only (k=3" in lib.osa_last_error()              # k = 5 unsupported
+    rc = lib.osa_deconv3d_redir_ndhwc_f32(f, f, None, None, f, 1, 2, 4, 4, 64, 64, 32, 32, 3, 1, 1,
+                                          f, 128, 128, f, None, None, 1, 0.0, None)
+    assert rc != 0 and b"64 channels" in lib.osa_last_error()            # redir input wider than 64 channels
+    rc = lib.osa_gru_combine_f32(f, f, f, f, 10, 6, 8, 8, 8, 8, None)
+    assert rc != 0 and b"multiple of 4" in lib.osa_last_error()
+    assert lib.osa_deconv2d_packed_floats(64, 32, 3) == (4 * 9 * 2 * 2 * 32 * 4) + 4 * 2 * 2 * 32 * 4
