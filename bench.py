@@ -169,6 +169,20 @@ def main():
             net.reset_engine()
             out = eager_step()
 
+    # single-pair latency ("report B=1 latency and best-throughput B"), eager launches
+    latency_1 = None
+    if rank == 0 and world == 1 and B != 1:
+        with torch.no_grad():
+            one = {"left": L[:1], "right": R[:1]}
+            for _ in range(3):
+                net(dict(one))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                net(dict(one))
+            torch.cuda.synchronize()
+            latency_1 = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref as O      # CPU baseline leg only
@@ -190,7 +204,7 @@ def main():
             "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "GwcNet-gc inference, SceneFlow-shaped 540x960 padded to 544x960, D=192, "
                                    "G=40 + 12ch concat (BASELINE configs[1])",
-                       "pairs_per_gpu_per_step": B, "parallelism": f"independent pairs x{world}",
+                       "pairs_per_gpu_per_step": B, "latency_ms_1_pair": latency_1, "parallelism": f"independent pairs x{world}",
                        "precision": args.precision, "launch": "hipGraph replay" if graph is not None else "eager",
                        "weights": "deterministic synthetic (sharpened), random-init architecture"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precision": alt}))
