@@ -3,6 +3,7 @@
     import openstereo_amd.attach as A
     A.patch_reference()            # rebinds every per-model copy of the hot-path helpers
     ...build / load reference models as usual...
+    A.patch_reference_modules()    # optional: engine forwards grafted onto the reference's LightStereo / GRU module classes
     A.attach_gwcnet(model)         # optional: swap CostProcessor / DispProcessor / Backbone forwards
     A.unpatch_reference()
 
@@ -95,10 +96,54 @@ def patch_reference(verbose: bool = False) -> list[str]:
     return done
 
 
+def _graft(ref_cls, eng_cls, names):
+    """Give a reference nn.Module class the engine methods of its mirror (same attribute layout)."""
+    for n in names:
+        if hasattr(eng_cls, n):
+            _saved.append((ref_cls, n, ref_cls.__dict__.get(n, _MISSING)))
+            setattr(ref_cls, n, eng_cls.__dict__[n] if n in eng_cls.__dict__ else getattr(eng_cls, n))
+    for n in ("_eng", "_mask"):
+        if n not in ref_cls.__dict__:
+            _saved.append((ref_cls, n, _MISSING))
+            setattr(ref_cls, n, None)
+
+
+def patch_reference_modules(verbose: bool = False) -> list[str]:
+    """Graft the engine forwards onto the reference's OWN module classes (no model rebuild, parameters
+    stay where they are): LightStereo `Aggregation` / `MobileV2Residual` / `AttentionModule`
+    (models/lightstereo/aggregation.py) and the IGEV / StereoBase update block (`ConvGRU`,
+    `BasicMotionEncoder`, `DispHead`, `BasicMultiUpdateBlock`; models/igev/update.py,
+    models/stereobase/gru_blocks.py).  Works because the mirrors use the reference's attribute names."""
+    from .models import lightstereo as LS, igev_update as UP
+    plan = [("stereo.modeling.models.lightstereo.aggregation", LS, ("Aggregation", "MobileV2Residual", "AttentionModule")),
+            ("stereo.modeling.models.igev.update", UP, ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")),
+            ("stereo.modeling.models.stereobase.gru_blocks", UP, ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock"))]
+    done = []
+    for mod_name, eng_mod, classes in plan:
+        try:
+            mod = importlib.import_module(mod_name)
+        except Exception as ex:
+            if verbose:
+                print(f"[attach] skip {mod_name}: {type(ex).__name__}: {ex}")
+            continue
+        for cname in classes:
+            if hasattr(mod, cname):
+                _graft(getattr(mod, cname), getattr(eng_mod, cname), ("forward", "forward_cl", "_pack", "reset_engine"))
+                done.append(f"{mod_name}.{cname}")
+    return done
+
+
+_MISSING = object()
+
+
 def unpatch_reference():
     while _saved:
         obj, attr, old = _saved.pop()
-        setattr(obj, attr, old)
+        if old is _MISSING:
+            if attr in getattr(obj, "__dict__", {}):
+                delattr(obj, attr)
+        else:
+            setattr(obj, attr, old)
 
 
 def attach_gwcnet(model):

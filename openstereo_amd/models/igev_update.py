@@ -100,7 +100,7 @@ class ConvGRU(nn.Module):
             self._eng = (PackedConv3d(self.convz, None, ACT_SIGMOID), PackedConv3d(self.convr, None, ACT_SIGMOID),
                          PackedConv3d(self.convq, None, ACT_TANH))
         pz, pr, pq = self._eng
-        hd = self.hidden_dim
+        hd = self.convz.out_channels
         assert hd % 4 == 0 and h.shape[1] == hd
         hx = _cat_cl([h, *x_list], h.device)                   # [h | x]
         z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
@@ -115,7 +115,7 @@ class ConvGRU(nn.Module):
 
     def forward(self, h, cz, cr, cq, *x_list):
         c = nchw_to_cl
-        return cl_to_nchw(self.forward_cl(c(h), c(cz), c(cr), c(cq), *[c(x) for x in x_list]), self.hidden_dim)
+        return cl_to_nchw(self.forward_cl(c(h), c(cz), c(cr), c(cq), *[c(x) for x in x_list]), self.convz.out_channels)
 
 
 class BasicMotionEncoder(nn.Module):
@@ -175,23 +175,24 @@ class BasicMultiUpdateBlock(nn.Module):
 
     def forward_cl(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         """Engine tensors everywhere; `net` (list) is updated in place like the reference does."""
+        n_gru = self.args.N_GRU_LAYERS if hasattr(self, "args") else self.n_gru_layers    # igev/update.py vs stereobase/gru_blocks.py
         if iter16:
             net[2] = self.gru16.forward_cl(net[2], *(inp[2]), pool2x(net[1]))
         if iter08:
-            if self.args.N_GRU_LAYERS > 2:
+            if n_gru > 2:
                 net[1] = self.gru08.forward_cl(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
             else:
                 net[1] = self.gru08.forward_cl(net[1], *(inp[1]), pool2x(net[0]))
         if iter04:
             motion_features = self.encoder.forward_cl(disp, corr)
-            if self.args.N_GRU_LAYERS > 1:
+            if n_gru > 1:
                 net[0] = self.gru04.forward_cl(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
             else:
                 net[0] = self.gru04.forward_cl(net[0], *(inp[0]), motion_features)
         if not update:
             return net
         delta_disp = self.disp_head.forward_cl(net[0])
-        if self._mask is None:
+        if getattr(self, "_mask", None) is None:
             self._mask = PackedConv3d(self.mask_feat_4[0], None, ACT_RELU)
         return net, self._mask(net[0]), delta_disp
 

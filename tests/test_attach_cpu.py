@@ -41,3 +41,31 @@ def test_attach_gwcnet_shares_parameters():
     eng = attach.attach_gwcnet(ref)
     for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), eng.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_patch_reference_modules_grafts_engine_forwards():
+    """LightStereo aggregation and the IGEV update block of the REAL reference get the engine forwards
+    (class-level graft); on CPU tensors they refuse to run (no CPU path) and unpatch restores the originals."""
+    import importlib
+    import sys
+    import types
+    import torch
+    from openstereo_amd import attach
+    from openstereo_amd.models import lightstereo as LS
+    attach.stub_reference_packages(REF)
+    agg_mod = importlib.import_module("stereo.modeling.models.lightstereo.aggregation")
+    upd_mod = importlib.import_module("stereo.modeling.models.igev.update")
+    orig_fwd = agg_mod.Aggregation.forward
+    done = attach.patch_reference_modules()
+    try:
+        assert "stereo.modeling.models.lightstereo.aggregation.Aggregation" in done
+        assert "stereo.modeling.models.igev.update.BasicMultiUpdateBlock" in done
+        assert agg_mod.Aggregation.forward is LS.Aggregation.forward and hasattr(agg_mod.MobileV2Residual, "forward_cl")
+        agg = agg_mod.Aggregation(in_channels=48, left_att=True, blocks=[1, 2, 4], expanse_ratio=4,
+                                  backbone_channels=[24, 32, 96, 160]).eval()
+        with pytest.raises(RuntimeError, match="GPU engine only"):
+            agg(torch.zeros(1, 48, 8, 16), [torch.zeros(1, 24, 8, 16), torch.zeros(1, 32, 4, 8), torch.zeros(1, 96, 2, 4)])
+        assert upd_mod.ConvGRU._eng is None
+    finally:
+        attach.unpatch_reference()
+    assert agg_mod.Aggregation.forward is orig_fwd and not hasattr(agg_mod.MobileV2Residual, "forward_cl")
