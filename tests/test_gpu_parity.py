@@ -692,3 +692,26 @@ def test_psmnet_spp_backbone_engine_vs_reference_golden_and_torch_path():
     close(fe["ref_feature"], g["left_feature"], atol=2e-4, rtol=2e-4, what="engine SPP backbone (left)")
     close(fe["tgt_feature"], g["right_feature"], atol=2e-4, rtol=2e-4, what="engine SPP backbone (right)")
     close(fe["ref_feature"], ft["ref_feature"], atol=2e-4, rtol=2e-4, what="engine vs torch SPP backbone")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gwcnet_batch_invariance_and_odd_size(prec):
+    """Batched inference equals per-pair inference bit for bit (per-batch-item base pointers, 32-bit
+    offsets), also for an image size whose quarter resolution is not a multiple of the brick sizes."""
+    from openstereo_amd import engine
+    from openstereo_amd.models.gwcnet import GwcNet
+    old = engine.get_precision()
+    engine.set_precision(prec)
+    try:
+        net = GwcNet()
+        net.load_state_dict(synth_state_dict(net, seed=0))
+        net = net.to(DEV).eval()
+        L, R = synth_images(3, 96, 176, seed=5)              # quarter resolution 24 x 44
+        with torch.no_grad():
+            both = net({"left": L.to(DEV), "right": R.to(DEV)})["disp_pred"]
+            for i in range(3):
+                one = net({"left": L[i:i + 1].to(DEV), "right": R[i:i + 1].to(DEV)})["disp_pred"]
+                assert torch.equal(both[i:i + 1], one), f"pair {i}: batched != single ({(both[i:i+1] - one).abs().max().item():.3e})"
+        assert torch.isfinite(both).all() and both.std() > 1.0
+    finally:
+        engine.set_precision(old)
