@@ -204,7 +204,21 @@ class StereoBaseCostStage(nn.Module):
         self.classifier = nn.Conv3d(volume_channel, 1, 3, 1, 1, bias=False)
         self._cls = None
 
+    def forward_train(self, match_left, match_right, concat_left, concat_right, features_left):
+        """Training path (BASELINE configs[2]): differentiable engine ops end to end -- volumes, hourglass
+        convolutions, classifier, fused softmax + regression -- BatchNorm / activations as torch modules."""
+        from .. import autograd as A
+        D4 = self.max_disp // 4
+        vol = torch.cat((A.build_gwc_volume(match_left, match_right, D4, self.num_groups),
+                         A.build_concat_volume(concat_left, concat_right, D4)), 1)
+        geo = self.cost_agg.forward_train(vol, features_left)
+        cost = A.conv_module(self.classifier, geo).squeeze(1)
+        init_disp = A.softmax_disparity_regression(cost, keepdim=True)
+        return {"init_disp": init_disp, "prob": torch.softmax(cost, dim=1), "geo_encoding_volume": geo}
+
     def forward(self, match_left, match_right, concat_left, concat_right, features_left):
+        if self.training or (torch.is_grad_enabled() and (match_left.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(match_left, match_right, concat_left, concat_right, features_left)
         vol = ops.build_cost_volume_cl(match_left, match_right, self.num_groups, concat_left, concat_right,
                                        maxdisp=self.max_disp // 4)
         geo = self.cost_agg.forward_cl(vol, features_left)

@@ -193,6 +193,41 @@ def test_stereobase_hourglass_training_step_vs_oracle_autograd():
         close(params[k].grad, gr, 2e-3 * (float(gr.abs().max()) + 1e-12), 2e-3, f"grad {k}")
 
 
+def test_stereobase_cost_stage_training_vs_oracle_autograd():
+    """Volume -> hourglass -> classifier -> softmax regression of StereoBase in training mode (frozen BN):
+    init_disp and the gradients w.r.t. the matching features and selected weights vs torch-CPU autograd."""
+    from openstereo_amd.models.igev_style import StereoBaseCostStage
+    from oracle import torch_ref as O
+    st = StereoBaseCostStage(max_disp=64, num_groups=8, concat_channels=8, backbone_channels=[96, 64, 192, 120])
+    sd = synth_state_dict(st, seed=13)
+    st.load_state_dict(sd)
+    ml, mr = rn((1, 96, 16, 32), 40), rn((1, 96, 16, 32), 41)
+    cl, cr = rn((1, 8, 16, 32), 42), rn((1, 8, 16, 32), 43)
+    feats = [None, rn((1, 64, 8, 16), 44), rn((1, 192, 4, 8), 45), rn((1, 120, 2, 4), 46)]
+    gy = rn((1, 1, 16, 32), 47)
+    keys = ["classifier.weight", "cost_agg.conv1.0.block.0.weight", "cost_agg.agg_1.1.block.0.weight"]
+    sdr = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_()
+    mlr, mrr = ml.clone().requires_grad_(), mr.clone().requires_grad_()
+    d_ref, _, _ = O.stereobase_cost_stage(mlr, mrr, cl, cr, feats, sdr, 64, 8)
+    (d_ref * gy).sum().backward()
+    st = st.to(DEV).train()
+    for m in st.modules():
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.eval()
+    mle, mre = ml.to(DEV).requires_grad_(), mr.to(DEV).requires_grad_()
+    out = st(mle, mre, cl.to(DEV), cr.to(DEV), [None] + [f.to(DEV) for f in feats[1:]])
+    close(out["init_disp"], d_ref, 2e-4, 2e-4, "init_disp (train path)")
+    (out["init_disp"] * gy.to(DEV)).sum().backward()
+    for name, g, gr in (("d match_left", mle.grad, mlr.grad), ("d match_right", mre.grad, mrr.grad)):
+        close(g, gr, 3e-3 * float(gr.abs().max()), 3e-3, name)
+    params = dict(st.named_parameters())
+    for k in keys:
+        gr = sdr[k].grad
+        close(params[k].grad, gr, 3e-3 * (float(gr.abs().max()) + 1e-12), 3e-3, f"grad {k}")
+
+
 def test_ddp_wrapped_training_steps_reduce_loss():
     """The autograd Functions under stock DistributedDataParallel (world_size 1, nccl == RCCL): DDP's
     gradient hooks fire, an optimiser step lowers the loss."""
