@@ -279,6 +279,18 @@ int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const floa
                                   int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
                                   void* stream);
 
+/* Same convolution with the weights packed once ([cin-chunk][tap][Co][16], 64-byte aligned) by
+ * osa_conv3d_small_co_pack_f32: the workgroups then read them through the scalar cache instead of
+ * re-ordering the reference layout into LDS. */
+size_t osa_conv3d_small_co_packed_floats(int Ci, int Co, int kd, int kh, int kw);
+int    osa_conv3d_small_co_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                    int kd, int kh, int kw, void* stream);
+int    osa_conv3d_small_co_packed_ndhwc_f32(const float* x, const float* w_packed, const float* bias,
+                                            const float* residual, float* y,
+                                            int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
+                                            int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
+                                            void* stream);
+
 /* ---- disparity regression (a10-a12) ------------------------- */
 /* out[b,h,w] = sum_d d * prob[b,d,h,w] */
 int osa_softargmin_f32(const float* prob, float* out, int B, int D, int H, int W, void* stream);

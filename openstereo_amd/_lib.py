@@ -74,6 +74,11 @@ SIGNATURES = {
     "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_conv3d_small_co_packed_floats": (C.c_size_t, [c_i, c_i, c_i, c_i, c_i]),
+    "osa_conv3d_small_co_pack_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_conv3d_small_co_packed_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
+                                            c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                            c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_build_volume_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),

@@ -869,7 +869,11 @@ static int deconv_dim_taps(int k, int pad, int par, int* delta, int* kk) {
 // on the same LDS brick: one thread per output voxel, all taps x 16-channel chunks read from LDS
 // as float4, the (tiny) weight set re-ordered into LDS as [chunk][tap][co][16] and read by
 // broadcast.  HBM traffic = one pass over the input; LDS-read bound.
-template <int CO>
+// WG = false: weights in the reference layout, re-ordered into LDS by every workgroup.
+// WG = true : weights pre-packed [chunk][tap][co][16] in global memory; the address is wave-uniform, so
+//             they arrive through the scalar cache (s_load_dwordx16) and feed the FMAs as SGPR operands --
+//             half the LDS instructions per FMA of the WG = false form.
+template <int CO, bool WG>
 __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs p, const float* __restrict__ wref,
                                                                   const float* __restrict__ bias) {
     constexpr int TD = 4, TH = 8, TW = 8;
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
     const int a0d = tdi * TD, a0h = thi * TH, a0w = twi * TW;
     const int g0d = a0d + p.dmin, g0h = a0h + p.hmin, g0w = a0w + p.wmin;
 
-    const int nw = p.nchunks * p.T * CO * 16;
+    const int nw = WG ? 0 : p.nchunks * p.T * CO * 16;
     for (int i = tid; i < nw; i += 256) {
         const int e = i & 15; int r = i >> 4;
         const int co = r % CO; r /= CO;
@@ -906,7 +910,8 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
         __syncthreads();
         for (int t = 0; t < p.T; ++t) {
             const float4* xp = smem + abase + p.toff[t];
-            const float4* wq = wl4 + (size_t)(ch * p.T + t) * CO * 4;
+            const float4* wq = WG ? reinterpret_cast<const float4*>(wref) + (size_t)(ch * p.T + t) * CO * 4
+                                  : wl4 + (size_t)(ch * p.T + t) * CO * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 xv = xp[q];
@@ -1228,11 +1233,60 @@ extern "C" int osa_deconv2d_nhwc_f16x3(OSA_DECONV2D_PARAMS, float out_scale, voi
     return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F16X3, out_scale, stream, true);
 }
 
+__global__ __launch_bounds__(256) void small_co_pack_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int Ci, int Co, int T, int nchunks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // dst index ((ch*T + t)*Co + co)*16 + e
+    if (i >= nchunks * T * Co * 16) return;
+    const int e = i & 15; int r = i >> 4;
+    const int co = r % Co; r /= Co;
+    const int t = r % T; const int ch = r / T;
+    const int ci = ch * CC + e;
+    dst[i] = (ci < Ci) ? src[((size_t)co * Ci + ci) * T + t] : 0.f;
+}
+
+extern "C" size_t osa_conv3d_small_co_packed_floats(int Ci, int Co, int kd, int kh, int kw) {
+    return (size_t)nchunks_of(Ci) * kd * kh * kw * Co * 16;
+}
+
+extern "C" int osa_conv3d_small_co_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
+                                            int kd, int kh, int kw, void* stream) {
+    OSA_REQUIRE(w_ref && w_packed, "conv3d_small_co_pack: NULL pointer");
+    OSA_REQUIRE(Ci > 0 && Co >= 1 && Co <= 4 && kd > 0 && kh > 0 && kw > 0, "conv3d_small_co_pack: bad dims");
+    const int n = (int)osa_conv3d_small_co_packed_floats(Ci, Co, kd, kh, kw);
+    hipLaunchKernelGGL(small_co_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_ref, w_packed, Ci, Co, kd * kh * kw, nchunks_of(Ci));
+    OSA_LAUNCH_CHECK("conv3d_small_co_pack");
+    return 0;
+}
+
+static int small_co_impl(const float* x, const float* w, bool packed, const float* bias,
+                         const float* residual, float* y,
+                         int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
+                         int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
+                         void* stream);
+
 extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref, const float* bias,
                                              const float* residual, float* y,
                                              int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
                                              int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
                                              void* stream) {
+    return small_co_impl(x, w_ref, false, bias, residual, y, B, D, H, W, Ci, xCs, Co, yCs, kd, kh, kw, pad_d, pad_h, pad_w, stream);
+}
+
+extern "C" int osa_conv3d_small_co_packed_ndhwc_f32(const float* x, const float* w_packed, const float* bias,
+                                                    const float* residual, float* y,
+                                                    int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
+                                                    int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
+                                                    void* stream) {
+    OSA_REQUIRE(((size_t)w_packed & 63) == 0, "conv3d_small_co_packed: packed weights must be 64-byte aligned");
+    return small_co_impl(x, w_packed, true, bias, residual, y, B, D, H, W, Ci, xCs, Co, yCs, kd, kh, kw, pad_d, pad_h, pad_w, stream);
+}
+
+static int small_co_impl(const float* x, const float* w_ref, bool packed, const float* bias,
+                         const float* residual, float* y,
+                         int B, int D, int H, int W, int Ci, int xCs, int Co, int yCs,
+                         int kd, int kh, int kw, int pad_d, int pad_h, int pad_w,
+                         void* stream) {
     OSA_REQUIRE(x && w_ref && y, "conv3d_small_co: NULL pointer");
     OSA_REQUIRE(Co >= 1 && Co <= 4, "conv3d_small_co: Co=%d unsupported (1..4)", Co);
     OSA_REQUIRE(xCs % 4 == 0 && xCs >= Ci && ((size_t)x & 15) == 0, "conv3d_small_co: x must be 16-byte aligned, xCs %% 4 == 0");
@@ -1255,20 +1309,21 @@ extern "C" int osa_conv3d_small_co_ndhwc_f32(const float* x, const float* w_ref,
     a.dmin = -pad_d; a.hmin = -pad_h; a.wmin = -pad_w;
     a.LD = 4 + 2 * pad_d; a.LH = 8 + 2 * pad_h; a.LW = 8 + 2 * pad_w;
     a.tilesD = cdiv(D, 4); a.tilesH = cdiv(H, 8); a.tilesW = cdiv(W, 8);
-    finish_geometry(a, 8, false);      // thread-per-voxel reads: the padded image is the conflict-free one
-    const size_t lds = ((size_t)a.LD * a.PlaneQ * 4 + (size_t)a.nchunks * a.T * Co * 16) * sizeof(float);
+    finish_geometry(a, 8, true);       // thread q reads voxel q of the 4x8x8 tile: the MFMA A-operand pattern, compact image
+    const size_t lds = ((size_t)a.LD * a.PlaneQ * 4 + (packed ? 0 : (size_t)a.nchunks * a.T * Co * 16)) * sizeof(float);
     OSA_REQUIRE(lds <= 160 * 1024, "conv3d_small_co: %zu B of LDS needed", lds);
     const long long nblk = (long long)B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "conv3d_small_co: grid too large");
     dim3 grid((unsigned)nblk), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define OSA_SC_LAUNCH(CO)                                                                                   \
+#define OSA_SC_LAUNCH1(CO, WG)                                                                              \
     do {                                                                                                    \
         if (lds > 64 * 1024)                                                                                \
-            (void)hipFuncSetAttribute((const void*)conv_small_co_tiled_kernel<CO>,                          \
+            (void)hipFuncSetAttribute((const void*)conv_small_co_tiled_kernel<CO, WG>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL(conv_small_co_tiled_kernel<CO>, grid, block, lds, st, a, w_ref, bias);           \
+        hipLaunchKernelGGL((conv_small_co_tiled_kernel<CO, WG>), grid, block, lds, st, a, w_ref, bias);     \
     } while (0)
+#define OSA_SC_LAUNCH(CO) do { if (packed) OSA_SC_LAUNCH1(CO, true); else OSA_SC_LAUNCH1(CO, false); } while (0)
     switch (Co) {
         case 1: OSA_SC_LAUNCH(1); break;
         case 2: OSA_SC_LAUNCH(2); break;

@@ -258,6 +258,11 @@ class SmallCoConv3d:
         self.bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
         self.Co, self.Ci = self.w.shape[:2]
         self.k, self.pad = tuple(conv.kernel_size), _t3(conv.padding)
+        n = _lib.load().osa_conv3d_small_co_packed_floats(self.Ci, self.Co, *self.k)
+        self.packed = torch.empty(n + 16, device=self.w.device, dtype=torch.float32)     # scalar-cache friendly layout
+        off = (-self.packed.data_ptr() // 4) % 16                                         # 64-byte alignment
+        self.packed = self.packed[off:off + n]
+        _lib.call("osa_conv3d_small_co_pack_f32", self.w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, _stream())
 
     def __call__(self, x, residual=None):
         """x NDHWC logical [B,Cs,D,H,W] -> logical [B,Co,D,H,W] stored [B,D,H,W,Co] (for Co==1 this
@@ -268,6 +273,6 @@ class SmallCoConv3d:
         if residual is not None:
             assert tuple(residual.shape) == (B, self.Co, D, H, W) and is_cl(residual)
         with timing.span("conv3d_small_co", self.Ci, self.Co, self.k[0], 1, D, H, W):
-            _lib.call("osa_conv3d_small_co_ndhwc_f32", x.data_ptr(), self.w.data_ptr(), _p(self.bias), _p(residual), y.data_ptr(),
+            _lib.call("osa_conv3d_small_co_packed_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.bias), _p(residual), y.data_ptr(),
                       B, D, H, W, self.Ci, Cs, self.Co, self.Co, *self.k, *self.pad, _stream())
         return y.permute(0, 4, 1, 2, 3)
