@@ -49,6 +49,11 @@ enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3,
 /* OR'ed into `act`: the gate tensor is a plain multiplier (LightStereo AttentionModule, attn * cost,
  * models/lightstereo/aggregation.py:134) instead of logits passed through a sigmoid */
 enum { OSA_GATE_RAW = 16 };
+/* OR'ed into `act` of the f16x3 conv / deconv calls: "split" activation tensors.  Same bytes per voxel as
+ * fp32 NDHWC, but every 16-channel chunk is stored as [16 x fp16 hi | 16 x fp16 lo] (x = hi + lo, the
+ * image the kernels stage into LDS), so a consumer copies instead of splitting and a producer splits each
+ * value once.  Channel counts must be multiples of 16.  Internal to chains of engine layers. */
+enum { OSA_IN_SPLIT = 32, OSA_OUT_SPLIT = 64, OSA_RES_SPLIT = 128, OSA_REDIR_SPLIT = 256 };
 
 /* ---- misc ------------------------------------------------------------- */
 int         osa_abi_version(void);

@@ -96,6 +96,19 @@ __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) 
 // NCL consecutive 16-channel chunks are staged in one pass (bricks back to back in LDS, brickQ apart):
 // the index arithmetic of an item is shared by its NCL loads, and the two 64-byte halves of a voxel's
 // 128-byte line are requested together.
+// inverse of split_f16 for one channel quad: x = float(hi) + float(lo)
+__device__ __forceinline__ float4 join_f16(const uint2 hi, const uint2 lo) {
+    const f16x4 h = __builtin_bit_cast(f16x4, hi), l = __builtin_bit_cast(f16x4, lo);
+    return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+}
+
+// "Split" activation tensors (OSA_IN_SPLIT / OSA_OUT_SPLIT / OSA_RES_SPLIT / OSA_REDIR_SPLIT, f16x3 mode only):
+// the same bytes per voxel as fp32 NDHWC, but every 16-channel chunk holds [16 x fp16 hi | 16 x fp16 lo]
+// -- exactly the LDS image of a staged chunk.  Element offset (in floats) of the hi / lo halves of the
+// channel quad starting at channel c (c % 4 == 0):
+__device__ __forceinline__ int split_off_hi(int c) { return (c >> 4) * 16 + ((c & 15) >> 2) * 2; }
+__device__ __forceinline__ int split_off_lo(int c) { return split_off_hi(c) + 8; }
+
 template <int NTHR, int PREC, int NCL>
 __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
                                             int g0d, int g0h, int g0w, int tid) {
@@ -141,6 +154,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                     if constexpr (PREC == PREC_F32) {
                         dst[lo[u]] = v[u][cl];
                     } else {
+                        if (p.act & OSA_IN_SPLIT) { dst[lo[u]] = v[u][cl]; continue; }   // already [hi | lo] in HBM
                         // voxel image: [16 x fp16 hi | 16 x fp16 lo]; this quad's 4 channels -> 8 B each
                         static_assert(NTHR % 4 == 0, "channel quad of an item must not depend on u");
                         const int c4 = base & 3;        // == (base + u*NTHR) & 3
@@ -447,7 +461,12 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.res && vok[k] && co < p.Co) {
                 const float* rp = resb + (v0[k] + coff) * p.rCs + co;
-                if (vec4) rv[k] = *reinterpret_cast<const float4*>(rp);
+                if (PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT)) {
+                    const float* rs = resb + (v0[k] + coff) * p.rCs;
+                    const uint2 h = *reinterpret_cast<const uint2*>(rs + split_off_hi(co));
+                    const uint2 l = *reinterpret_cast<const uint2*>(rs + split_off_lo(co));
+                    rv[k] = __builtin_bit_cast(float4, make_uint4(h.x, h.y, l.x, l.y));     // decoded in finish()
+                } else if (vec4) rv[k] = *reinterpret_cast<const float4*>(rp);
                 else {
                     float* rr = &rv[k].x;
 #pragma unroll
@@ -491,7 +510,12 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             float o[4];
             const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
             const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-            const float r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+            float4 rk = rv[k];
+            if (PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT) && p.res) {
+                const uint4 b4 = __builtin_bit_cast(uint4, rv[k]);
+                rk = join_f16(make_uint2(b4.x, b4.y), make_uint2(b4.z, b4.w));
+            }
+            const float r4[4] = {rk.x, rk.y, rk.z, rk.w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
@@ -505,7 +529,13 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             }
             if (vok[k] && cok) {
                 float* yp = yb + (v0[k] + coff) * p.yCs + co;
-                if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                if (PREC == PREC_F16X3 && (p.act & OSA_OUT_SPLIT)) {
+                    uint2 h2, l2;
+                    split_f16(make_float4(o[0], o[1], o[2], o[3]), h2, l2);
+                    float* ys = yb + (v0[k] + coff) * p.yCs;
+                    *reinterpret_cast<uint2*>(ys + split_off_hi(co)) = h2;
+                    *reinterpret_cast<uint2*>(ys + split_off_lo(co)) = l2;
+                } else if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -539,8 +569,10 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                     rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int ch = k >> 1, j = k & 1;
                     // f16x3: 8 consecutive channels 8hh..8hh+7 of the chunk (two float4s); f32: channels 8j+4hh..+3
-                    const int cin = ch * CC + ((PREC == PREC_F32) ? (8 * j + 4 * hh) : (8 * hh + 4 * j));
-                    if (ok && ch < rch && cin < p.rCi) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
+                    int cin = ch * CC + ((PREC == PREC_F32) ? (8 * j + 4 * hh) : (8 * hh + 4 * j));
+                    // split redir input: j = 0 -> the lane's 8 hi halves, j = 1 -> its 8 lo halves (16 B each)
+                    if (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) cin = ch * CC + 4 * hh + 8 * j;
+                    if (ok && ch < rch && ch * CC < p.rCi) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
                 }
             };
             auto add_redir = [&](int i, const float4 (&rv)[RV]) {
@@ -564,11 +596,16 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                             r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, r, 0, 0, 0);
                             r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, r, 0, 0, 0);
                         } else {
-                            uint2 h0, l0, h1, l1;
-                            split_f16(rv[2 * ch], h0, l0);
-                            split_f16(rv[2 * ch + 1], h1, l1);
-                            const f16x8 ah = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-                            const f16x8 al = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                            f16x8 ah, al;
+                            if (p.act & OSA_REDIR_SPLIT) {
+                                ah = __builtin_bit_cast(f16x8, rv[2 * ch]); al = __builtin_bit_cast(f16x8, rv[2 * ch + 1]);
+                            } else {
+                                uint2 h0, l0, h1, l1;
+                                split_f16(rv[2 * ch], h0, l0);
+                                split_f16(rv[2 * ch + 1], h1, l1);
+                                ah = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                                al = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                            }
                             const f16x8 bh = __builtin_bit_cast(f16x8, b0), bl = __builtin_bit_cast(f16x8, b1);
                             r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, r, 0, 0, 0);
                             r = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, r, 0, 0, 0);
@@ -781,6 +818,15 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         const int cs = a.yCs > a.rCs ? (a.yCs > a.gCs ? a.yCs : a.gCs) : (a.rCs > a.gCs ? a.rCs : a.gCs);
         OSA_REQUIRE(ovox * cs < (1ll << 31), "%s: one batch item of the output exceeds 2^31 elements", what);
         OSA_REQUIRE((long long)a.Di * a.Hi * a.Wi * a.xCs < (1ll << 31), "%s: one batch item of the input exceeds 2^31 elements", what);
+    }
+    if (a.act & (OSA_IN_SPLIT | OSA_OUT_SPLIT | OSA_RES_SPLIT | OSA_REDIR_SPLIT)) {
+        OSA_REQUIRE(prec == PREC_F16X3, "%s: split activation tensors exist in the f16x3 mode only", what);
+        if (a.act & OSA_IN_SPLIT) OSA_REQUIRE(a.Ci % 16 == 0, "%s: split input needs Ci %% 16 == 0 (got %d)", what, a.Ci);
+        if (a.act & OSA_OUT_SPLIT) OSA_REQUIRE(a.Co % 16 == 0 && a.yCs % 16 == 0 && !a.gate && ((size_t)a.y & 15) == 0,
+                                               "%s: split output needs Co, yCs %% 16 == 0 and no gate", what);
+        if ((a.act & OSA_RES_SPLIT) && a.res) OSA_REQUIRE(a.Co % 16 == 0 && a.rCs % 16 == 0 && ((size_t)a.res & 15) == 0,
+                                                          "%s: split residual needs Co, rCs %% 16 == 0", what);
+        if ((a.act & OSA_REDIR_SPLIT) && a.rx) OSA_REQUIRE(a.rCi % 16 == 0, "%s: split redir input needs channels %% 16 == 0", what);
     }
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = getenv("OSA_NORING") != nullptr;

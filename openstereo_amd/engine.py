@@ -18,6 +18,13 @@ import os
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_RELU6, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4, 5
 GATE_RAW = 16          # OR'ed into act: the gate is a plain multiplier, not sigmoid logits
+# "split" activation tensors (f16x3 mode): every 16-channel chunk stored as [16 x fp16 hi | 16 x fp16 lo]
+# (same bytes as fp32), see include/openstereo_amd.h.  A tensor written that way carries `_osa_split = True`.
+IN_SPLIT, OUT_SPLIT, RES_SPLIT, REDIR_SPLIT = 32, 64, 128, 256
+
+
+def is_split(t) -> bool:
+    return t is not None and getattr(t, "_osa_split", False)
 enable_timing, collect_timing = timing.enable, timing.collect
 
 # Arithmetic mode of the MFMA convolutions:
@@ -137,14 +144,17 @@ class PackedConv3d:
         return (f(D, self.k[0], self.pad[0], self.dil[0], sd), f(H, self.k[1], self.pad[1], self.dil[1], s),
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
-    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False, redir=None):
+    def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False, redir=None,
+                 out_split=False):
         """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
         Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
         multiplied by sigmoid(gate) broadcast over D (FeatureAtt); gate_raw=True multiplies by the
         gate itself (LightStereo AttentionModule: attn * cost).  redir=(layer, t): a transposed conv adds
         layer(t) -- a 1x1x1 PackedConv3d (+BN) on the output-resolution tensor t (<= 64 channels) -- inside
-        its epilogue (GwcNet hourglass conv6 + redir1); replaces `residual`."""
+        its epilogue (GwcNet hourglass conv6 + redir1); replaces `residual`.  out_split=True (f16x3 only)
+        writes the output as a split tensor (see IN_SPLIT ...); split inputs / residuals are recognised by
+        their `_osa_split` tag, so chains of engine layers pass them along without further arguments."""
         assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
         B, Cs, D, H, W = x.shape
         assert Cs >= x_off + self.Ci and Cs % 4 == 0 and x_off % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
@@ -169,6 +179,13 @@ class PackedConv3d:
         xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
         rp = None if residual is None else residual.data_ptr() + 4 * res_off
         act = self.act | (GATE_RAW if (gate is not None and gate_raw) else 0)
+        fmt = (IN_SPLIT if is_split(x) else 0) | (OUT_SPLIT if out_split else 0) | (RES_SPLIT if is_split(residual) else 0) \
+            | (REDIR_SPLIT if (redir is not None and is_split(redir[1])) else 0)
+        if fmt:
+            assert self.precision == "f16x3", "split activation tensors exist in the f16x3 mode only"
+            assert x_off == 0 and out_off == 0 and res_off == 0 and gate is None
+            assert not out_split or (self.Co % 16 == 0 and yCs == self.Co)
+            act |= fmt
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
             tail = (self.out_scale, _stream()) if self.precision == "f16x3" else (_stream(),)
             sfx = "f16x3" if self.precision == "f16x3" else "f32"
@@ -197,6 +214,8 @@ class PackedConv3d:
                           self.k[0], self.k[1], self.k[2], self.stride[1],
                           self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
                           _p(gate), gCs, act, self.slope, *tail)
+        if out_split:
+            out._osa_split = True
         return out
 
 
@@ -267,7 +286,7 @@ class SmallCoConv3d:
     def __call__(self, x, residual=None):
         """x NDHWC logical [B,Cs,D,H,W] -> logical [B,Co,D,H,W] stored [B,D,H,W,Co] (for Co==1 this
         is plain contiguous [B,1,D,H,W]).  residual: an earlier output of the same shape (added)."""
-        assert is_cl(x)
+        assert is_cl(x) and not is_split(x), "SmallCoConv3d reads fp32 NDHWC tensors"
         B, Cs, D, H, W = x.shape
         y = torch.empty((B, D, H, W, self.Co), device=x.device, dtype=torch.float32)
         if residual is not None:

@@ -46,6 +46,7 @@ def _cb2(cin, cout, k, stride, pad, dil):
 
 
 _FUSE_REDIR = os.environ.get("OSA_FUSE_REDIR", "1") != "0"
+_SPLIT_ACT = os.environ.get("OSA_SPLIT_ACT", "1") != "0"     # f16x3: 3-D activations stored pre-split between engine layers
 
 class _ResBlock(nn.Module):
     def __init__(self, cin, cout, stride, shortcut, pad, dil):
@@ -243,18 +244,21 @@ class Hourglass(nn.Module):
                 r1=P(self.redir1[0], self.redir1[1], ACT_NONE), r2=P(self.redir2[0], self.redir2[1], ACT_NONE))
         return self._packed
 
-    def forward_cl(self, x):
+    def forward_cl(self, x, split=False):
+        """split=True (f16x3 mode, inside GwcDispProcessor): intermediate and output tensors are written in the
+        split hi/lo format by the producing epilogues (engine.OUT_SPLIT), x may be a split tensor."""
         p = self._pack()
-        c1 = p["c1"](x)
-        c2 = p["c2"](c1)
-        c4 = p["c4"](p["c3"](c2))
+        s = dict(out_split=True) if split else {}
+        c1 = p["c1"](x, **s)
+        c2 = p["c2"](c1, **s)
+        c4 = p["c4"](p["c3"](c2, **s), **s)
         if _FUSE_REDIR and p["r2"].Ci <= 64:
-            c5 = p["c5"](c4, redir=(p["r2"], c2))  # relu(conv5(c4) + redir2(c2)), redir2 inside conv5's epilogue
+            c5 = p["c5"](c4, redir=(p["r2"], c2), **s)  # relu(conv5(c4) + redir2(c2)), redir2 inside conv5's epilogue
         else:
-            c5 = p["c5"](c4, residual=p["r2"](c2))
+            c5 = p["c5"](c4, residual=p["r2"](c2, **s), **s)
         if _FUSE_REDIR and p["r1"].Ci <= 32:
-            return p["c6"](c5, redir=(p["r1"], x))  # relu(conv6(c5) + redir1(x)), redir1 inside conv6's epilogue
-        return p["c6"](c5, residual=p["r1"](x))    # relu(conv6(c5) + redir1(x))
+            return p["c6"](c5, redir=(p["r1"], x), **s)  # relu(conv6(c5) + redir1(x)), redir1 inside conv6's epilogue
+        return p["c6"](c5, residual=p["r1"](x, **s), **s)    # relu(conv6(c5) + redir1(x))
 
     def forward_train(self, x):
         """hourglass.py:46-56 with autograd: convs on the engine, BN/ReLU/add in torch."""
@@ -308,10 +312,12 @@ class GwcDispProcessor(nn.Module):
     def aggregate_cl(self, volume):
         """NDHWC volume -> low-res cost [B,1,D/4,H/4,W/4] (classif3 output)."""
         p = self._pack()
-        cost0 = p["d02"](p["d00"](volume))
-        cost0 = p["d12"](p["d10"](cost0), residual=cost0)      # dres1(cost0) + cost0
-        out3 = self.dres4.forward_cl(self.dres3.forward_cl(self.dres2.forward_cl(cost0)))
-        return p["k2"](p["k0"](out3))
+        split = _SPLIT_ACT and p["d00"].precision == "f16x3"
+        s = dict(out_split=True) if split else {}
+        cost0 = p["d02"](p["d00"](volume, **s), **s)
+        cost0 = p["d12"](p["d10"](cost0, **s), residual=cost0, **s)      # dres1(cost0) + cost0
+        out3 = self.dres4.forward_cl(self.dres3.forward_cl(self.dres2.forward_cl(cost0, split), split), split)
+        return p["k2"](p["k0"](out3))                                   # k0 writes plain fp32 for the VALU head
 
     def forward_train(self, inputs):
         """gwcnet_disp_processor.py:83-126: four supervised outputs, everything differentiable."""

@@ -78,6 +78,7 @@ def to_cl(x: torch.Tensor, pad_to: int = 4) -> torch.Tensor:
 
 def to_ncdhw(x: torch.Tensor, channels: int | None = None) -> torch.Tensor:
     """NDHWC -> contiguous NCDHW (first `channels` channels)."""
+    assert not getattr(x, "_osa_split", False), "split activation tensors are internal to engine layer chains"
     _chk(x, "x", 5)
     if not is_cl(x):
         return x.contiguous()

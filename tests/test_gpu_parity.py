@@ -715,3 +715,36 @@ def test_gwcnet_batch_invariance_and_odd_size(prec):
         assert torch.isfinite(both).all() and both.std() > 1.0
     finally:
         engine.set_precision(old)
+
+
+def test_split_activation_format_chain():
+    """f16x3 mode: activations handed from one engine layer to the next in the split hi/lo format
+    (producer epilogue splits, consumer staging copies).  Without residuals the chain is bit-identical
+    to the fp32-tensor chain (the consumer would have computed the same split); with a split residual
+    and a fused redir branch it stays within the usual tolerance of the torch reference."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d, is_split
+    mk = lambda ci, co, k, s, name: (lambda c: (setattr(c.weight, "data", synth_tensor(name, c.weight.shape, 1)), c)[1])(
+        nn.Conv3d(ci, co, k, s, k // 2, bias=False))
+    ca, cb, cc = mk(64, 32, 3, 1, "sp.a"), mk(32, 32, 3, 1, "sp.b"), mk(32, 64, 3, 2, "sp.c")
+    bna, bnb, bnc = _bn_for(32, 2, "sp.a"), _bn_for(32, 3, "sp.b"), _bn_for(64, 4, "sp.c")
+    x = T(np.random.default_rng(3).normal(0, 1, (2, 64, 6, 10, 13)).astype(np.float32))
+    with torch.no_grad():
+        ra = F.relu(bna(ca(x)))
+        rb = F.relu(bnb(cb(ra)) + ra)
+        rc_ = F.relu(bnc(cc(rb)))
+    pa = PackedConv3d(ca.to(DEV), bna.to(DEV), 1, precision="f16x3")
+    pb = PackedConv3d(cb.to(DEV), bnb.to(DEV), 1, precision="f16x3")
+    pc = PackedConv3d(cc.to(DEV), bnc.to(DEV), 1, precision="f16x3")
+    xc = ops.to_cl(x.to(DEV))
+    ya_plain = pa(xc)
+    ya = pa(xc, out_split=True)
+    assert is_split(ya) and not is_split(ya_plain)
+    # consumer of a split tensor (no residual) == consumer of the fp32 tensor, bit for bit
+    assert torch.equal(pb(ya), pb(ya_plain))
+    yb = pb(ya, residual=ya, out_split=True)                 # split input, split residual, split output
+    yc = pc(yb)                                              # split input, fp32 output, stride 2
+    assert not is_split(yc)
+    close(yc[:, :64], rc_, atol=3e-5, rtol=3e-5, what="split chain vs torch")
+    with pytest.raises(AssertionError):
+        ops.to_ncdhw(yb)                                     # split tensors never leave the engine chain
