@@ -175,7 +175,9 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 // NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
-template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0>
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0, int OUTS = 0>
+// OUTS = 1: the output is a split tensor (OSA_OUT_SPLIT) -- separate instantiation: a lane finalises 8
+// channels of 2 voxels (16-byte hi and lo stores) instead of 4 channels of 4 voxels.
 // Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
 // (MT = 2, NT = 1: the dominant 32 -> 32 layers) are held to 128 registers so that 4 workgroups
 // share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
@@ -529,18 +531,103 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             }
             if (vok[k] && cok) {
                 float* yp = yb + (v0[k] + coff) * p.yCs + co;
-                if (PREC == PREC_F16X3 && (p.act & OSA_OUT_SPLIT)) {
-                    uint2 h2, l2;
-                    split_f16(make_float4(o[0], o[1], o[2], o[3]), h2, l2);
-                    float* ys = yb + (v0[k] + coff) * p.yCs;
-                    *reinterpret_cast<uint2*>(ys + split_off_hi(co)) = h2;
-                    *reinterpret_cast<uint2*>(ys + split_off_lo(co)) = l2;
-                } else if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (co + e < p.Co) yp[e] = o[e];
                 }
+            }
+        }
+    };
+    // ---- split-output epilogue (OUTS): a lane takes 8 consecutive channels of 2 voxels of the tile, so the
+    // hi halves and the lo halves of its 8 values are one 16-byte store each; a split residual is read the
+    // same way (host: a split output takes a split residual, no gate).
+    const int vs2 = lane >> 2, c8 = (lane & 3) * 8;
+    auto rows2 = [&](int m, int (&v0)[2], bool (&vok)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = (wm * MT + m) * 32 + vs2 + 16 * k;
+            const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+            vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+            v0[k] = ((ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;
+        }
+    };
+    auto load_res8 = [&](int i, float4 (&rv)[4]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[2], coff, goff; bool vok[2];
+        rows2(m, v0, vok);
+        class_off(c, coff, goff);
+        const int co = n0 + (wn * NT + n) * 32 + c8;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            rv[2 * k] = make_float4(0.f, 0.f, 0.f, 0.f); rv[2 * k + 1] = rv[2 * k];
+            if (p.res && vok[k] && co < p.Co) {
+                const float* rs = resb + (v0[k] + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                rv[2 * k] = *reinterpret_cast<const float4*>(rs);            // 8 hi halves
+                rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);    // 8 lo halves
+            }
+        }
+    };
+    auto finish8 = [&](int i, const float4 (&rv)[4], const float4 (&sc8)[2], const float4 (&sh8)[2]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[2], coff, goff; bool vok[2];
+        rows2(m, v0, vok);
+        class_off(c, coff, goff);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
+        const int co = n0 + (wn * NT + n) * 32 + c8;
+        const bool cok = co < p.Co;
+        float4 av[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            av[k][0] = *reinterpret_cast<const float4*>(tb + (vs2 + 16 * k) * 36 + c8);
+            av[k][1] = *reinterpret_cast<const float4*>(tb + (vs2 + 16 * k) * 36 + c8 + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint2 hq[2], lq[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res) {
+                    const uint4 hb = __builtin_bit_cast(uint4, rv[2 * k]), lb = __builtin_bit_cast(uint4, rv[2 * k + 1]);
+                    r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
+                }
+                const float a4[4] = {av[k][h2].x, av[k][h2].y, av[k][h2].z, av[k][h2].w};
+                const float s4[4] = {sc8[h2].x, sc8[h2].y, sc8[h2].z, sc8[h2].w}, t4[4] = {sh8[h2].x, sh8[h2].y, sh8[h2].z, sh8[h2].w};
+                const float r4[4] = {r.x, r.y, r.z, r.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(a4[e], s4[e], t4[e]) + r4[e];
+                    if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                    else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                    else if (actk == OSA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    else if (actk == OSA_ACT_TANH) v = tanhf(v);
+                    o[e] = v;
+                }
+                split_f16(make_float4(o[0], o[1], o[2], o[3]), hq[h2], lq[h2]);
+            }
+            if (vok[k] && cok) {
+                float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                *reinterpret_cast<uint4*>(ys) = make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+                *reinterpret_cast<uint4*>(ys + 8) = make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y);
+            }
+        }
+    };
+    // BN scale / shift of the lane's 8 channels in that mapping (REDIR: already applied in accumulator layout)
+    auto bn8 = [&](int n, float4 (&sc8)[2], float4 (&sh8)[2]) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int co = n0 + (wn * NT + n) * 32 + c8 + 4 * h2;
+            sc8[h2] = make_float4(p.oscale, p.oscale, p.oscale, p.oscale); sh8[h2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (REDIR) { sc8[h2] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
+            if (co + 3 < p.Co && p.scale) {
+                sc8[h2] = *reinterpret_cast<const float4*>(p.scale + co); sh8[h2] = *reinterpret_cast<const float4*>(p.shift + co);
+                sc8[h2].x *= p.oscale; sc8[h2].y *= p.oscale; sc8[h2].z *= p.oscale; sc8[h2].w *= p.oscale;
             }
         }
     };
@@ -631,12 +718,28 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             for (int i = 0; i < NI; ++i) {
                 add_redir(i, rvb[i % PD]);
                 if (i + PD < NI) load_x(i + PD, rvb[i % PD]);
-                finish(i, zero4);
+                if constexpr (OUTS) {
+                    float4 sc8[2], sh8[2];
+                    bn8(i % NT, sc8, sh8);
+                    finish8(i, zero4, sc8, sh8);
+                } else finish(i, zero4);
             }
             return;
         }
     }
-    if constexpr (!REDIR) {
+    if constexpr (!REDIR && OUTS) {
+        float4 sc8[NT][2], sh8[NT][2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bn8(n, sc8[n], sh8[n]);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) load_res8(i, rvb[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            finish8(i, rvb[i % PD], sc8[i % NT], sh8[i % NT]);
+            if (i + PD < NI) load_res8(i + PD, rvb[i % PD]);
+        }
+    }
+    if constexpr (!REDIR && !OUTS) {
 #pragma unroll
         for (int i = 0; i < PD; ++i) load_res(i, rvb[i]);
 #pragma unroll
@@ -654,6 +757,7 @@ struct KernelCfg {
     int TD, TH, TW, threads;
     void (*fn[2])(const ConvArgs);      // [PREC_F32], [PREC_F16X3]
     void (*fn3[2])(const ConvArgs);     // same, B-ring pipeline (tap count a multiple of 3); may be null
+    void (*fns[2])(const ConvArgs);     // f16x3 with split output (OUTS = 1): [ping-pong], [B ring or null]
 };
 
 constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong pipeline
@@ -663,7 +767,9 @@ constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong p
       { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
         conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
       { conv_mfma_kernel<PREC_F32, 1, 3, MT, NT, WM, WN, TH, TW>,                             \
-        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW> } }
+        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW> },                         \
+      { conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 1>,         \
+        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW, 0, 1> } }
 
 // same tile without the B ring: at 4 waves per SIMD (128 registers) the ring version of the
 // 256-voxel x 32-channel tile spills, the ping-pong version (116 registers) does not
@@ -672,7 +778,8 @@ constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong p
       WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
       { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
         conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
-      { nullptr, nullptr } }
+      { nullptr, nullptr },                                                                  \
+      { conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 1>, nullptr } }
 
 static const KernelCfg g_cfgs[] = {
     OSA_CFG_PINGPONG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
@@ -698,20 +805,20 @@ constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 static const KernelCfg g_deconv_redir_cfg = {
     "deconv8_redir_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
     { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, 1>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 1> },
-    { nullptr, nullptr } };
+    { nullptr, nullptr }, { conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1>, nullptr } };
 static const KernelCfg g_deconv_redir64_cfg = {
     "deconv8_redir64_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
     { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, 2>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 2> },
-    { nullptr, nullptr } };
+    { nullptr, nullptr }, { conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 2, 1>, nullptr } };
 static const KernelCfg g_deconv_cfg = {
     "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
     { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> },
-    { nullptr, nullptr } };
+    { nullptr, nullptr }, { conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 0, 1>, nullptr } };
 // fused 2-D transposed conv (D = 1): 128 input-resolution pixels x 32 channels x 4 parity classes
 static const KernelCfg g_deconv_flat_cfg = {
     "deconv4_1x1_4x1_8x16", 128, 32, 1, 8, 16, 256,
     { conv_mfma_kernel<PREC_F32, 4, 1, 1, 1, 4, 1, 8, 16>, conv_mfma_kernel<PREC_F16X3, 4, 1, 1, 1, 4, 1, 8, 16> },
-    { nullptr, nullptr } };
+    { nullptr, nullptr }, { nullptr, nullptr } };
 
 static int pick_cfg(const ConvArgs& a, int stride) {
     const char* ov = getenv("OSA_CONV_CFG");
@@ -824,6 +931,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         if (a.act & OSA_IN_SPLIT) OSA_REQUIRE(a.Ci % 16 == 0, "%s: split input needs Ci %% 16 == 0 (got %d)", what, a.Ci);
         if (a.act & OSA_OUT_SPLIT) OSA_REQUIRE(a.Co % 16 == 0 && a.yCs % 16 == 0 && !a.gate && ((size_t)a.y & 15) == 0,
                                                "%s: split output needs Co, yCs %% 16 == 0 and no gate", what);
+        if ((a.act & OSA_OUT_SPLIT) && a.res) OSA_REQUIRE(a.act & OSA_RES_SPLIT, "%s: a split output takes a split residual", what);
         if ((a.act & OSA_RES_SPLIT) && a.res) OSA_REQUIRE(a.Co % 16 == 0 && a.rCs % 16 == 0 && ((size_t)a.res & 15) == 0,
                                                           "%s: split residual needs Co, rCs %% 16 == 0", what);
         if ((a.act & OSA_REDIR_SPLIT) && a.rx) OSA_REQUIRE(a.rCi % 16 == 0, "%s: split redir input needs channels %% 16 == 0", what);
@@ -831,6 +939,10 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = getenv("OSA_NORING") != nullptr;
     void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];
+    if (a.act & OSA_OUT_SPLIT) {
+        fn = (k.fns[1] && a.T % 3 == 0 && !no_ring) ? k.fns[1] : k.fns[0];
+        OSA_REQUIRE(fn != nullptr, "%s: this tile configuration has no split-output variant", what);
+    }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
