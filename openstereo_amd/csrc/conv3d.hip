@@ -67,6 +67,8 @@ struct ConvArgs {
     // T = 1), rscale / rshift = its folded BN, roscale = its f16x3 output scale.  NULL rx = not fused.
     const float* rx; const float4* rw; const float* rscale; const float* rshift; float roscale; int rxCs, rCi;
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
+    unsigned magicH;              // ceil(2^32/LH)
+    int dma;                      // 1: split input + compact LDS image -> stage rows by LDS-DMA (global_load_lds_dwordx4)
     int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
 };
@@ -167,6 +169,40 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                     }
                 }
             }
+    }
+}
+
+// Staging of a SPLIT input chunk (already [hi | lo] in HBM) into the COMPACT LDS image by LDS-DMA: one
+// global_load_lds_dwordx4 per (d, h) row of the brick -- lane = (w, 16-byte quad), LDS destination = row
+// base + lane * 16 (exactly the compact row), global source per lane.  A wave takes whole rows, so the
+// row arithmetic is scalar; no VGPR round trip, no ds_write.  Lanes / rows outside the tensor are zero
+// filled with ordinary LDS stores.  Requires LW * 4 <= 64 (one row per instruction).
+template <int NTHR>
+__device__ __forceinline__ void stage_brick_dma(const ConvArgs& p, float4* smem, int b, int c0,
+                                                int g0d, int g0h, int g0w, int tid) {
+    constexpr int NWV = NTHR / 64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows = p.LD * p.LH;
+    const int lw = lane >> 2, c4 = lane & 3;
+    const bool lane_in = lw < p.LW;
+    const int gw = g0w + lw;
+    const bool w_ok = lane_in && ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci);
+    const int goff = gw * p.xCs + c0 + c4 * 4;                 // floats from the start of the (d, h) row
+    const float* xb = p.x + (size_t)b * p.Di * p.Hi * p.Wi * p.xCs;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = wave; r < rows; r += NWV) {                   // wave-uniform
+        const int ld = (p.LH == 1) ? r : (int)__umulhi((unsigned)r, p.magicH), lh = r - ld * p.LH;
+        const int gd = g0d + ld, gh = g0h + lh;
+        float4* row = smem + ld * p.PlaneQ + lh * p.RowQ;      // wave-uniform LDS row base
+        const bool row_ok = ((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi);
+        if (row_ok) {
+            const float* rowp = xb + ((size_t)gd * p.Hi + gh) * (size_t)p.Wi * p.xCs;
+            if (w_ok)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + goff),
+                                                 (__attribute__((address_space(3))) void*)row, 16, 0, 0);
+            else if (lane_in) row[lane] = zero;
+        } else if (lane_in) row[lane] = zero;
     }
 }
 
@@ -320,7 +356,10 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
     for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
         if (ch0) __syncthreads();
         const int ncl = (p.nchunks - ch0 < p.cps) ? (p.nchunks - ch0) : p.cps;
-        if (!(p.dbg & 1)) {
+        if (!(p.dbg & 1) && PREC == PREC_F16X3 && p.dma) {
+            for (int cl = 0; cl < ncl; ++cl)
+                stage_brick_dma<NW * 64>(p, smem + cl * brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+        } else if (!(p.dbg & 1)) {
             int cl = 0;
             for (; cl + 2 <= ncl; cl += 2)
                 stage_brick<NW * 64, PREC, 2>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
@@ -869,6 +908,7 @@ static void finish_geometry(ConvArgs& a, int TW, bool compact) {
     for (int t = 0; t < a.T; ++t)
         a.toff[t] = (a.td[t] - a.dmin) * a.PlaneQ + (a.th[t] - a.hmin) * a.RowQ + (a.tw[t] - a.wmin) * a.VQ;
     a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    a.magicH = (unsigned)((0x100000000ull + a.LH - 1) / a.LH);
     a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
     const char* dbg = getenv("OSA_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
@@ -936,6 +976,10 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
                                                           "%s: split residual needs Co, rCs %% 16 == 0", what);
         if ((a.act & OSA_REDIR_SPLIT) && a.rx) OSA_REQUIRE(a.rCi % 16 == 0, "%s: split redir input needs channels %% 16 == 0", what);
     }
+    // LDS-DMA staging of split inputs: measured throughput-neutral at 4 workgroups per CU (block-level overlap
+    // already hides the staging), so it is opt-in (OSA_DMA=1) until the tap loop is pipelined across barriers
+    { const char* e = getenv("OSA_DMA");
+      a.dma = (e && atoi(e) && prec == PREC_F16X3 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0; }
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = getenv("OSA_NORING") != nullptr;
     void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];

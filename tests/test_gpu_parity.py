@@ -748,3 +748,22 @@ def test_split_activation_format_chain():
     close(yc[:, :64], rc_, atol=3e-5, rtol=3e-5, what="split chain vs torch")
     with pytest.raises(AssertionError):
         ops.to_ncdhw(yb)                                     # split tensors never leave the engine chain
+
+
+def test_lds_dma_staging_of_split_inputs(monkeypatch):
+    """OSA_DMA=1: split inputs are staged with global_load_lds_dwordx4 (one instruction per brick row) --
+    bit-identical to the register-staged path, including bricks that hang over the volume border."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d
+    ca = nn.Conv3d(32, 32, 3, 1, 1, bias=False)
+    ca.weight.data = synth_tensor("dma.a", ca.weight.shape, 1)
+    cb = nn.Conv3d(32, 32, 3, 1, 1, bias=False)
+    cb.weight.data = synth_tensor("dma.b", cb.weight.shape, 1)
+    x = T(np.random.default_rng(3).normal(0, 1, (2, 32, 7, 13, 19)).astype(np.float32))     # ragged vs the 4x8x8 bricks
+    pa = PackedConv3d(ca.to(DEV), _bn_for(32, 2, "dma.a").to(DEV), 1, precision="f16x3")
+    pb = PackedConv3d(cb.to(DEV), _bn_for(32, 3, "dma.b").to(DEV), 1, precision="f16x3")
+    ya = pa(ops.to_cl(x.to(DEV)), out_split=True)
+    ref = pb(ya)
+    monkeypatch.setenv("OSA_DMA", "1")
+    dma = pb(ya)
+    assert torch.equal(ref, dma)
