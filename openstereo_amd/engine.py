@@ -183,8 +183,10 @@ class PackedConv3d:
             | (REDIR_SPLIT if (redir is not None and is_split(redir[1])) else 0)
         if fmt:
             assert self.precision == "f16x3", "split activation tensors exist in the f16x3 mode only"
-            assert x_off == 0 and out_off == 0 and res_off == 0 and gate is None
-            assert not out_split or (self.Co % 16 == 0 and yCs == self.Co)
+            assert gate is None
+            assert not (fmt & IN_SPLIT) or x_off % 16 == 0          # split layout is per 16-channel chunk
+            assert not (fmt & RES_SPLIT) or res_off % 16 == 0
+            assert not out_split or (self.Co % 16 == 0 and yCs % 16 == 0 and out_off % 16 == 0)
             act |= fmt
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
             tail = (self.out_scale, _stream()) if self.precision == "f16x3" else (_stream(),)

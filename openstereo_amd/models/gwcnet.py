@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .. import autograd as AG
 from .. import ops, timing
-from ..engine import PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+from ..engine import is_split, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
 
 
 def run_train(mod, x):
@@ -108,16 +108,19 @@ class _Features(nn.Module):
         """img: [N,3,H,W] (NCHW, any float dtype).  Returns (gwc_feature [N,320,1,H/4,W/4] NDHWC,
         concat_feature [N,12,1,H/4,W/4] NDHWC or None)."""
         pk = self._pack()
+        # f16x3: maps that only engine layers read travel in the split hi/lo format (engine.OUT_SPLIT); the
+        # l2|l3|l4 buffer the volume builder reads, and anything added to a slice of it, stay plain fp32
+        sp = _SPLIT_ACT and pk["first"][0].precision == "f16x3"
         x = ops.to_cl(img.unsqueeze(2))                 # [N,4,1,H,W], 4th channel zero
         for conv in pk["first"]:
-            x = conv(x)
+            x = conv(x, out_split=sp)
         xoff, cat, slices = 0, None, {1: 0, 2: 64, 3: 192}
         for li, blocks in enumerate(pk["layers"]):
             for bi, (c1, c2, ds) in enumerate(blocks):
                 last = bi == len(blocks) - 1
-                y = c1(x, x_off=xoff)
+                y = c1(x, x_off=xoff, out_split=sp)
                 if ds is not None:
-                    skip, soff = ds(x, x_off=xoff), 0
+                    skip, soff = ds(x, x_off=xoff, out_split=sp), 0
                 else:
                     skip, soff = x, xoff
                 if last and li >= 1:
@@ -127,11 +130,11 @@ class _Features(nn.Module):
                     c2(y, residual=skip, res_off=soff, out=cat, out_off=slices[li])
                     x, xoff = cat, slices[li]
                 else:
-                    x, xoff = c2(y, residual=skip, res_off=soff), 0
+                    x, xoff = c2(y, residual=skip, res_off=soff, out_split=sp and is_split(skip)), 0
         if not self.concat_feature:
             return cat, None
         l0, l2 = pk["last"]
-        return cat, l2(l0(cat))
+        return cat, l2(l0(cat, out_split=sp))
 
     def forward(self, x):
         x = self.layer1(self.firstconv(x))
