@@ -171,3 +171,29 @@ class Aggregation(nn.Module):
             raise RuntimeError("openstereo_amd Aggregation runs on the GPU engine only (no CPU path)")
         out = self.forward_cl(nchw_to_cl(x), [nchw_to_cl(f) for f in features_left[:3]])
         return [cl_to_nchw(out, self.conv6[0].out_channels)]
+
+
+class LightStereoCostStage(nn.Module):
+    """The volume -> aggregation -> initial-disparity slice of lightstereo.py:51-56 with the reference's
+    attribute name (`cost_agg`), so those checkpoint keys load:
+        correlation_volume(features_left[0], features_right[0], max_disp // 4)        (a4)
+        -> Aggregation(in_channels = max_disp // 4 = 48, ...)                         (a9)
+        -> softmax over the disparity channels + disparity_regression                 (a12)
+    All three stages on the engine; the quarter-resolution disparity is what `context_upsample` (a13) consumes."""
+
+    def __init__(self, max_disp=192, left_att=True, blocks=(1, 2, 4), expanse_ratio=4, backbone_channels=(24, 32, 96, 160)):
+        super().__init__()
+        self.max_disp = max_disp
+        self.cost_agg = Aggregation(in_channels=max_disp // 4, left_att=left_att, blocks=list(blocks),
+                                    expanse_ratio=expanse_ratio, backbone_channels=list(backbone_channels))
+
+    def forward(self, features_left, feature_right):
+        from .. import ops
+        if not features_left[0].is_cuda:
+            raise RuntimeError("openstereo_amd LightStereoCostStage runs on the GPU engine only (no CPU path)")
+        D4 = self.max_disp // 4
+        vol = ops.correlation_volume(features_left[0], feature_right, D4)              # [B, D/4, H/4, W/4]
+        enc = self.cost_agg.forward_cl(nchw_to_cl(vol), [nchw_to_cl(f) for f in features_left[:3]])
+        cost = cl_to_nchw(enc, D4)                                                     # squeezed_encoding
+        init_disp, prob = ops.softmax_disparity_regression(cost, D4, keepdim=True, return_prob=True)
+        return {"init_disp": init_disp, "prob": prob, "encoding_volume": cost}

@@ -525,3 +525,12 @@ def igev_update_block(net, inp, corr, disp, sd, p="", n_gru_layers=3, iter04=Tru
     delta = _conv_b(F.relu(_conv_b(net[0], sd, q + "disp_head.conv1", 1)), sd, q + "disp_head.conv2", 1)
     mask = F.relu(_conv_b(net[0], sd, q + "mask_feat_4.0", 1))
     return net, mask, delta
+
+
+def lightstereo_cost_stage(features_left, feature_right, sd, max_disp, blocks=(1, 2, 4), left_att=True):
+    """lightstereo.py:51-56: correlation volume -> cost_agg -> softmax -> disparity_regression (sd: `cost_agg.*` keys)."""
+    D4 = max_disp // 4
+    vol = corr_volume(features_left[0], feature_right, D4)
+    enc = lightstereo_aggregation(vol, features_left, sd, "cost_agg", blocks=blocks, left_att=left_att)
+    prob = F.softmax(enc, dim=1)
+    return disparity_regression(prob, D4, keepdim=True), prob, enc

@@ -71,3 +71,16 @@ def igev_update_case():
     inp = [[rnd((1, 128, H >> i, W >> i), 80 + 3 * i + j) * 0.5 for j in range(3)] for i in range(3)]
     corr, disp = rnd((1, 162, H, W), 90), rnd((1, 1, H, W), 91).abs() * 10
     return blk, sd, net, inp, corr, disp
+
+
+def lightstereo_stage_case():
+    """Cost-stage fixture (make_golden.gen_lightstereo, second half): module with the same seeded weights, inputs."""
+    import torch
+    from openstereo_amd.utils.weights import synth_state_dict
+    from openstereo_amd.models.lightstereo import LightStereoCostStage
+    agg, sd, _, feats = lightstereo_case()
+    st = LightStereoCostStage(max_disp=192).eval()
+    st.cost_agg.load_state_dict(sd)
+    fl = [rnd((1, 24, 32, 64), 56)] + feats[1:]
+    fr0 = torch.roll(fl[0], shifts=-3, dims=3) + 0.1 * rnd((1, 24, 32, 64), 57)
+    return st, {"cost_agg." + k: v for k, v in sd.items()}, fl, fr0

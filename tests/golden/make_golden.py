@@ -66,6 +66,17 @@ def gen_lightstereo():
     y = agg(x, feats)[0]
     print("LightStereo aggregation out range", y.min().item(), y.max().item(), y.std().item())
     save("lightstereo_agg.npz", y=y, **taps)      # inputs: rnd(shape, 51..54), see tests/conftest.py lightstereo_inputs()
+    # cost stage of lightstereo.py:51-56 from the reference's own functions (the LightStereo class itself needs timm)
+    import torch.nn.functional as F
+    from stereo.modeling.cost_volume.cost_volume import correlation_volume
+    from stereo.modeling.disp_pred.disp_regression import disparity_regression
+    fl = [rnd((1, 24, 32, 64), 56)] + feats[1:]
+    fr0 = torch.roll(fl[0], shifts=-3, dims=3) + 0.1 * rnd((1, 24, 32, 64), 57)
+    vol = correlation_volume(fl[0], fr0, 48)
+    enc = agg(vol, fl)[0]
+    init = disparity_regression(F.softmax(enc, dim=1), 48)
+    print("LightStereo cost stage: init_disp range", init.min().item(), init.max().item())
+    save("lightstereo_stage.npz", init_disp=init, enc=enc)
 
 
 def gen_igev_update():

@@ -767,3 +767,23 @@ def test_lds_dma_staging_of_split_inputs(monkeypatch):
     monkeypatch.setenv("OSA_DMA", "1")
     dma = pb(ya)
     assert torch.equal(ref, dma)
+
+
+def test_lightstereo_cost_stage_vs_reference_golden():
+    """LightStereo's correlation volume -> 2-D aggregation -> softmax regression on the engine (f16x3) vs the
+    output of the reference's own functions (EPE bar 1e-3 px at quarter resolution)."""
+    from conftest import lightstereo_stage_case
+    from openstereo_amd import engine
+    g = golden("lightstereo_stage.npz")
+    st, sd, fl, fr0 = lightstereo_stage_case()
+    old = engine.get_precision()
+    engine.set_precision("f16x3")
+    try:
+        st = st.to(DEV)
+        with torch.no_grad():
+            out = st([f.to(DEV) for f in fl], fr0.to(DEV))
+    finally:
+        engine.set_precision(old)
+    close(out["encoding_volume"], g["enc"], atol=2e-4 * max(1.0, float(np.abs(g["enc"]).max())), rtol=1e-4, what="encoding volume")
+    epe = np.abs(out["init_disp"].cpu().numpy() - g["init_disp"]).mean()
+    assert epe < 1e-3, epe

@@ -149,3 +149,14 @@ def test_igev_update_block_against_reference():
         ref = torch.from_numpy(g[k])
         assert v.shape == ref.shape
         assert (v - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_lightstereo_cost_stage_against_reference():
+    """a4 -> a9 -> a12 chained as in lightstereo.py:51-56, oracle vs the real reference's functions."""
+    from conftest import lightstereo_stage_case
+    st, sd, fl, fr0 = lightstereo_stage_case()
+    g = golden("lightstereo_stage.npz")
+    with torch.no_grad():
+        init, prob, enc = O.lightstereo_cost_stage(fl, fr0, sd, 192)
+    assert (enc - torch.from_numpy(g["enc"])).abs().max().item() <= 2e-4 * max(1.0, float(np.abs(g["enc"]).max()))
+    assert (init - torch.from_numpy(g["init_disp"])).abs().max().item() <= 1e-3
