@@ -534,3 +534,22 @@ def lightstereo_cost_stage(features_left, feature_right, sd, max_disp, blocks=(1
     enc = lightstereo_aggregation(vol, features_left, sd, "cost_agg", blocks=blocks, left_att=left_att)
     prob = F.softmax(enc, dim=1)
     return disparity_regression(prob, D4, keepdim=True), prob, enc
+
+
+def igev_refine(match_l, match_r, geo_volume, net, inp, init_disp, sd, iters, p="update_block", n_gru_layers=3,
+                slow_fast=True, radius=4, num_levels=2):
+    """GRU refinement loop, stereo/modeling/models/igev/igev_stereo.py:181-203 (test mode, no final upsample)."""
+    geo_fn = GeoEncodingVolume(match_l, match_r, geo_volume, num_levels=num_levels, radius=radius)
+    b, _, h, w = match_l.shape
+    coords = torch.arange(w).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+    disp, net, mask = init_disp, list(net), None
+    for _ in range(iters):
+        geo_feat = geo_fn(disp, coords)
+        if n_gru_layers == 3 and slow_fast:
+            net = igev_update_block(net, inp, None, None, sd, p, n_gru_layers, iter16=True, iter08=False, iter04=False, update=False)
+        if n_gru_layers >= 2 and slow_fast:
+            net = igev_update_block(net, inp, None, None, sd, p, n_gru_layers, iter16=n_gru_layers == 3, iter08=True, iter04=False, update=False)
+        net, mask, delta = igev_update_block(net, inp, geo_feat, disp, sd, p, n_gru_layers,
+                                             iter16=n_gru_layers == 3, iter08=n_gru_layers >= 2)
+        disp = disp + delta
+    return disp, mask, net

@@ -84,3 +84,19 @@ def lightstereo_stage_case():
     fl = [rnd((1, 24, 32, 64), 56)] + feats[1:]
     fr0 = torch.roll(fl[0], shifts=-3, dims=3) + 0.1 * rnd((1, 24, 32, 64), 57)
     return st, {"cost_agg." + k: v for k, v in sd.items()}, fl, fr0
+
+
+def igev_refine_case():
+    """Refinement-loop fixture (make_golden.gen_igev_update, second half)."""
+    import torch
+    from openstereo_amd.utils.weights import synth_state_dict
+    from openstereo_amd.models.igev_update import IGEVRefiner
+    blk, sd, net, inp, _, _ = igev_update_case()
+    args = _Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2, SLOW_FAST_GRU=True)
+    ref = IGEVRefiner(args, hidden_dims=[128, 128, 128]).eval()
+    ref.update_block.load_state_dict(sd)
+    H, W = 16, 32
+    ml, mr = rnd((1, 96, H, W), 92), rnd((1, 96, H, W), 93)
+    gvol = rnd((1, 8, 12, H, W), 94)
+    d0 = rnd((1, 1, H, W), 95).abs() * 3
+    return ref, {"update_block." + k: v for k, v in sd.items()}, ml, mr, gvol, net, inp, d0

@@ -97,6 +97,23 @@ def gen_igev_update():
     n, mask, delta = blk([t.clone() for t in net], inp, corr, disp)
     print("IGEV update block: delta range", delta.min().item(), delta.max().item())
     save("igev_update.npz", net0=n[0], net1=n[1], net2=n[2], mask=mask, delta=delta)   # inputs: rnd(...) as in tests/conftest.py igev_update_case()
+    # ---- three iterations of the refinement loop of igev_stereo.py:181-203 built from the reference's own pieces
+    sys.modules.setdefault("timm", types.ModuleType("timm"))
+    from stereo.modeling.models.igev.geometry import Combined_Geo_Encoding_Volume
+    ml, mr = rnd((1, 96, H, W), 92), rnd((1, 96, H, W), 93)
+    gvol = rnd((1, 8, 12, H, W), 94)
+    geo_fn = Combined_Geo_Encoding_Volume(ml, mr, gvol, radius=4, num_levels=2)
+    coords = torch.arange(W).float().reshape(1, 1, W, 1).repeat(1, H, 1, 1)
+    d = rnd((1, 1, H, W), 95).abs() * 3
+    nl = [t.clone() for t in net]
+    for _ in range(3):
+        gf = geo_fn(d, coords)
+        nl = blk(nl, inp, iter16=True, iter08=False, iter04=False, update=False)
+        nl = blk(nl, inp, iter16=True, iter08=True, iter04=False, update=False)
+        nl, mk, dd = blk(nl, inp, gf, d, iter16=True, iter08=True)
+        d = d + dd
+    print("IGEV refine loop: disp range", d.min().item(), d.max().item())
+    save("igev_refine.npz", disp=d, mask=mk, net0=nl[0])
 
 
 def main():

@@ -787,3 +787,25 @@ def test_lightstereo_cost_stage_vs_reference_golden():
     close(out["encoding_volume"], g["enc"], atol=2e-4 * max(1.0, float(np.abs(g["enc"]).max())), rtol=1e-4, what="encoding volume")
     epe = np.abs(out["init_disp"].cpu().numpy() - g["init_disp"]).mean()
     assert epe < 1e-3, epe
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_igev_refine_loop_vs_reference_golden(prec):
+    """BASELINE configs[4]: three GRU refinement iterations (geometry-encoding lookup + update block with the
+    slow-fast schedule + disparity update) on the engine vs the reference's own modules."""
+    from conftest import igev_refine_case
+    from openstereo_amd import engine
+    g = golden("igev_refine.npz")
+    ref, sd, ml, mr, gvol, net, inp, d0 = igev_refine_case()
+    old = engine.get_precision()
+    engine.set_precision(prec)
+    try:
+        ref = ref.to(DEV)
+        dv = lambda ts: [t.to(DEV) for t in ts]
+        with torch.no_grad():
+            out = ref(ml.to(DEV), mr.to(DEV), gvol.to(DEV), dv(net), [dv(ts) for ts in inp], d0.to(DEV), 3)
+    finally:
+        engine.set_precision(old)
+    close(out["disp"], g["disp"], atol=2e-4, rtol=1e-4, what=f"refined disparity [{prec}]")
+    close(out["mask_feat_4"], g["mask"], atol=2e-4, rtol=2e-4, what=f"mask features [{prec}]")
+    close(out["net_list"][0], g["net0"], atol=1e-4, rtol=1e-4, what=f"hidden state [{prec}]")

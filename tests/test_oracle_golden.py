@@ -160,3 +160,15 @@ def test_lightstereo_cost_stage_against_reference():
         init, prob, enc = O.lightstereo_cost_stage(fl, fr0, sd, 192)
     assert (enc - torch.from_numpy(g["enc"])).abs().max().item() <= 2e-4 * max(1.0, float(np.abs(g["enc"]).max()))
     assert (init - torch.from_numpy(g["init_disp"])).abs().max().item() <= 1e-3
+
+
+def test_igev_refine_loop_against_reference():
+    """Three iterations of geometry lookup + slow-fast GRU updates + disparity update: oracle vs the reference's pieces."""
+    from conftest import igev_refine_case
+    _, sd, ml, mr, gvol, net, inp, d0 = igev_refine_case()
+    g = golden("igev_refine.npz")
+    with torch.no_grad():
+        disp, mask, n = O.igev_refine(ml, mr, gvol, net, inp, d0, sd, 3)
+    for k, v in (("disp", disp), ("mask", mask), ("net0", n[0])):
+        ref = torch.from_numpy(g[k])
+        assert (v - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
