@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OSA_ABI_VERSION 1
+#define OSA_ABI_VERSION 2
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
 enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3, OSA_ACT_SIGMOID = 4, OSA_ACT_TANH = 5 };
@@ -72,19 +72,21 @@ const char* osa_target_arch(void);
  * Either part may be absent: C==0 (no gwc part) or Cc==0 (no concat part).
  * left/right feature maps are NCHW contiguous.  `vol` has `vol_channels`
  * channels in `layout`; this call writes channels [c_off, c_off+G+2*Cc).
+ * vol_meta: NULL, or the volume's range block (see osa_f16x3_ranges): the NDHWC kernels fold max |value|
+ * into vol_meta[0] so that an f16x3 consumer can scale its operands.
  */
 int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups,
                          const float* left_cat, const float* right_cat, int Cc,
                          float* vol, int layout, int vol_channels, int c_off,
                          int B, int H, int W, int maxdisp, int mask_left_concat,
-                         void* stream);
+                         float* vol_meta, void* stream);
 
 /* Same, for channels-last feature maps [B][H][W][stride] (what the engine's own 2-D backbone
  * produces; *_stride = floats per pixel, >= channel count).  Always writes the NDHWC volume. */
 int osa_build_volume_nhwc_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                               const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                               float* vol, int vol_channels, int c_off,
-                              int B, int H, int W, int maxdisp, int mask_left_concat, void* stream);
+                              int B, int H, int W, int maxdisp, int mask_left_concat, float* vol_meta, void* stream);
 
 /* correlation layer: vol[b,d,h,w] = mean_c L[b,c,h,w]*R[b,c,h,w-d], 0 for w<d. vol is [B,D,H,W]. */
 int osa_corr_volume_f32(const float* left, const float* right, float* vol,
@@ -158,8 +160,34 @@ int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
  * matrix cores with fp32 accumulation -- fp32-class accuracy at a fraction of the fp32-MFMA time.
  * Tensors in HBM stay fp32.  Weights are packed by the *_pack_f16x3 calls (same buffer size as the
  * f32 packing) after multiplication by `wscale`, a power of two that moves them into the fp16
- * normal range; pass out_scale = 1/wscale to the matching conv call.
+ * normal range; pass out_scale = 1/wscale to the matching conv call.  Activations: osa_f16x3_ranges below.
  */
+/*
+ * Operand ranges of the f16x3 mode.  fp16 halves have a 5-bit exponent, so every operand tensor is brought
+ * into range by a per-tensor POWER-OF-TWO scale (exact to apply and to undo): the largest |value| lands in
+ * [2^14, 2^15), everything down to 2^-18 of it keeps 22 significant bits, smaller values degrade gracefully
+ * and nothing is clamped.  The scale is derived ON THE DEVICE from a 16-float "range block" that travels with
+ * each activation tensor (no host synchronisation, hipGraph friendly):
+ *     meta[0]  running max |value| of the tensor -- every producing kernel folds its outputs in with an
+ *              atomic max (zero the block before the first producer runs)
+ *     meta[1]  split tensors only: the scale their stored hi/lo halves carry (written by the producer)
+ *     meta[2..15] reserved (work-queue words of the persistent kernels)
+ * A plain fp32 input is scaled by pow2(meta[0]) while it is staged; a split OUTPUT must choose its scale
+ * before the maximum is known, from the rigorous bound
+ *     max|y| <= bound_coef[0] * max|x| + bound_coef[1] (+ max|residual|) (+ redir_bound_coef[0] * max|rx| + redir_bound_coef[1])
+ * with bound_coef = { max_co |bn_scale[co]| * sum|w[co]|, max_co |bn_shift[co]| } (device pointer, 2 floats).
+ * Any pointer may be NULL (and `ranges` itself): that operand is then used unscaled / not tracked.  A value
+ * that leaves the fp16 range becomes inf/NaN in the output -- never a silently clamped number.
+ */
+typedef struct osa_f16x3_ranges {
+    const float* x_meta;            /* range block of x */
+    const float* residual_meta;     /* range block of the residual */
+    const float* redir_meta;        /* range block of the fused redir input (osa_deconv3d_redir_*) */
+    float*       y_meta;            /* range block of y (updated) */
+    const float* bound_coef;        /* 2 floats, see above */
+    const float* redir_bound_coef;  /* 2 floats of the fused redir layer */
+} osa_f16x3_ranges;
+
 int osa_conv3d_pack_f16x3(const float* w_ref, float* w_packed,
                           int Ci, int Co, int kd, int kh, int kw, float wscale, void* stream);
 int osa_deconv3d_pack_f16x3(const float* w_ref, float* w_packed,
@@ -173,7 +201,7 @@ int osa_conv3d_ndhwc_f16x3(const float* x, const float* w_packed,
                            int pad_d, int pad_h, int pad_w,
                            int dil_d, int dil_h, int dil_w,
                            const float* gate_logits, int gCs,
-                           int act, float slope, float out_scale, void* stream);
+                           int act, float slope, float out_scale, const osa_f16x3_ranges* ranges, void* stream);
 int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
                              const float* scale, const float* shift, const float* residual,
                              float* y,
@@ -181,7 +209,7 @@ int osa_deconv3d_ndhwc_f16x3(const float* x, const float* w_packed,
                              int Co, int yCs, int rCs,
                              int k, int pad, int opad,
                              const float* gate_logits, int gCs,
-                             int act, float slope, float out_scale, void* stream);
+                             int act, float slope, float out_scale, const osa_f16x3_ranges* ranges, void* stream);
 
 /*
  * Transposed conv with a fused 1x1x1 "redir" branch: GwcNet Hourglass,
@@ -204,7 +232,7 @@ int osa_deconv3d_redir_ndhwc_f16x3(const float* x, const float* w_packed, const 
                                    int k, int pad, int opad,
                                    const float* rx, int rxCs, int rCi, const float* rw_packed,
                                    const float* rscale, const float* rshift, float r_out_scale,
-                                   int act, float slope, float out_scale, void* stream);
+                                   int act, float slope, float out_scale, const osa_f16x3_ranges* ranges, void* stream);
 
 /*
  * 2-D transposed convolution (nn.ConvTranspose2d, stride 2) on an NHWC map: the D = 1 case of the
@@ -231,7 +259,7 @@ int osa_deconv2d_nhwc_f16x3(const float* x, const float* w_packed,
                             int Co, int yCs, int rCs,
                             int k, int pad, int opad,
                             const float* gate_logits, int gCs,
-                            int act, float slope, float out_scale, void* stream);
+                            int act, float slope, float out_scale, const osa_f16x3_ranges* ranges, void* stream);
 
 /*
  * Depthwise 2-D convolution on an NHWC map (groups == channels): LightStereo MobileV2Residual.dwconv
@@ -241,13 +269,14 @@ int osa_deconv2d_nhwc_f16x3(const float* x, const float* w_packed,
  *   w_packed: [kh*kw][C], made by osa_dwconv2d_pack_f32 from the reference layout [C][1][kh][kw]
  *   scale/shift: folded eval BatchNorm or (1, bias); NULL = 1 / 0.   add: NHWC addend (stride aCs) or NULL
  *   act: OSA_ACT_NONE / OSA_ACT_RELU / OSA_ACT_RELU6.   C and all strides multiples of 4, fp32 exact (fmaf per tap).
+ *   y_meta: NULL or y's range block (max |y| is folded into y_meta[0] for f16x3 consumers, see osa_f16x3_ranges).
  */
 int osa_dwconv2d_pack_f32(const float* w_ref, float* w_packed, int C, int kh, int kw, void* stream);
 int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
                           const float* scale, const float* shift, const float* add, float* y,
                           int B, int Hi, int Wi, int C, int xCs, int yCs, int aCs,
                           int kh, int kw, int stride, int pad_h, int pad_w, int dil_h, int dil_w,
-                          int act, void* stream);
+                          int act, float* y_meta, void* stream);
 
 /*
  * ConvGRU state update (models/igev/update.py:42, models/stereobase/gru_blocks.py ConvGRU):
@@ -256,7 +285,7 @@ int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
  * the conv epilogues (OSA_ACT_SIGMOID / OSA_ACT_TANH, residual = cz / cq, r*h = sigmoid(...) with h as raw gate).
  */
 int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
-                        long long npix, int C, int zCs, int qCs, int hCs, int oCs, void* stream);
+                        long long npix, int C, int zCs, int qCs, int hCs, int oCs, float* out_meta, void* stream);
 
 /* Packing for backward passes.  Ci/Co are the roles of the convolution that will be EXECUTED with the
  * packed buffer; src_transposed=1 reads w_ref as [Ci][Co][k] (instead of [Co][Ci][k]); flip=1 mirrors taps.

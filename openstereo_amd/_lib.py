@@ -21,6 +21,15 @@ c_f = C.c_float
 c_st = C.c_void_p      # hipStream_t
 c_ll = C.c_longlong
 
+
+class F16x3Ranges(C.Structure):
+    """osa_f16x3_ranges (include/openstereo_amd.h): device pointers of the operands' range blocks."""
+    _fields_ = [("x_meta", C.c_void_p), ("residual_meta", C.c_void_p), ("redir_meta", C.c_void_p),
+                ("y_meta", C.c_void_p), ("bound_coef", C.c_void_p), ("redir_bound_coef", C.c_void_p)]
+
+
+c_rng = C.POINTER(F16x3Ranges)
+
 # name -> (restype, argtypes).  Mirrors include/openstereo_amd.h one to one; tests check that
 # every symbol declared in the header is listed here and exported by the .so.
 SIGNATURES = {
@@ -28,9 +37,9 @@ SIGNATURES = {
     "osa_last_error": (C.c_char_p, []),
     "osa_target_arch": (C.c_char_p, []),
     "osa_build_volume_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_i, c_i, c_i,
-                                   c_i, c_i, c_i, c_i, c_i, c_st]),
+                                   c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
     "osa_build_volume_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i, c_i,
-                                        c_i, c_i, c_i, c_i, c_i, c_st]),
+                                        c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
     "osa_corr_volume_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_ncdhw_to_ndhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_ll, c_i, c_i, c_st]),
     "osa_ndhwc_to_ncdhw_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_ll, c_i, c_i, c_st]),
@@ -61,13 +70,13 @@ SIGNATURES = {
                                      c_i, c_i, c_i,
                                      c_i, c_i, c_i,
                                      c_fp, c_i,
-                                     c_i, c_f, c_f, c_st]),
+                                     c_i, c_f, c_f, c_rng, c_st]),
     "osa_deconv3d_ndhwc_f16x3": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                        c_i, c_i, c_i, c_i, c_i, c_i,
                                        c_i, c_i, c_i,
                                        c_i, c_i, c_i,
                                        c_fp, c_i,
-                                       c_i, c_f, c_f, c_st]),
+                                       c_i, c_f, c_f, c_rng, c_st]),
     "osa_conv3d_pack_ex": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
     "osa_conv3d_wgrad_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
@@ -92,7 +101,7 @@ SIGNATURES = {
                                              c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                              c_i, c_i, c_i,
                                              c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_f,
-                                             c_i, c_f, c_f, c_st]),
+                                             c_i, c_f, c_f, c_rng, c_st]),
     "osa_deconv2d_packed_floats": (C.c_size_t, [c_i, c_i, c_i]),
     "osa_deconv2d_pack_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_deconv2d_pack_f16x3": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_f, c_st]),
@@ -105,13 +114,13 @@ SIGNATURES = {
                                       c_i, c_i, c_i, c_i, c_i,
                                       c_i, c_i, c_i,
                                       c_i, c_i, c_i,
-                                      c_fp, c_i, c_i, c_f, c_f, c_st]),
+                                      c_fp, c_i, c_i, c_f, c_f, c_rng, c_st]),
     "osa_dwconv2d_pack_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_st]),
     "osa_dwconv2d_nhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i,
-                                    c_i, c_st]),
-    "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_st]),
+                                    c_i, c_fp, c_st]),
+    "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
     "osa_context_upsample_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
     "osa_allpairs_corr_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_geo_rows_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
@@ -146,7 +155,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        if lib.osa_abi_version() != 1:
+        if lib.osa_abi_version() != 2:
             raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}")
         _lib = lib
     return _lib

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib, engine, ops
 from .ops import _f32c, _p, _stream, empty_cl, is_cl, to_cl
+from .ranges import input_meta, attach_meta
 
 
 # ----------------------------------------------------------------------------- volumes
@@ -171,6 +172,13 @@ def _pack(w, Ci, Co, k, mode, precision):
     return buf, 1.0 / ws
 
 
+def _ranges(x, y):
+    """f16x3 operand ranges of a plain conv call: x (activations or incoming gradients -- whose magnitudes are
+    routinely 1e-5 .. 1e-8) is scaled by a power of two derived from its measured max |.| on the device, so the
+    hi/lo fp16 halves keep 22 significant bits whatever the magnitude; exact to undo."""
+    return _lib.F16x3Ranges(input_meta(x).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None)
+
+
 def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape):
     """x NDHWC (channels padded to 4). plain conv, no epilogue extras."""
     B, Cs, D, H, W = x.shape
@@ -179,7 +187,7 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (oscale, _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = ("f16x3", (oscale, _ranges(x, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
     _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
               B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
               None, 0, 0, 0.0, *tail)
@@ -194,7 +202,7 @@ def _run_deconv(x, packed, oscale, Ci, Co, k, pad, opad, precision):
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (oscale, _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = ("f16x3", (oscale, _ranges(x, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
     _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
               B, D, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
     return y

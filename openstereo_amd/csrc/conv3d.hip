@@ -69,6 +69,12 @@ struct ConvArgs {
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
     unsigned magicH;              // ceil(2^32/LH)
     int dma;                      // 1: split input + compact LDS image -> stage rows by LDS-DMA (global_load_lds_dwordx4)
+    // f16x3 range tracking (see osa_f16x3_ranges in the header); every pointer may be NULL.  A "meta" block is
+    // 16 floats of device memory per tensor: [0] = running max |value| (atomic max of uint bit patterns),
+    // [1] = power-of-two scale of the stored hi/lo halves when the tensor is a split tensor.
+    const float* in_meta; const float* res_meta; const float* rx_meta; float* out_meta;
+    const float* coef;            // [0] max_co |bn scale| * sum|w_co|, [1] max_co |bn shift|   (output bound of this layer)
+    const float* rcoef;           // same for the fused redir layer
     int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
     signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
 };
@@ -80,10 +86,11 @@ typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
 // x = hi + lo with hi, lo fp16.  hi uses the packed round-toward-zero convert (2 floats per
 // instruction): any rounding is fine for hi because lo = x - float(hi) is exact in fp32 and carries
 // the remainder; lo is rounded to nearest, error <= 2^-12 |lo| <= 2^-22 |x|.
+// No saturation: operands are brought into range by the per-tensor power-of-two scale below (pow2_scale);
+// a value that still exceeds the fp16 range becomes inf and poisons the result visibly instead of being
+// clamped silently.
 __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) {
-    const float m = 65504.f;      // saturate instead of producing inf (one v_med3_f32 per element)
-    const float x0 = __builtin_amdgcn_fmed3f(v.x, -m, m), x1 = __builtin_amdgcn_fmed3f(v.y, -m, m);
-    const float x2 = __builtin_amdgcn_fmed3f(v.z, -m, m), x3 = __builtin_amdgcn_fmed3f(v.w, -m, m);
+    const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
     const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
     // lo is rounded to nearest (unbiased): its error is what remains of the split
     const f16x4 l = {(_Float16)(x0 - (float)h01[0]), (_Float16)(x1 - (float)h01[1]),
@@ -91,6 +98,20 @@ __device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) 
     hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
     lo = __builtin_bit_cast(uint2, l);
 }
+
+// Power-of-two scale s with amax * s in [2^14, 2^15): the largest operand sits one binade under the fp16
+// maximum and every element down to 2^-18 * amax keeps a NORMAL lo half (22 significant bits); smaller
+// elements degrade gracefully (absolute error <= 2^-25 / s, i.e. 2^-39 * amax).  Exact to undo (1 / s).
+// amax == 0, denormal, inf or NaN: unscaled.
+__device__ __forceinline__ float pow2_scale(float amax) {
+    const unsigned b = __builtin_bit_cast(unsigned, amax);
+    const int eb = (int)((b >> 23) & 0xffu);
+    if (eb == 0 || eb == 255) return 1.f;
+    int k = 15 - (eb - 126);
+    k = k < -60 ? -60 : (k > 60 ? 60 : k);
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+__device__ __forceinline__ float4 mul4(const float4 v, const float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
 
 // Thread-linear item order (every lane busy on every load).  A row-wise variant with wave-uniform
 // row arithmetic (2x fewer VALU instructions) was measured slower overall on MI355X: rows of 10-18
@@ -113,7 +134,7 @@ __device__ __forceinline__ int split_off_lo(int c) { return split_off_hi(c) + 8;
 
 template <int NTHR, int PREC, int NCL>
 __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
-                                            int g0d, int g0h, int g0w, int tid) {
+                                            int g0d, int g0h, int g0w, int tid, float s_in = 1.f) {
 #ifndef OSA_STAGE_U
 #define OSA_STAGE_U 4
 #endif
@@ -161,7 +182,7 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                         static_assert(NTHR % 4 == 0, "channel quad of an item must not depend on u");
                         const int c4 = base & 3;        // == (base + u*NTHR) & 3
                         uint2 h2, l2;
-                        split_f16(v[u][cl], h2, l2);
+                        split_f16(mul4(v[u][cl], s_in), h2, l2);
                         uint2* s2 = reinterpret_cast<uint2*>(dst);
                         const int vbase = (lo[u] - c4) * 2;                 // voxel start in 8-byte units
                         s2[vbase + c4] = h2;
@@ -239,6 +260,29 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
     const int a0d = tdi * TD, a0h = thi * TH, a0w = twi * TW;
     const int g0d = a0d * p.isd + p.dmin, g0h = a0h * p.ish + p.hmin, g0w = a0w * p.isw + p.wmin;
     const int n0 = blockIdx.y * (WN * NT * 32);
+
+    // ---- f16x3 operand ranges: power-of-two scales of the input / residual / redir operands and of a split
+    // output (all wave-uniform scalar loads of a few device words; all 1 when no range block was passed)
+    float s_in = 1.f, s_res_inv = 1.f, s_rx = 1.f, s_out = 1.f;
+    if constexpr (PREC == PREC_F16X3) {
+        if (p.in_meta) s_in = (p.act & OSA_IN_SPLIT) ? p.in_meta[1] : pow2_scale(p.in_meta[0]);
+        if (p.res && p.res_meta && (p.act & OSA_RES_SPLIT)) s_res_inv = 1.0f / p.res_meta[1];
+        if (REDIR && p.rx_meta) s_rx = (p.act & OSA_REDIR_SPLIT) ? p.rx_meta[1] : pow2_scale(p.rx_meta[0]);
+        if (OUTS && p.coef && p.in_meta) {
+            // rigorous bound of |output|: sum|w| * max|x| * |bn scale| + |bn shift| (+ residual / redir branch);
+            // activations only shrink it (sigmoid / tanh: 1)
+            float bound = p.coef[0] * p.in_meta[0] + p.coef[1];
+            if (p.res && p.res_meta) bound += p.res_meta[0];
+            if (REDIR && p.rcoef && p.rx_meta) bound += p.rcoef[0] * p.rx_meta[0] + p.rcoef[1];
+            const int ak = p.act & 15;
+            if (ak == OSA_ACT_SIGMOID || ak == OSA_ACT_TANH) bound = 1.f;
+            s_out = pow2_scale(bound * 1.0625f);
+        }
+        if (OUTS && p.out_meta && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.out_meta[1] = s_out;
+    }
+    const float osc = p.oscale * (1.0f / s_in);      // undoes the weight pre-scale and the input scale (exact)
+    const float rosc = p.roscale * (1.0f / s_rx);
+    float am = 0.f;                                  // running max |output| of this lane (unscaled values)
 
     int abase[MT];
 #pragma unroll
@@ -362,9 +406,9 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
         } else if (!(p.dbg & 1)) {
             int cl = 0;
             for (; cl + 2 <= ncl; cl += 2)
-                stage_brick<NW * 64, PREC, 2>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+                stage_brick<NW * 64, PREC, 2>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
             if (cl < ncl)
-                stage_brick<NW * 64, PREC, 1>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+                stage_brick<NW * 64, PREC, 1>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
         }
         __syncthreads();
         for (int cl = 0; cl < ncl; ++cl) {
@@ -428,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = n0 + (wn * NT + n) * 32 + (lane & 7) * 4;
-        float4 sc = make_float4(p.oscale, p.oscale, p.oscale, p.oscale), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sc = make_float4(osc, osc, osc, osc), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (co < p.Co && p.scale) {
             if (co + 3 < p.Co) { sc = *reinterpret_cast<const float4*>(p.scale + co); sh = *reinterpret_cast<const float4*>(p.shift + co); }
             else {
@@ -436,7 +480,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                 if (co + 1 < p.Co) { sc.y = p.scale[co + 1]; sh.y = p.shift[co + 1]; }
                 if (co + 2 < p.Co) { sc.z = p.scale[co + 2]; sh.z = p.shift[co + 2]; }
             }
-            sc.x *= p.oscale; sc.y *= p.oscale; sc.z *= p.oscale; sc.w *= p.oscale;
+            sc.x *= osc; sc.y *= osc; sc.z *= osc; sc.w *= osc;
         }
         scv[n] = sc; shv[n] = sh;
     }
@@ -554,7 +598,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             float4 rk = rv[k];
             if (PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT) && p.res) {
                 const uint4 b4 = __builtin_bit_cast(uint4, rv[k]);
-                rk = join_f16(make_uint2(b4.x, b4.y), make_uint2(b4.z, b4.w));
+                rk = mul4(join_f16(make_uint2(b4.x, b4.y), make_uint2(b4.z, b4.w)), s_res_inv);
             }
             const float r4[4] = {rk.x, rk.y, rk.z, rk.w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
 #pragma unroll
@@ -569,6 +613,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                 o[e] = v;
             }
             if (vok[k] && cok) {
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 float* yp = yb + (v0[k] + coff) * p.yCs + co;
                 if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
                 else {
@@ -633,6 +678,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                 if (p.res) {
                     const uint4 hb = __builtin_bit_cast(uint4, rv[2 * k]), lb = __builtin_bit_cast(uint4, rv[2 * k + 1]);
                     r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
+                    r = mul4(r, s_res_inv);
                 }
                 const float a4[4] = {av[k][h2].x, av[k][h2].y, av[k][h2].z, av[k][h2].w};
                 const float s4[4] = {sc8[h2].x, sc8[h2].y, sc8[h2].z, sc8[h2].w}, t4[4] = {sh8[h2].x, sh8[h2].y, sh8[h2].z, sh8[h2].w};
@@ -648,7 +694,8 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                     else if (actk == OSA_ACT_TANH) v = tanhf(v);
                     o[e] = v;
                 }
-                split_f16(make_float4(o[0], o[1], o[2], o[3]), hq[h2], lq[h2]);
+                if (vok[k] && cok) am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
             }
             if (vok[k] && cok) {
                 float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
@@ -662,11 +709,11 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int co = n0 + (wn * NT + n) * 32 + c8 + 4 * h2;
-            sc8[h2] = make_float4(p.oscale, p.oscale, p.oscale, p.oscale); sh8[h2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sc8[h2] = make_float4(osc, osc, osc, osc); sh8[h2] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (REDIR) { sc8[h2] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
             if (co + 3 < p.Co && p.scale) {
                 sc8[h2] = *reinterpret_cast<const float4*>(p.scale + co); sh8[h2] = *reinterpret_cast<const float4*>(p.shift + co);
-                sc8[h2].x *= p.oscale; sc8[h2].y *= p.oscale; sc8[h2].z *= p.oscale; sc8[h2].w *= p.oscale;
+                sc8[h2].x *= osc; sc8[h2].y *= osc; sc8[h2].z *= osc; sc8[h2].w *= osc;
             }
         }
     };
@@ -727,8 +774,8 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                                 ah = __builtin_bit_cast(f16x8, rv[2 * ch]); al = __builtin_bit_cast(f16x8, rv[2 * ch + 1]);
                             } else {
                                 uint2 h0, l0, h1, l1;
-                                split_f16(rv[2 * ch], h0, l0);
-                                split_f16(rv[2 * ch + 1], h1, l1);
+                                split_f16(mul4(rv[2 * ch], s_rx), h0, l0);
+                                split_f16(mul4(rv[2 * ch + 1], s_rx), h1, l1);
                                 ah = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
                                 al = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
                             }
@@ -742,8 +789,8 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                 // per-lane (channel `col`) BN factors of both branches
                 const int cl = n0 + (wn * NT + n) * 32 + col;
                 const bool lok = cl < p.Co;
-                const float s6 = (lok && p.scale) ? p.scale[cl] * p.oscale : p.oscale, t6 = (lok && p.shift) ? p.shift[cl] : 0.f;
-                const float sr = (lok && p.rscale) ? p.rscale[cl] * p.roscale : p.roscale, tr = (lok && p.rshift) ? p.rshift[cl] : 0.f;
+                const float s6 = (lok && p.scale) ? p.scale[cl] * osc : osc, t6 = (lok && p.shift) ? p.shift[cl] : 0.f;
+                const float sr = (lok && p.rscale) ? p.rscale[cl] * rosc : rosc, tr = (lok && p.rshift) ? p.rshift[cl] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][m][n][e] = fmaf(acc[c][m][n][e], s6, t6) + fmaf(r[e], sr, tr);
             };
@@ -763,7 +810,6 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
                     finish8(i, zero4, sc8, sh8);
                 } else finish(i, zero4);
             }
-            return;
         }
     }
     if constexpr (!REDIR && OUTS) {
@@ -787,6 +833,8 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
             if (i + PD < NI) load_res(i + PD, rvb[i % PD]);
         }
     }
+    // ---- publish max |output| of this wave into the output's range block
+    if (p.out_meta) publish_amax(p.out_meta, am);
 }
 
 // ------------------------------------------------------------------ dispatch --
@@ -860,9 +908,8 @@ static const KernelCfg g_deconv_flat_cfg = {
     { nullptr, nullptr }, { nullptr, nullptr } };
 
 static int pick_cfg(const ConvArgs& a, int stride) {
-    const char* ov = getenv("OSA_CONV_CFG");
-    if (ov && *ov) {
-        int v = atoi(ov);
+    {
+        const int v = exp_int("OSA_CONV_CFG", -1);
         if (v >= 0 && v < N_CFGS && a.CoP % g_cfgs[v].N == 0) return v;
     }
     const bool flat = (a.Ad == 1);
@@ -892,7 +939,7 @@ static int pick_cfg(const ConvArgs& a, int stride) {
 //  * padded (TW = 16, strided or dilated taps): voxels 5 slots apart (conflict free within a row of
 //    16), row stride a multiple of 16 slots for TW = 16 and 8 (mod 16) for TW = 8.
 static void finish_geometry(ConvArgs& a, int TW, bool compact) {
-    if (getenv("OSA_NOCOMPACT")) compact = false;
+    if (exp_set("OSA_NOCOMPACT")) compact = false;
     int rowq;
     if (compact) {
         a.VQ = 4;
@@ -902,7 +949,7 @@ static void finish_geometry(ConvArgs& a, int TW, bool compact) {
         const int want = (TW == 8) ? 8 : 0;              // slots mod 16
         rowq = a.LW * 5;
         while ((rowq & 15) != want) ++rowq;
-        if (getenv("OSA_NOPAD")) rowq = a.LW * 5;
+        if (exp_set("OSA_NOPAD")) rowq = a.LW * 5;
     }
     a.RowQ = rowq; a.PlaneQ = a.LH * a.RowQ;
     for (int t = 0; t < a.T; ++t)
@@ -910,8 +957,7 @@ static void finish_geometry(ConvArgs& a, int TW, bool compact) {
     a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
     a.magicH = (unsigned)((0x100000000ull + a.LH - 1) / a.LH);
     a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
-    const char* dbg = getenv("OSA_DBG");
-    a.dbg = dbg ? atoi(dbg) : 0;
+    a.dbg = exp_int("OSA_DBG", 0);
 }
 
 static size_t brick_bytes(ConvArgs& a, const KernelCfg& k) {
@@ -948,16 +994,14 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     // workgroup stays under ~40 KiB of LDS, i.e. as long as it does not cost residency
     a.cps = 1;
     {
-        const char* e = getenv("OSA_CPS");
-        const int want = e ? atoi(e) : 4;
-        size_t cap = 40 * 1024;
-        { const char* c = getenv("OSA_CPS_LDS"); if (c && atoi(c) > 0) cap = (size_t)atoi(c); }
+        const int want = exp_int("OSA_CPS", 4);
+        const size_t cap = (size_t)exp_int("OSA_CPS_LDS", 40 * 1024);
         while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= cap) ++a.cps;
     }
     size_t lds = brick * a.cps;
     const size_t epi = (size_t)(k.threads / 64) * 32 * 36 * sizeof(float);   // wave-private transpose tiles of the epilogue
     if (lds < epi) lds = epi;
-    { const char* e = getenv("OSA_LDS_MIN"); if (e && (size_t)atoi(e) > lds) lds = (size_t)atoi(e); }   // experiments: cap residency
+    { const size_t m = (size_t)exp_int("OSA_LDS_MIN", 0); if (m > lds) lds = m; }   // experiments: cap residency
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "%s: grid too large", what);
     {   // the epilogue addresses one batch item with 32-bit element offsets
@@ -978,10 +1022,9 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     }
     // LDS-DMA staging of split inputs: measured throughput-neutral at 4 workgroups per CU (block-level overlap
     // already hides the staging), so it is opt-in (OSA_DMA=1) until the tap loop is pipelined across barriers
-    { const char* e = getenv("OSA_DMA");
-      a.dma = (e && atoi(e) && prec == PREC_F16X3 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0; }
+    a.dma = (exp_int("OSA_DMA", 0) && prec == PREC_F16X3 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0;
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
-    const bool no_ring = getenv("OSA_NORING") != nullptr;
+    const bool no_ring = exp_set("OSA_NORING");
     void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];
     if (a.act & OSA_OUT_SPLIT) {
         fn = (k.fns[1] && a.T % 3 == 0 && !no_ring) ? k.fns[1] : k.fns[0];
@@ -1270,6 +1313,12 @@ extern "C" int osa_deconv2d_pack_f16x3(const float* w_ref, float* w_packed, int 
     return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, wscale, stream, true);
 }
 
+static void set_ranges(ConvArgs& a, const osa_f16x3_ranges* r) {
+    if (!r) return;
+    a.in_meta = r->x_meta; a.res_meta = r->residual_meta; a.rx_meta = r->redir_meta; a.out_meta = r->y_meta;
+    a.coef = r->bound_coef; a.rcoef = r->redir_bound_coef;
+}
+
 static int check_common(const char* what, const float* x, const float* w, float* y,
                         int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs,
                         const float* residual) {
@@ -1292,7 +1341,8 @@ static int conv3d_impl(const float* x, const float* w_packed,
                        int pad_d, int pad_h, int pad_w,
                        int dil_d, int dil_h, int dil_w,
                        const float* gate_logits, int gCs,
-                       int act, float slope, int prec, float oscale, void* stream) {
+                       int act, float slope, int prec, float oscale, void* stream,
+                       const osa_f16x3_ranges* rng = nullptr) {
     if (gate_logits) OSA_REQUIRE(gCs >= Co, "conv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("conv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     const int T = kd * kh * kw;
@@ -1321,6 +1371,7 @@ static int conv3d_impl(const float* x, const float* w_packed,
     }
     a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
     a.act = act; a.slope = slope; a.oscale = oscale;
+    set_ranges(a, rng);
     return launch_conv(a, stride, prec, (hipStream_t)stream, "conv3d");
 }
 
@@ -1337,8 +1388,8 @@ extern "C" int osa_conv3d_ndhwc_f32(OSA_CONV_PARAMS, void* stream) {
     return conv3d_impl(OSA_CONV_ARGS, PREC_F32, 1.f, stream);
 }
 
-extern "C" int osa_conv3d_ndhwc_f16x3(OSA_CONV_PARAMS, float out_scale, void* stream) {
-    return conv3d_impl(OSA_CONV_ARGS, PREC_F16X3, out_scale, stream);
+extern "C" int osa_conv3d_ndhwc_f16x3(OSA_CONV_PARAMS, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
+    return conv3d_impl(OSA_CONV_ARGS, PREC_F16X3, out_scale, stream, ranges);
 }
 
 static int deconv3d_impl(const float* x, const float* w_packed,
@@ -1350,7 +1401,8 @@ static int deconv3d_impl(const float* x, const float* w_packed,
                          const float* gate_logits, int gCs,
                          int act, float slope, int prec, float oscale, void* stream, bool flat = false,
                          const float* rx = nullptr, int rxCs = 0, int rCi = 0, const float* rw_packed = nullptr,
-                         const float* rscale = nullptr, const float* rshift = nullptr, float roscale = 1.f) {
+                         const float* rscale = nullptr, const float* rshift = nullptr, float roscale = 1.f,
+                         const osa_f16x3_ranges* rng = nullptr) {
     if (gate_logits) OSA_REQUIRE(gCs >= Co, "deconv3d: gate stride %d < Co %d", gCs, Co);
     if (check_common("deconv3d", x, w_packed, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, rCs, residual)) return -1;
     if (flat) OSA_REQUIRE(Di == 1, "deconv2d: the tensor must have D == 1 (got %d)", Di);
@@ -1382,6 +1434,7 @@ static int deconv3d_impl(const float* x, const float* w_packed,
         a.rx = rx; a.rxCs = rxCs; a.rCi = rCi; a.rw = reinterpret_cast<const float4*>(rw_packed);
         a.rscale = rscale; a.rshift = rshift; a.roscale = roscale;
     }
+    set_ranges(a, rng);
     return launch_conv(a, 1, prec, (hipStream_t)stream, flat ? "deconv2d" : "deconv3d",
                        flat ? &g_deconv_flat_cfg : (rx ? (rCi > 32 ? &g_deconv_redir64_cfg : &g_deconv_redir_cfg) : &g_deconv_cfg));
 }
@@ -1398,8 +1451,8 @@ extern "C" int osa_deconv3d_ndhwc_f32(OSA_DECONV_PARAMS, void* stream) {
     return deconv3d_impl(OSA_DECONV_ARGS, PREC_F32, 1.f, stream);
 }
 
-extern "C" int osa_deconv3d_ndhwc_f16x3(OSA_DECONV_PARAMS, float out_scale, void* stream) {
-    return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16X3, out_scale, stream);
+extern "C" int osa_deconv3d_ndhwc_f16x3(OSA_DECONV_PARAMS, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
+    return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16X3, out_scale, stream, false, nullptr, 0, 0, nullptr, nullptr, nullptr, 1.f, ranges);
 }
 
 // transposed conv with the 1x1x1 redir branch computed in its epilogue (see ConvArgs::rx)
@@ -1414,9 +1467,9 @@ extern "C" int osa_deconv3d_redir_ndhwc_f32(const float* x, const float* w_packe
 extern "C" int osa_deconv3d_redir_ndhwc_f16x3(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                                               int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs,
                                               int k, int pad, int opad, OSA_REDIR_PARAMS, float r_out_scale,
-                                              int act, float slope, float out_scale, void* stream) {
+                                              int act, float slope, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
     return deconv3d_impl(x, w_packed, scale, shift, nullptr, y, B, Di, Hi, Wi, Ci, xCs, Co, yCs, 0, k, pad, opad, nullptr, 0,
-                         act, slope, PREC_F16X3, out_scale, stream, false, rx, rxCs, rCi, rw_packed, rscale, rshift, r_out_scale);
+                         act, slope, PREC_F16X3, out_scale, stream, false, rx, rxCs, rCi, rw_packed, rscale, rshift, r_out_scale, ranges);
 }
 
 #define OSA_DECONV2D_PARAMS                                                                     \
@@ -1431,8 +1484,8 @@ extern "C" int osa_deconv2d_nhwc_f32(OSA_DECONV2D_PARAMS, void* stream) {
     return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F32, 1.f, stream, true);
 }
 
-extern "C" int osa_deconv2d_nhwc_f16x3(OSA_DECONV2D_PARAMS, float out_scale, void* stream) {
-    return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F16X3, out_scale, stream, true);
+extern "C" int osa_deconv2d_nhwc_f16x3(OSA_DECONV2D_PARAMS, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
+    return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F16X3, out_scale, stream, true, nullptr, 0, 0, nullptr, nullptr, nullptr, 1.f, ranges);
 }
 
 __global__ __launch_bounds__(256) void small_co_pack_kernel(const float* __restrict__ src, float* __restrict__ dst,

@@ -14,6 +14,7 @@ namespace osa {
 
 struct DwArgs {
     const float* x; const float* w; const float* scale; const float* shift; const float* add; float* y;
+    float* meta;         // range block of y (max |y| folded into meta[0]) or NULL
     int B, Hi, Wi, Ho, Wo, C, xCs, yCs, aCs;
     int kh, kw, stride, pad_h, pad_w, dil_h, dil_w, act;
     long long total;     // B*Ho*Wo*(C/4)
@@ -21,7 +22,8 @@ struct DwArgs {
 
 __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.total) return;
+    float am = 0.f;
+    if (idx < p.total) {
     const int nq = p.C >> 2;
     const int q = (int)(idx % nq);
     long long pix = idx / nq;
@@ -59,6 +61,9 @@ __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
         o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
     }
     *reinterpret_cast<float4*>(p.y + opix * p.yCs + c) = make_float4(o[0], o[1], o[2], o[3]);
+    am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    if (p.meta) publish_amax(p.meta, am);
 }
 
 __global__ __launch_bounds__(256) void dwconv2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int T) {
@@ -85,7 +90,7 @@ extern "C" int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
                                      const float* scale, const float* shift, const float* add, float* y,
                                      int B, int Hi, int Wi, int C, int xCs, int yCs, int aCs,
                                      int kh, int kw, int stride, int pad_h, int pad_w, int dil_h, int dil_w,
-                                     int act, void* stream) {
+                                     int act, float* y_meta, void* stream) {
     OSA_REQUIRE(x && w_packed && y, "dwconv2d: NULL pointer");
     OSA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && C > 0, "dwconv2d: bad dims B=%d H=%d W=%d C=%d", B, Hi, Wi, C);
     OSA_REQUIRE(C % 4 == 0 && xCs % 4 == 0 && yCs % 4 == 0 && xCs >= C && yCs >= C,
@@ -98,7 +103,7 @@ extern "C" int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
     OSA_REQUIRE(kh > 0 && kw > 0 && dil_h > 0 && dil_w > 0 && pad_h >= 0 && pad_w >= 0, "dwconv2d: bad kernel geometry");
     OSA_REQUIRE(act == OSA_ACT_NONE || act == OSA_ACT_RELU || act == OSA_ACT_RELU6, "dwconv2d: act %d unsupported", act);
     DwArgs a;
-    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.add = add; a.y = y;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.add = add; a.y = y; a.meta = y_meta;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.C = C; a.xCs = xCs; a.yCs = yCs; a.aCs = aCs;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil_h = dil_h; a.dil_w = dil_w; a.act = act;
     a.Ho = (Hi + 2 * pad_h - dil_h * (kh - 1) - 1) / stride + 1;

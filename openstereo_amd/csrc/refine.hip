@@ -132,9 +132,10 @@ extern "C" int osa_preprocess_pair_f32(const void* left_hwc, const void* right_h
 namespace osa {
 __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restrict__ z, const float* __restrict__ q,
                                                           const float* __restrict__ h, float* __restrict__ out,
-                                                          long long total, int nq, int zCs, int qCs, int hCs, int oCs) {
+                                                          long long total, int nq, int zCs, int qCs, int hCs, int oCs, float* meta) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    float am = 0.f;
+    if (i < total) {
     const long long px = i / nq;
     const int c = (int)(i - px * nq) * 4;
     const float4 zv = *reinterpret_cast<const float4*>(z + px * zCs + c);
@@ -144,11 +145,14 @@ __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restric
     o.x = (1.f - zv.x) * hv.x + zv.x * qv.x; o.y = (1.f - zv.y) * hv.y + zv.y * qv.y;
     o.z = (1.f - zv.z) * hv.z + zv.z * qv.z; o.w = (1.f - zv.w) * hv.w + zv.w * qv.w;
     *reinterpret_cast<float4*>(out + px * oCs + c) = o;
+    am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (meta) publish_amax(meta, am);
 }
 }  // namespace osa
 
 extern "C" int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
-                                   long long npix, int C, int zCs, int qCs, int hCs, int oCs, void* stream) {
+                                   long long npix, int C, int zCs, int qCs, int hCs, int oCs, float* out_meta, void* stream) {
     OSA_REQUIRE(z && q && h && out, "gru_combine: NULL pointer");
     OSA_REQUIRE(npix > 0 && C > 0 && C % 4 == 0, "gru_combine: bad dims npix=%lld C=%d (C must be a multiple of 4)", npix, C);
     OSA_REQUIRE(zCs >= C && qCs >= C && hCs >= C && oCs >= C && ((zCs | qCs | hCs | oCs) & 3) == 0, "gru_combine: bad channel strides");
@@ -156,7 +160,7 @@ extern "C" int osa_gru_combine_f32(const float* z, const float* q, const float* 
     const long long total = npix * (C / 4);
     OSA_REQUIRE((total + 255) / 256 < (1ll << 31), "gru_combine: grid too large");
     hipLaunchKernelGGL(osa::gru_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       z, q, h, out, total, C / 4, zCs, qCs, hCs, oCs);
+                       z, q, h, out, total, C / 4, zCs, qCs, hCs, oCs, out_meta);
     OSA_LAUNCH_CHECK("gru_combine");
     return 0;
 }

@@ -19,6 +19,7 @@ namespace osa {
 struct VolArgs {
     const float* lg; const float* rg; const float* lc; const float* rc;
     float* vol;
+    float* meta;           // range block of the volume (meta[0] = running max |value|) or NULL
     int B, C, Cc, H, W, D, G, K;
     int VC, coff;          // volume channel count / first channel written
     int gstride, cstride;  // >0: features are NHWC with this many floats per pixel (engine backbone); 0: NCHW
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
     const int nch = p.G + 2 * p.Cc;
     const float invK = 1.0f / (float)p.K;
     (void)invK;
+    float am = 0.f;
     for (int c = lane; c < nch; c += 64) {
         for (int wl = wave; wl < VOL_WT; wl += 4) {
             const int w = w0 + wl;
@@ -145,9 +147,11 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
                 }
                 const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
                 p.vol[vox * p.VC + p.coff + c] = v;
+                am = fmaxf(am, fabsf(v));
             }
         }
     }
+    if (p.meta) publish_amax(p.meta, am);
 }
 
 // ---- NDHWC, quad lanes: every lane produces 4 consecutive output channels of one voxel ----
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
     const float Kinv = 1.0f / Kf;
     const int rq = nq_g + (cq - G4 - nq_c);           // right-concat slot of this lane (role 2)
     float* vout = p.vol + p.coff + cq * 4;
+    float am = 0.f;
 #pragma unroll 4
     for (int dd = 0; dd < q.DCH; ++dd) {
         const int d = d0 + dd;
@@ -312,8 +317,10 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
         if (wlive && (!(q.dbg & 1) || o.x == 12345.678f)) {
             const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
             *reinterpret_cast<float4*>(vout + vox * p.VC) = o;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
     }
+    if (p.meta) publish_amax(p.meta, am);
 }
 
 // ------------------------------------------------------------------ NCDHW ----
@@ -359,34 +366,34 @@ using namespace osa;
 static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                              const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                              float* vol, int layout, int vol_channels, int c_off,
-                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream);
+                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta = nullptr);
 
 extern "C" int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups,
                                     const float* left_cat, const float* right_cat, int Cc,
                                     float* vol, int layout, int vol_channels, int c_off,
                                     int B, int H, int W, int maxdisp, int mask_left_concat,
-                                    void* stream) {
+                                    float* vol_meta, void* stream) {
     return build_volume_impl(left_gwc, right_gwc, C, num_groups, 0, left_cat, right_cat, Cc, 0, vol, layout,
-                             vol_channels, c_off, B, H, W, maxdisp, mask_left_concat, stream);
+                             vol_channels, c_off, B, H, W, maxdisp, mask_left_concat, stream, vol_meta);
 }
 
 extern "C" int osa_build_volume_nhwc_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                                          const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                                          float* vol, int vol_channels, int c_off,
-                                         int B, int H, int W, int maxdisp, int mask_left_concat, void* stream) {
+                                         int B, int H, int W, int maxdisp, int mask_left_concat, float* vol_meta, void* stream) {
     OSA_REQUIRE((C == 0 || (gwc_stride >= C && gwc_stride % 4 == 0 && ((size_t)left_gwc & 15) == 0 && ((size_t)right_gwc & 15) == 0)),
                 "build_volume_nhwc: gwc features need stride >= C, stride %% 4 == 0 and 16-byte alignment");
     OSA_REQUIRE((Cc == 0 || cat_stride >= Cc), "build_volume_nhwc: concat stride %d < Cc %d", cat_stride, Cc);
     OSA_REQUIRE(C == 0 || (C / (num_groups > 0 ? num_groups : 1)) % 4 == 0, "build_volume_nhwc: channels per group must be a multiple of 4");
     return build_volume_impl(left_gwc, right_gwc, C, num_groups, gwc_stride ? gwc_stride : C, left_cat, right_cat, Cc,
                              cat_stride ? cat_stride : Cc, vol, OSA_NDHWC, vol_channels, c_off, B, H, W, maxdisp,
-                             mask_left_concat, stream);
+                             mask_left_concat, stream, vol_meta);
 }
 
 static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                              const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                              float* vol, int layout, int vol_channels, int c_off,
-                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream) {
+                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta) {
     OSA_REQUIRE(vol != nullptr, "build_volume: vol is NULL");
     OSA_REQUIRE(B > 0 && H > 0 && W > 0 && maxdisp > 0, "build_volume: bad dims B=%d H=%d W=%d D=%d", B, H, W, maxdisp);
     OSA_REQUIRE(C >= 0 && Cc >= 0 && (C > 0 || Cc > 0), "build_volume: nothing to build (C=%d Cc=%d)", C, Cc);
@@ -414,11 +421,11 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
         const int nq4 = nch / 4;
         const bool quads = (G % 4 == 0) && (Cc % 4 == 0) && nq4 >= 1 && nq4 <= 64 && (nq4 & (nq4 - 1)) == 0 &&
                            (vol_channels % 4 == 0) && (c_off % 4 == 0) && (((size_t)vol & 15) == 0) &&
-                           !getenv("OSA_VOL_PERCHANNEL");
+                           !exp_set("OSA_VOL_PERCHANNEL");
         if (quads) {
             VolQArgs qa;
             VolArgs& a = qa.v;
-            a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol;
+            a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol; a.meta = vol_meta;
             a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;
             a.VC = vol_channels; a.coff = c_off; a.mask_left = mask_left_concat;
             a.gstride = gwc_stride; a.cstride = cat_stride;
@@ -428,19 +435,19 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             while ((1 << qa.lgNQ) < nq4) ++qa.lgNQ;
             // 8 waves per workgroup when the map is wide enough (amortises the right window over 2x the pixels)
             int nwv = (W >= 8 * (64 / nq4) * 2) ? 8 : 4;
-            { const char* e = getenv("OSA_VOL_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) nwv = atoi(e); }
+            { const int e = exp_int("OSA_VOL_WAVES", 0); if (e == 4 || e == 8) nwv = e; }
             const int WT = nwv * (64 / nq4);
             qa.RSq = ((G > 0) ? QG * G : 0) + Cc / 4;
             if (qa.RSq % 16 > 6) qa.RSq += 16 - qa.RSq % 16;     // keeps the lanes of two neighbouring voxels on distinct 16-byte slots
             // disparity chunk: D split evenly into the fewest chunks whose right window fits ~52 KiB of
             // LDS (3 workgroups per CU); very wide feature vectors may use up to the whole 160 KiB
             size_t budget = (nwv == 8) ? 78 * 1024 : 52 * 1024;   // 2 x 8 waves or 3 x 4 waves per CU
-            { const char* e = getenv("OSA_VOL_LDS"); if (e && atoi(e) > 0) budget = (size_t)atoi(e); }
+            { const int e = exp_int("OSA_VOL_LDS", 0); if (e > 0) budget = (size_t)e; }
             int nchunk = 1;
             while (nchunk < maxdisp && (size_t)(WT + cdiv(maxdisp, nchunk) - 1) * qa.RSq * 16 > budget) ++nchunk;
             const int dch = cdiv(maxdisp, nchunk);
             qa.DCH = dch;
-            { const char* e = getenv("OSA_VOL_DBG"); qa.dbg = e ? atoi(e) : 0; }
+            qa.dbg = exp_int("OSA_VOL_DBG", 0);
             a.nWt = cdiv(W, WT); a.nDch = cdiv(maxdisp, dch);
             const size_t lds = (size_t)(WT + dch - 1) * qa.RSq * 16;
             OSA_REQUIRE(lds <= 160 * 1024, "build_volume: %zu B of LDS needed (> 160 KiB); too many channels", lds);
@@ -467,7 +474,7 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             return 0;
         }
         VolArgs a;
-        a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol;
+        a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol; a.meta = vol_meta;
         a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;
         a.VC = vol_channels; a.coff = c_off; a.mask_left = mask_left_concat;
         a.gstride = gwc_stride; a.cstride = cat_stride;
@@ -516,5 +523,5 @@ extern "C" int osa_corr_volume_f32(const float* left, const float* right, float*
                                    int B, int C, int H, int W, int maxdisp, void* stream) {
     // correlation layer == one group over all channels, volume [B,1,D,H,W] == [B,D,H,W]
     return osa_build_volume_f32(left, right, C, 1, nullptr, nullptr, 0, vol, OSA_NCDHW, 1, 0,
-                                B, H, W, maxdisp, 1, stream);
+                                B, H, W, maxdisp, 1, nullptr, stream);
 }

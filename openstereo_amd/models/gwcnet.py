@@ -9,8 +9,9 @@ regression stages runs on the engine:
   features --build_cost_volume_cl--> NDHWC volume --PackedConv3d chain (MFMA)--> cost3
            --upsample_softargmin--> disparity [B,H,W]
 
-The 2-D feature extractor is not part of the engine: it runs as ordinary
-PyTorch-ROCm modules.
+The 2-D feature extractor runs on the same conv kernel (D = 1, NHWC, fused conv+BN+ReLU+residual launches,
+SURVEY 8f #4); the PyTorch-ROCm module path stays selectable (`Backbone.use_engine = False`).
+Packed weights are cached per module and rebuilt automatically when a parameter or BN statistic changes.
 """
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import autograd as AG
 from .. import ops, timing
-from ..engine import is_split, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+from ..engine import is_split, cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
 
 
 def run_train(mod, x):
@@ -92,7 +93,7 @@ class _Features(nn.Module):
     # ---- engine path: every conv+BN(+ReLU)(+residual) is one fused MFMA launch, NHWC activations,
     # the l2|l3|l4 concat is written in place (channel slices of one 320-channel buffer).
     def _pack(self):
-        if getattr(self, "_pk", None) is None:
+        def build():
             P = lambda cb, act: PackedConv3d(cb[0], cb[1], act)
             fc = self.firstconv
             pk = {"first": [P(fc[0], ACT_RELU), P(fc[2], ACT_RELU), P(fc[4], ACT_RELU)], "layers": []}
@@ -101,8 +102,8 @@ class _Features(nn.Module):
                                       None if b.downsample is None else P(b.downsample, ACT_NONE)) for b in layer])
             if self.concat_feature:
                 pk["last"] = (P(self.lastconv[0], ACT_RELU), PackedConv3d(self.lastconv[2]))
-            self._pk = pk
-        return self._pk
+            return pk
+        return cached_pack(self, "_pk", build)      # repacked automatically when a weight / BN statistic changes
 
     def forward_cl(self, img):
         """img: [N,3,H,W] (NCHW, any float dtype).  Returns (gwc_feature [N,320,1,H/4,W/4] NDHWC,
@@ -238,14 +239,12 @@ class Hourglass(nn.Module):
         self._packed = None
 
     def _pack(self):
-        if self._packed is None:
-            P = PackedConv3d
-            self._packed = dict(
-                c1=P(self.conv1[0][0], self.conv1[0][1], ACT_RELU), c2=P(self.conv2[0][0], self.conv2[0][1], ACT_RELU),
-                c3=P(self.conv3[0][0], self.conv3[0][1], ACT_RELU), c4=P(self.conv4[0][0], self.conv4[0][1], ACT_RELU),
-                c5=P(self.conv5[0], self.conv5[1], ACT_RELU), c6=P(self.conv6[0], self.conv6[1], ACT_RELU),
-                r1=P(self.redir1[0], self.redir1[1], ACT_NONE), r2=P(self.redir2[0], self.redir2[1], ACT_NONE))
-        return self._packed
+        P = PackedConv3d
+        return cached_pack(self, "_packed", lambda: dict(
+            c1=P(self.conv1[0][0], self.conv1[0][1], ACT_RELU), c2=P(self.conv2[0][0], self.conv2[0][1], ACT_RELU),
+            c3=P(self.conv3[0][0], self.conv3[0][1], ACT_RELU), c4=P(self.conv4[0][0], self.conv4[0][1], ACT_RELU),
+            c5=P(self.conv5[0], self.conv5[1], ACT_RELU), c6=P(self.conv6[0], self.conv6[1], ACT_RELU),
+            r1=P(self.redir1[0], self.redir1[1], ACT_NONE), r2=P(self.redir2[0], self.redir2[1], ACT_NONE)))
 
     def forward_cl(self, x, split=False):
         """split=True (f16x3 mode, inside GwcDispProcessor): intermediate and output tensors are written in the
@@ -304,13 +303,12 @@ class GwcDispProcessor(nn.Module):
             h._packed = None
 
     def _pack(self):
-        if self._packed is None:
-            P = PackedConv3d
-            self._packed = dict(
-                d00=P(self.dres0[0][0], self.dres0[0][1], ACT_RELU), d02=P(self.dres0[2][0], self.dres0[2][1], ACT_RELU),
-                d10=P(self.dres1[0][0], self.dres1[0][1], ACT_RELU), d12=P(self.dres1[2][0], self.dres1[2][1], ACT_NONE),
-                k0=P(self.classif3[0][0], self.classif3[0][1], ACT_RELU), k2=SmallCoConv3d(self.classif3[2]))
-        return self._packed
+        P = PackedConv3d
+        return cached_pack(self, "_packed", lambda: dict(
+            d00=P(self.dres0[0][0], self.dres0[0][1], ACT_RELU), d02=P(self.dres0[2][0], self.dres0[2][1], ACT_RELU),
+            d10=P(self.dres1[0][0], self.dres1[0][1], ACT_RELU), d12=P(self.dres1[2][0], self.dres1[2][1], ACT_NONE),
+            k0=P(self.classif3[0][0], self.classif3[0][1], ACT_RELU), k2=SmallCoConv3d(self.classif3[2])),
+            mods=(self.dres0, self.dres1, self.classif3))
 
     def aggregate_cl(self, volume):
         """NDHWC volume -> low-res cost [B,1,D/4,H/4,W/4] (classif3 output)."""

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..engine import PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_LEAKY
+from ..engine import cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_LEAKY
 from ..ops import empty_cl
 
 
@@ -137,15 +137,17 @@ class Hourglass(nn.Module):
         self.feature_att_up_8 = FeatureAtt(2 * c, backbone_channels[1])
         self._packed = None
 
+    def reset_engine(self):
+        self._packed = None
+
     def _pack(self):
-        if self._packed is None:
-            P = _pack_sb
-            self._packed = dict(
-                c1a=P(self.conv1[0]), c1b=P(self.conv1[1]), c2a=P(self.conv2[0]), c2b=P(self.conv2[1]),
-                c3a=P(self.conv3[0]), c3b=P(self.conv3[1]), c3up=P(self.conv3_up), c2up=P(self.conv2_up),
-                c1up=P(self.conv1_up), a0a=P(self.agg_0[0]), a0b=P(self.agg_0[1]), a0c=P(self.agg_0[2]),
-                a1a=P(self.agg_1[0]), a1b=P(self.agg_1[1]), a1c=P(self.agg_1[2]))
-        return self._packed
+        P = _pack_sb
+        return cached_pack(self, "_packed", lambda: dict(
+            c1a=P(self.conv1[0]), c1b=P(self.conv1[1]), c2a=P(self.conv2[0]), c2b=P(self.conv2[1]),
+            c3a=P(self.conv3[0]), c3b=P(self.conv3[1]), c3up=P(self.conv3_up), c2up=P(self.conv2_up),
+            c1up=P(self.conv1_up), a0a=P(self.agg_0[0]), a0b=P(self.agg_0[1]), a0c=P(self.agg_0[2]),
+            a1a=P(self.agg_1[0]), a1b=P(self.agg_1[1]), a1c=P(self.agg_1[2])),
+            mods=(self.conv1, self.conv2, self.conv3, self.conv3_up, self.conv2_up, self.conv1_up, self.agg_0, self.agg_1))
 
     def gate_logits(self, features):
         return dict(g8=self.feature_att_8.logits(features[1]), g16=self.feature_att_16.logits(features[2]),
@@ -204,6 +206,10 @@ class StereoBaseCostStage(nn.Module):
         self.classifier = nn.Conv3d(volume_channel, 1, 3, 1, 1, bias=False)
         self._cls = None
 
+    def reset_engine(self):
+        self._cls = None
+        self.cost_agg.reset_engine()
+
     def forward_train(self, match_left, match_right, concat_left, concat_right, features_left):
         """Training path (BASELINE configs[2]): differentiable engine ops end to end -- volumes, hourglass
         convolutions, classifier, fused softmax + regression -- BatchNorm / activations as torch modules."""
@@ -222,9 +228,7 @@ class StereoBaseCostStage(nn.Module):
         vol = ops.build_cost_volume_cl(match_left, match_right, self.num_groups, concat_left, concat_right,
                                        maxdisp=self.max_disp // 4)
         geo = self.cost_agg.forward_cl(vol, features_left)
-        if self._cls is None:
-            self._cls = SmallCoConv3d(self.classifier)
-        cost = self._cls(geo)                                    # [B,1,D/4,H/4,W/4]
+        cost = cached_pack(self, "_cls", lambda: SmallCoConv3d(self.classifier), mods=(self.classifier,))(geo)   # [B,1,D/4,H/4,W/4]
         init_disp, prob = ops.softmax_disparity_regression(cost[:, 0], self.max_disp // 4, keepdim=True, return_prob=True)
         return {"init_disp": init_disp, "prob": prob, "geo_encoding_volume": geo}
 
@@ -291,17 +295,17 @@ class hourglass(nn.Module):
         self.feature_att_up_8 = IGEVFeatureAtt(2 * c, 64)
         self._packed = None
 
-    _pack = None
+    def reset_engine(self):
+        self._packed = None
 
     def _packed_layers(self):
-        if self._packed is None:
-            P = _pack_igev
-            self._packed = dict(
-                c1a=P(self.conv1[0]), c1b=P(self.conv1[1]), c2a=P(self.conv2[0]), c2b=P(self.conv2[1]),
-                c3a=P(self.conv3[0]), c3b=P(self.conv3[1]), c3up=P(self.conv3_up), c2up=P(self.conv2_up),
-                c1up=P(self.conv1_up), a0a=P(self.agg_0[0]), a0b=P(self.agg_0[1]), a0c=P(self.agg_0[2]),
-                a1a=P(self.agg_1[0]), a1b=P(self.agg_1[1]), a1c=P(self.agg_1[2]))
-        return self._packed
+        P = _pack_igev
+        return cached_pack(self, "_packed", lambda: dict(
+            c1a=P(self.conv1[0]), c1b=P(self.conv1[1]), c2a=P(self.conv2[0]), c2b=P(self.conv2[1]),
+            c3a=P(self.conv3[0]), c3b=P(self.conv3[1]), c3up=P(self.conv3_up), c2up=P(self.conv2_up),
+            c1up=P(self.conv1_up), a0a=P(self.agg_0[0]), a0b=P(self.agg_0[1]), a0c=P(self.agg_0[2]),
+            a1a=P(self.agg_1[0]), a1b=P(self.agg_1[1]), a1c=P(self.agg_1[2])),
+            mods=(self.conv1, self.conv2, self.conv3, self.conv3_up, self.conv2_up, self.conv1_up, self.agg_0, self.agg_1))
 
     def forward_cl(self, x, features):
         gates = dict(g8=self.feature_att_8.logits(features[1]), g16=self.feature_att_16.logits(features[2]),

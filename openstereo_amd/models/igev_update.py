@@ -23,8 +23,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from ..engine import PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from ..ops import empty_cl, is_cl, _stream
+from ..ranges import attach_meta, fold_amax, meta_of, new_meta
 from .lightstereo import nchw_to_cl, cl_to_nchw
 
 
@@ -59,8 +60,14 @@ def _cat_cl(parts, dev):
     out = empty_cl(B, C, 1, H, W, dev)
     o = 0
     for p in parts:
+        assert p.shape[1] % 4 == 0, "engine tensors are channel-padded to 4: a part with padded channels would shift the next one"
         out[:, o:o + p.shape[1]] = p
         o += p.shape[1]
+    metas = [meta_of(p) for p in parts]
+    if all(m is not None for m in metas):        # f16x3 chains: max |.| of the concatenation = max over the parts (device side)
+        m = new_meta(dev)
+        m[0:1] = torch.stack([t[0] for t in metas]).amax().reshape(1)
+        out._osa_meta = m
     return out
 
 
@@ -75,9 +82,8 @@ class DispHead(nn.Module):
         self._eng = None
 
     def forward_cl(self, x):
-        if self._eng is None:
-            self._eng = (PackedConv3d(self.conv1, None, ACT_RELU), PackedConv3d(self.conv2))
-        return self._eng[1](self._eng[0](x))
+        e = cached_pack(self, "_eng", lambda: (PackedConv3d(self.conv1, None, ACT_RELU), PackedConv3d(self.conv2)))
+        return e[1](e[0](x))
 
     def forward(self, x):
         return cl_to_nchw(self.forward_cl(nchw_to_cl(x)), self.conv2.out_channels)
@@ -96,21 +102,23 @@ class ConvGRU(nn.Module):
         self._eng = None
 
     def forward_cl(self, h, cz, cr, cq, *x_list):
-        if self._eng is None:
-            self._eng = (PackedConv3d(self.convz, None, ACT_SIGMOID), PackedConv3d(self.convr, None, ACT_SIGMOID),
-                         PackedConv3d(self.convq, None, ACT_TANH))
-        pz, pr, pq = self._eng
+        pz, pr, pq = cached_pack(self, "_eng", lambda: (PackedConv3d(self.convz, None, ACT_SIGMOID),
+                                                        PackedConv3d(self.convr, None, ACT_SIGMOID),
+                                                        PackedConv3d(self.convq, None, ACT_TANH)))
         hd = self.convz.out_channels
         assert hd % 4 == 0 and h.shape[1] == hd
         hx = _cat_cl([h, *x_list], h.device)                   # [h | x]
         z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
         rhx = hx.clone()                                       # [r*h | x]: the x part is shared, r*h overwrites the h slice
+        if meta_of(hx) is not None:                            # same range: |r*h| <= |h|
+            rhx._osa_meta = new_meta(h.device)
+            rhx._osa_meta.copy_(meta_of(hx))
         pr(hx, residual=cr, gate=_nhwc(h), gate_raw=True, out=rhx, out_off=0)   # sigmoid(convr(hx) + cr) * h
         q = pq(rhx, residual=cq)                               # tanh(convq([r*h, x]) + cq)
         out = empty_cl(*h.shape, h.device)
         B, _, _, H, W = h.shape
         _lib.call("osa_gru_combine_f32", z.data_ptr(), q.data_ptr(), h.data_ptr(), out.data_ptr(),
-                  B * H * W, hd, z.shape[1], q.shape[1], h.shape[1], out.shape[1], _stream())
+                  B * H * W, hd, z.shape[1], q.shape[1], h.shape[1], out.shape[1], attach_meta(out).data_ptr(), _stream())
         return out
 
     def forward(self, h, cz, cr, cq, *x_list):
@@ -135,10 +143,9 @@ class BasicMotionEncoder(nn.Module):
 
     def forward_cl(self, disp, corr):
         """disp: engine tensor with the disparity in channel 0 (channels 1..3 zero); corr: engine tensor."""
-        if self._eng is None:
-            R = lambda m: PackedConv3d(m, None, ACT_RELU)
-            self._eng = dict(c1=R(self.convc1), c2=R(self.convc2), d1=R(self.convd1), d2=R(self.convd2), conv=R(self.conv))
-        e = self._eng
+        R = lambda m: PackedConv3d(m, None, ACT_RELU)
+        e = cached_pack(self, "_eng", lambda: dict(c1=R(self.convc1), c2=R(self.convc2), d1=R(self.convd1), d2=R(self.convd2),
+                                                   conv=R(self.conv)))
         B, _, _, H, W = disp.shape
         cor_disp = empty_cl(B, 128, 1, H, W, disp.device)      # [cor | disp_]
         e["c2"](e["c1"](corr), out=cor_disp, out_off=0)
@@ -146,6 +153,8 @@ class BasicMotionEncoder(nn.Module):
         out = empty_cl(B, 128, 1, H, W, disp.device)           # [conv(cor_disp) (127) | disp]
         e["conv"](cor_disp, out=out, out_off=0)
         out[:, 127] = disp[:, 0]
+        if meta_of(out) is not None:
+            fold_amax(out, disp[:, 0])
         return out
 
     def forward(self, disp, corr):
@@ -192,9 +201,8 @@ class BasicMultiUpdateBlock(nn.Module):
         if not update:
             return net
         delta_disp = self.disp_head.forward_cl(net[0])
-        if getattr(self, "_mask", None) is None:
-            self._mask = PackedConv3d(self.mask_feat_4[0], None, ACT_RELU)
-        return net, self._mask(net[0]), delta_disp
+        mask = cached_pack(self, "_mask", lambda: PackedConv3d(self.mask_feat_4[0], None, ACT_RELU), mods=(self.mask_feat_4,))
+        return net, mask(net[0]), delta_disp
 
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         if not net[0].is_cuda:

@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..engine import PackedConv3d, DepthwiseConv2d, ACT_NONE, ACT_RELU, ACT_RELU6
+from ..engine import cached_pack, PackedConv3d, DepthwiseConv2d, ACT_NONE, ACT_RELU, ACT_RELU6
 from ..ops import empty_cl, is_cl
 
 
@@ -57,11 +57,9 @@ class MobileV2Residual(nn.Module):
         self._eng = None
 
     def _pack(self):
-        if self._eng is None:
-            self._eng = (PackedConv3d(self.pwconv[0], self.pwconv[1], ACT_RELU6),
-                         DepthwiseConv2d(self.dwconv[0], self.dwconv[1], ACT_RELU6),
-                         PackedConv3d(self.pwliner[0], self.pwliner[1], ACT_NONE))
-        return self._eng
+        return cached_pack(self, "_eng", lambda: (PackedConv3d(self.pwconv[0], self.pwconv[1], ACT_RELU6),
+                                                  DepthwiseConv2d(self.dwconv[0], self.dwconv[1], ACT_RELU6),
+                                                  PackedConv3d(self.pwliner[0], self.pwliner[1], ACT_NONE)))
 
     def forward_cl(self, x):
         pw, dw, pl = self._pack()
@@ -87,11 +85,9 @@ class AttentionModule(nn.Module):
         self._eng = None
 
     def _pack(self):
-        if self._eng is None:
-            self._eng = dict(conv0=PackedConv3d(self.conv0), conv3=PackedConv3d(self.conv3),
-                             **{n: DepthwiseConv2d(getattr(self, n)) for n in
-                                ("conv0_1", "conv0_2", "conv1_1", "conv1_2", "conv2_1", "conv2_2")})
-        return self._eng
+        return cached_pack(self, "_eng", lambda: dict(
+            conv0=PackedConv3d(self.conv0), conv3=PackedConv3d(self.conv3),
+            **{n: DepthwiseConv2d(getattr(self, n)) for n in ("conv0_1", "conv0_2", "conv1_1", "conv1_2", "conv2_1", "conv2_2")}))
 
     def forward_cl(self, cost, x):
         e = self._pack()
@@ -140,9 +136,9 @@ class Aggregation(nn.Module):
                 m._eng = None
 
     def _pack(self):
-        if self._eng is None:
-            self._eng = (PackedConv3d(self.conv5[0], self.conv5[1], ACT_RELU), PackedConv3d(self.conv6[0], self.conv6[1], ACT_RELU))
-        return self._eng
+        return cached_pack(self, "_eng", lambda: (PackedConv3d(self.conv5[0], self.conv5[1], ACT_RELU),
+                                                  PackedConv3d(self.conv6[0], self.conv6[1], ACT_RELU)),
+                           mods=(self.conv5, self.conv6))
 
     def forward_cl(self, x, features_left):
         """x: NHWC volume (logical [B,D4,1,H4,W4]); features_left: NHWC maps at 1/4, 1/8, 1/16."""

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, timing
-from ..engine import PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+from ..engine import cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU, fold_amax
 
 
 # ----------------------------------------------------------------------------- 2-D backbone (submodule.py factories)
@@ -88,7 +88,7 @@ class PSMBackbone(nn.Module):
         self._pk = None
 
     def _pack(self):
-        if getattr(self, "_pk", None) is None:
+        def build():
             P = lambda cb, act: PackedConv3d(cb[0], cb[1], act)
             pk = {"first": [P(m, ACT_RELU) for m in self.firstconv], "layers": []}
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -96,8 +96,8 @@ class PSMBackbone(nn.Module):
                                       None if b.downsample is None else P(b.downsample, ACT_NONE)) for b in layer])
             pk["branch"] = [P(getattr(self, f"branch{i}")[1], ACT_RELU) for i in (1, 2, 3, 4)]
             pk["last"] = (P(self.lastconv[0], ACT_RELU), PackedConv3d(self.lastconv[1]))
-            self._pk = pk
-        return self._pk
+            return pk
+        return cached_pack(self, "_pk", build)
 
     def forward_cl(self, img):
         """img [N,3,H,W] -> NHWC feature map (logical [N,32,1,H/4,W/4])."""
@@ -127,7 +127,10 @@ class PSMBackbone(nn.Module):
             pcl = ops.empty_cl(N_, C_, 1, ph, pw, pooled.device)
             pcl[:, :, 0] = pooled
             br = pk["branch"][i - 1](pcl)                                      # 1x1 conv + BN + ReLU
-            cat[:, 192 + 32 * slot:224 + 32 * slot, 0] = F.interpolate(br[:, :, 0], (h4, w4), mode="bilinear", align_corners=True)
+            up = F.interpolate(br[:, :, 0], (h4, w4), mode="bilinear", align_corners=True)
+            cat[:, 192 + 32 * slot:224 + 32 * slot, 0] = up
+            if getattr(cat, "_osa_meta", None) is not None:            # f16x3: torch wrote into an engine buffer
+                fold_amax(cat, up)
         l0, l1 = pk["last"]
         return l1(l0(cat))
 
@@ -172,12 +175,11 @@ class Hourglass(nn.Module):
         self._packed = None
 
     def _pack(self):
-        if self._packed is None:
-            P = PackedConv3d
-            self._packed = dict(c1=P(self.conv1[0], self.conv1[1], ACT_RELU), c2=P(self.conv2[0], self.conv2[1], ACT_RELU),
-                                c3=P(self.conv3[0], self.conv3[1], ACT_RELU), c4=P(self.conv4[0], self.conv4[1], ACT_RELU),
-                                c5=P(self.conv5[0], self.conv5[1], ACT_RELU), c6=P(self.conv6[0], self.conv6[1], ACT_NONE))
-        return self._packed
+        P = PackedConv3d
+        return cached_pack(self, "_packed", lambda: dict(
+            c1=P(self.conv1[0], self.conv1[1], ACT_RELU), c2=P(self.conv2[0], self.conv2[1], ACT_RELU),
+            c3=P(self.conv3[0], self.conv3[1], ACT_RELU), c4=P(self.conv4[0], self.conv4[1], ACT_RELU),
+            c5=P(self.conv5[0], self.conv5[1], ACT_RELU), c6=P(self.conv6[0], self.conv6[1], ACT_NONE)))
 
     def forward_cl(self, x, presqu=None, postsqu=None, out_residual=None):
         """NDHWC tensors. out_residual is added to conv6's output (the aggregator's `out + cost0`)."""
@@ -217,15 +219,15 @@ class PSMAggregator(nn.Module):
             h._packed = None
 
     def _pack(self):
-        if self._packed is None:
+        def build():
             P = PackedConv3d
             d = dict(d00=P(self.dres0[0][0], self.dres0[0][1], ACT_RELU), d01=P(self.dres0[1][0], self.dres0[1][1], ACT_RELU),
                      d10=P(self.dres1[0][0], self.dres1[0][1], ACT_RELU), d11=P(self.dres1[1][0], self.dres1[1][1], ACT_NONE))
             for i in (1, 2, 3):
                 c = getattr(self, f"classif{i}")
                 d[f"k{i}a"], d[f"k{i}b"] = P(c[0][0], c[0][1], ACT_RELU), SmallCoConv3d(c[1])
-            self._packed = d
-        return self._packed
+            return d
+        return cached_pack(self, "_packed", build, mods=(self.dres0, self.dres1, self.classif1, self.classif2, self.classif3))
 
     def aggregate_cl(self, raw_cost):
         p = self._pack()

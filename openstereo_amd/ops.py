@@ -21,6 +21,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib, timing
+from .ranges import attach_meta
 
 NCDHW, NDHWC = 0, 1
 
@@ -104,9 +105,10 @@ def _build(lg, rg, G, lc, rc, maxdisp, layout, mask_left=True, out=None, vol_cha
                 out.zero_()
         else:
             out = torch.empty((B, VC, maxdisp, H, W), device=ref.device, dtype=torch.float32)
+    meta = attach_meta(out).data_ptr() if layout == NDHWC else None     # range block for f16x3 consumers
     with timing.span("build_volume", Cg, G, Cc, layout, maxdisp, H, W):
         _lib.call("osa_build_volume_f32", _p(lg), _p(rg), Cg, G, _p(lc), _p(rc), Cc,
-                  out.data_ptr(), layout, VC, c_off, B, H, W, maxdisp, 1 if mask_left else 0, _stream())
+                  out.data_ptr(), layout, VC, c_off, B, H, W, maxdisp, 1 if mask_left else 0, meta, _stream())
     return out
 
 
@@ -199,7 +201,7 @@ def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_ch
         out.zero_()
     with timing.span("build_volume", C, num_groups, Cc, NDHWC, maxdisp, H, W):
         _lib.call("osa_build_volume_nhwc_f32", lg, rg, C, num_groups, Gs, lc, rc, Cc, cs, out.data_ptr(), VC, 0,
-                  B, H, W, maxdisp, 1 if mask_left else 0, _stream())
+                  B, H, W, maxdisp, 1 if mask_left else 0, attach_meta(out).data_ptr(), _stream())
     return out
 
 

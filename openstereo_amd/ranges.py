@@ -1,0 +1,76 @@
+"""f16x3 operand ranges: the per-tensor "range blocks" the split-precision conv kernels scale their operands by.
+
+Layout and arithmetic are documented with `osa_f16x3_ranges` in include/openstereo_amd.h."""
+from __future__ import annotations
+
+import torch
+
+# ----------------------------------------------------------------------------- f16x3 operand ranges
+# Every activation tensor that f16x3 layers touch carries a 16-float "range block" in device memory
+# (`t._osa_meta`; layout in include/openstereo_amd.h, osa_f16x3_ranges): [0] = running max |value|, folded in
+# by each producing kernel with an atomic max, [1] = the power-of-two scale of a split tensor's halves.  The
+# consumer derives its operand scale from it ON THE DEVICE, so nothing here synchronises with the host and
+# the whole chain can be captured in a hipGraph.  Blocks are slices of zero-filled arenas; an arena is never
+# reused (a slot is handed out once), and stream capture gets an arena of its own so that the captured
+# zero-fill is replayed with the graph.
+META_FLOATS = 16
+_ARENA_SLOTS = 256
+_arena = None        # [tensor, next free slot, allocated during stream capture?]
+
+
+def new_meta(device) -> torch.Tensor:
+    """A fresh zeroed range block on `device`."""
+    global _arena
+    cap = torch.cuda.is_current_stream_capturing()
+    if _arena is None or _arena[0].device != device or _arena[1] >= _ARENA_SLOTS or _arena[2] != cap:
+        _arena = [torch.zeros(_ARENA_SLOTS * META_FLOATS, device=device, dtype=torch.float32), 0, cap]
+    t, i, _ = _arena
+    _arena[1] = i + 1
+    return t[i * META_FLOATS:(i + 1) * META_FLOATS]
+
+
+def meta_of(t):
+    return None if t is None else getattr(t, "_osa_meta", None)
+
+
+def input_meta(t) -> torch.Tensor:
+    """Range block for an operand of an engine call.  Engine-produced tensors carry theirs; for anything else
+    (torch ops, user input) max |t| is computed NOW by torch (device side, no host sync) into a fresh block that is
+    NOT cached on the tensor -- the caller may overwrite the tensor in place before the next call (static hipGraph
+    inputs), and a captured graph must contain the reduction."""
+    m = getattr(t, "_osa_meta", None)
+    if m is None:
+        m = new_meta(t.device)
+        m[0:1] = t.detach().abs().amax().reshape(1).float()
+    return m
+
+
+def ensure_meta(t) -> torch.Tensor:
+    """Like input_meta, but the block is attached to `t`: for tensors the caller has just created and will not
+    modify (several engine layers then share one reduction)."""
+    m = getattr(t, "_osa_meta", None)
+    if m is None:
+        m = new_meta(t.device)
+        m[0:1] = t.detach().abs().amax().reshape(1).float()
+        t._osa_meta = m
+    return m
+
+
+def fold_amax(t, values):
+    """`values` were written into the engine buffer `t` by torch ops (slice assignment): fold their max |.| into
+    t's range block, as an engine producer would have done."""
+    m = getattr(t, "_osa_meta", None)
+    if m is None:
+        m = new_meta(t.device)
+        t._osa_meta = m
+    m[0:1] = torch.maximum(m[0:1], values.detach().abs().amax().reshape(1).float())
+    return t
+
+
+def attach_meta(t):
+    """Give an engine-allocated output buffer a fresh (zero) range block if it has none."""
+    m = getattr(t, "_osa_meta", None)
+    if m is None:
+        m = new_meta(t.device)
+        t._osa_meta = m
+    return m

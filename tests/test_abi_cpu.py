@@ -40,15 +40,15 @@ def test_argument_counts_match_header():
 
 
 def test_version_and_target(lib):
-    assert lib.osa_abi_version() == 1
+    assert lib.osa_abi_version() == 2
     assert lib.osa_target_arch() == b"gfx950"
 
 
 def test_argument_validation_reports_errors_without_gpu(lib):
     """Validation happens before any launch, so it is testable on CPU."""
-    rc = lib.osa_build_volume_f32(None, None, 10, 3, None, None, 0, None, 0, 3, 0, 1, 4, 8, 4, 1, None)
+    rc = lib.osa_build_volume_f32(None, None, 10, 3, None, None, 0, None, 0, 3, 0, 1, 4, 8, 4, 1, None, None)
     assert rc != 0 and b"vol is NULL" in lib.osa_last_error()
-    rc = lib.osa_build_volume_f32(1, 1, 10, 3, None, None, 0, 1, 0, 3, 0, 1, 4, 8, 4, 1, None)
+    rc = lib.osa_build_volume_f32(1, 1, 10, 3, None, None, 0, 1, 0, 3, 0, 1, 4, 8, 4, 1, None, None)
     assert rc != 0 and b"not divisible" in lib.osa_last_error()          # cost_volume.py:61
     slack = 4 * 2 * 2 * 32 * 4                      # four prefetched tap steps
     assert lib.osa_conv3d_packed_floats(32, 32, 3, 3, 3) == (2 * 27 * 2 * 2 * 32 * 4) + slack
@@ -91,17 +91,17 @@ def test_argument_validation_of_round1_additions(lib):
     """Depthwise conv, 2-D transposed conv, fused redir branch, GRU combine: argument errors are reported
     (non-zero return + message) before anything is launched."""
     f = 16                                                      # any non-NULL, 16-byte aligned "pointer"
-    rc = lib.osa_dwconv2d_nhwc_f32(f, f, None, None, None, f, 1, 8, 8, 6, 8, 8, 0, 3, 3, 1, 1, 1, 1, 1, 0, None)
+    rc = lib.osa_dwconv2d_nhwc_f32(f, f, None, None, None, f, 1, 8, 8, 6, 8, 8, 0, 3, 3, 1, 1, 1, 1, 1, 0, None, None)
     assert rc != 0 and b"multiples of 4" in lib.osa_last_error()         # C = 6
-    rc = lib.osa_dwconv2d_nhwc_f32(f, f, None, None, None, f, 1, 8, 8, 8, 8, 8, 0, 3, 3, 3, 1, 1, 1, 1, 0, None)
+    rc = lib.osa_dwconv2d_nhwc_f32(f, f, None, None, None, f, 1, 8, 8, 8, 8, 8, 0, 3, 3, 3, 1, 1, 1, 1, 0, None, None)
     assert rc != 0 and b"stride" in lib.osa_last_error()
-    rc = lib.osa_dwconv2d_nhwc_f32(None, f, None, None, None, f, 1, 8, 8, 8, 8, 8, 0, 3, 3, 1, 1, 1, 1, 1, 0, None)
+    rc = lib.osa_dwconv2d_nhwc_f32(None, f, None, None, None, f, 1, 8, 8, 8, 8, 8, 0, 3, 3, 1, 1, 1, 1, 1, 0, None, None)
     assert rc != 0 and b"NULL" in lib.osa_last_error()
     rc = lib.osa_deconv2d_nhwc_f32(f, f, None, None, None, f, 1, 4, 4, 8, 8, 8, 8, 0, 5, 1, 1, None, 0, 0, 0.0, None)
     assert rc != 0 and b"only (k=3" in lib.osa_last_error()              # k = 5 unsupported
     rc = lib.osa_deconv3d_redir_ndhwc_f32(f, f, None, None, f, 1, 2, 4, 4, 64, 64, 32, 32, 3, 1, 1,
                                           f, 128, 128, f, None, None, 1, 0.0, None)
     assert rc != 0 and b"64 channels" in lib.osa_last_error()            # redir input wider than 64 channels
-    rc = lib.osa_gru_combine_f32(f, f, f, f, 10, 6, 8, 8, 8, 8, None)
+    rc = lib.osa_gru_combine_f32(f, f, f, f, 10, 6, 8, 8, 8, 8, None, None)
     assert rc != 0 and b"multiple of 4" in lib.osa_last_error()
     assert lib.osa_deconv2d_packed_floats(64, 32, 3) == (4 * 9 * 2 * 2 * 32 * 4) + 4 * 2 * 2 * 32 * 4

@@ -639,7 +639,7 @@ def test_gru_combine_and_sigmoid_tanh_epilogues():
     z, q, h = (T(np.random.default_rng(s).uniform(-1, 1, (2, 32, 9, 14)).astype(np.float32)) for s in (5, 6, 7))
     zc, qc, hc = (nchw_to_cl(t.to(DEV)) for t in (z, q, h))
     out = ops.empty_cl(2, 32, 1, 9, 14, DEV)
-    _lib.call("osa_gru_combine_f32", zc.data_ptr(), qc.data_ptr(), hc.data_ptr(), out.data_ptr(), 2 * 9 * 14, 32, 32, 32, 32, 32, ops._stream())
+    _lib.call("osa_gru_combine_f32", zc.data_ptr(), qc.data_ptr(), hc.data_ptr(), out.data_ptr(), 2 * 9 * 14, 32, 32, 32, 32, 32, None, ops._stream())
     close(cl_to_nchw(out), (1 - z) * h + z * q, 0, 0, "gru combine")
 
 
