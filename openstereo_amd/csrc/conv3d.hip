@@ -484,6 +484,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
         }
         scv[n] = sc; shv[n] = sh;
     }
+    const unsigned amax_seen = p.out_meta ? amax_peek(p.out_meta) : 0u;   // early: its latency hides behind the epilogue
     __syncthreads();                                   // everyone is done reading the input brick
     if (p.dbg & 8) {                                   // timing only: no epilogue (keeps the accumulators live)
         float s = 0.f;
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
         }
     }
     // ---- publish max |output| of this wave into the output's range block
-    if (p.out_meta) publish_amax(p.out_meta, am);
+    if (p.out_meta) publish_amax(p.out_meta, am, amax_seen);
 }
 
 // ------------------------------------------------------------------ dispatch --

@@ -23,6 +23,7 @@ struct DwArgs {
 __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     float am = 0.f;
+    const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
     if (idx < p.total) {
     const int nq = p.C >> 2;
     const int q = (int)(idx % nq);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
     *reinterpret_cast<float4*>(p.y + opix * p.yCs + c) = make_float4(o[0], o[1], o[2], o[3]);
     am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
-    if (p.meta) publish_amax(p.meta, am);
+    if (p.meta) publish_amax(p.meta, am, am_seen);
 }
 
 __global__ __launch_bounds__(256) void dwconv2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int T) {

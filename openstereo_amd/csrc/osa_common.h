@@ -40,17 +40,19 @@ static inline int exp_int(const char*, int dflt) { return dflt; }
 static inline bool exp_set(const char*) { return false; }
 #endif
 
-// Publish a wave's max |value| into a tensor's range block (meta[0], uint bit pattern of a float >= 0):
-// one conditional atomic per wave; the relaxed pre-check keeps almost every wave off the atomic unit once
-// the maximum has settled.  Call with all 64 lanes active.
-__device__ __forceinline__ void publish_amax(float* meta, float am) {
+// Range blocks (osa_f16x3_ranges): a producing kernel folds max |value| of its outputs into meta[0] (uint bit
+// pattern of a float >= 0, so integer order == float order).  amax_peek() is issued EARLY (before the epilogue /
+// store loop) so that the L2 round trip of the pre-check overlaps real work; publish_amax() then costs a wave
+// reduction and, only while the maximum is still rising, one fire-and-forget atomic.  The peeked value may be
+// stale (lower): that only means a redundant atomic.  Call publish_amax with all 64 lanes active.
+__device__ __forceinline__ unsigned amax_peek(const float* meta) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(meta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_amax(float* meta, float am, unsigned seen) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-    if ((threadIdx.x & 63) == 0 && am > 0.f) {
-        unsigned* a = reinterpret_cast<unsigned*>(meta);
-        const unsigned mb = __builtin_bit_cast(unsigned, am);
-        if (mb > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, mb);
-    }
+    const unsigned mb = __builtin_bit_cast(unsigned, am);
+    if ((threadIdx.x & 63) == 0 && mb > seen) atomicMax(reinterpret_cast<unsigned*>(meta), mb);
 }
 
 // MI355X: 8 XCDs, each with a private L2; workgroup b is observed on XCD b % 8.

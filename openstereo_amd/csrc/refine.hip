@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restric
                                                           long long total, int nq, int zCs, int qCs, int hCs, int oCs, float* meta) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     float am = 0.f;
+    const unsigned am_seen = meta ? amax_peek(meta) : 0u;
     if (i < total) {
     const long long px = i / nq;
     const int c = (int)(i - px * nq) * 4;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restric
     *reinterpret_cast<float4*>(out + px * oCs + c) = o;
     am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    if (meta) publish_amax(meta, am);
+    if (meta) publish_amax(meta, am, am_seen);
 }
 }  // namespace osa
 

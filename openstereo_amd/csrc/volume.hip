@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
     const float invK = 1.0f / (float)p.K;
     (void)invK;
     float am = 0.f;
+    const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
     for (int c = lane; c < nch; c += 64) {
         for (int wl = wave; wl < VOL_WT; wl += 4) {
             const int w = w0 + wl;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
             }
         }
     }
-    if (p.meta) publish_amax(p.meta, am);
+    if (p.meta) publish_amax(p.meta, am, am_seen);
 }
 
 // ---- NDHWC, quad lanes: every lane produces 4 consecutive output channels of one voxel ----
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
     const int rq = nq_g + (cq - G4 - nq_c);           // right-concat slot of this lane (role 2)
     float* vout = p.vol + p.coff + cq * 4;
     float am = 0.f;
+    const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
 #pragma unroll 4
     for (int dd = 0; dd < q.DCH; ++dd) {
         const int d = d0 + dd;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
     }
-    if (p.meta) publish_amax(p.meta, am);
+    if (p.meta) publish_amax(p.meta, am, am_seen);
 }
 
 // ------------------------------------------------------------------ NCDHW ----

@@ -240,15 +240,15 @@ class PackedConv3d:
             assert not (fmt & RES_SPLIT) or res_off % 16 == 0
             assert not out_split or (self.Co % 16 == 0 and yCs % 16 == 0 and out_off % 16 == 0)
             act |= fmt
-        rng = None
+        rng, st = None, _stream()
         if self.precision == "f16x3":
             # operand ranges (device-side): scale of x / residual / redir input, bound for a split output, and the
             # output's own running maximum
             rng = _lib.F16x3Ranges(input_meta(x).data_ptr(), None if residual is None else input_meta(residual).data_ptr(),
-                                   None if redir is None else input_meta(redir[1]).data_ptr(), attach_meta(out).data_ptr(),
+                                   None if redir is None else input_meta(redir[1]).data_ptr(), attach_meta(out, st).data_ptr(),
                                    self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
-            tail = (self.out_scale, rng, _stream()) if self.precision == "f16x3" else (_stream(),)
+            tail = (self.out_scale, rng, st) if self.precision == "f16x3" else (st,)
             sfx = "f16x3" if self.precision == "f16x3" else "f32"
             if redir is not None:
                 rl, rt = redir

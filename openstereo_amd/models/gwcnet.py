@@ -149,12 +149,13 @@ class _Features(nn.Module):
 
 
 class GwcBackbone(nn.Module):
+    use_engine = True        # False: the feature extractor runs as PyTorch-ROCm (MIOpen) modules
+
     def __init__(self, use_concat_volume=True, concat_channels=12):
         super().__init__()
         self.use_concat_volume = use_concat_volume
         self.concat_channels = concat_channels if use_concat_volume else 0
         self.feature_extraction = _Features(use_concat_volume, self.concat_channels)
-        self.use_engine = True
 
     def forward(self, inputs):
         """Reference contract: NCHW feature dicts.  engine=True (default on GPU in eval mode) runs the
@@ -162,14 +163,19 @@ class GwcBackbone(nn.Module):
         that conversion and hands the NHWC maps straight to the volume builder."""
         left, right = inputs["left"], inputs["right"]
         B = left.shape[0]
-        if self.use_engine and not self.training and left.is_cuda:
+        if self.use_engine and not self.training and ops.on_engine(left):
             gwc, catf = self.forward_cl(left, right)
             f = {"gwc_feature": ops.to_ncdhw(gwc)[:, :, 0]}
             if catf is not None:
                 f["concat_feature"] = ops.to_ncdhw(catf, self.concat_channels)[:, :, 0]
+        elif self.training:
+            # gwcnet_backbone.py:108-109: two separate calls -- with FREEZE_BN off (the GwcNet / PSMNet default) each call has
+            # its own batch statistics and its own momentum update of the running statistics
+            with timing.span("backbone2d", left.shape[2], left.shape[3]):
+                return {"ref_feature": self.feature_extraction(left), "tgt_feature": self.feature_extraction(right)}
         else:
             with timing.span("backbone2d", left.shape[2], left.shape[3]):
-                f = self.feature_extraction(torch.cat((left, right), 0))
+                f = self.feature_extraction(torch.cat((left, right), 0))       # eval: per-sample arithmetic, one pass
         ref = {k: v[:B] for k, v in f.items()}
         tgt = {k: v[B:] for k, v in f.items()}
         return {"ref_feature": ref, "tgt_feature": tgt}
@@ -377,7 +383,7 @@ class GwcNet(nn.Module):
         self.DispProcessor.reset_engine()
 
     def forward(self, inputs):
-        if self.Backbone.use_engine and not self.training and inputs["left"].is_cuda:
+        if self.Backbone.use_engine and not self.training and ops.on_engine(inputs["left"]):
             # fused engine path: NHWC features never leave the engine layout
             B = inputs["left"].shape[0]
             gwc, catf = self.Backbone.forward_cl(inputs["left"], inputs["right"])

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
-from ..ops import empty_cl, is_cl, _stream
+from ..ops import empty_cl, is_cl, on_engine, _stream
 from ..ranges import attach_meta, fold_amax, meta_of, new_meta
 from .lightstereo import nchw_to_cl, cl_to_nchw
 
@@ -205,7 +205,7 @@ class BasicMultiUpdateBlock(nn.Module):
         return net, mask(net[0]), delta_disp
 
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
-        if not net[0].is_cuda:
+        if not on_engine(net[0]):
             raise RuntimeError("openstereo_amd BasicMultiUpdateBlock runs on the GPU engine only (no CPU path)")
         c = nchw_to_cl
         net_cl = [c(t) for t in net]
@@ -239,7 +239,7 @@ class IGEVRefiner(nn.Module):
 
     def forward(self, match_left, match_right, geo_encoding_volume, net_list, inp_list, init_disp, iters):
         from ..geometry import CombinedGeoEncodingVolume
-        if not match_left.is_cuda:
+        if not on_engine(match_left):
             raise RuntimeError("openstereo_amd IGEVRefiner runs on the GPU engine only (no CPU path)")
         a = self.args
         geo_fn = CombinedGeoEncodingVolume(match_left.float(), match_right.float(), geo_encoding_volume.float(),

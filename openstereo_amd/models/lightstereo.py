@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from ..engine import cached_pack, PackedConv3d, DepthwiseConv2d, ACT_NONE, ACT_RELU, ACT_RELU6
-from ..ops import empty_cl, is_cl
+from ..ops import empty_cl, is_cl, on_engine
 
 
 def nchw_to_cl(x):
@@ -163,7 +163,7 @@ class Aggregation(nn.Module):
         return conv6
 
     def forward(self, x, features_left):
-        if not x.is_cuda:
+        if not on_engine(x):
             raise RuntimeError("openstereo_amd Aggregation runs on the GPU engine only (no CPU path)")
         out = self.forward_cl(nchw_to_cl(x), [nchw_to_cl(f) for f in features_left[:3]])
         return [cl_to_nchw(out, self.conv6[0].out_channels)]
@@ -185,7 +185,7 @@ class LightStereoCostStage(nn.Module):
 
     def forward(self, features_left, feature_right):
         from .. import ops
-        if not features_left[0].is_cuda:
+        if not on_engine(features_left[0]):
             raise RuntimeError("openstereo_amd LightStereoCostStage runs on the GPU engine only (no CPU path)")
         D4 = self.max_disp // 4
         vol = ops.correlation_volume(features_left[0], feature_right, D4)              # [B, D/4, H/4, W/4]

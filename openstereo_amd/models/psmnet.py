@@ -138,8 +138,10 @@ class PSMBackbone(nn.Module):
         left, right = inputs["left"], inputs["right"]
         B = left.shape[0]
         with timing.span("backbone2d", left.shape[2], left.shape[3]):
+            if self.training:          # psmnet_backbone.py:119-133: separate calls (separate BatchNorm batch statistics)
+                return {"ref_feature": self._forward(left), "tgt_feature": self._forward(right)}
             x = torch.cat((left, right), 0)
-            if self.use_engine and x.is_cuda and not self.training:
+            if self.use_engine and ops.on_engine(x):
                 f = self.forward_cl(x)[:, :32, 0].contiguous()
             else:
                 f = self._forward(x)
@@ -263,7 +265,7 @@ class PSMCostProcessor(nn.Module):
     def forward(self, inputs):
         """Engine path: keeps the three costs at 1/4 resolution (the fused heads upsample on the fly)."""
         l, r = inputs["ref_feature"], inputs["tgt_feature"]
-        vol = ops.build_cost_volume_cl(None, None, 0, l, r, maxdisp=int(self.max_disp // 4))
+        vol = ops.build_cost_volume_cl(None, None, 0, l, r, maxdisp=int(self.aggregator.max_disp // 4))   # attribute the reference class has too
         cost3, cost2, cost1 = self.aggregator.aggregate_cl(vol)
         return {"cost1": cost1, "cost2": cost2, "cost3": cost3}
 
@@ -286,7 +288,7 @@ class PSMDispProcessor(nn.Module):
         for k in ("cost1", "cost2", "cost3"):
             c = inputs[k]
             if c.dim() == 5:
-                out.append(ops.upsample_softargmin(c, self.max_disp, h, w, align_corners=True))
+                out.append(ops.upsample_softargmin(c, self.disp_processor.max_disp, h, w, align_corners=True))
             else:
                 out.append(self.disp_processor(c))
         return out

@@ -26,6 +26,12 @@ from .ranges import attach_meta
 NCDHW, NDHWC = 0, 1
 
 
+def on_engine(t) -> bool:
+    """True when tensor `t` lives where the engine runs (a GPU).  The one place the module forwards ask; the CPU
+    wiring tests (tests/engine_emulation.py) swap it together with the engine layer classes."""
+    return t.is_cuda
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -315,6 +321,10 @@ class FasterSoftArgmin(torch.nn.Module):
         if self.start_disp != 0 or self.dilation != 1:
             raise NotImplementedError("FasterSoftArgmin: only start_disp=0, dilation=1")
         c = cost_volume * self.alpha if self.alpha != 1.0 else cost_volume
+        if torch.is_grad_enabled() and c.requires_grad:          # training: forward + backward on the engine through autograd
+            from . import autograd as AG
+            out = AG.softmax_disparity_regression(c, keepdim=False) if self.normalize else AG.disparity_regression(c, c.shape[1], keepdim=False)
+            return out.to(cost_volume.dtype)
         if self.normalize:
             return softmax_disparity_regression(c, keepdim=False)
         return disparity_regression(c, c.shape[1], keepdim=False)

@@ -15,18 +15,26 @@ import torch
 # zero-fill is replayed with the graph.
 META_FLOATS = 16
 _ARENA_SLOTS = 256
-_arena = None        # [tensor, next free slot, allocated during stream capture?]
+_arena = None        # [tensor, next free slot, allocated during stream capture?, stream handle it was made on]
 
 
-def new_meta(device) -> torch.Tensor:
-    """A fresh zeroed range block on `device`."""
+def new_meta(device, stream=None) -> torch.Tensor:
+    """A fresh zeroed range block on `device`.  `stream` (raw handle of the current stream, when the caller has it
+    anyway) keys the arena: stream capture runs on a stream of its own, so a change of stream is when the capture
+    state is re-examined -- the per-call cost is then one integer comparison.  (A block from a pre-capture arena
+    baked into a graph would merely never be re-zeroed: its maximum then covers every replay so far -- still a
+    valid bound, the results just stop being independent of history.)"""
     global _arena
-    cap = torch.cuda.is_current_stream_capturing()
-    if _arena is None or _arena[0].device != device or _arena[1] >= _ARENA_SLOTS or _arena[2] != cap:
-        _arena = [torch.zeros(_ARENA_SLOTS * META_FLOATS, device=device, dtype=torch.float32), 0, cap]
-    t, i, _ = _arena
-    _arena[1] = i + 1
-    return t[i * META_FLOATS:(i + 1) * META_FLOATS]
+    a = _arena
+    if a is None or a[1] >= _ARENA_SLOTS or a[0].device != device or stream is None or a[3] != stream:
+        cap = torch.cuda.is_current_stream_capturing()
+        if a is None or a[1] >= _ARENA_SLOTS or a[0].device != device or a[2] != cap:
+            a = _arena = [torch.zeros(_ARENA_SLOTS * META_FLOATS, device=device, dtype=torch.float32), 0, cap, stream]
+        else:
+            a[3] = stream
+    i = a[1]
+    a[1] = i + 1
+    return a[0][i * META_FLOATS:(i + 1) * META_FLOATS]
 
 
 def meta_of(t):
@@ -67,10 +75,10 @@ def fold_amax(t, values):
     return t
 
 
-def attach_meta(t):
+def attach_meta(t, stream=None):
     """Give an engine-allocated output buffer a fresh (zero) range block if it has none."""
     m = getattr(t, "_osa_meta", None)
     if m is None:
-        m = new_meta(t.device)
+        m = new_meta(t.device, stream)
         t._osa_meta = m
     return m

@@ -17,7 +17,7 @@ def test_patch_and_unpatch_reference():
     orig = cv.build_gwc_volume
     done = attach.patch_reference()
     try:
-        assert cv.build_gwc_volume is ops.build_gwc_volume and cv.correlation_volume is ops.correlation_volume
+        assert cv.build_gwc_volume is attach.build_gwc_volume and cv.correlation_volume is attach.correlation_volume
         assert "stereo.modeling.cost_volume.cost_volume.build_gwc_volume" in done
         assert "stereo.modeling.models.psmnet.psmnet_cost_processor.cat_fms" in done
         assert "GwcVolumeCostProcessor.build_gwc_volume" in done
@@ -26,21 +26,6 @@ def test_patch_and_unpatch_reference():
     finally:
         attach.unpatch_reference()
     assert cv.build_gwc_volume is orig
-
-
-def test_attach_gwcnet_shares_parameters():
-    import importlib
-    import torch
-    from openstereo_amd import attach
-    attach.stub_reference_packages(REF)
-    RefGwc = importlib.import_module("stereo.modeling.models.gwcnet.gwcnet").GwcNet
-
-    class C(dict):
-        __getattr__ = dict.__getitem__
-    ref = RefGwc(C(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40)).eval()
-    eng = attach.attach_gwcnet(ref)
-    for (k1, v1), (k2, v2) in zip(ref.state_dict().items(), eng.state_dict().items()):
-        assert k1 == k2 and torch.equal(v1, v2)
 
 
 def test_patch_reference_modules_grafts_engine_forwards():
@@ -60,10 +45,11 @@ def test_patch_reference_modules_grafts_engine_forwards():
     try:
         assert "stereo.modeling.models.lightstereo.aggregation.Aggregation" in done
         assert "stereo.modeling.models.igev.update.BasicMultiUpdateBlock" in done
-        assert agg_mod.Aggregation.forward is LS.Aggregation.forward and hasattr(agg_mod.MobileV2Residual, "forward_cl")
+        assert agg_mod.Aggregation.forward is not orig_fwd and agg_mod.Aggregation.forward_cl is LS.Aggregation.forward_cl
+        assert hasattr(agg_mod.MobileV2Residual, "forward_cl")
         agg = agg_mod.Aggregation(in_channels=48, left_att=True, blocks=[1, 2, 4], expanse_ratio=4,
                                   backbone_channels=[24, 32, 96, 160]).eval()
-        with pytest.raises(RuntimeError, match="GPU engine only"):
+        with torch.no_grad(), pytest.raises(RuntimeError, match="GPU engine only"):
             agg(torch.zeros(1, 48, 8, 16), [torch.zeros(1, 24, 8, 16), torch.zeros(1, 32, 4, 8), torch.zeros(1, 96, 2, 4)])
         assert upd_mod.ConvGRU._eng is None
     finally:

@@ -1,0 +1,190 @@
+"""CPU (build container only: needs /root/reference): reference-BUILT models run through the engine forwards that
+`attach.patch_reference_modules()` grafts onto the reference's own classes, with every engine layer replaced by
+its torch-CPU stand-in (tests/engine_emulation.py), and must reproduce the reference's own forward on the same
+parameters and inputs.  This pins the wiring of the grafts (SURVEY 8a patch list: gwcnet.hourglass.Hourglass,
+GwcDispProcessor, PSM Hourglass / PSMAggregator, stereobase.hourglass.Hourglass, igev_stereo.hourglass) against
+the real classes; the kernels behind the layers are pinned on the GPU by tests/test_gpu_parity.py."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rnd
+from openstereo_amd.utils.weights import synth_state_dict, synth_images
+
+REF = os.environ.get("OPENSTEREO_REF", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not mounted")
+
+
+class C(dict):
+    __getattr__ = dict.__getitem__
+
+    def get(self, k, d=None):
+        return dict.get(self, k, d)
+
+
+@pytest.fixture()
+def patched():
+    from openstereo_amd import attach
+    import engine_emulation as EMU
+    attach.stub_reference_packages(REF)
+    state = {}
+
+    def on():
+        state["fn"] = attach.patch_reference()
+        state["cls"] = attach.patch_reference_modules()
+        state["un"] = EMU.install()
+
+    def off():
+        if "un" in state:
+            state.pop("un")()
+            attach.unpatch_reference()
+    yield on, off, state
+    off()
+
+
+def _max_err(a, b):
+    return float((a - b).abs().max())
+
+
+def test_reference_gwcnet_runs_on_grafted_engine_forwards(patched):
+    on, off, st = patched
+    from openstereo_amd import attach
+    attach.stub_reference_packages(REF)
+    RefGwc = importlib.import_module("stereo.modeling.models.gwcnet.gwcnet").GwcNet
+    net = RefGwc(C(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40))
+    net.load_state_dict(synth_state_dict(net, seed=0))
+    net.eval()
+    L, R = synth_images(1, 64, 128, seed=1)
+    with torch.no_grad():
+        ref = net({"left": L, "right": R})["disp_pred"]
+    g = golden("gwcnet_small.npz")
+    assert np.abs(ref.numpy() - g["disp"]).mean() < 1e-5            # same model / inputs as the committed golden
+    orig_hg = type(net.DispProcessor.dres2).forward
+    on()
+    assert "stereo.modeling.models.gwcnet.hourglass.Hourglass" in st["cls"]
+    assert "stereo.modeling.models.gwcnet.gwcnet_disp_processor.GwcDispProcessor" in st["cls"]
+    assert type(net.DispProcessor.dres2).forward is not orig_hg      # class-level graft reaches the existing instance
+    with torch.no_grad():
+        eng = net({"left": L, "right": R})["disp_pred"]               # fused path: GwcNet.forward graft
+        f = net.Backbone({"left": L, "right": R})                     # stage contracts (NCHW feature dicts)
+        hg_in = rnd((1, 32, 8, 8, 16), 77)
+        hg_out = net.DispProcessor.dres2(hg_in)
+    off()
+    with torch.no_grad():
+        assert _max_err(net.DispProcessor.dres2(hg_in), hg_out) < 1e-4
+        f_ref = net.Backbone({"left": L, "right": R})
+    assert type(net.DispProcessor.dres2).forward is orig_hg
+    assert eng.shape == ref.shape and float((eng - ref).abs().mean()) < 1e-4, float((eng - ref).abs().mean())
+    for side in ("ref_feature", "tgt_feature"):
+        for k in ("gwc_feature", "concat_feature"):
+            assert _max_err(f[side][k], f_ref[side][k]) < 1e-3 * max(1.0, float(f_ref[side][k].abs().max()))
+
+
+def test_reference_psmnet_runs_on_grafted_engine_forwards(patched):
+    on, off, st = patched
+    RefPSM = importlib.import_module("stereo.modeling.models.psmnet.psmnet").PSMNet
+    net = RefPSM(C(MAX_DISP=64))
+    net.load_state_dict(synth_state_dict(net, seed=0, head_gain=3.0), strict=False)
+    net.eval()
+    L, R = synth_images(1, 256, 256, seed=1, max_shift=16.0)      # SPP pools 64x64 at quarter resolution
+    with torch.no_grad():
+        ref = net({"left": L, "right": R})
+    on()
+    assert "stereo.modeling.models.psmnet.psmnet_cost_processor.PSMAggregator" in st["cls"]
+    with torch.no_grad():
+        eng = net({"left": L, "right": R})
+        hg = net.CostProcessor.aggregator.dres2
+        x, pre, post = rnd((1, 32, 8, 8, 12), 1), rnd((1, 64, 4, 4, 6), 2), rnd((1, 64, 4, 4, 6), 3)
+        got = hg(x, pre, post)
+    off()
+    with torch.no_grad():
+        want = net.CostProcessor.aggregator.dres2(x, pre, post)
+    for a, b in zip(got, want):
+        assert _max_err(a, b) < 1e-4
+    for a, b in zip(eng["train_preds"], ref["train_preds"]):
+        assert a.shape == b.shape and float((a - b).abs().mean()) < 1e-4
+
+
+def test_reference_stereobase_hourglass(patched):
+    on, off, st = patched
+    SB = importlib.import_module("stereo.modeling.models.stereobase.hourglass").Hourglass
+    hg = SB(24, backbone_channels=[96, 64, 192, 120])
+    hg.load_state_dict(synth_state_dict(hg, seed=6))
+    hg.eval()
+    g = golden("stereobase_hourglass.npz")
+    T = torch.from_numpy
+    x, feats = T(g["x"]), [None, T(g["f1"]), T(g["f2"]), T(g["f3"])]
+    on()
+    assert "stereo.modeling.models.stereobase.hourglass.Hourglass" in st["cls"]
+    with torch.no_grad():
+        y, y1, y2 = hg(x, feats, return_multi=True)
+    off()
+    for got, key in ((y, "y"), (y1, "y1"), (y2, "y2")):
+        assert _max_err(got, T(g[key])) < 3e-5 * max(1.0, float(np.abs(g[key]).max())), key
+
+
+def test_reference_igev_hourglass(patched):
+    on, off, st = patched
+    T = torch.from_numpy
+    import sys
+    import types
+    if "timm" not in sys.modules:                                    # igev_stereo imports timm through its 2-D extractor (not used here)
+        sys.modules["timm"] = types.ModuleType("timm")
+    try:
+        IG = importlib.import_module("stereo.modeling.models.igev.igev_stereo").hourglass
+    except Exception as ex:
+        pytest.skip(f"igev_stereo not importable here: {type(ex).__name__}: {ex}")
+    ih = IG(8)
+    ih.load_state_dict(synth_state_dict(ih, seed=7))
+    ih.eval()
+    gi = golden("igev_hourglass.npz")
+    on()
+    with torch.no_grad():
+        yi = ih(T(gi["x"]), [None, T(gi["f1"]), T(gi["f2"]), T(gi["f3"])])
+    off()
+    assert _max_err(yi, T(gi["y"])) < 3e-5 * max(1.0, float(np.abs(gi["y"]).max()))
+
+
+def test_patched_functions_are_differentiable_dispatch(patched, monkeypatch):
+    """Under the patch the helpers route to the autograd Functions as soon as an argument requires grad (ADVICE r1:
+    the round-1 patch bound non-differentiable entries -> silent zero gradient into the backbone)."""
+    from openstereo_amd import attach, autograd as AG
+    attach.stub_reference_packages(REF)
+    cv = importlib.import_module("stereo.modeling.cost_volume.cost_volume")
+    calls = []
+    monkeypatch.setattr(AG, "build_gwc_volume", lambda l, r, d, g: calls.append("gwc") or (l[:, :g, None] * r[:, :g, None]).expand(-1, -1, d, -1, -1))
+    monkeypatch.setattr(AG, "disparity_regression", lambda x, d, keepdim=True: calls.append("reg") or x.sum(1, keepdim=keepdim))
+    attach.patch_reference()
+    try:
+        l = torch.randn(1, 8, 4, 6, requires_grad=True)
+        v = cv.build_gwc_volume(l, torch.randn(1, 8, 4, 6), 3, 4)
+        assert calls == ["gwc"] and v.requires_grad
+        v.sum().backward()
+        assert l.grad is not None and float(l.grad.abs().sum()) > 0
+        dr = importlib.import_module("stereo.modeling.disp_pred.disp_regression")
+        p = torch.softmax(torch.randn(1, 5, 4, 6, requires_grad=True), 1)
+        out = dr.disparity_regression(p, 5)
+        assert calls == ["gwc", "reg"] and out.shape == (1, 1, 4, 6) and out.requires_grad
+        with torch.no_grad(), pytest.raises(Exception, match="no CPU path|engine"):
+            cv.build_gwc_volume(l, l, 3, 4)                           # no grad -> the non-recording engine entry (GPU only)
+    finally:
+        attach.unpatch_reference()
+
+
+def test_attach_gwcnet_shares_parameter_objects():
+    from openstereo_amd import attach
+    attach.stub_reference_packages(REF)
+    RefGwc = importlib.import_module("stereo.modeling.models.gwcnet.gwcnet").GwcNet
+    ref = RefGwc(C(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40)).eval()
+    eng = attach.attach_gwcnet(ref)
+    rp, ep = dict(ref.named_parameters()), dict(eng.named_parameters())
+    assert rp.keys() == ep.keys() and all(ep[k] is rp[k] for k in rp)              # the SAME Parameter objects
+    rb, eb = dict(ref.named_buffers()), dict(eng.named_buffers())
+    assert rb.keys() == eb.keys() and all(eb[k] is rb[k] for k in rb)
+    with torch.no_grad():
+        ref.DispProcessor.dres0[0][0].weight.add_(1.0)
+    assert torch.equal(eng.DispProcessor.dres0[0][0].weight, ref.DispProcessor.dres0[0][0].weight)
+    assert not eng.training
