@@ -1,22 +1,33 @@
-"""Headline benchmark: stereo-pairs/s, GwcNet-gc forward (inference), 540x960 padded to 544x960,
-D=192 (BASELINE.json configs[1]) on N MI355X -- one process per GPU, independent pairs, no
-data-path collective (weak scaling).
+"""Headline benchmark: stereo-pairs/s, GwcNet-gc forward (inference), 540x960 padded to 544x960, D=192
+(BASELINE.json configs[1]) on N MI355X -- one process per GPU, independent pairs, no data-path collective
+(weak scaling).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py                                   # 1 GPU, default K / W
+    python bench.py --gpus 8 --steps 20 --warmup 5    # re-executes itself under torch.distributed.run, 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W           # what the driver does
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : the dominant kernel (fp32-MFMA 3x3x3 conv, 32->32 @ 48x136x240), timed live with
-                 HIP events on the launch stream in an instrumented replay of the same forward
-  cpu_baseline : the CPU oracle (torch fp32 restatement of the reference path) on this box's host
-                 cores, one full-size pair (rank 0, N=1 only)
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline     : the dominant kernel (3x3x3 conv 32->32 @ 48x136x240), timed live with HIP events on the launch
+                 stream in an instrumented replay of the same forward; `rooflines` holds the same record for the
+                 volume builder (HBM), the 2-D backbone (MFMA), the fused soft-argmin head (HBM) and the classifier
+  cpu_baseline : the CPU path on this box's host cores (rank 0, N=1): the REAL reference modules through the import
+                 shim when /root/reference is mounted ("reference"), else the oracle restatement ("port");
+                 1 warm-up + 3 timed full-size pairs, median, per-stage split
+Other workloads (BASELINE configs [2]-[4]; same JSON contract, their own metric string):
+  --workload lightstereo_kitti15   correlation volume -> 2-D aggregation -> soft-argmin -> convex upsample, 384x1248
+  --workload igev_refine32         geometry-encoding lookup + 3-level ConvGRU update x 32 iterations, 544x960
+  --workload stereobase_train      StereoBase cost stage training step (fwd + bwd + SGD), 320x736 crop, DDP over RCCL
+  --workload gwcnet_train          GwcNet training step, 256x512 crop, DDP over RCCL
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,74 +37,413 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 H_IMG, W_IMG, H_PAD, W_PAD, MAXDISP = 540, 960, 544, 960, 192
-# MI355X_MICROARCH.md dense peaks.  f16x3 executes 3 fp16 MFMAs per fp32-equivalent product, so the
-# roofline for ALGORITHMIC flops in that mode is 2500 / 3.
+# MI355X_MICROARCH.md dense peaks.  f16x3 executes 3 fp16 MFMAs per fp32-equivalent product, so the roofline for
+# ALGORITHMIC flops in that mode is 2500 / 3.
 PEAKS = {"f32": (157.3, "v_mfma_f32_32x32x2_f32 dense peak"),
          "f16x3": (2500.0 / 3.0, "fp16 MFMA dense peak 2500 TF / 3 MFMAs per fp32-equivalent product")}
+HBM_PEAK = 8000.0          # GB/s (spec; ~6.3 TB/s achievable)
 DTYPES = {"f32": "f32", "f16x3": "f32 via f16x3 split-MFMA (hi/lo fp16 operands, f32 accumulate; HBM tensors f32)"}
-# algorithmic MACs per pair of one 3x3x3 32->32 layer at 48x136x240 (43.32 GMAC)
-DOM_GFLOP = 2 * 27 * 32 * 32 * 48 * 136 * 240 / 1e9
+# algorithmic work per pair
+DOM_GFLOP = 2 * 27 * 32 * 32 * 48 * 136 * 240 / 1e9       # one 3x3x3 32->32 layer at 48x136x240 (43.32 GMAC)
+BACKBONE_GFLOP = 461.6
+VOLUME_MB, HEAD_MB, CLASSIF_MB = 487.8, 8.36, 200.5 + 6.27
+# rocprofv3 names of the timed kernels (verbatim, as in profiles/round2/*_kernel_stats.csv)
+KERNEL_NAMES = {
+    ("conv", "f16x3"): "void osa::conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1>(osa::ConvArgs)",
+    ("conv", "f32"): "void osa::conv_mfma_kernel<0, 1, 1, 2, 1, 4, 1, 8, 8, 0, 0>(osa::ConvArgs)",
+    "volume": "void osa::build_volume_quads_kernel<2, 8>(osa::VolQArgs)",
+    "head": "osa::upsample4_softargmin_kernel(osa::UpArgs)",
+    "classifier": "void osa::conv_small_co_tiled_kernel<1, true>(osa::ConvArgs, float const*, float const*)",
+}
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: 2 inference, 1 training)")
+    ap.add_argument("--workload", default="gwcnet",
+                    choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "gwcnet_train"))
     ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling runs: nothing but warm-up + the timed configuration (no other-precision leg, no B=1 loop, no CPU leg)")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU plumbing self-test (tests/test_sharding_gloo.py): gloo backend, the forward replaced by a sleep")
+    return ap.parse_args()
+
+
+# ============================================================================================ workloads
+class GwcNetInference:
+    metric = "stereo-pairs/s at 540x960 D=192 (GwcNet fwd)"
+    scaling, graphable, training = "weak", True, False
+
+    def __init__(self, args, dev, rank):
+        from openstereo_amd.models.gwcnet import GwcNet
+        from openstereo_amd.utils.weights import synth_state_dict, synth_images
+        self.B = args.batch or 2
+        net = GwcNet()
+        self.sd = synth_state_dict(net, seed=0)
+        net.load_state_dict(self.sd)
+        self.net = net.to(dev).eval()
+        # 540x960 SceneFlow-shaped pair, edge-padded top/right to 544x960 (RightTopPad, stereo_trans.py:243-267)
+        L0, R0 = synth_images(self.B, H_IMG, W_IMG, seed=1 + rank)
+        pad = lambda t: torch.nn.functional.pad(t, (0, W_PAD - W_IMG, H_PAD - H_IMG, 0), mode="replicate")
+        self.L, self.R = pad(L0).to(dev), pad(R0).to(dev)        # inputs resident in HBM before timing starts
+
+    def step(self):
+        with torch.no_grad():
+            return self.net({"left": self.L, "right": self.R})["disp_pred"]
+
+    def config(self, args):
+        return {"workload": "GwcNet-gc inference, SceneFlow-shaped 540x960 padded to 544x960, D=192, G=40 + 12ch concat "
+                            "(BASELINE configs[1])",
+                "weights": "deterministic synthetic (sharpened), random-init architecture"}
+
+
+class LightStereoKitti15:
+    """BASELINE configs[3]: LightStereo-S hot path at KITTI15 size (375x1242 padded to 384x1248, cfgs/lightstereo/kitti15_eval.yaml:12):
+    correlation_volume -> Aggregation -> softmax + disparity_regression -> context_upsample (lightstereo.py:51-62).  The timm
+    feature extractor is not available offline: its outputs are synthetic NCHW feature maps of the documented shapes."""
+    metric = "stereo-pairs/s, LightStereo-S cost stage at 384x1248 D=192"
+    scaling, graphable, training = "weak", True, False
+
+    def __init__(self, args, dev, rank):
+        from openstereo_amd.models.lightstereo import LightStereoCostStage
+        from openstereo_amd.utils.weights import synth_state_dict
+        self.B = B = args.batch or 2
+        st = LightStereoCostStage(max_disp=192)
+        st.load_state_dict(synth_state_dict(st, seed=9))
+        self.st = st.to(dev).eval()
+        g = torch.Generator().manual_seed(60 + rank)
+        r = lambda *s: torch.randn(*s, generator=g).to(dev)
+        self.fl = [r(B, 24, 96, 312), r(B, 32, 48, 156), r(B, 96, 24, 78)]
+        self.fr = torch.roll(self.fl[0], -3, 3) + 0.1 * r(B, 24, 96, 312)
+        self.spx = r(B, 9, 384, 1248)
+
+    def step(self):
+        from openstereo_amd import ops
+        with torch.no_grad():
+            out = self.st(self.fl, self.fr)
+            return ops.context_upsample(out["init_disp"], self.spx, softmax_weights=True, gain=4.0)
+
+    def config(self, args):
+        return {"workload": "LightStereo-S: correlation volume (24ch, D/4=48) -> 2-D aggregation -> soft-argmin -> convex x4 upsample, "
+                            "KITTI15 375x1242 padded to 384x1248 (BASELINE configs[3]); synthetic feature maps stand in for the timm backbone"}
+
+
+class IGEVRefine32:
+    """BASELINE configs[4]: the IGEV refinement loop at SceneFlow size (quarter resolution 136x240), VALID_ITERS = 32
+    (cfgs/igev/igev_sceneflow_amp.yaml:31; igev_stereo.py:181-203) + the final convex upsample."""
+    metric = "stereo-pairs/s, IGEV GRU refinement x32 at 544x960"
+    scaling, graphable, training = "weak", False, False
+
+    def __init__(self, args, dev, rank):
+        from openstereo_amd.models.igev_update import IGEVRefiner
+        from openstereo_amd.utils.weights import synth_state_dict
+        self.B = B = args.batch or 1
+        a = _Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2, SLOW_FAST_GRU=True)
+        ref = IGEVRefiner(a, hidden_dims=[128, 128, 128])
+        ref.load_state_dict(synth_state_dict(ref, seed=11))
+        self.ref = ref.to(dev).eval()
+        g = torch.Generator().manual_seed(70 + rank)
+        r = lambda *s: torch.randn(*s, generator=g).to(dev)
+        H, W = 136, 240
+        self.ml, self.mr, self.gvol = r(B, 96, H, W), r(B, 96, H, W), r(B, 8, 48, H, W)
+        self.net = [torch.tanh(r(B, 128, H >> i, W >> i)) for i in range(3)]
+        self.inp = [[0.5 * r(B, 128, H >> i, W >> i) for _ in range(3)] for i in range(3)]
+        self.d0 = r(B, 1, H, W).abs() * 3
+        self.spx = r(B, 9, 4 * H, 4 * W)
+
+    def step(self):
+        from openstereo_amd import ops
+        with torch.no_grad():
+            out = self.ref(self.ml, self.mr, self.gvol, list(self.net), self.inp, self.d0, 32)
+            return ops.context_upsample(out["disp"], self.spx, softmax_weights=True, gain=4.0)
+
+    def config(self, args):
+        return {"workload": "IGEV refinement: geometry-encoding volume (all-pairs corr + pyramid) once, then 32 x (fused 2-level 9-tap lookup "
+                            "+ 3-level ConvGRU update block + disparity update) at 136x240, + convex x4 upsample to 544x960 "
+                            "(BASELINE configs[4]); synthetic features / hidden states stand in for the timm extractor"}
+
+
+class StereoBaseTrain:
+    """BASELINE configs[2]: StereoBase training step on the hot path -- gwc(8) + concat volume -> Hourglass(24) with FeatureAtt ->
+    classifier -> softmax regression (stereobase_gru.py:139-164), forward + backward + SGD, SceneFlow crop 320x736
+    (cfgs/stereobase/stereobase_sceneflow.yaml:15-16), data parallel with DistributedDataParallel (RCCL all-reduce)."""
+    metric = "training stereo-pairs/s, StereoBase cost stage at 320x736 crop"
+    scaling, graphable, training = "weak", False, True
+
+    def __init__(self, args, dev, rank):
+        from openstereo_amd.models.igev_style import StereoBaseCostStage
+        from openstereo_amd.utils.weights import synth_state_dict
+        self.B = B = args.batch or 1
+        st = StereoBaseCostStage(max_disp=192, num_groups=8, concat_channels=8, backbone_channels=[48, 64, 192, 120])
+        st.load_state_dict(synth_state_dict(st, seed=8, head_gain=20.0))
+        st = st.to(dev).train()
+        for m in st.modules():                                    # FREEZE_BN: true (stereobase_sceneflow.yaml:48)
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+                m.eval()
+        self.raw = st
+        self.model = st
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            self.model = torch.nn.parallel.DistributedDataParallel(st, device_ids=[dev.index])
+        self.opt = torch.optim.SGD([p for p in st.parameters() if p.requires_grad], lr=1e-4)
+        g = torch.Generator().manual_seed(80 + rank)
+        r = lambda *s: torch.randn(*s, generator=g).to(dev)
+        H, W = 80, 184
+        self.x = [r(B, 96, H, W).requires_grad_(), r(B, 96, H, W).requires_grad_(), r(B, 8, H, W), r(B, 8, H, W)]
+        self.feats = [None, r(B, 64, H // 2, W // 2), r(B, 192, H // 4, W // 4), r(B, 120, H // 8, W // 8)]
+        self.gt = torch.rand(B, 1, H, W, generator=g).to(dev) * 40
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model(*self.x, self.feats)
+        loss = torch.nn.functional.smooth_l1_loss(out["init_disp"], self.gt)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def config(self, args):
+        return {"workload": "StereoBase cost stage training step (volume -> Hourglass(24)+FeatureAtt -> classifier -> softmax regression; "
+                            "fwd + bwd + SGD, frozen BN), SceneFlow crop 320x736, 1 pair per GPU (BASELINE configs[2]); synthetic feature "
+                            "maps stand in for the timm backbone"}
+
+
+class GwcNetTrain:
+    metric = "training stereo-pairs/s, GwcNet at 256x512 crop"
+    scaling, graphable, training = "weak", False, True
+
+    def __init__(self, args, dev, rank):
+        import numpy as np
+        from openstereo_amd.models.gwcnet import GwcNet
+        from openstereo_amd.utils.weights import synth_state_dict, synth_images
+        self.B = B = args.batch or 1
+        net = GwcNet()
+        net.load_state_dict(synth_state_dict(net, seed=0))
+        self.raw = net.to(dev).train()
+        self.model = self.raw
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            self.model = torch.nn.parallel.DistributedDataParallel(self.raw, device_ids=[dev.index])
+        self.opt = torch.optim.RMSprop(self.model.parameters(), lr=1e-3)      # cfgs/gwcnet/gwcnet_sceneflow.yaml
+        L, R = synth_images(B, 256, 512, seed=10 + rank)
+        self.L, self.R = L.to(dev), R.to(dev)
+        self.gt = torch.from_numpy(np.random.default_rng(rank).uniform(1, 100, (B, 256, 512)).astype("float32")).to(dev)
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model({"left": self.L, "right": self.R})
+        loss, _ = self.raw.get_loss(out, {"disp": self.gt})
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def config(self, args):
+        return {"workload": "GwcNet-gc training step (4 supervised heads, fwd + bwd + RMSprop, batch statistics BN), SceneFlow crop 256x512 "
+                            "(cfgs/gwcnet/gwcnet_sceneflow.yaml), 1 pair per GPU"}
+
+
+class _Stub:
+    """--stub: no GPU, no engine; exercises launcher, process group, barrier, MAX-over-ranks timing and the JSON line."""
+    metric = "stub-pairs/s"
+    scaling, graphable, training = "weak", False, False
+
+    def __init__(self, args, dev, rank):
+        self.B, self.rank = args.batch or 2, rank
+
+    def step(self):
+        time.sleep(0.002 * (1 + self.rank))
+        return torch.zeros(1)
+
+    def config(self, args):
+        return {"workload": "stub"}
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+WORKLOADS = {"gwcnet": GwcNetInference, "lightstereo_kitti15": LightStereoKitti15, "igev_refine32": IGEVRefine32,
+             "stereobase_train": StereoBaseTrain, "gwcnet_train": GwcNetTrain}
+
+
+# ============================================================================================ rooflines (GwcNet)
+def gwcnet_rooflines(wl, args, eager_step, nrep):
+    """Instrumented replay: HIP events around every engine launch on the launch stream."""
+    from openstereo_amd import engine
+    B, prec = wl.B, args.precision
+    rec = engine.enable_timing()
+    for _ in range(nrep):
+        eager_step()
+    torch.cuda.synchronize()
+    stats = engine.collect_timing(rec)
+    per_step = {"/".join(map(str, k)): round(sum(v) / nrep, 4) for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1]))}
+    traffic = {}
+    tj = os.path.join(ROOT, "profiles", "traffic.json")                    # PMC bytes per launch, measured offline (profiles/round2)
+    if os.path.exists(tj):
+        traffic = json.load(open(tj))
+
+    def avg_ms(pred):
+        sel = [v for k, v in stats.items() if pred(k)]
+        n = sum(len(v) for v in sel)
+        return (sum(sum(v) for v in sel) / n) if n else None
+
+    peak, why = PEAKS[prec]
+    out = []
+    ms = avg_ms(lambda k: k[0] == "conv3d" and k[1:] == (32, 32, 3, 1, 48, 136, 240))
+    if ms:
+        ach = DOM_GFLOP * B / ms
+        out.append({"kernel": KERNEL_NAMES[("conv", prec)], "what": f"3x3x3 conv 32->32 @48x136x240, {B} pairs per launch (4 launches per step)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "peak_note": why, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "algorithmic_gflop_per_launch": round(DOM_GFLOP * B, 2),
+                    "traffic": traffic.get(f"conv3d_32_32_V0_{prec}_B{B}"), "avg_launch_ms": round(ms, 4)})
+    ms = avg_ms(lambda k: k[0] == "build_volume")
+    if ms:
+        ach = VOLUME_MB * B / ms                                             # MB / ms = GB/s
+        out.append({"kernel": KERNEL_NAMES["volume"], "what": f"fused gwc(40)+concat(24) volume, NDHWC, {B} pairs per launch", "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                    "algorithmic_mb_per_launch": round(VOLUME_MB * B, 1), "traffic": traffic.get(f"volume_B{B}"), "avg_launch_ms": round(ms, 4)})
+    ms = avg_ms(lambda k: k[0] == "backbone2d_engine")
+    if ms:
+        ach = BACKBONE_GFLOP * B / ms
+        out.append({"kernel": "2-D feature extractor: ~85 launches of osa::conv_mfma_kernel<...> with D = 1 (both images of every pair)",
+                    "what": f"GwcNet backbone, {2 * B} images per step", "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(ms, 4)})
+    ms = avg_ms(lambda k: k[0] == "upsample_softargmin")
+    if ms:
+        ach = HEAD_MB * B / ms
+        out.append({"kernel": KERNEL_NAMES["head"], "what": f"fused trilinear x4 + softmax + expectation, {B} pairs per launch", "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                    "traffic": traffic.get(f"head_B{B}"), "avg_launch_ms": round(ms, 4)})
+    ms = avg_ms(lambda k: k[0] == "conv3d_small_co")
+    if ms:
+        ach = CLASSIF_MB * B / ms
+        out.append({"kernel": KERNEL_NAMES["classifier"], "what": f"classif3.2: 3x3x3 conv 32->1 @48x136x240, {B} pairs per launch", "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                    "traffic": traffic.get(f"classifier_B{B}"), "avg_launch_ms": round(ms, 4)})
+    return out, per_step
+
+
+# ============================================================================================ CPU baseline (GwcNet)
+def gwcnet_cpu_baseline(wl, gpu_out):
+    """SURVEY 8d procedure: the reference modules through the import shim when the checkout is mounted, else the oracle
+    restatement; fp32, no_grad, all host cores, 1 warm-up + 3 timed full-size pairs, median, per-stage split."""
+    from oracle import torch_ref as O           # CPU-baseline leg only (the checker / the "port")
+    Lc, Rc, sd = wl.L[:1].cpu(), wl.R[:1].cpu(), wl.sd
+    ref_root = os.environ.get("OPENSTEREO_REF", "/root/reference")
+    kind, run = "port", None
+    if os.path.isdir(os.path.join(ref_root, "stereo")):
+        try:
+            import importlib
+            from openstereo_amd import attach
+            attach.stub_reference_packages(ref_root)
+            RefGwc = importlib.import_module("stereo.modeling.models.gwcnet.gwcnet").GwcNet
+            net = RefGwc(_CfgGet(MAX_DISP=192, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=12, DOWNSAMPLE=4, NUM_GROUPS=40))
+            net.load_state_dict(sd)
+            net.eval()
+
+            def run(stages):
+                inputs = {"left": Lc, "right": Rc}
+                t = time.perf_counter(); inputs.update(net.Backbone(inputs)); stages["backbone"] = time.perf_counter() - t
+                t = time.perf_counter(); inputs.update(net.CostProcessor(inputs)); stages["volume"] = time.perf_counter() - t
+                t = time.perf_counter(); out = net.DispProcessor(inputs); stages["aggregation+head"] = time.perf_counter() - t
+                return out["inference_disp"]["disp_est"]
+            kind = "reference"
+        except Exception as ex:
+            print(f"[bench] reference not importable ({type(ex).__name__}: {ex}); CPU baseline = oracle port", file=sys.stderr)
+    if run is None:
+        def run(stages):
+            t = time.perf_counter(); lg, lc = O.gwc_features(Lc, sd); rg, rc = O.gwc_features(Rc, sd); stages["backbone"] = time.perf_counter() - t
+            t = time.perf_counter()
+            vol = torch.cat((O.gwc_volume(lg, rg, 48, 40), O.concat_volume(lc, rc, 48)), 1); stages["volume"] = time.perf_counter() - t
+            t = time.perf_counter(); c3 = O.gwc_aggregate(vol, sd); stages["aggregation"] = time.perf_counter() - t
+            t = time.perf_counter(); d = O.upsample_regression(c3, 192, Lc.shape[2], Lc.shape[3]); stages["upsample+softargmin"] = time.perf_counter() - t
+            return d
+    with torch.no_grad():
+        O.gwcnet_forward(Lc[..., :64, :128].contiguous(), Rc[..., :64, :128].contiguous(), sd)     # warm-up (thread pool, allocator): small pair
+        times, splits, ref = [], [], None
+        for _ in range(3):
+            st = {}
+            t0 = time.perf_counter()
+            ref = run(st)
+            times.append(time.perf_counter() - t0)
+            splits.append(st)
+    med = statistics.median(times)
+    mid = splits[times.index(med)]
+    return {"value": round(1.0 / med, 5), "unit": "stereo-pairs/s", "cores": torch.get_num_threads(), "kind": kind,
+            "sample": "3 timed full-size 544x960 D=192 GwcNet forwards after a warm-up, fp32, torch.no_grad; value = 1 / median seconds",
+            "seconds": [round(t, 3) for t in times], "stage_seconds": {k: round(v, 3) for k, v in mid.items()},
+            "epe_gpu_vs_cpu_px": float((gpu_out[:1].cpu() - ref).abs().mean())}
+
+
+class _CfgGet(dict):
+    __getattr__ = dict.__getitem__
+
+
+# ============================================================================================ main
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one process per GPU over RCCL, exactly what the driver's torch.distributed.run line does
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)"
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
-    from openstereo_amd import _lib, engine
-    from openstereo_amd.models.gwcnet import GwcNet
-    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    if args.stub:
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=dev)       # "nccl" == RCCL on ROCm
+        from openstereo_amd import _lib, engine
+        _lib.load()
+        engine.set_precision(args.precision)
     from openstereo_amd.parallel import reduce_step_time, whole_job_rate
-    _lib.load()
-    engine.set_precision(args.precision)
 
-    net = GwcNet()
-    sd = synth_state_dict(net, seed=0)
-    net.load_state_dict(sd)
-    net = net.to(dev).eval()
-    B = args.batch
-    # 540x960 SceneFlow-shaped pair, edge-padded top/right to 544x960 (RightTopPad, stereo_trans.py:243-267)
-    L0, R0 = synth_images(B, H_IMG, W_IMG, seed=1 + rank)
-    pad = lambda t: torch.nn.functional.pad(t, (0, W_PAD - W_IMG, H_PAD - H_IMG, 0), mode="replicate")
-    L, R = pad(L0).to(dev), pad(R0).to(dev)        # inputs resident in HBM before timing starts
-
-    def step():
-        with torch.no_grad():
-            return net({"left": L, "right": R})["disp_pred"]
+    wl = (_Stub if args.stub else WORKLOADS[args.workload])(args, dev, rank)
+    B = wl.B
 
     def sync():
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
+    step = eager_step = wl.step
     for _ in range(args.warmup):
         step()
     sync()
-    # The forward is a fixed sequence of ~125 launches on static buffers: capture it once into a
-    # hipGraph (launch-bound inner loop -> one graph launch per step).  Warm-up above has already
-    # packed every weight, so nothing but kernels (and the caching allocator's graph pool) is recorded.
-    eager_step, graph = step, None
-    if not args.no_graph:
+    # The inference forwards are fixed sequences of launches on static buffers: capture once into a hipGraph (launch-bound
+    # inner loop -> one graph launch per step).  Warm-up has packed every weight, so only kernels (and the caching allocator's
+    # graph pool) are recorded.
+    graph = None
+    if wl.graphable and not args.no_graph and dev.type == "cuda":
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -108,106 +458,74 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
             graph, step = None, eager_step
             torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync()
     dt = reduce_step_time(time.perf_counter() - t0, dev)       # MAX over ranks
     assert torch.isfinite(out).all()
-    pairs_per_s = whole_job_rate(B, args.steps, world, dt)
+    rate = whole_job_rate(B, args.steps, world, dt)
 
-    # ---- instrumented replay: per-layer HIP events on the launch stream ----
-    def measure_roofline(prec, nrep):
-        rec = engine.enable_timing()
-        for _ in range(nrep):
-            eager_step()
-        torch.cuda.synchronize()
-        stats = engine.collect_timing(rec)
-        dom = [v for k, v in stats.items() if k[0] == "conv3d" and k[1:] == (32, 32, 3, 1, 48, 136, 240)]
-        if not dom:
-            return None, stats
-        ms = sum(sum(v) for v in dom) / sum(len(v) for v in dom) / B           # per pair
-        ach = DOM_GFLOP / ms                                                    # GFLOP / ms = TFLOP/s
-        peak, why = PEAKS[prec]
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")                    # PMC bytes per launch, measured offline
-        if os.path.exists(tj):
-            traffic = json.load(open(tj)).get(f"conv3d_32_32_V0_{prec}")
-        per_step = {"/".join(map(str, k)): round(sum(v) / nrep, 4) for k, v in
-                    sorted(stats.items(), key=lambda kv: -sum(kv[1]))}
-        return ({"kernel": f"conv_mfma_kernel<PREC_{prec.upper()},2,1,4,1,8,8> 3x3x3 32->32 @48x136x240 "
-                           f"(4 launches per pair, {DOM_GFLOP:.2f} algorithmic GFLOP each)",
-                 "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "peak_note": why,
-                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                 "avg_launch_ms": round(ms * B, 4),
-                 "stage_ms_per_step": dict(list(per_step.items())[:12])}, per_step)
+    line = {"metric": wl.metric, "value": round(rate, 3), "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": wl.scaling,
+            "vs_baseline": None, "dtype": "n/a (stub)" if args.stub else DTYPES[args.precision], "data": "synthetic"}
+    cfg = wl.config(args)
+    cfg.update({"pairs_per_gpu_per_step": B, "parallelism": (f"DDP x{world} (RCCL all-reduce of gradients)" if wl.training else f"independent pairs x{world}"),
+                "precision": args.precision, "launch": "hipGraph replay" if graph is not None else "eager"})
+    line["config"] = cfg
 
-    roofline, alt = None, None
+    if args.workload == "gwcnet" and not args.stub and rank == 0:
+        from openstereo_amd import engine
+        roofs, alt, latency_1, cpu = [], None, None, None
+        if not args.timed_only:
+            nrep = max(2, min(args.steps, 5))
+            roofs, per_step = gwcnet_rooflines(wl, args, eager_step, nrep)
+            cfg["stage_ms_per_step"] = dict(list(per_step.items())[:14])
+            if args.stages:
+                json.dump(per_step, open(args.stages, "w"), indent=1)
+            if world == 1:
+                # the other arithmetic mode, same workload (packed weights follow the mode switch by themselves)
+                other = "f32" if args.precision == "f16x3" else "f16x3"
+                engine.set_precision(other)
+                for _ in range(2):
+                    eager_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nrep):
+                    eager_step()
+                torch.cuda.synchronize()
+                t_other = (time.perf_counter() - t1) / nrep
+                args_o = argparse.Namespace(**{**vars(args), "precision": other})
+                r_other, _ = gwcnet_rooflines(wl, args_o, eager_step, 2)
+                alt = {"precision": other, "dtype": DTYPES[other], "value": round(B / t_other, 3), "unit": "stereo-pairs/s",
+                       "ms_per_step": round(t_other * 1e3, 3), "launch": "eager",
+                       "roofline": None if not r_other else {k: r_other[0][k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms")}}
+                engine.set_precision(args.precision)
+                out = eager_step()
+                # single-pair latency ("report B=1 latency and best-throughput B"), eager launches
+                if B != 1:
+                    with torch.no_grad():
+                        one = {"left": wl.L[:1], "right": wl.R[:1]}
+                        for _ in range(3):
+                            wl.net(dict(one))
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(10):
+                            wl.net(dict(one))
+                        torch.cuda.synchronize()
+                        latency_1 = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+                if not args.no_cpu_baseline:
+                    cpu = gwcnet_cpu_baseline(wl, out)
+        cfg["latency_ms_1_pair"] = latency_1
+        line["roofline"] = roofs[0] if roofs else None
+        line["rooflines"] = roofs[1:]
+        line["cpu_baseline"] = cpu
+        line["other_precision"] = alt
+    elif rank == 0:
+        line["roofline"], line["cpu_baseline"] = None, None
     if rank == 0:
-        nrep = max(2, min(args.steps, 5))
-        roofline, per_step = measure_roofline(args.precision, nrep)
-        if args.stages:
-            json.dump(per_step, open(args.stages, "w"), indent=1)
-        if world == 1:
-            # the other arithmetic mode, same workload, for reference (short run)
-            other = "f32" if args.precision == "f16x3" else "f16x3"
-            engine.set_precision(other)
-            net.reset_engine()
-            for _ in range(2):
-                eager_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(nrep):
-                eager_step()
-            torch.cuda.synchronize()
-            t_other = (time.perf_counter() - t1) / nrep
-            r_other, _ = measure_roofline(other, 2)
-            alt = {"precision": other, "dtype": DTYPES[other], "value": round(B / t_other, 3), "unit": "stereo-pairs/s",
-                   "ms_per_step": round(t_other * 1e3, 3),
-                   "roofline": None if r_other is None else {k: r_other[k] for k in ("kernel", "achieved", "peak", "frac")}}
-            engine.set_precision(args.precision)
-            net.reset_engine()
-            out = eager_step()
-
-    # single-pair latency ("report B=1 latency and best-throughput B"), eager launches
-    latency_1 = None
-    if rank == 0 and world == 1 and B != 1:
-        with torch.no_grad():
-            one = {"left": L[:1], "right": R[:1]}
-            for _ in range(3):
-                net(dict(one))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                net(dict(one))
-            torch.cuda.synchronize()
-            latency_1 = round((time.perf_counter() - t1) / 10 * 1e3, 3)
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import torch_ref as O      # CPU baseline leg only
-        Lc, Rc = L[:1].cpu(), R[:1].cpu()
-        with torch.no_grad():
-            t1 = time.perf_counter()
-            ref = O.gwcnet_forward(Lc, Rc, sd)
-            tc = time.perf_counter() - t1
-        epe = float((out[:1].cpu() - ref).abs().mean())
-        cpu_baseline = {"value": round(1.0 / tc, 5), "unit": "stereo-pairs/s", "cores": torch.get_num_threads(),
-                        "kind": "port", "sample": "1 full 544x960 D=192 GwcNet forward (oracle/torch_ref.py, fp32, no warm-up)",
-                        "epe_gpu_vs_cpu_px": epe}
-
-    if rank == 0:
-        print(json.dumps({
-            "metric": "stereo-pairs/s at 540x960 D=192 (GwcNet fwd)", "value": round(pairs_per_s, 3),
-            "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
-            "config": {"workload": "GwcNet-gc inference, SceneFlow-shaped 540x960 padded to 544x960, D=192, "
-                                   "G=40 + 12ch concat (BASELINE configs[1])",
-                       "pairs_per_gpu_per_step": B, "latency_ms_1_pair": latency_1, "parallelism": f"independent pairs x{world}",
-                       "precision": args.precision, "launch": "hipGraph replay" if graph is not None else "eager",
-                       "weights": "deterministic synthetic (sharpened), random-init architecture"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_precision": alt}))
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

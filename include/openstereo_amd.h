@@ -43,6 +43,7 @@ extern "C" {
 #endif
 
 #define OSA_ABI_VERSION 2
+#define OSA_META_FLOATS 128   /* floats per range block (osa_f16x3_ranges) */
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
 enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3, OSA_ACT_SIGMOID = 4, OSA_ACT_TANH = 5 };
@@ -73,7 +74,7 @@ const char* osa_target_arch(void);
  * left/right feature maps are NCHW contiguous.  `vol` has `vol_channels`
  * channels in `layout`; this call writes channels [c_off, c_off+G+2*Cc).
  * vol_meta: NULL, or the volume's range block (see osa_f16x3_ranges): the NDHWC kernels fold max |value|
- * into vol_meta[0] so that an f16x3 consumer can scale its operands.
+ * into it so that an f16x3 consumer can scale its operands.
  */
 int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups,
                          const float* left_cat, const float* right_cat, int Cc,
@@ -166,13 +167,14 @@ int osa_deconv3d_ndhwc_f32(const float* x, const float* w_packed,
  * Operand ranges of the f16x3 mode.  fp16 halves have a 5-bit exponent, so every operand tensor is brought
  * into range by a per-tensor POWER-OF-TWO scale (exact to apply and to undo): the largest |value| lands in
  * [2^14, 2^15), everything down to 2^-18 of it keeps 22 significant bits, smaller values degrade gracefully
- * and nothing is clamped.  The scale is derived ON THE DEVICE from a 16-float "range block" that travels with
- * each activation tensor (no host synchronisation, hipGraph friendly):
- *     meta[0]  running max |value| of the tensor -- every producing kernel folds its outputs in with an
- *              atomic max (zero the block before the first producer runs)
+ * and nothing is clamped.  The scale is derived ON THE DEVICE from a "range block" of OSA_META_FLOATS floats
+ * (512 bytes) that travels with each activation tensor (no host synchronisation, hipGraph friendly):
+ *     meta[16*s], s = 0..7   running max |value| of the tensor, in 8 slots on separate cache lines: every producing
+ *              workgroup folds its outputs into one slot with (at most) one atomic max; max|x| = max over the slots
+ *              (zero the block before the first producer runs; a host that knows max|x| may write it to meta[0])
  *     meta[1]  split tensors only: the scale their stored hi/lo halves carry (written by the producer)
- *     meta[2..15] reserved (work-queue words of the persistent kernels)
- * A plain fp32 input is scaled by pow2(meta[0]) while it is staged; a split OUTPUT must choose its scale
+ *     others   reserved (work-queue words of the persistent kernels)
+ * A plain fp32 input is scaled by pow2(max|x|) while it is staged; a split OUTPUT must choose its scale
  * before the maximum is known, from the rigorous bound
  *     max|y| <= bound_coef[0] * max|x| + bound_coef[1] (+ max|residual|) (+ redir_bound_coef[0] * max|rx| + redir_bound_coef[1])
  * with bound_coef = { max_co |bn_scale[co]| * sum|w[co]|, max_co |bn_shift[co]| } (device pointer, 2 floats).
@@ -269,7 +271,7 @@ int osa_deconv2d_nhwc_f16x3(const float* x, const float* w_packed,
  *   w_packed: [kh*kw][C], made by osa_dwconv2d_pack_f32 from the reference layout [C][1][kh][kw]
  *   scale/shift: folded eval BatchNorm or (1, bias); NULL = 1 / 0.   add: NHWC addend (stride aCs) or NULL
  *   act: OSA_ACT_NONE / OSA_ACT_RELU / OSA_ACT_RELU6.   C and all strides multiples of 4, fp32 exact (fmaf per tap).
- *   y_meta: NULL or y's range block (max |y| is folded into y_meta[0] for f16x3 consumers, see osa_f16x3_ranges).
+ *   y_meta: NULL or y's range block (max |y| is folded into it for f16x3 consumers, see osa_f16x3_ranges).
  */
 int osa_dwconv2d_pack_f32(const float* w_ref, float* w_packed, int C, int kh, int kw, void* stream);
 int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,

@@ -70,7 +70,7 @@ struct ConvArgs {
     unsigned magicH;              // ceil(2^32/LH)
     int dma;                      // 1: split input + compact LDS image -> stage rows by LDS-DMA (global_load_lds_dwordx4)
     // f16x3 range tracking (see osa_f16x3_ranges in the header); every pointer may be NULL.  A "meta" block is
-    // 16 floats of device memory per tensor: [0] = running max |value| (atomic max of uint bit patterns),
+    // OSA_META_FLOATS floats of device memory per tensor: running max |value| in 8 slots (osa_common.h),
     // [1] = power-of-two scale of the stored hi/lo halves when the tensor is a split tensor.
     const float* in_meta; const float* res_meta; const float* rx_meta; float* out_meta;
     const float* coef;            // [0] max_co |bn scale| * sum|w_co|, [1] max_co |bn shift|   (output bound of this layer)
@@ -265,15 +265,15 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
     // output (all wave-uniform scalar loads of a few device words; all 1 when no range block was passed)
     float s_in = 1.f, s_res_inv = 1.f, s_rx = 1.f, s_out = 1.f;
     if constexpr (PREC == PREC_F16X3) {
-        if (p.in_meta) s_in = (p.act & OSA_IN_SPLIT) ? p.in_meta[1] : pow2_scale(p.in_meta[0]);
+        if (p.in_meta) s_in = (p.act & OSA_IN_SPLIT) ? p.in_meta[1] : pow2_scale(amax_read(p.in_meta));
         if (p.res && p.res_meta && (p.act & OSA_RES_SPLIT)) s_res_inv = 1.0f / p.res_meta[1];
-        if (REDIR && p.rx_meta) s_rx = (p.act & OSA_REDIR_SPLIT) ? p.rx_meta[1] : pow2_scale(p.rx_meta[0]);
+        if (REDIR && p.rx_meta) s_rx = (p.act & OSA_REDIR_SPLIT) ? p.rx_meta[1] : pow2_scale(amax_read(p.rx_meta));
         if (OUTS && p.coef && p.in_meta) {
             // rigorous bound of |output|: sum|w| * max|x| * |bn scale| + |bn shift| (+ residual / redir branch);
             // activations only shrink it (sigmoid / tanh: 1)
-            float bound = p.coef[0] * p.in_meta[0] + p.coef[1];
-            if (p.res && p.res_meta) bound += p.res_meta[0];
-            if (REDIR && p.rcoef && p.rx_meta) bound += p.rcoef[0] * p.rx_meta[0] + p.rcoef[1];
+            float bound = p.coef[0] * amax_read(p.in_meta) + p.coef[1];
+            if (p.res && p.res_meta) bound += amax_read(p.res_meta);
+            if (REDIR && p.rcoef && p.rx_meta) bound += p.rcoef[0] * amax_read(p.rx_meta) + p.rcoef[1];
             const int ak = p.act & 15;
             if (ak == OSA_ACT_SIGMOID || ak == OSA_ACT_TANH) bound = 1.f;
             s_out = pow2_scale(bound * 1.0625f);
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
         }
     }
     // ---- publish max |output| of this wave into the output's range block
-    if (p.out_meta) publish_amax(p.out_meta, am, amax_seen);
+    if (p.out_meta) publish_amax(p.out_meta, am, amax_seen, reinterpret_cast<float*>(smem));   // (barrier inside: every wave is past its tiles)
 }
 
 // ------------------------------------------------------------------ dispatch --

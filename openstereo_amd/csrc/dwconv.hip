@@ -21,6 +21,7 @@ struct DwArgs {
 };
 
 __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
+    __shared__ float red[4];
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     float am = 0.f;
     const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
     *reinterpret_cast<float4*>(p.y + opix * p.yCs + c) = make_float4(o[0], o[1], o[2], o[3]);
     am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
-    if (p.meta) publish_amax(p.meta, am, am_seen);
+    if (p.meta) publish_amax(p.meta, am, am_seen, red);
 }
 
 __global__ __launch_bounds__(256) void dwconv2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int T) {

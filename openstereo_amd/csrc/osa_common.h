@@ -40,19 +40,39 @@ static inline int exp_int(const char*, int dflt) { return dflt; }
 static inline bool exp_set(const char*) { return false; }
 #endif
 
-// Range blocks (osa_f16x3_ranges): a producing kernel folds max |value| of its outputs into meta[0] (uint bit
-// pattern of a float >= 0, so integer order == float order).  amax_peek() is issued EARLY (before the epilogue /
-// store loop) so that the L2 round trip of the pre-check overlaps real work; publish_amax() then costs a wave
-// reduction and, only while the maximum is still rising, one fire-and-forget atomic.  The peeked value may be
-// stale (lower): that only means a redundant atomic.  Call publish_amax with all 64 lanes active.
-__device__ __forceinline__ unsigned amax_peek(const float* meta) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned*>(meta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Range blocks (osa_f16x3_ranges), OSA_META_FLOATS floats per tensor.  max |value| lives in 8 slots on separate
+// 64-byte lines (meta[0], meta[16], ... meta[112]; a consumer takes their maximum): atomics on one address
+// serialise at ~12 ns each, so producers (a) reduce inside the workgroup first -- at most ONE atomic per workgroup --,
+// (b) spread over the slots by blockIdx, and (c) skip the atomic when an EARLY relaxed peek of their slot (issued
+// before the epilogue / store loop, so its L2 round trip overlaps real work; possibly stale = lower, which only
+// means a redundant atomic) already covers their maximum.  Values are uint bit patterns of floats >= 0, so
+// integer order == float order; the atomics are fire-and-forget.
+constexpr int OSA_AMAX_SLOTS = 8, OSA_AMAX_STRIDE = 16;
+__device__ __forceinline__ float amax_read(const float* meta) {          // consumer side (after the producer kernel ended)
+    float m = meta[0];
+#pragma unroll
+    for (int s = 1; s < OSA_AMAX_SLOTS; ++s) m = fmaxf(m, meta[s * OSA_AMAX_STRIDE]);
+    return m;
 }
-__device__ __forceinline__ void publish_amax(float* meta, float am, unsigned seen) {
+__device__ __forceinline__ float* amax_slot(float* meta) { return meta + (blockIdx.x & (OSA_AMAX_SLOTS - 1)) * OSA_AMAX_STRIDE; }
+__device__ __forceinline__ unsigned amax_peek(float* meta) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(amax_slot(meta)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// All threads of the workgroup call this (it contains barriers).  `red`: >= blockDim.x / 64 floats of LDS nobody
+// else touches any more.
+__device__ __forceinline__ void publish_amax(float* meta, float am, unsigned seen, float* red) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-    const unsigned mb = __builtin_bit_cast(unsigned, am);
-    if ((threadIdx.x & 63) == 0 && mb > seen) atomicMax(reinterpret_cast<unsigned*>(meta), mb);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        float m = red[0];
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+        const unsigned mb = __builtin_bit_cast(unsigned, m);
+        if (mb > seen) atomicMax(reinterpret_cast<unsigned*>(amax_slot(meta)), mb);
+    }
 }
 
 // MI355X: 8 XCDs, each with a private L2; workgroup b is observed on XCD b % 8.

@@ -133,6 +133,7 @@ namespace osa {
 __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restrict__ z, const float* __restrict__ q,
                                                           const float* __restrict__ h, float* __restrict__ out,
                                                           long long total, int nq, int zCs, int qCs, int hCs, int oCs, float* meta) {
+    __shared__ float red[4];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     float am = 0.f;
     const unsigned am_seen = meta ? amax_peek(meta) : 0u;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restric
     *reinterpret_cast<float4*>(out + px * oCs + c) = o;
     am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    if (meta) publish_amax(meta, am, am_seen);
+    if (meta) publish_amax(meta, am, am_seen, red);
 }
 }  // namespace osa
 

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void build_volume_ndhwc_kernel(const VolArgs p
             }
         }
     }
-    if (p.meta) publish_amax(p.meta, am, am_seen);
+    if (p.meta) publish_amax(p.meta, am, am_seen, smem);
 }
 
 // ---- NDHWC, quad lanes: every lane produces 4 consecutive output channels of one voxel ----
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
     }
-    if (p.meta) publish_amax(p.meta, am, am_seen);
+    if (p.meta) publish_amax(p.meta, am, am_seen, reinterpret_cast<float*>(smq));
 }
 
 // ------------------------------------------------------------------ NCDHW ----

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from .. import _lib
 from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from ..ops import empty_cl, is_cl, on_engine, _stream
-from ..ranges import attach_meta, fold_amax, meta_of, new_meta
+from ..ranges import amax_of, attach_meta, ensure_meta, fold_amax, meta_of, new_meta
 from .lightstereo import nchw_to_cl, cl_to_nchw
 
 
@@ -66,7 +66,7 @@ def _cat_cl(parts, dev):
     metas = [meta_of(p) for p in parts]
     if all(m is not None for m in metas):        # f16x3 chains: max |.| of the concatenation = max over the parts (device side)
         m = new_meta(dev)
-        m[0:1] = torch.stack([t[0] for t in metas]).amax().reshape(1)
+        m[0:1] = torch.cat([amax_of(t) for t in metas]).amax().reshape(1)
         out._osa_meta = m
     return out
 
@@ -110,9 +110,9 @@ class ConvGRU(nn.Module):
         hx = _cat_cl([h, *x_list], h.device)                   # [h | x]
         z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
         rhx = hx.clone()                                       # [r*h | x]: the x part is shared, r*h overwrites the h slice
-        if meta_of(hx) is not None:                            # same range: |r*h| <= |h|
-            rhx._osa_meta = new_meta(h.device)
-            rhx._osa_meta.copy_(meta_of(hx))
+        if pz.precision == "f16x3":                            # range block of [r*h | x]: that of [h | x] (|r*h| <= |h|); convr only
+            rhx._osa_meta = new_meta(h.device)                 # folds its own slice in, the cloned x part would be missed
+            rhx._osa_meta.copy_(ensure_meta(hx))
         pr(hx, residual=cr, gate=_nhwc(h), gate_raw=True, out=rhx, out_off=0)   # sigmoid(convr(hx) + cr) * h
         q = pq(rhx, residual=cq)                               # tanh(convq([r*h, x]) + cq)
         out = empty_cl(*h.shape, h.device)

@@ -7,13 +7,13 @@ import torch
 
 # ----------------------------------------------------------------------------- f16x3 operand ranges
 # Every activation tensor that f16x3 layers touch carries a 16-float "range block" in device memory
-# (`t._osa_meta`; layout in include/openstereo_amd.h, osa_f16x3_ranges): [0] = running max |value|, folded in
-# by each producing kernel with an atomic max, [1] = the power-of-two scale of a split tensor's halves.  The
+# (`t._osa_meta`; layout in include/openstereo_amd.h, osa_f16x3_ranges): running max |value| in 8 slots, folded in
+# by each producing workgroup with an atomic max, [1] = the power-of-two scale of a split tensor's halves.  The
 # consumer derives its operand scale from it ON THE DEVICE, so nothing here synchronises with the host and
 # the whole chain can be captured in a hipGraph.  Blocks are slices of zero-filled arenas; an arena is never
 # reused (a slot is handed out once), and stream capture gets an arena of its own so that the captured
 # zero-fill is replayed with the graph.
-META_FLOATS = 16
+META_FLOATS = 128      # OSA_META_FLOATS: max |value| in 8 slots at [0], [16], ... [112]; [1] = scale of a split tensor
 _ARENA_SLOTS = 256
 _arena = None        # [tensor, next free slot, allocated during stream capture?, stream handle it was made on]
 
@@ -73,6 +73,11 @@ def fold_amax(t, values):
         t._osa_meta = m
     m[0:1] = torch.maximum(m[0:1], values.detach().abs().amax().reshape(1).float())
     return t
+
+
+def amax_of(meta) -> torch.Tensor:
+    """max |value| recorded in a range block (device tensor, shape [1])."""
+    return meta[0:META_FLOATS:16].amax().reshape(1)
 
 
 def attach_meta(t, stream=None):

@@ -696,7 +696,7 @@ def test_psmnet_spp_backbone_engine_vs_reference_golden_and_torch_path():
 
 @pytest.mark.parametrize("prec", PRECS)
 def test_gwcnet_batch_invariance_and_odd_size(prec):
-    """Batched inference equals per-pair inference bit for bit (per-batch-item base pointers, 32-bit
+    """Batched inference equals per-pair inference (bit for bit in exact-f32 mode: per-batch-item base pointers, 32-bit
     offsets), also for an image size whose quarter resolution is not a multiple of the brick sizes."""
     from openstereo_amd import engine
     from openstereo_amd.models.gwcnet import GwcNet
@@ -711,7 +711,11 @@ def test_gwcnet_batch_invariance_and_odd_size(prec):
             both = net({"left": L.to(DEV), "right": R.to(DEV)})["disp_pred"]
             for i in range(3):
                 one = net({"left": L[i:i + 1].to(DEV), "right": R[i:i + 1].to(DEV)})["disp_pred"]
-                assert torch.equal(both[i:i + 1], one), f"pair {i}: batched != single ({(both[i:i+1] - one).abs().max().item():.3e})"
+                if prec == "f32":
+                    assert torch.equal(both[i:i + 1], one), f"pair {i}: batched != single ({(both[i:i+1] - one).abs().max().item():.3e})"
+                else:       # f16x3: the operand scale is a power of two derived from the max over the WHOLE batch tensor, so elements below
+                    # 2^-18 of that maximum round differently when the batch changes: agreement to fp32 rounding, not bit for bit
+                    assert float((both[i:i + 1] - one).abs().max()) < 2e-4, f"pair {i}: {(both[i:i+1] - one).abs().max().item():.3e}"
         assert torch.isfinite(both).all() and both.std() > 1.0
     finally:
         engine.set_precision(old)
@@ -719,9 +723,8 @@ def test_gwcnet_batch_invariance_and_odd_size(prec):
 
 def test_split_activation_format_chain():
     """f16x3 mode: activations handed from one engine layer to the next in the split hi/lo format
-    (producer epilogue splits, consumer staging copies).  Without residuals the chain is bit-identical
-    to the fp32-tensor chain (the consumer would have computed the same split); with a split residual
-    and a fused redir branch it stays within the usual tolerance of the torch reference."""
+    (producer epilogue splits, consumer staging copies): same results as the fp32-tensor chain to fp32
+    rounding; with a split residual and a fused redir branch within the usual tolerance of the torch reference."""
     from openstereo_amd import ops
     from openstereo_amd.engine import PackedConv3d, is_split
     mk = lambda ci, co, k, s, name: (lambda c: (setattr(c.weight, "data", synth_tensor(name, c.weight.shape, 1)), c)[1])(
@@ -740,8 +743,9 @@ def test_split_activation_format_chain():
     ya_plain = pa(xc)
     ya = pa(xc, out_split=True)
     assert is_split(ya) and not is_split(ya_plain)
-    # consumer of a split tensor (no residual) == consumer of the fp32 tensor, bit for bit
-    assert torch.equal(pb(ya), pb(ya_plain))
+    # consumer of a split tensor == consumer of the fp32 tensor (the two carry different power-of-two scales -- bound-based
+    # vs measured maximum -- so only elements below 2^-18 of the maximum may round differently)
+    close(pb(ya), pb(ya_plain), atol=2e-6, rtol=2e-6, what="split vs fp32 hand-over")
     yb = pb(ya, residual=ya, out_split=True)                 # split input, split residual, split output
     yc = pc(yb)                                              # split input, fp32 output, stride 2
     assert not is_split(yc)

@@ -56,3 +56,28 @@ def test_single_process_degenerates():
     assert shard_pairs(5, 0, 1) == [0, 1, 2, 3, 4]
     assert reduce_step_time(0.5, torch.device("cpu")) == 0.5
     assert whole_job_rate(2, 10, 1, 4.0) == 5.0
+
+
+def test_bench_self_launches_n_ranks_and_reports_whole_job_rate():
+    """`python bench.py --gpus 2` re-executes itself under torch.distributed.run with 2 ranks (the flag
+    used to be ignored).  --stub swaps the GPU forward for a sleep and RCCL for gloo, everything else is the real script:
+    launcher, process group, barrier + MAX-over-ranks timing, the one JSON line of rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak"
+    # rank 1 sleeps 4 ms per step, rank 0 2 ms: the MAX over ranks sets the time, both ranks' pairs count
+    assert 4.0 <= d["ms_per_step"] < 40.0
+    assert abs(d["value"] - 2 * 2 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-2
+    # a world size that does not match --gpus is an error, not a silent 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--stub"], capture_output=True, text=True,
+                         timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
