@@ -1,0 +1,986 @@
+// 3-D cost-aggregation convolutions for gfx950.
+//
+// im2col-free implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+//   M = output voxels (32 per MFMA tile), N = output channels (32 per tile),
+//   K = taps x input channels.
+// A workgroup owns a (TD x TH x TW) brick of "a-space" positions; the input brick it needs
+// (halo included) is staged channels-last into LDS one 16-channel chunk at a time with a
+// voxel stride of 20 floats (80 B: 16-byte aligned and conflict-free for ds_read_b128).  Every
+// tap is then just a wave-uniform LDS offset: the A operand of 4 consecutive MFMAs is one
+// ds_read_b128 per lane, the B operand one 16-byte load of the pre-packed weights
+// ([chunk][tap][octet][half][Cout][4]) that all waves of all workgroups share through L2.
+//
+// One kernel covers every layer shape through a tap table:
+//   out[a*os + oo] = sum_t  in[a*is + delta_t] . W_t
+//   stride-1/2 conv : os=1, is=stride, delta = k*dil - pad
+//   1x1x1           : one tap
+//   transposed conv (stride 2): 8 output-parity classes, os=2, oo=parity, is=1, only the
+//                     taps that hit real (non-inserted) inputs -> no zero insertion, no wasted MACs
+// Epilogue (fused): folded eval-mode BatchNorm (scale/shift), residual add, ReLU/LeakyReLU.
+//
+// This header holds the kernel template and its device helpers; conv3d.hip instantiates the tile configurations of
+// the stage -> barrier -> taps form, conv_pipe.hip the persistent LDS-DMA pipelined form (PIPE = 1).
+#pragma once
+#include "osa_common.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace osa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Arithmetic modes of the implicit GEMM:
+//   PREC_F32   v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak)
+//   PREC_F16X3 every fp32 operand x is split x = hi + lo (two fp16, 22 significant bits) and
+//              A.B ~= Ahi.Bhi + Ahi.Blo + Alo.Bhi on v_mfma_f32_32x32x16_f16 with fp32 accumulation:
+//              3 MFMAs of 32 cycles per K=16 instead of 8 of 64 -> 5.3x less matrix-pipe time at
+//              fp32-class accuracy (dropped term Alo.Blo ~ 2^-22 relative).  Weights are pre-scaled
+//              by a power of two into the fp16 normal range (undone exactly in the epilogue);
+//              activations are saturated to +-65504 when split.
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
+
+constexpr int CC = 16;        // input channels staged per pass (packed-weight format constant)
+constexpr int VS = CC + 4;    // LDS voxel stride in floats
+constexpr int JO = CC / 8;    // k-octets per chunk
+constexpr int MAX_TAPS = 64;   // 3x3x3 = 27; a fused k=4 transposed conv carries all 64 taps
+
+struct ConvArgs {
+    const float* x; const float4* w; const float* scale; const float* shift; const float* res; float* y;
+    const float* gate; int gCs;   // optional sigmoid channel gate, NHWC logits [B][Ho][Wo][gCs]
+    int B, Di, Hi, Wi, Ci, xCs;
+    int Do, Ho, Wo, Co, yCs, rCs;
+    int Ad, Ah, Aw;               // a-space extent of this launch
+    int isd, ish, isw;            // input step per a (per dim)
+    int os, ood, ooh, oow;        // output position = a*os + oo
+    int T;                        // taps
+    int cls_end[8];               // fused transposed conv: taps [cls_end[c-1], cls_end[c]) belong to output-parity class c
+    int dmin, hmin, wmin;         // min delta per dim
+    int LD, LH, LW;               // LDS brick dims (voxels)
+    int RowQ, PlaneQ;             // LDS float4s per brick row (padded) / per d-plane (16-byte units keep ds_read_b128)
+    int dbg;                      // debug switch (OSA_DBG): 1 = skip staging (timing experiments only)
+    int tilesD, tilesH, tilesW;
+    int nchunks, CoP;
+    int cps;                      // channel chunks staged per pass (LDS holds cps bricks back to back)
+    int act; float slope;
+    float oscale;                 // f16x3: 1 / (weight pre-scale), exact power of two; 1 for f32
+    int VQ;                       // LDS voxel stride in 16-byte slots: 4 (compact) or 5 (padded), see finish_geometry
+    // fused 1x1x1 "redir" branch of a transposed conv (GwcNet hourglass: relu(conv6(c5) + redir1(x))):
+    // rx = NDHWC tensor at OUTPUT resolution (<= 32 channels), rw = its packed 1x1x1 weights (same packing,
+    // T = 1), rscale / rshift = its folded BN, roscale = its f16x3 output scale.  NULL rx = not fused.
+    const float* rx; const float4* rw; const float* rscale; const float* rshift; float roscale; int rxCs, rCi;
+    unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
+    unsigned magicH;              // ceil(2^32/LH)
+    int dma;                      // 1: split input + compact LDS image -> stage rows by LDS-DMA (global_load_lds_dwordx4)
+    // f16x3 range tracking (see osa_f16x3_ranges in the header); every pointer may be NULL.  A "meta" block is
+    // OSA_META_FLOATS floats of device memory per tensor: running max |value| in 8 slots (osa_common.h),
+    // [1] = power-of-two scale of the stored hi/lo halves when the tensor is a split tensor.
+    const float* in_meta; const float* res_meta; const float* rx_meta; float* out_meta;
+    const float* coef;            // [0] max_co |bn scale| * sum|w_co|, [1] max_co |bn shift|   (output bound of this layer)
+    const float* rcoef;           // same for the fused redir layer
+    int toff[MAX_TAPS];           // LDS offset of every tap in float4 units (host computed -> scalar loads)
+    signed char td[MAX_TAPS], th[MAX_TAPS], tw[MAX_TAPS];
+};
+
+// Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
+// Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with hi, lo fp16.  hi uses the packed round-toward-zero convert (2 floats per
+// instruction): any rounding is fine for hi because lo = x - float(hi) is exact in fp32 and carries
+// the remainder; lo is rounded to nearest, error <= 2^-12 |lo| <= 2^-22 |x|.
+// No saturation: operands are brought into range by the per-tensor power-of-two scale below (pow2_scale);
+// a value that still exceeds the fp16 range becomes inf and poisons the result visibly instead of being
+// clamped silently.
+__device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) {
+    const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+    const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    // lo is rounded to nearest (unbiased): its error is what remains of the split
+    const f16x4 l = {(_Float16)(x0 - (float)h01[0]), (_Float16)(x1 - (float)h01[1]),
+                     (_Float16)(x2 - (float)h23[0]), (_Float16)(x3 - (float)h23[1])};
+    hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+// Power-of-two scale s with amax * s in [2^14, 2^15): the largest operand sits one binade under the fp16
+// maximum and every element down to 2^-18 * amax keeps a NORMAL lo half (22 significant bits); smaller
+// elements degrade gracefully (absolute error <= 2^-25 / s, i.e. 2^-39 * amax).  Exact to undo (1 / s).
+// amax == 0, denormal, inf or NaN: unscaled.
+__device__ __forceinline__ float pow2_scale(float amax) {
+    const unsigned b = __builtin_bit_cast(unsigned, amax);
+    const int eb = (int)((b >> 23) & 0xffu);
+    if (eb == 0 || eb == 255) return 1.f;
+    int k = 15 - (eb - 126);
+    k = k < -60 ? -60 : (k > 60 ? 60 : k);
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+__device__ __forceinline__ float4 mul4(const float4 v, const float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+
+// Thread-linear item order (every lane busy on every load).  A row-wise variant with wave-uniform
+// row arithmetic (2x fewer VALU instructions) was measured slower overall on MI355X: rows of 10-18
+// voxels leave 40-45 % of the lanes idle, which costs more than the index arithmetic saves.
+// NCL consecutive 16-channel chunks are staged in one pass (bricks back to back in LDS, brickQ apart):
+// the index arithmetic of an item is shared by its NCL loads, and the two 64-byte halves of a voxel's
+// 128-byte line are requested together.
+// inverse of split_f16 for one channel quad: x = float(hi) + float(lo)
+__device__ __forceinline__ float4 join_f16(const uint2 hi, const uint2 lo) {
+    const f16x4 h = __builtin_bit_cast(f16x4, hi), l = __builtin_bit_cast(f16x4, lo);
+    return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+}
+
+// "Split" activation tensors (OSA_IN_SPLIT / OSA_OUT_SPLIT / OSA_RES_SPLIT / OSA_REDIR_SPLIT, f16x3 mode only):
+// the same bytes per voxel as fp32 NDHWC, but every 16-channel chunk holds [16 x fp16 hi | 16 x fp16 lo]
+// -- exactly the LDS image of a staged chunk.  Element offset (in floats) of the hi / lo halves of the
+// channel quad starting at channel c (c % 4 == 0):
+__device__ __forceinline__ int split_off_hi(int c) { return (c >> 4) * 16 + ((c & 15) >> 2) * 2; }
+__device__ __forceinline__ int split_off_lo(int c) { return split_off_hi(c) + 8; }
+
+template <int NTHR, int PREC, int NCL>
+__device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
+                                            int g0d, int g0h, int g0w, int tid, float s_in = 1.f) {
+#ifndef OSA_STAGE_U
+#define OSA_STAGE_U 4
+#endif
+    constexpr int U = (NCL == 1) ? OSA_STAGE_U : OSA_STAGE_U / 2;
+    const int total = p.LD * p.LH * p.LW * (CC / 4);
+    const int LHW = p.LH * p.LW;
+    // wave-uniform 64-bit base of batch item b / chunk c0; per-lane offsets are 32-bit (host checks < 2^31 elements)
+    const float* xb = p.x + (size_t)b * p.Di * p.Hi * p.Wi * p.xCs + c0;
+    for (int base = tid; base < total; base += NTHR * U) {
+        float4 v[U][NCL];
+        int lo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = base + u * NTHR;
+            lo[u] = -1;
+#pragma unroll
+            for (int cl = 0; cl < NCL; ++cl) v[u][cl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < total) {
+                const int c4 = it & 3, vx = it >> 2;
+                const int ld = __umulhi((unsigned)vx, p.magicHW);
+                const int r = vx - ld * LHW;
+                const int lh = __umulhi((unsigned)r, p.magicW);
+                const int lw = r - lh * p.LW;
+                const int gd = g0d + ld, gh = g0h + lh, gw = g0w + lw;
+                lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * p.VQ + c4;
+                if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) && ((unsigned)gw < (unsigned)p.Wi)) {
+                    const float* src = xb + ((gd * p.Hi + gh) * p.Wi + gw) * p.xCs + c4 * 4;
+#pragma unroll
+                    for (int cl = 0; cl < NCL; ++cl)
+                        if (c0 + cl * CC + c4 * 4 < p.Ci) v[u][cl] = *reinterpret_cast<const float4*>(src + cl * CC);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lo[u] >= 0) {
+#pragma unroll
+                for (int cl = 0; cl < NCL; ++cl) {
+                    float4* dst = smem + cl * brickQ;
+                    if constexpr (PREC == PREC_F32) {
+                        dst[lo[u]] = v[u][cl];
+                    } else {
+                        if (p.act & OSA_IN_SPLIT) { dst[lo[u]] = v[u][cl]; continue; }   // already [hi | lo] in HBM
+                        // voxel image: [16 x fp16 hi | 16 x fp16 lo]; this quad's 4 channels -> 8 B each
+                        static_assert(NTHR % 4 == 0, "channel quad of an item must not depend on u");
+                        const int c4 = base & 3;        // == (base + u*NTHR) & 3
+                        uint2 h2, l2;
+                        split_f16(mul4(v[u][cl], s_in), h2, l2);
+                        uint2* s2 = reinterpret_cast<uint2*>(dst);
+                        const int vbase = (lo[u] - c4) * 2;                 // voxel start in 8-byte units
+                        s2[vbase + c4] = h2;
+                        s2[vbase + 4 + c4] = l2;
+                    }
+                }
+            }
+    }
+}
+
+// Staging of a SPLIT input chunk (already [hi | lo] in HBM) into the COMPACT LDS image by LDS-DMA: one
+// global_load_lds_dwordx4 per (d, h) row of the brick -- lane = (w, 16-byte quad), LDS destination = row
+// base + lane * 16 (exactly the compact row), global source per lane.  A wave takes whole rows, so the
+// row arithmetic is scalar; no VGPR round trip, no ds_write.  Lanes / rows outside the tensor are zero
+// filled with ordinary LDS stores.  Requires LW * 4 <= 64 (one row per instruction).
+template <int NTHR>
+__device__ __forceinline__ void stage_brick_dma(const ConvArgs& p, float4* smem, int b, int c0,
+                                                int g0d, int g0h, int g0w, int tid) {
+    constexpr int NWV = NTHR / 64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows = p.LD * p.LH;
+    const int lw = lane >> 2, c4 = lane & 3;
+    const bool lane_in = lw < p.LW;
+    const int gw = g0w + lw;
+    const bool w_ok = lane_in && ((unsigned)gw < (unsigned)p.Wi) && (c0 + c4 * 4 < p.Ci);
+    const int goff = gw * p.xCs + c0 + c4 * 4;                 // floats from the start of the (d, h) row
+    const float* xb = p.x + (size_t)b * p.Di * p.Hi * p.Wi * p.xCs;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = wave; r < rows; r += NWV) {                   // wave-uniform
+        const int ld = (p.LH == 1) ? r : (int)__umulhi((unsigned)r, p.magicH), lh = r - ld * p.LH;
+        const int gd = g0d + ld, gh = g0h + lh;
+        float4* row = smem + ld * p.PlaneQ + lh * p.RowQ;      // wave-uniform LDS row base
+        const bool row_ok = ((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi);
+        if (row_ok) {
+            const float* rowp = xb + ((size_t)gd * p.Hi + gh) * (size_t)p.Wi * p.xCs;
+            if (w_ok)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + goff),
+                                                 (__attribute__((address_space(3))) void*)row, 16, 0, 0);
+            else if (lane_in) row[lane] = zero;
+        } else if (lane_in) row[lane] = zero;
+    }
+}
+
+// CFG: MT m-tiles x NT n-tiles per wave, WM x WN waves, brick TD x TH x TW (TD derived)
+// NCLS = 1: ordinary (strided / dilated / 1x1x1) convolution.
+// NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
+//           brick is staged once, every class has its own accumulator set and its own run of taps
+//           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0, int OUTS = 0, int PIPE = 0>
+// OUTS = 1: the output is a split tensor (OSA_OUT_SPLIT) -- separate instantiation: a lane finalises 8
+// channels of 2 voxels (16-byte hi and lo stores) instead of 4 channels of 4 voxels.
+// Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
+// (MT = 2, NT = 1: the dominant 32 -> 32 layers) are held to 128 registers so that 4 workgroups
+// share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
+// limit costs the 64-channel tiles 5 %, so they keep the default).
+// PIPE = 1: persistent workgroups walking a list of bricks, the input brick double-buffered in LDS and fed by LDS-DMA
+// (buffer_load ... lds) that is issued from inside the tap loop of the PREVIOUS chunk, so staging never waits (see the
+// PIPE block below).  Split (OSA_IN_SPLIT) inputs, compact LDS image, unit input step; 2 workgroups per CU.
+#define OSA_MIN_BLOCKS (PIPE ? 2 : ((NCLS >= 4) ? 2 : ((MT == 2 && NT == 1 && WM * WN == 4) ? 4 : 1)))
+__global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TD = WM * MT * 32 / (TH * TW);
+    static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
+    static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "TH/TW powers of two");
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 31, hh = lane >> 5;
+
+    // current brick: batch item, first a-space position, first input position (fixed per workgroup unless PIPE)
+    int b, a0d, a0h, a0w, g0d, g0h, g0w;
+    auto set_brick = [&](int b_, int tdi, int thi, int twi) {
+        b = b_;
+        a0d = tdi * TD; a0h = thi * TH; a0w = twi * TW;
+        g0d = a0d * p.isd + p.dmin; g0h = a0h * p.ish + p.hmin; g0w = a0w * p.isw + p.wmin;
+    };
+    // PIPE brick order: d fastest, then 4-row strips of h (h % 4, then w, then h / 4), then batch item -- bricks that
+    // run at the same time on one XCD (xcd_remap: 64 consecutive ids) share their halos in d, w and h through its L2
+    auto decode_item = [&](int id, int& b_, int& tdi, int& thi, int& twi) {
+        tdi = id % p.tilesD;
+        const int colid = id / p.tilesD, cpb = p.tilesH * p.tilesW;
+        b_ = colid / cpb;
+        const int c = colid - b_ * cpb, fullrows = p.tilesH & ~3, full = fullrows * p.tilesW;
+        if (c < full) { const int hb = c / (4 * p.tilesW), r = c - hb * 4 * p.tilesW; twi = r >> 2; thi = hb * 4 + (r & 3); }
+        else { const int r = c - full, rem = p.tilesH - fullrows; twi = r / rem; thi = fullrows + r - twi * rem; }
+    };
+    if constexpr (!PIPE) {
+        unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+        const int twi = bid % p.tilesW; bid /= p.tilesW;
+        const int thi = bid % p.tilesH; bid /= p.tilesH;
+        const int tdi = bid % p.tilesD;
+        set_brick((int)(bid / p.tilesD), tdi, thi, twi);
+    }
+    const int n0 = blockIdx.y * (WN * NT * 32);
+
+    // ---- f16x3 operand ranges: power-of-two scales of the input / residual / redir operands and of a split
+    // output (all wave-uniform scalar loads of a few device words; all 1 when no range block was passed)
+    float s_in = 1.f, s_res_inv = 1.f, s_rx = 1.f, s_out = 1.f;
+    if constexpr (PREC == PREC_F16X3) {
+        if (p.in_meta) s_in = (p.act & OSA_IN_SPLIT) ? p.in_meta[1] : pow2_scale(amax_read(p.in_meta));
+        if (p.res && p.res_meta && (p.act & OSA_RES_SPLIT)) s_res_inv = 1.0f / p.res_meta[1];
+        if (REDIR && p.rx_meta) s_rx = (p.act & OSA_REDIR_SPLIT) ? p.rx_meta[1] : pow2_scale(amax_read(p.rx_meta));
+        if (OUTS && p.coef && p.in_meta) {
+            // rigorous bound of |output|: sum|w| * max|x| * |bn scale| + |bn shift| (+ residual / redir branch);
+            // activations only shrink it (sigmoid / tanh: 1)
+            float bound = p.coef[0] * amax_read(p.in_meta) + p.coef[1];
+            if (p.res && p.res_meta) bound += amax_read(p.res_meta);
+            if (REDIR && p.rcoef && p.rx_meta) bound += p.rcoef[0] * amax_read(p.rx_meta) + p.rcoef[1];
+            const int ak = p.act & 15;
+            if (ak == OSA_ACT_SIGMOID || ak == OSA_ACT_TANH) bound = 1.f;
+            s_out = pow2_scale(bound * 1.0625f);
+        }
+        if (OUTS && p.out_meta && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.out_meta[1] = s_out;
+    }
+    const float osc = p.oscale * (1.0f / s_in);      // undoes the weight pre-scale and the input scale (exact)
+    const float rosc = p.roscale * (1.0f / s_rx);
+    float am = 0.f;                                  // running max |output| of this lane (unscaled values)
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int q = (wm * MT + m) * 32 + col;
+        const int tw_ = q % TW, th_ = (q / TW) % TH, td_ = q / (TW * TH);
+        abase[m] = (td_ * p.isd) * p.PlaneQ + (th_ * p.ish) * p.RowQ + (tw_ * p.isw) * p.VQ + hh;
+    }
+
+    f32x16 acc[NCLS][MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][m][n][r] = 0.f;
+    };
+    zero_acc();
+
+    // One linear stream of B operands: [chunk][tap][octet] "tap steps" of JO*2*CoP float4 each.
+    // Copy-free software pipeline: two static register sets (0/1) ping-pong.  Each half-iteration
+    // first requests the A (LDS) and B (global/L2) operands of the NEXT group of up to TU taps into
+    // the other set, then issues the MFMAs of the current set (sched_barrier pins that order).  A
+    // half-iteration with cnt == 0 only prefetches, so every tap run (chunk, parity class) ends with
+    // "set 0 holds the next group" and no register rotation is ever needed.  The packed buffer
+    // carries a few tap steps of slack for the last prefetch.
+    const size_t bstep = (size_t)2 * p.CoP;          // float4s per octet
+    const size_t tstep = (p.dbg & 4) ? 0 : (size_t)JO * bstep;   // float4s per tap (dbg 4: stationary B stream, timing only)
+    const float4* const wp0 = p.w + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
+    const float4* wp = wp0;
+    constexpr bool RING3 = (TU == 3);     // TU == 3 selects the 3-deep B ring (taps % 3 == 0, NCLS == 1)
+    constexpr int TUA = RING3 ? 1 : TU;
+    static_assert(!RING3 || NCLS == 1, "the B ring needs tap runs that are multiples of 3");
+    float4 B0[TUA][JO][NT], B1[TUA][JO][NT], B2[TUA][JO][NT], A0[TUA][JO][MT], A1[TUA][JO][MT];
+    auto init_b = [&]() {                 // B operands of the first tap(s) of the stream (start of a brick)
+        wp = wp0;
+#pragma unroll
+        for (int u = 0; u < TUA; ++u)
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    B0[u][j][n] = wp[u * tstep + j * bstep + n * 32];
+                    if constexpr (RING3) B1[u][j][n] = wp[tstep + j * bstep + n * 32];
+                }
+    };
+    init_b();
+
+    const int brickQ = p.LD * p.PlaneQ;          // float4s per staged chunk
+    const int Tm1 = p.T - 1;
+    const float4* sm = smem;
+    int t = 0;
+    // tap-offset table in one VGPR (lane i holds toff[i], T <= 64): v_readlane instead of a scalar
+    // memory load + lgkmcnt wait in front of every tap's LDS reads
+    const int toff_v = p.toff[(lane < p.T) ? lane : 0];
+
+    // prefetch group starting at flat tap `tn` (B: `skip` tap steps ahead of wp) into (An, Bn)
+    auto prefetch = [&](float4 (&An)[TUA][JO][MT], float4 (&Bn)[TUA][JO][NT], int tn, int skip) {
+#pragma unroll
+        for (int u = 0; u < TUA; ++u)
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) Bn[u][j][n] = wp[(size_t)(skip + u) * tstep + j * bstep + n * 32];
+#pragma unroll
+        for (int u = 0; u < TUA; ++u) {
+            const int ti = tn + u;
+            const int to = __builtin_amdgcn_readlane(toff_v, (ti < Tm1) ? ti : Tm1);
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) An[u][j][m] = sm[abase[m] + to + j * 2];
+        }
+    };
+    // MFMAs of the first `cnt` taps of (Ac, Bc) into accumulator set ac
+    auto compute = [&](const float4 (&Ac)[TUA][JO][MT], const float4 (&Bc)[TUA][JO][NT], f32x16 (&ac)[MT][NT], int cnt) {
+#pragma unroll
+        for (int u = 0; u < TUA; ++u) {
+            if (u < cnt) {
+                if constexpr (PREC == PREC_F32) {
+#pragma unroll
+                    for (int j = 0; j < JO; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) {
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].x, Bc[u][j][n].x, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].y, Bc[u][j][n].y, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].z, Bc[u][j][n].z, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].w, Bc[u][j][n].w, ac[m][n], 0, 0, 0);
+                            }
+                } else {
+                    // [0] = hi halves, [1] = lo halves of the 16 channels of this chunk (K = 16 per MFMA);
+                    // small cross terms first, then hi.hi
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, Ac[u][0][m]), al = __builtin_bit_cast(f16x8, Ac[u][1][m]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, Bc[u][0][n]), bl = __builtin_bit_cast(f16x8, Bc[u][1][n]);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ac[m][n], 0, 0, 0);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, ac[m][n], 0, 0, 0);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, ac[m][n], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    };
+    // B ring step: request A of tap `ta` into An and B of stream position wp + sb tap steps into Bn,
+    // then issue the MFMAs of (Ac, Bc).  B operands are requested two taps ahead of their use (the
+    // L2 round trip is longer than one tap's MFMAs), A operands (LDS) one tap ahead.
+    auto ring_step = [&](float4 (&An)[TUA][JO][MT], int ta, float4 (&Bn)[TUA][JO][NT], int sb,
+                         const float4 (&Ac)[TUA][JO][MT], const float4 (&Bc)[TUA][JO][NT]) {
+        prefetch(An, Bn, ta, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(Ac, Bc, acc[0], 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // taps of ONE staged chunk (sm points at it).  `hook` runs once per tap step between the MFMA groups: the PIPE
+    // form issues one row of the next chunk's LDS-DMA there, so the transfers are spread over the whole tap loop.
+    auto chunk_taps = [&](auto&& hook) {
+        // A operands of the first TU taps of this chunk -> set 0 (B0 already holds their B operands)
+#pragma unroll
+        for (int u = 0; u < TUA; ++u) {
+            const int to = __builtin_amdgcn_readlane(toff_v, (u < Tm1) ? u : Tm1);
+#pragma unroll
+            for (int j = 0; j < JO; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) A0[u][j][m] = sm[abase[m] + to + j * 2];
+        }
+        t = 0;
+        if constexpr (RING3) {
+            // invariant at the top: A0 = tap t, B0 = tap t, B1 = tap t+1 (stream positions wp, wp+1).
+            // Three steps are one full turn of the B ring, so leaving after the first triple keeps
+            // the invariant for the next chunk (whose A0 is reloaded anyway).
+            for (; t < p.T; t += 6) {
+                hook(); ring_step(A1, t + 1, B2, 2, A0, B0);
+                hook(); ring_step(A0, t + 2, B0, 3, A1, B1);
+                hook(); ring_step(A1, t + 3, B1, 4, A0, B2);
+                if (t + 3 >= p.T) { wp += (size_t)3 * tstep; break; }
+                hook(); ring_step(A0, t + 4, B2, 5, A1, B0);
+                hook(); ring_step(A1, t + 5, B0, 6, A0, B1);
+                hook(); ring_step(A0, t + 6, B1, 7, A1, B2);
+                wp += (size_t)6 * tstep;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const int tend = (NCLS == 1) ? p.T : p.cls_end[c];
+                while (t < tend) {
+                    const int cnt0 = (tend - t < TU) ? (tend - t) : TU;
+                    hook();
+                    prefetch(A1, B1, t + cnt0, cnt0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(A0, B0, acc[c], cnt0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wp += (size_t)cnt0 * tstep; t += cnt0;
+                    const int cnt1 = (tend - t < TU) ? (tend - t) : TU;     // 0 when the run had an odd number of groups
+                    hook();
+                    prefetch(A0, B0, t + cnt1, cnt1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(A1, B1, acc[c], cnt1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wp += (size_t)cnt1 * tstep; t += cnt1;
+                }
+            }
+        }
+    };
+
+    if constexpr (!PIPE) {
+    for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
+        if (ch0) __syncthreads();
+        const int ncl = (p.nchunks - ch0 < p.cps) ? (p.nchunks - ch0) : p.cps;
+        if (!(p.dbg & 1) && PREC == PREC_F16X3 && p.dma) {
+            for (int cl = 0; cl < ncl; ++cl)
+                stage_brick_dma<NW * 64>(p, smem + cl * brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+        } else if (!(p.dbg & 1)) {
+            int cl = 0;
+            for (; cl + 2 <= ncl; cl += 2)
+                stage_brick<NW * 64, PREC, 2>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
+            if (cl < ncl)
+                stage_brick<NW * 64, PREC, 1>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
+        }
+        __syncthreads();
+        for (int cl = 0; cl < ncl; ++cl) {
+            sm = smem + cl * brickQ;
+            chunk_taps([]() {});
+        }
+    }
+    }
+
+    unsigned amax_seen = 0u;
+    auto epilogue = [&](float* tbase) {
+    // ---- epilogue: BN affine + residual + activation (+ sigmoid gate), NDHWC store ----
+    // MFMA result layout: lane -> output channel `col`, accumulator r -> voxel row (r&3)+8(r>>2)+4hh.
+    // Each 32x32 tile is transposed through a wave-private LDS buffer (row stride 36 floats, conflict
+    // free both ways) so that a lane ends up with 4 consecutive channels of one voxel: residual /
+    // gate loads and output stores are float4, 8 lanes cover one voxel's 128-byte channel row and a
+    // wave instruction covers 8 consecutive voxels (1 KB contiguous for a 32-channel tensor).
+    // folded-BN scale / shift of this lane's channel quads: requested before the barrier so the loads
+    // overlap the tail of the tap loop instead of stalling the first tile of the epilogue
+    float4 scv[NT], shv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n0 + (wn * NT + n) * 32 + (lane & 7) * 4;
+        float4 sc = make_float4(osc, osc, osc, osc), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < p.Co && p.scale) {
+            if (co + 3 < p.Co) { sc = *reinterpret_cast<const float4*>(p.scale + co); sh = *reinterpret_cast<const float4*>(p.shift + co); }
+            else {
+                sc.x = p.scale[co]; sh.x = p.shift[co];
+                if (co + 1 < p.Co) { sc.y = p.scale[co + 1]; sh.y = p.shift[co + 1]; }
+                if (co + 2 < p.Co) { sc.z = p.scale[co + 2]; sh.z = p.shift[co + 2]; }
+            }
+            sc.x *= osc; sc.y *= osc; sc.z *= osc; sc.w *= osc;
+        }
+        scv[n] = sc; shv[n] = sh;
+    }
+    if (p.out_meta) amax_seen = amax_peek(p.out_meta);   // early: its latency hides behind the epilogue
+    if constexpr (!PIPE) __syncthreads();              // everyone is done reading the input brick (PIPE: the chunk's end barrier)
+    if (p.dbg & 8) {                                   // timing only: no epilogue (keeps the accumulators live)
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += acc[c][m][n][r];
+        if (s == 12345.678f) p.y[0] = s;
+        return;
+    }
+    float* tb = tbase + wave * (32 * 36);
+    // per-batch-item base pointers (wave-uniform, 64-bit); everything per lane is a 32-bit element offset
+    const size_t bvox = (size_t)b * p.Do * p.Ho * p.Wo;
+    float* yb = p.y + bvox * p.yCs;
+    const float* resb = p.res ? p.res + bvox * p.rCs : nullptr;
+    const float* gateb = p.gate ? p.gate + (size_t)b * p.Ho * p.Wo * p.gCs : nullptr;
+    const bool vec4 = ((p.yCs & 3) == 0) && ((p.Co & 3) == 0) && (((size_t)p.y & 15) == 0) &&
+                      (!p.res || (((p.rCs & 3) == 0) && (((size_t)p.res & 15) == 0))) &&
+                      (!p.gate || (((p.gCs & 3) == 0) && (((size_t)p.gate & 15) == 0)));
+    const int vsub = lane >> 3, cq = (lane & 7) * 4;   // voxel within a group of 8, channel quad
+    const int actk = p.act & 15;
+    const bool gate_raw = (p.act & OSA_GATE_RAW) != 0;
+    // A wave finalises NI = MT*NCLS*NT tiles of 32 voxels x 32 channels one after the other.  The
+    // residual rows of tile i+PD are requested before tile i is processed (rolling window of PD
+    // tiles, static register sets), so the HBM round trip of a residual overlaps the LDS transposes,
+    // arithmetic and stores of the PD-1 tiles in front of it -- the fused transposed conv has 8 tiles
+    // per wave and spent half of its time waiting for them one by one.
+    constexpr int NI = MT * NCLS * NT;
+    constexpr int PD = REDIR ? 2 : ((NCLS >= 4) ? 3 : ((NI < 2) ? NI : 2));
+    // voxel bookkeeping of the 4 rows (vsub + 8k) this lane finalises in M tile m
+    auto rows_of = [&](int m, int (&v0)[4], int (&g0)[4], bool (&vok)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = (wm * MT + m) * 32 + vsub + 8 * k;
+            const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+            vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+            v0[k] = ((ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;      // voxel index inside batch item b (host: < 2^31 elements)
+            g0[k] = (ah * p.os) * p.Wo + aw * p.os;
+        }
+    };
+    auto class_off = [&](int c, int& coff, int& goff) {
+        const int ood = (NCLS == 1) ? p.ood : ((c >> 2) & 1), ooh = (NCLS == 1) ? p.ooh : ((c >> 1) & 1),
+                  oow = (NCLS == 1) ? p.oow : (c & 1);
+        coff = (ood * p.Ho + ooh) * p.Wo + oow;              // supported transposed convs: Do == 2*Di
+        goff = ooh * p.Wo + oow;
+    };
+    // tile order: m outer, class, n inner
+    auto load_res = [&](int i, float4 (&rv)[4]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[4], g0[4], coff, goff; bool vok[4];
+        rows_of(m, v0, g0, vok);
+        class_off(c, coff, goff);
+        const int co = n0 + (wn * NT + n) * 32 + cq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.res && vok[k] && co < p.Co) {
+                const float* rp = resb + (v0[k] + coff) * p.rCs + co;
+                if (PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT)) {
+                    const float* rs = resb + (v0[k] + coff) * p.rCs;
+                    const uint2 h = *reinterpret_cast<const uint2*>(rs + split_off_hi(co));
+                    const uint2 l = *reinterpret_cast<const uint2*>(rs + split_off_lo(co));
+                    rv[k] = __builtin_bit_cast(float4, make_uint4(h.x, h.y, l.x, l.y));     // decoded in finish()
+                } else if (vec4) rv[k] = *reinterpret_cast<const float4*>(rp);
+                else {
+                    float* rr = &rv[k].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Co) rr[e] = rp[e];
+                }
+            }
+        }
+    };
+    auto finish = [&](int i, const float4 (&rv)[4]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[4], g0[4], coff, goff; bool vok[4];
+        rows_of(m, v0, g0, vok);
+        class_off(c, coff, goff);
+        // registers -> LDS (tile[voxel row][channel])
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
+        const int co = n0 + (wn * NT + n) * 32 + cq;
+        const bool cok = co < p.Co;
+        const float4 sc = scv[n], sh = shv[n];
+        // LDS -> registers (4 voxels x 4 channels per lane); gate rows requested together
+        float4 av[4], gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
+            gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!REDIR && p.gate && vok[k] && cok) {
+                const float* gp = gateb + (g0[k] + goff) * p.gCs + co;
+                if (vec4) gv[k] = *reinterpret_cast<const float4*>(gp);
+                else {
+                    float* gg = &gv[k].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Co) gg[e] = gp[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[4];
+            const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+            const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+            float4 rk = rv[k];
+            if (PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT) && p.res) {
+                const uint4 b4 = __builtin_bit_cast(uint4, rv[k]);
+                rk = mul4(join_f16(make_uint2(b4.x, b4.y), make_uint2(b4.z, b4.w)), s_res_inv);
+            }
+            const float r4[4] = {rk.x, rk.y, rk.z, rk.w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
+                if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                else if (actk == OSA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                else if (actk == OSA_ACT_TANH) v = tanhf(v);
+                if (!REDIR && p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
+                o[e] = v;
+            }
+            if (vok[k] && cok) {
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                float* yp = yb + (v0[k] + coff) * p.yCs + co;
+                if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.Co) yp[e] = o[e];
+                }
+            }
+        }
+    };
+    // ---- split-output epilogue (OUTS): a lane takes 8 consecutive channels of 2 voxels of the tile, so the
+    // hi halves and the lo halves of its 8 values are one 16-byte store each; a split residual is read the
+    // same way (host: a split output takes a split residual, no gate).
+    const int vs2 = lane >> 2, c8 = (lane & 3) * 8;
+    auto rows2 = [&](int m, int (&v0)[2], bool (&vok)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = (wm * MT + m) * 32 + vs2 + 16 * k;
+            const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+            vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+            v0[k] = ((ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;
+        }
+    };
+    auto load_res8 = [&](int i, float4 (&rv)[4]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[2], coff, goff; bool vok[2];
+        rows2(m, v0, vok);
+        class_off(c, coff, goff);
+        const int co = n0 + (wn * NT + n) * 32 + c8;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            rv[2 * k] = make_float4(0.f, 0.f, 0.f, 0.f); rv[2 * k + 1] = rv[2 * k];
+            if (p.res && vok[k] && co < p.Co) {
+                const float* rs = resb + (v0[k] + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                rv[2 * k] = *reinterpret_cast<const float4*>(rs);            // 8 hi halves
+                rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);    // 8 lo halves
+            }
+        }
+    };
+    auto finish8 = [&](int i, const float4 (&rv)[4], const float4 (&sc8)[2], const float4 (&sh8)[2]) {
+        const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+        int v0[2], coff, goff; bool vok[2];
+        rows2(m, v0, vok);
+        class_off(c, coff, goff);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
+        const int co = n0 + (wn * NT + n) * 32 + c8;
+        const bool cok = co < p.Co;
+        float4 av[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            av[k][0] = *reinterpret_cast<const float4*>(tb + (vs2 + 16 * k) * 36 + c8);
+            av[k][1] = *reinterpret_cast<const float4*>(tb + (vs2 + 16 * k) * 36 + c8 + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint2 hq[2], lq[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res) {
+                    const uint4 hb = __builtin_bit_cast(uint4, rv[2 * k]), lb = __builtin_bit_cast(uint4, rv[2 * k + 1]);
+                    r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
+                    r = mul4(r, s_res_inv);
+                }
+                const float a4[4] = {av[k][h2].x, av[k][h2].y, av[k][h2].z, av[k][h2].w};
+                const float s4[4] = {sc8[h2].x, sc8[h2].y, sc8[h2].z, sc8[h2].w}, t4[4] = {sh8[h2].x, sh8[h2].y, sh8[h2].z, sh8[h2].w};
+                const float r4[4] = {r.x, r.y, r.z, r.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(a4[e], s4[e], t4[e]) + r4[e];
+                    if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                    else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                    else if (actk == OSA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    else if (actk == OSA_ACT_TANH) v = tanhf(v);
+                    o[e] = v;
+                }
+                if (vok[k] && cok) am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
+            }
+            if (vok[k] && cok) {
+                float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                *reinterpret_cast<uint4*>(ys) = make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+                *reinterpret_cast<uint4*>(ys + 8) = make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y);
+            }
+        }
+    };
+    // BN scale / shift of the lane's 8 channels in that mapping (REDIR: already applied in accumulator layout)
+    auto bn8 = [&](int n, float4 (&sc8)[2], float4 (&sh8)[2]) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int co = n0 + (wn * NT + n) * 32 + c8 + 4 * h2;
+            sc8[h2] = make_float4(osc, osc, osc, osc); sh8[h2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (REDIR) { sc8[h2] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
+            if (co + 3 < p.Co && p.scale) {
+                sc8[h2] = *reinterpret_cast<const float4*>(p.scale + co); sh8[h2] = *reinterpret_cast<const float4*>(p.shift + co);
+                sc8[h2].x *= osc; sc8[h2].y *= osc; sc8[h2].z *= osc; sc8[h2].w *= osc;
+            }
+        }
+    };
+    constexpr int RV = (REDIR == 2) ? 8 : 4;      // float4 rows held per prefetched tile
+    float4 rvb[PD][RV];
+    if constexpr (REDIR) {
+        {
+            // ---- fused redir branch: R = BN_r(W_r . x) for the 32 output voxels of every tile, on the
+            // MFMA in accumulator layout (lane = channel, register = voxel row), then
+            // z = fma(acc, s, t) + fma(R, s_r, t_r) replaces the accumulator and the common path below
+            // runs with unit scale and no residual -- the same arithmetic, in the same order, as the
+            // separate 1x1x1 launch whose output used to be read back as the residual.
+            const float* rxb = p.rx + bvox * p.rxCs;
+            const size_t rbstep = (size_t)2 * p.CoP, rtstep = (size_t)JO * rbstep;
+            constexpr int RCH = RV / 2;                            // chunks of 16 redir input channels held per tile
+            const int rch = (p.rCi + CC - 1) / CC;
+            // x rows of tile i in MFMA A-operand order: lane (col, hh) -> voxel row `col`
+            auto load_x = [&](int i, float4 (&rv)[RV]) {
+                const int c = (i / NT) % NCLS, m = i / (NT * NCLS);
+                const int q = (wm * MT + m) * 32 + col;
+                const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+                const bool ok = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+                const int vox = ((ad * 2 + ((c >> 2) & 1)) * p.Ho + ah * 2 + ((c >> 1) & 1)) * p.Wo + aw * 2 + (c & 1);
+#pragma unroll
+                for (int k = 0; k < RV; ++k) {
+                    rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int ch = k >> 1, j = k & 1;
+                    // f16x3: 8 consecutive channels 8hh..8hh+7 of the chunk (two float4s); f32: channels 8j+4hh..+3
+                    int cin = ch * CC + ((PREC == PREC_F32) ? (8 * j + 4 * hh) : (8 * hh + 4 * j));
+                    // split redir input: j = 0 -> the lane's 8 hi halves, j = 1 -> its 8 lo halves (16 B each)
+                    if (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) cin = ch * CC + 4 * hh + 8 * j;
+                    if (ok && ch < rch && ch * CC < p.rCi) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
+                }
+            };
+            auto add_redir = [&](int i, const float4 (&rv)[RV]) {
+                const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
+                const float4* rwp = p.rw + (size_t)hh * p.CoP + n0 + (wn * NT + n) * 32 + col;
+                f32x16 r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) r[e] = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < RCH; ++ch) {
+                    if (ch < rch) {
+                        const float4 b0 = rwp[ch * rtstep], b1 = rwp[ch * rtstep + rbstep];
+                        if constexpr (PREC == PREC_F32) {
+                            const float4 a0 = rv[2 * ch], a1 = rv[2 * ch + 1];
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, r, 0, 0, 0);
+                        } else {
+                            f16x8 ah, al;
+                            if (p.act & OSA_REDIR_SPLIT) {
+                                ah = __builtin_bit_cast(f16x8, rv[2 * ch]); al = __builtin_bit_cast(f16x8, rv[2 * ch + 1]);
+                            } else {
+                                uint2 h0, l0, h1, l1;
+                                split_f16(mul4(rv[2 * ch], s_rx), h0, l0);
+                                split_f16(mul4(rv[2 * ch + 1], s_rx), h1, l1);
+                                ah = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                                al = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                            }
+                            const f16x8 bh = __builtin_bit_cast(f16x8, b0), bl = __builtin_bit_cast(f16x8, b1);
+                            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, r, 0, 0, 0);
+                            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, r, 0, 0, 0);
+                        }
+                    }
+                }
+                // per-lane (channel `col`) BN factors of both branches
+                const int cl = n0 + (wn * NT + n) * 32 + col;
+                const bool lok = cl < p.Co;
+                const float s6 = (lok && p.scale) ? p.scale[cl] * osc : osc, t6 = (lok && p.shift) ? p.shift[cl] : 0.f;
+                const float sr = (lok && p.rscale) ? p.rscale[cl] * rosc : rosc, tr = (lok && p.rshift) ? p.rshift[cl] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][m][n][e] = fmaf(acc[c][m][n][e], s6, t6) + fmaf(r[e], sr, tr);
+            };
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { scv[n] = make_float4(1.f, 1.f, 1.f, 1.f); shv[n] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            const float4 zero4[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                                     make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+            for (int i = 0; i < PD; ++i) load_x(i, rvb[i]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                add_redir(i, rvb[i % PD]);
+                if (i + PD < NI) load_x(i + PD, rvb[i % PD]);
+                if constexpr (OUTS) {
+                    float4 sc8[2], sh8[2];
+                    bn8(i % NT, sc8, sh8);
+                    finish8(i, zero4, sc8, sh8);
+                } else finish(i, zero4);
+            }
+        }
+    }
+    if constexpr (!REDIR && OUTS) {
+        float4 sc8[NT][2], sh8[NT][2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bn8(n, sc8[n], sh8[n]);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) load_res8(i, rvb[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            finish8(i, rvb[i % PD], sc8[i % NT], sh8[i % NT]);
+            if (i + PD < NI) load_res8(i + PD, rvb[i % PD]);
+        }
+    }
+    if constexpr (!REDIR && !OUTS) {
+#pragma unroll
+        for (int i = 0; i < PD; ++i) load_res(i, rvb[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            finish(i, rvb[i % PD]);
+            if (i + PD < NI) load_res(i + PD, rvb[i % PD]);
+        }
+    }
+    };   // epilogue
+
+    if constexpr (!PIPE) {
+        epilogue(reinterpret_cast<float*>(smem));
+    } else {
+        static_assert(NCLS == 1 && !REDIR && PREC == PREC_F16X3, "PIPE: plain f16x3 convolutions");
+        // ---- persistent, LDS-DMA pipelined form ------------------------------------------------------------------
+        // The workgroup walks bricks id = xcd_remap(blockIdx.x) + k * gridDim.x.  Two LDS buffers hold chunk gc and
+        // chunk gc + 1 of the running (brick, 16-channel chunk) sequence; while the taps of chunk gc run, every wave
+        // issues its share of chunk gc + 1's rows -- one `buffer_load_dwordx4 ... lds` per (d, h) row of the brick, one row
+        // per tap step -- straight from the split tensor in HBM/L2 into the other buffer (no VGPR round trip, no
+        // ds_write; a per-row buffer descriptor with num_records = row bytes, or 0 for rows outside the tensor, makes
+        // the hardware zero-fill every out-of-range voxel).  The DMA is inline asm, so the compiler's vmcnt bookkeeping
+        // for the B-operand loads never drains it (it can only over-wait); one explicit vmcnt(0) + barrier per chunk
+        // publishes the landed buffer.  The epilogue transposes through the buffer that was just consumed; a third
+        // barrier keeps the next DMA out of it until every wave is done.  Staging time is gone from the critical path,
+        // the epilogue of one workgroup overlaps the taps of the other one on the CU.
+        const int G = (int)gridDim.x;
+        const int nitems = p.B * p.tilesD * p.tilesH * p.tilesW;
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const unsigned bufbytes = (unsigned)brickQ * 16u;
+        const unsigned rowbytes = (unsigned)(p.Wi * p.xCs) * 4u;
+        const size_t itembytes = (size_t)p.Di * p.Hi * rowbytes;
+        const int lw_ = lane >> 2, c4_ = lane & 3;
+        const bool lane_in = lw_ < p.LW;
+        // DMA cursor: rows d_row, d_row + NW, ... < d_rows of the brick whose first input voxel is (d_g0d, d_g0h, .) go to d_lds
+        int d_row = 0, d_rows = 0, d_g0d = 0, d_g0h = 0;
+        unsigned d_lds = 0, d_voff = 0;
+        const char* d_base = nullptr;
+        auto dma_target = [&](int b_, int c0, int g0d_, int g0h_, int g0w_, unsigned lds_) {
+            d_base = reinterpret_cast<const char*>(p.x) + (size_t)b_ * itembytes + (size_t)c0 * 4;
+            d_g0d = g0d_; d_g0h = g0h_;
+            d_voff = (unsigned)((g0w_ + lw_) * p.xCs * 4 + c4_ * 16);     // negative / beyond the row -> >= num_records -> zero fill
+            d_lds = lds_;
+            d_row = wave; d_rows = p.LD * p.LH;
+        };
+        auto dma_one = [&]() {
+            if (d_row < d_rows) {                                         // wave-uniform
+                const int ld = (p.LH == 1) ? d_row : (int)__umulhi((unsigned)d_row, p.magicH), lh = d_row - ld * p.LH;
+                const int gd = d_g0d + ld, gh = d_g0h + lh;
+                const bool ok = ((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi);
+                const unsigned long long rowp = (unsigned long long)(d_base + ((long long)gd * p.Hi + gh) * (long long)rowbytes);
+                u32x4 srd;
+                srd.x = __builtin_amdgcn_readfirstlane((unsigned)rowp);
+                srd.y = __builtin_amdgcn_readfirstlane((unsigned)(rowp >> 32));
+                srd.z = __builtin_amdgcn_readfirstlane(ok ? rowbytes : 0u);
+                srd.w = 0x00020000u;
+                const unsigned ldsrow = __builtin_amdgcn_readfirstlane(d_lds + (unsigned)(ld * p.PlaneQ + lh * p.RowQ) * 16u);
+                if (lane_in) {
+                    unsigned keep;
+                    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                                 "buffer_load_dwordx4 %2, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "s"(srd), "v"(d_voff), "s"(ldsrow) : "memory");
+                }
+                d_row += NW;
+            }
+        };
+        auto dma_flush = [&]() { while (d_row < d_rows) dma_one(); };
+        auto chunk_sync = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows of the next chunk have landed
+            __syncthreads();                                            // ... and everybody else's; all reads of this chunk are done
+        };
+
+        int item = (int)xcd_remap(blockIdx.x, (unsigned)G);
+        int gc = 0;
+        if (item < nitems) {
+            int b_, td_, th_, tw_;
+            decode_item(item, b_, td_, th_, tw_);
+            set_brick(b_, td_, th_, tw_);
+            dma_target(b, 0, g0d, g0h, g0w, lds0);
+            dma_flush();
+        }
+        chunk_sync();
+        while (item < nitems) {
+            zero_acc();
+            init_b();
+            const int nitem = item + G;
+            for (int ch = 0; ch < p.nchunks; ++ch, ++gc) {
+                const unsigned nbuf = lds0 + (unsigned)((gc + 1) & 1) * bufbytes;
+                if (ch + 1 < p.nchunks) dma_target(b, (ch + 1) * CC, g0d, g0h, g0w, nbuf);
+                else if (nitem < nitems) {
+                    int b_, td_, th_, tw_;
+                    decode_item(nitem, b_, td_, th_, tw_);
+                    dma_target(b_, 0, td_ * TD * p.isd + p.dmin, th_ * TH * p.ish + p.hmin, tw_ * TW * p.isw + p.wmin, nbuf);
+                } else d_rows = 0;
+                sm = smem + (size_t)(gc & 1) * brickQ;
+                chunk_taps(dma_one);
+                dma_flush();
+                chunk_sync();
+            }
+            epilogue(reinterpret_cast<float*>(smem + (size_t)((gc - 1) & 1) * brickQ));
+            __syncthreads();                                            // the epilogue's transpose tiles are free again
+            item = nitem;
+            if (item < nitems) {
+                int b_, td_, th_, tw_;
+                decode_item(item, b_, td_, th_, tw_);
+                set_brick(b_, td_, th_, tw_);
+            }
+        }
+    }
+    // ---- publish max |output| of this wave into the output's range block
+    if (p.out_meta) publish_amax(p.out_meta, am, amax_seen, reinterpret_cast<float*>(smem));   // (barrier inside: every wave is past its tiles)
+}
+
+}  // namespace osa

@@ -1,0 +1,22 @@
+// Instantiations of the persistent, LDS-DMA pipelined form of the conv kernel (conv_kernel.h, PIPE = 1): stride-1
+// f16x3 convolutions whose input is a split tensor -- the 3x3x3 layers of the 3-D aggregation networks at every
+// resolution and (D = 1) the 3x3 layers of the 2-D backbones.  Own translation unit: compiles in parallel with conv3d.hip.
+#include "conv_kernel.h"
+
+namespace osa {
+
+#define OSA_PIPE(TU, MT, NT, WM, WN, TH, TW, OUTS) conv_mfma_kernel<PREC_F16X3, 1, TU, MT, NT, WM, WN, TH, TW, 0, OUTS, 1>
+
+// [tile][B ring (tap count % 3 == 0) ? 1 : 0][split output ? 1 : 0]
+static void (*const g_pipe[3][2][2])(const ConvArgs) = {
+    { { OSA_PIPE(1, 2, 1, 4, 1, 8, 8, 0), OSA_PIPE(1, 2, 1, 4, 1, 8, 8, 1) },      // 256 voxels x  32 channels, brick 4x8x8
+      { OSA_PIPE(3, 2, 1, 4, 1, 8, 8, 0), OSA_PIPE(3, 2, 1, 4, 1, 8, 8, 1) } },
+    { { OSA_PIPE(1, 2, 2, 4, 1, 8, 8, 0), OSA_PIPE(1, 2, 2, 4, 1, 8, 8, 1) },      // 256 voxels x  64 channels
+      { OSA_PIPE(3, 2, 2, 4, 1, 8, 8, 0), OSA_PIPE(3, 2, 2, 4, 1, 8, 8, 1) } },
+    { { OSA_PIPE(1, 2, 2, 2, 2, 8, 8, 0), OSA_PIPE(1, 2, 2, 2, 2, 8, 8, 1) },      // 128 voxels x 128 channels, brick 2x8x8
+      { OSA_PIPE(3, 2, 2, 2, 2, 8, 8, 0), OSA_PIPE(3, 2, 2, 2, 2, 8, 8, 1) } },
+};
+
+void (*pipe_kernel(int tile, int ring, int outs))(const ConvArgs) { return g_pipe[tile][ring ? 1 : 0][outs ? 1 : 0]; }
+
+}  // namespace osa

@@ -754,25 +754,6 @@ def test_split_activation_format_chain():
         ops.to_ncdhw(yb)                                     # split tensors never leave the engine chain
 
 
-def test_lds_dma_staging_of_split_inputs(monkeypatch):
-    """OSA_DMA=1: split inputs are staged with global_load_lds_dwordx4 (one instruction per brick row) --
-    bit-identical to the register-staged path, including bricks that hang over the volume border."""
-    from openstereo_amd import ops
-    from openstereo_amd.engine import PackedConv3d
-    ca = nn.Conv3d(32, 32, 3, 1, 1, bias=False)
-    ca.weight.data = synth_tensor("dma.a", ca.weight.shape, 1)
-    cb = nn.Conv3d(32, 32, 3, 1, 1, bias=False)
-    cb.weight.data = synth_tensor("dma.b", cb.weight.shape, 1)
-    x = T(np.random.default_rng(3).normal(0, 1, (2, 32, 7, 13, 19)).astype(np.float32))     # ragged vs the 4x8x8 bricks
-    pa = PackedConv3d(ca.to(DEV), _bn_for(32, 2, "dma.a").to(DEV), 1, precision="f16x3")
-    pb = PackedConv3d(cb.to(DEV), _bn_for(32, 3, "dma.b").to(DEV), 1, precision="f16x3")
-    ya = pa(ops.to_cl(x.to(DEV)), out_split=True)
-    ref = pb(ya)
-    monkeypatch.setenv("OSA_DMA", "1")
-    dma = pb(ya)
-    assert torch.equal(ref, dma)
-
-
 def test_lightstereo_cost_stage_vs_reference_golden():
     """LightStereo's correlation volume -> 2-D aggregation -> softmax regression on the engine (f16x3) vs the
     output of the reference's own functions (EPE bar 1e-3 px at quarter resolution)."""
@@ -813,3 +794,57 @@ def test_igev_refine_loop_vs_reference_golden(prec):
     close(out["disp"], g["disp"], atol=2e-4, rtol=1e-4, what=f"refined disparity [{prec}]")
     close(out["mask_feat_4"], g["mask"], atol=2e-4, rtol=2e-4, what=f"mask features [{prec}]")
     close(out["net_list"][0], g["net0"], atol=1e-4, rtol=1e-4, what=f"hidden state [{prec}]")
+
+
+# ----------------------------------------------------------------------------- persistent LDS-DMA pipelined conv (PIPE)
+PIPE_CASES = [
+    # name, Ci, Co, k, pad, dil, (B, D, H, W), residual (None | "split" | "plain"), split output
+    ("32-32 k3 ragged", 32, 32, 3, 1, 1, (2, 7, 13, 19), None, True),
+    ("32-32 k3 res split", 32, 32, 3, 1, 1, (1, 9, 17, 25), "split", True),
+    ("32-32 k3 plain out", 32, 32, 3, 1, 1, (3, 5, 8, 8), None, False),
+    ("64-32 k3", 64, 32, 3, 1, 1, (2, 6, 10, 12), None, True),
+    ("64-64 k3 res plain", 64, 64, 3, 1, 1, (1, 8, 9, 17), "plain", False),
+    ("128-128 k3", 128, 128, 3, 1, 1, (2, 3, 9, 10), None, True),
+    ("32-32 1x1x1", 32, 32, 1, 0, 1, (2, 5, 7, 9), None, True),
+    ("32-64 many bricks", 32, 64, 3, 1, 1, (1, 13, 40, 33), None, False),
+]
+
+
+@pytest.mark.parametrize("case", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
+def test_pipelined_conv_on_split_inputs_vs_torch(case):
+    """Stride-1 f16x3 convs whose input is a split tensor run as persistent workgroups with the brick double-buffered in
+    LDS by LDS-DMA (conv_kernel.h, PIPE): ragged volumes (zero fill by the buffer descriptor), several bricks per workgroup,
+    several batch items, split / plain residuals and outputs -- against torch, and bit-identical when repeated."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d, is_split
+    name, Ci, Co, k, pad, dil, (B, D, H, W), res_kind, out_split = case
+    pre = nn.Conv3d(Ci, Ci, 1, bias=False)                       # produces the split input (identity-like 1x1x1 layer)
+    pre.weight.data = torch.eye(Ci).reshape(Ci, Ci, 1, 1, 1).clone()
+    conv = nn.Conv3d(Ci, Co, k, 1, pad, dil, bias=False)
+    conv.weight.data = synth_tensor(name + ".w", conv.weight.shape, 1)
+    bn = _bn_for(Co, 2, name)
+    x = T(np.random.default_rng(3).normal(0, 1, (B, Ci, D, H, W)).astype(np.float32))
+    res = torch.randn(B, Co, D, H, W, generator=torch.Generator().manual_seed(4)) if res_kind else None
+    with torch.no_grad():
+        ref = bn(conv(x))
+        if res is not None:
+            ref = ref + res
+        ref = F.relu(ref)
+    xs = PackedConv3d(pre.to(DEV), None, 0, precision="f16x3")(ops.to_cl(x.to(DEV)), out_split=True)
+    assert is_split(xs)
+    rs = None
+    if res_kind == "plain":
+        rs = ops.to_cl(res.to(DEV))
+    elif res_kind == "split":
+        eye = nn.Conv3d(Co, Co, 1, bias=False)
+        eye.weight.data = torch.eye(Co).reshape(Co, Co, 1, 1, 1).clone()
+        rs = PackedConv3d(eye.to(DEV), None, 0, precision="f16x3")(ops.to_cl(res.to(DEV)), out_split=True)
+    pc = PackedConv3d(conv.to(DEV), bn.to(DEV), 1, precision="f16x3")
+    y = pc(xs, residual=rs, out_split=out_split)
+    y2 = pc(xs, residual=rs, out_split=out_split)
+    assert torch.equal(y, y2)
+    if out_split:                                                # read back through an identity layer
+        eye = nn.Conv3d(Co, Co, 1, bias=False)
+        eye.weight.data = torch.eye(Co).reshape(Co, Co, 1, 1, 1).clone()
+        y = PackedConv3d(eye.to(DEV), None, 0, precision="f16x3")(y)
+    close(y[:, :Co], ref, atol=3e-5, rtol=3e-5, what=f"pipelined conv {name}")
