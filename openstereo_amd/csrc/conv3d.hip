@@ -180,13 +180,14 @@ static int launch_conv_pipe(ConvArgs& a, int stride, int prec, hipStream_t st, c
         OSA_REQUIRE(ovox * cs < (1ll << 31), "%s: one batch item of the output exceeds 2^31 elements", what);
     }
     void (*fn)(const ConvArgs) = pipe_kernel(tile, a.T % 3 == 0, (a.act & OSA_OUT_SPLIT) != 0);
+    if (!fn) return 0;
     const int lds = (int)(2 * brick);
     static bool attr_set[3][2][2];
     bool& done = attr_set[tile][a.T % 3 == 0][(a.act & OSA_OUT_SPLIT) != 0];
     if (!done) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
     const int resident = 2 * 256;                                                    // 2 workgroups per CU x 256 CUs
     const unsigned grid = (unsigned)(nitems < resident ? nitems : resident);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(k.threads), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(k.threads + 64), lds, st, a);         // + the loader wave
     OSA_LAUNCH_CHECK(what);
     return 1;
 }

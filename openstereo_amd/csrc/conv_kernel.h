@@ -245,10 +245,11 @@ template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, in
 // share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
 // limit costs the 64-channel tiles 5 %, so they keep the default).
 // PIPE = 1: persistent workgroups walking a list of bricks, the input brick double-buffered in LDS and fed by LDS-DMA
-// (buffer_load ... lds) that is issued from inside the tap loop of the PREVIOUS chunk, so staging never waits (see the
-// PIPE block below).  Split (OSA_IN_SPLIT) inputs, compact LDS image, unit input step; 2 workgroups per CU.
-#define OSA_MIN_BLOCKS (PIPE ? 2 : ((NCLS >= 4) ? 2 : ((MT == 2 && NT == 1 && WM * WN == 4) ? 4 : 1)))
-__global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
+// (buffer_load ... lds) from a loader wave while the compute waves run the taps of the previous chunk, so staging
+// never waits (see the PIPE block below).  Split (OSA_IN_SPLIT) inputs, compact LDS image, unit input step; 2 workgroups
+// of NW + 1 waves per CU.
+#define OSA_MIN_BLOCKS (PIPE ? 3 : ((NCLS >= 4) ? 2 : ((MT == 2 && NT == 1 && WM * WN == 4) ? 4 : 1)))   // PIPE: 2 x 5 waves per CU = 3 on some SIMDs
+__global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -886,96 +887,111 @@ __global__ __launch_bounds__(WM * WN * 64, OSA_MIN_BLOCKS) void conv_mfma_kernel
     } else {
         static_assert(NCLS == 1 && !REDIR && PREC == PREC_F16X3, "PIPE: plain f16x3 convolutions");
         // ---- persistent, LDS-DMA pipelined form ------------------------------------------------------------------
-        // The workgroup walks bricks id = xcd_remap(blockIdx.x) + k * gridDim.x.  Two LDS buffers hold chunk gc and
-        // chunk gc + 1 of the running (brick, 16-channel chunk) sequence; while the taps of chunk gc run, every wave
-        // issues its share of chunk gc + 1's rows -- one `buffer_load_dwordx4 ... lds` per (d, h) row of the brick, one row
-        // per tap step -- straight from the split tensor in HBM/L2 into the other buffer (no VGPR round trip, no
-        // ds_write; a per-row buffer descriptor with num_records = row bytes, or 0 for rows outside the tensor, makes
-        // the hardware zero-fill every out-of-range voxel).  The DMA is inline asm, so the compiler's vmcnt bookkeeping
-        // for the B-operand loads never drains it (it can only over-wait); one explicit vmcnt(0) + barrier per chunk
-        // publishes the landed buffer.  The epilogue transposes through the buffer that was just consumed; a third
-        // barrier keeps the next DMA out of it until every wave is done.  Staging time is gone from the critical path,
-        // the epilogue of one workgroup overlaps the taps of the other one on the CU.
+        // The workgroup (NW compute waves + ONE loader wave) walks bricks id = xcd_remap(blockIdx.x) + k * gridDim.x.  Two
+        // LDS buffers hold chunk gc and chunk gc + 1 of the running (brick, 16-channel chunk) sequence.  While the compute
+        // waves run the taps of chunk gc, the loader wave streams chunk gc + 1 into the other buffer: one
+        // `buffer_load_dwordx4 ... lds` per (d, h) row of the brick, straight from the split tensor in HBM/L2 -- no VGPR
+        // round trip, no ds_write; a per-row buffer descriptor with num_records = row bytes (0 for rows outside the
+        // tensor) makes the hardware zero-fill every out-of-range voxel.  The loader is a wave of its own because vmcnt
+        // retires in order: with the DMA in the compute waves' queue every wait for a B operand (an L2 hit) would also
+        // wait for the DMA rows in front of it (measured: -14 %).  One barrier per chunk publishes the landed buffer (the
+        // loader waits vmcnt(0) first); the epilogue transposes through the buffer that was just consumed and one more
+        // barrier keeps the next DMA out of it.  Staging is off the critical path; the epilogue of one workgroup overlaps
+        // the taps of the other workgroup on the CU.
         const int G = (int)gridDim.x;
         const int nitems = p.B * p.tilesD * p.tilesH * p.tilesW;
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-        const unsigned bufbytes = (unsigned)brickQ * 16u;
-        const unsigned rowbytes = (unsigned)(p.Wi * p.xCs) * 4u;
-        const size_t itembytes = (size_t)p.Di * p.Hi * rowbytes;
-        const int lw_ = lane >> 2, c4_ = lane & 3;
-        const bool lane_in = lw_ < p.LW;
-        // DMA cursor: rows d_row, d_row + NW, ... < d_rows of the brick whose first input voxel is (d_g0d, d_g0h, .) go to d_lds
-        int d_row = 0, d_rows = 0, d_g0d = 0, d_g0h = 0;
-        unsigned d_lds = 0, d_voff = 0;
-        const char* d_base = nullptr;
-        auto dma_target = [&](int b_, int c0, int g0d_, int g0h_, int g0w_, unsigned lds_) {
-            d_base = reinterpret_cast<const char*>(p.x) + (size_t)b_ * itembytes + (size_t)c0 * 4;
-            d_g0d = g0d_; d_g0h = g0h_;
-            d_voff = (unsigned)((g0w_ + lw_) * p.xCs * 4 + c4_ * 16);     // negative / beyond the row -> >= num_records -> zero fill
-            d_lds = lds_;
-            d_row = wave; d_rows = p.LD * p.LH;
-        };
-        auto dma_one = [&]() {
-            if (d_row < d_rows) {                                         // wave-uniform
-                const int ld = (p.LH == 1) ? d_row : (int)__umulhi((unsigned)d_row, p.magicH), lh = d_row - ld * p.LH;
-                const int gd = d_g0d + ld, gh = d_g0h + lh;
-                const bool ok = ((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi);
-                const unsigned long long rowp = (unsigned long long)(d_base + ((long long)gd * p.Hi + gh) * (long long)rowbytes);
-                u32x4 srd;
-                srd.x = __builtin_amdgcn_readfirstlane((unsigned)rowp);
-                srd.y = __builtin_amdgcn_readfirstlane((unsigned)(rowp >> 32));
-                srd.z = __builtin_amdgcn_readfirstlane(ok ? rowbytes : 0u);
-                srd.w = 0x00020000u;
-                const unsigned ldsrow = __builtin_amdgcn_readfirstlane(d_lds + (unsigned)(ld * p.PlaneQ + lh * p.RowQ) * 16u);
-                if (lane_in) {
-                    unsigned keep;
-                    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                                 "buffer_load_dwordx4 %2, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "s"(srd), "v"(d_voff), "s"(ldsrow) : "memory");
-                }
-                d_row += NW;
-            }
-        };
-        auto dma_flush = [&]() { while (d_row < d_rows) dma_one(); };
-        auto chunk_sync = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows of the next chunk have landed
-            __syncthreads();                                            // ... and everybody else's; all reads of this chunk are done
-        };
-
         int item = (int)xcd_remap(blockIdx.x, (unsigned)G);
         int gc = 0;
-        if (item < nitems) {
-            int b_, td_, th_, tw_;
-            decode_item(item, b_, td_, th_, tw_);
-            set_brick(b_, td_, th_, tw_);
-            dma_target(b, 0, g0d, g0h, g0w, lds0);
-            dma_flush();
-        }
-        chunk_sync();
-        while (item < nitems) {
-            zero_acc();
-            init_b();
-            const int nitem = item + G;
-            for (int ch = 0; ch < p.nchunks; ++ch, ++gc) {
-                const unsigned nbuf = lds0 + (unsigned)((gc + 1) & 1) * bufbytes;
-                if (ch + 1 < p.nchunks) dma_target(b, (ch + 1) * CC, g0d, g0h, g0w, nbuf);
-                else if (nitem < nitems) {
-                    int b_, td_, th_, tw_;
-                    decode_item(nitem, b_, td_, th_, tw_);
-                    dma_target(b_, 0, td_ * TD * p.isd + p.dmin, th_ * TH * p.ish + p.hmin, tw_ * TW * p.isw + p.wmin, nbuf);
-                } else d_rows = 0;
-                sm = smem + (size_t)(gc & 1) * brickQ;
-                chunk_taps(dma_one);
-                dma_flush();
-                chunk_sync();
-            }
-            epilogue(reinterpret_cast<float*>(smem + (size_t)((gc - 1) & 1) * brickQ));
-            __syncthreads();                                            // the epilogue's transpose tiles are free again
-            item = nitem;
+        if (wave == NW) {
+            // ================= loader wave =================
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+            const unsigned bufbytes = (unsigned)brickQ * 16u;
+            const unsigned rowbytes = (unsigned)(p.Wi * p.xCs) * 4u;
+            const long long planebytes = (long long)p.Hi * rowbytes;
+            const size_t itembytes = (size_t)p.Di * planebytes;
+            const int lw_ = lane >> 2, c4_ = lane & 3;
+            const bool lane_in = lw_ < p.LW;
+            auto dma_chunk = [&](int b_, int c0, int gd0, int gh0, int gw0, unsigned ldsbuf) {
+                const char* base = reinterpret_cast<const char*>(p.x) + (size_t)b_ * itembytes + (size_t)c0 * 4;
+                const unsigned voff = (unsigned)((gw0 + lw_) * p.xCs * 4 + c4_ * 16);    // left of / beyond the row: >= num_records -> 0
+                for (int ld = 0; ld < p.LD; ++ld) {
+                    const int gd = gd0 + ld;
+                    const bool dok = (unsigned)gd < (unsigned)p.Di;
+                    const char* rowp = base + (long long)gd * planebytes + (long long)gh0 * rowbytes;
+                    unsigned ldsrow = ldsbuf + (unsigned)(ld * p.PlaneQ) * 16u;
+                    for (int lh = 0; lh < p.LH; ++lh, rowp += rowbytes, ldsrow += (unsigned)p.RowQ * 16u) {
+                        const bool ok = dok && ((unsigned)(gh0 + lh) < (unsigned)p.Hi);
+                        const unsigned long long rp = (unsigned long long)rowp;
+                        u32x4 srd;
+                        srd.x = __builtin_amdgcn_readfirstlane((unsigned)rp);
+                        srd.y = __builtin_amdgcn_readfirstlane((unsigned)(rp >> 32));
+                        srd.z = __builtin_amdgcn_readfirstlane(ok ? rowbytes : 0u);
+                        srd.w = 0x00020000u;
+                        const unsigned m0v = __builtin_amdgcn_readfirstlane(ldsrow);
+                        if (lane_in) {
+                            unsigned keep;
+                            asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                                         "buffer_load_dwordx4 %2, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
+                                         : "=&s"(keep) : "s"(srd), "v"(voff), "s"(m0v) : "memory");
+                        }
+                    }
+                }
+            };
+            auto land = [&]() {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every row of the chunk has landed in LDS ...
+                __syncthreads();                                        // ... hand it to the compute waves (their chunk-end barrier)
+            };
             if (item < nitems) {
                 int b_, td_, th_, tw_;
                 decode_item(item, b_, td_, th_, tw_);
                 set_brick(b_, td_, th_, tw_);
+                dma_chunk(b, 0, g0d, g0h, g0w, lds0);
+            }
+            land();
+            while (item < nitems) {
+                const int nitem = item + G;
+                for (int ch = 0; ch < p.nchunks; ++ch, ++gc) {
+                    const unsigned nbuf = lds0 + (unsigned)((gc + 1) & 1) * bufbytes;
+                    if (ch + 1 < p.nchunks) dma_chunk(b, (ch + 1) * CC, g0d, g0h, g0w, nbuf);
+                    else if (nitem < nitems) {
+                        int b_, td_, th_, tw_;
+                        decode_item(nitem, b_, td_, th_, tw_);
+                        dma_chunk(b_, 0, td_ * TD * p.isd + p.dmin, th_ * TH * p.ish + p.hmin, tw_ * TW * p.isw + p.wmin, nbuf);
+                    }
+                    land();
+                }
+                __syncthreads();                                        // (the compute waves' post-epilogue barrier)
+                item = nitem;
+                if (item < nitems) {
+                    int b_, td_, th_, tw_;
+                    decode_item(item, b_, td_, th_, tw_);
+                    set_brick(b_, td_, th_, tw_);
+                }
+            }
+        } else {
+            // ================= compute waves =================
+            if (item < nitems) {
+                int b_, td_, th_, tw_;
+                decode_item(item, b_, td_, th_, tw_);
+                set_brick(b_, td_, th_, tw_);
+            }
+            __syncthreads();                                            // chunk 0 of the first brick has landed
+            while (item < nitems) {
+                zero_acc();
+                init_b();
+                for (int ch = 0; ch < p.nchunks; ++ch, ++gc) {
+                    sm = smem + (size_t)(gc & 1) * brickQ;
+                    chunk_taps([]() {});
+                    __syncthreads();                                    // chunk gc is consumed, chunk gc + 1 has landed
+                }
+                epilogue(reinterpret_cast<float*>(smem + (size_t)((gc - 1) & 1) * brickQ));
+                __syncthreads();                                        // the epilogue's transpose tiles are free again
+                item += G;
+                if (item < nitems) {
+                    int b_, td_, th_, tw_;
+                    decode_item(item, b_, td_, th_, tw_);
+                    set_brick(b_, td_, th_, tw_);
+                }
             }
         }
     }

@@ -7,16 +7,11 @@ namespace osa {
 
 #define OSA_PIPE(TU, MT, NT, WM, WN, TH, TW, OUTS) conv_mfma_kernel<PREC_F16X3, 1, TU, MT, NT, WM, WN, TH, TW, 0, OUTS, 1>
 
-// [tile][B ring (tap count % 3 == 0) ? 1 : 0][split output ? 1 : 0]
-static void (*const g_pipe[3][2][2])(const ConvArgs) = {
-    { { OSA_PIPE(1, 2, 1, 4, 1, 8, 8, 0), OSA_PIPE(1, 2, 1, 4, 1, 8, 8, 1) },      // 256 voxels x  32 channels, brick 4x8x8
-      { OSA_PIPE(3, 2, 1, 4, 1, 8, 8, 0), OSA_PIPE(3, 2, 1, 4, 1, 8, 8, 1) } },
-    { { OSA_PIPE(1, 2, 2, 4, 1, 8, 8, 0), OSA_PIPE(1, 2, 2, 4, 1, 8, 8, 1) },      // 256 voxels x  64 channels
-      { OSA_PIPE(3, 2, 2, 4, 1, 8, 8, 0), OSA_PIPE(3, 2, 2, 4, 1, 8, 8, 1) } },
-    { { OSA_PIPE(1, 2, 2, 2, 2, 8, 8, 0), OSA_PIPE(1, 2, 2, 2, 2, 8, 8, 1) },      // 128 voxels x 128 channels, brick 2x8x8
-      { OSA_PIPE(3, 2, 2, 2, 2, 8, 8, 0), OSA_PIPE(3, 2, 2, 2, 2, 8, 8, 1) } },
-};
+// [split output ? 1 : 0].  256 voxels x 32 channels, brick 4x8x8, ping-pong operand pipeline: 140 / 161 registers, so a SIMD
+// holds 3 of the 10 waves two workgroups (4 compute + 1 loader wave each) put on a CU.  (The B-ring form and the 64- / 128-
+// channel tiles need more than the 168 registers that residency allows and spill.)
+static void (*const g_pipe[2])(const ConvArgs) = { OSA_PIPE(1, 2, 1, 4, 1, 8, 8, 0), OSA_PIPE(1, 2, 1, 4, 1, 8, 8, 1) };
 
-void (*pipe_kernel(int tile, int ring, int outs))(const ConvArgs) { return g_pipe[tile][ring ? 1 : 0][outs ? 1 : 0]; }
+void (*pipe_kernel(int tile, int ring, int outs))(const ConvArgs) { return (tile == 0) ? g_pipe[outs ? 1 : 0] : nullptr; }
 
 }  // namespace osa
