@@ -141,14 +141,16 @@ static size_t brick_bytes(ConvArgs& a, const KernelCfg& k) {
     return (size_t)a.LD * a.LH * (a.LW * VS + 64) * sizeof(float);   // upper bound incl. row padding
 }
 
-// conv_pipe.hip
+#ifdef OSA_EXPERIMENTS
+// conv_pipe.hip -- experiments build only (tools/build_variant.sh, OSA_PIPE=1): measured slower than the form below on every
+// layer it covers (profiles/round2/pipe_ablation.txt), so the shipped library neither links nor selects it.
 void (*pipe_kernel(int tile, int ring, int outs))(const ConvArgs);
 
 // Persistent LDS-DMA pipelined launch (conv_kernel.h, PIPE = 1) for the layers it covers: f16x3, split input, unit
 // stride, no gate, output channels filling one N tile of 32 / 64 / 128.  Returns 1 when launched, 0 when not eligible.
 static int launch_conv_pipe(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what) {
     if (prec != PREC_F16X3 || !(a.act & OSA_IN_SPLIT) || stride != 1 || a.isd != 1 || a.ish != 1 || a.isw != 1) return 0;
-    if (a.gate || a.rx || a.os != 1 || a.Ci % CC != 0 || exp_set("OSA_NOPIPE")) return 0;
+    if (a.gate || a.rx || a.os != 1 || a.Ci % CC != 0 || !exp_int("OSA_PIPE", 0)) return 0;
     if (a.Ad < 2) return 0;                            // flat (2-D) maps: the 3-D bricks below would idle 3 of their 4 planes
     const int tile = (a.CoP == 32) ? 0 : ((a.CoP == 64) ? 1 : ((a.CoP == 128) ? 2 : -1));
     if (tile < 0) return 0;
@@ -185,19 +187,24 @@ static int launch_conv_pipe(ConvArgs& a, int stride, int prec, hipStream_t st, c
     static bool attr_set[3][2][2];
     bool& done = attr_set[tile][a.T % 3 == 0][(a.act & OSA_OUT_SPLIT) != 0];
     if (!done) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-    const int resident = 2 * 256;                                                    // 2 workgroups per CU x 256 CUs
+    const int resident = exp_int("OSA_PIPE_WGS", 2) * 256;                           // 2 workgroups per CU x 256 CUs
+    a.dbg = exp_int("OSA_DBG", 0);
     const unsigned grid = (unsigned)(nitems < resident ? nitems : resident);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(k.threads + 64), lds, st, a);         // + the loader wave
     OSA_LAUNCH_CHECK(what);
     return 1;
 }
 
+#endif   // OSA_EXPERIMENTS
+
 static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what,
                        const KernelCfg* forced = nullptr) {
+#ifdef OSA_EXPERIMENTS
     if (!forced) {
         const int r = launch_conv_pipe(a, stride, prec, st, what);
         if (r != 0) return r < 0 ? r : 0;
     }
+#endif
     int ci = forced ? 0 : pick_cfg(a, stride);
     if (!forced && brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
         // e.g. a stride-2 3x3x3 layer whose output depth collapses to 1: fall back to the small bricks

@@ -912,6 +912,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             const int lw_ = lane >> 2, c4_ = lane & 3;
             const bool lane_in = lw_ < p.LW;
             auto dma_chunk = [&](int b_, int c0, int gd0, int gh0, int gw0, unsigned ldsbuf) {
+                if (p.dbg & 1) return;                                   // experiments: no staging (timing only)
                 const char* base = reinterpret_cast<const char*>(p.x) + (size_t)b_ * itembytes + (size_t)c0 * 4;
                 const unsigned voff = (unsigned)((gw0 + lw_) * p.xCs * 4 + c4_ * 16);    // left of / beyond the row: >= num_records -> 0
                 for (int ld = 0; ld < p.LD; ++ld) {
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
                 init_b();
                 for (int ch = 0; ch < p.nchunks; ++ch, ++gc) {
                     sm = smem + (size_t)(gc & 1) * brickQ;
-                    chunk_taps([]() {});
+                    if (!(p.dbg & 16)) chunk_taps([]() {});             // (experiments: dbg 16 = no taps, timing only)
                     __syncthreads();                                    // chunk gc is consumed, chunk gc + 1 has landed
                 }
                 epilogue(reinterpret_cast<float*>(smem + (size_t)((gc - 1) & 1) * brickQ));

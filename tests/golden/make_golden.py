@@ -116,10 +116,77 @@ def gen_igev_update():
     save("igev_refine.npz", disp=d, mask=mk, net0=nl[0])
 
 
+def gen_at_size():
+    """BASELINE configs [2] and [4] at their real sizes, sub-sampled taps so the fixtures stay small:
+      * geometry-encoding lookup at [1,96,136,240] features / [1,8,48,136,240] volume (igev/geometry.py:7-66),
+      * the IGEV refinement loop at 136x240 with VALID_ITERS = 32 (igev_stereo.py:181-203, cfgs/igev/igev_sceneflow_amp.yaml:31),
+      * the StereoBase cost stage at the 320x736 training crop (quarter resolution 80x184, D/4 = 48; stereobase_gru.py:139-164).
+    Inputs are regenerated from seeds by tests/conftest.py (igev_at_size_case / stereobase_at_size_case).
+    GRU weights use gain 0.8: with the unit-gain synthetic weights the 32-step recurrence amplifies a 1e-6 perturbation 800x
+    (chaotic regime, measured with the oracle), which would turn a kernel comparison into a lottery; at 0.8 the map is
+    contractive (amplification ~7x), disparities still move by +-17 px over the 32 iterations."""
+    import importlib.util
+    import torch.nn.functional as F
+    from openstereo_amd.utils.weights import synth_state_dict
+    sys.modules.setdefault("timm", types.ModuleType("timm"))
+    from stereo.modeling.models.igev.geometry import Combined_Geo_Encoding_Volume
+    spec = importlib.util.spec_from_file_location("ref_igev_update", os.path.join(REF, "stereo/modeling/models/igev/update.py"))
+    upd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(upd)
+    H, W = 136, 240
+    ml, mr = rnd((1, 96, H, W), 192), rnd((1, 96, H, W), 193)
+    gvol = rnd((1, 8, 48, H, W), 194)
+    coords = torch.arange(W).float().reshape(1, 1, W, 1).repeat(1, H, 1, 1)
+    d0 = rnd((1, 1, H, W), 195).abs() * 3
+    geo_fn = Combined_Geo_Encoding_Volume(ml, mr, gvol, radius=4, num_levels=2)
+    lk = geo_fn(d0 * 8.0, coords)                                        # disparities up to ~100: taps leave the volume on both levels
+    args = Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2)
+    blk = upd.BasicMultiUpdateBlock(args, hidden_dims=[128, 128, 128]).eval()
+    blk.load_state_dict(synth_state_dict(blk, seed=11, gain=0.8))
+    net = [torch.tanh(rnd((1, 128, H >> i, W >> i), 170 + i)) for i in range(3)]
+    inp = [[rnd((1, 128, H >> i, W >> i), 180 + 3 * i + j) * 0.5 for j in range(3)] for i in range(3)]
+    d, nl, t = d0, [x.clone() for x in net], time.time()
+    trace = []
+    for it in range(32):
+        gf = geo_fn(d, coords)
+        nl = blk(nl, inp, iter16=True, iter08=False, iter04=False, update=False)
+        nl = blk(nl, inp, iter16=True, iter08=True, iter04=False, update=False)
+        nl, mk, dd = blk(nl, inp, gf, d, iter16=True, iter08=True)
+        d = d + dd
+        if it in (0, 7, 15):
+            trace.append(d[:, :, ::4, ::4].clone())
+    print(f"IGEV refine x32 at {H}x{W}: {time.time() - t:.1f} s, disp range {d.min().item():.2f}..{d.max().item():.2f}")
+    save("igev_at_size.npz", lookup_sub=lk[:, :, ::8, ::8], disp=d, disp_it1=trace[0], disp_it8=trace[1], disp_it16=trace[2],
+         mask_sub=mk[:, :, ::4, ::4], net0_sub=nl[0][:, :, ::4, ::4])
+
+    # ---- StereoBase cost stage at the training crop
+    from stereo.modeling.cost_volume.cost_volume import build_gwc_volume, build_concat_volume
+    from stereo.modeling.disp_pred.disp_regression import disparity_regression
+    from stereo.modeling.models.stereobase.hourglass import Hourglass as SBHourglass
+    from openstereo_amd.models.igev_style import StereoBaseCostStage
+    h, w = 80, 184
+    st = StereoBaseCostStage(max_disp=192, num_groups=8, concat_channels=8, backbone_channels=[48, 64, 192, 120])
+    sd = synth_state_dict(st, seed=8, head_gain=20.0)
+    hg = SBHourglass(24, [48, 64, 192, 120]).eval()
+    hg.load_state_dict({k[len("cost_agg."):]: v for k, v in sd.items() if k.startswith("cost_agg.")})
+    fm_l, fm_r = rnd((1, 96, h, w), 201), rnd((1, 96, h, w), 202)
+    ct_l, ct_r = rnd((1, 8, h, w), 203), rnd((1, 8, h, w), 204)
+    feats = [None, rnd((1, 64, h // 2, w // 2), 205), rnd((1, 192, h // 4, w // 4), 206), rnd((1, 120, h // 8, w // 8), 207)]
+    t = time.time()
+    vol = torch.cat((build_gwc_volume(fm_l, fm_r, 48, 8), build_concat_volume(ct_l, ct_r, 48)), 1)     # stereobase_gru.py:156-160
+    geo = hg(vol, feats)
+    cost = F.conv3d(geo, sd["classifier.weight"], None, 1, 1).squeeze(1)                              # :162
+    prob = F.softmax(cost, dim=1)
+    init_disp = disparity_regression(prob, 48)                                                         # :163-164
+    print(f"StereoBase cost stage at {h}x{w}: {time.time() - t:.1f} s, init disp range {init_disp.min().item():.2f}..{init_disp.max().item():.2f}"
+          f" std {init_disp.std().item():.2f}")
+    save("stereobase_at_size.npz", init_disp=init_disp, prob_sub=prob[:, :, ::4, ::4], geo_sub=geo[:, :, ::4, ::4, ::4])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -129,6 +196,9 @@ def main():
         return
     if args.only == "igev_update":
         gen_igev_update()
+        return
+    if args.only == "at_size":
+        gen_at_size()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -252,6 +322,7 @@ def main():
     # ------------------------------------------------------------------ LightStereo 2-D aggregation (a9)
     gen_lightstereo()
     gen_igev_update()
+    gen_at_size()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet
