@@ -100,3 +100,33 @@ def igev_refine_case():
     gvol = rnd((1, 8, 12, H, W), 94)
     d0 = rnd((1, 1, H, W), 95).abs() * 3
     return ref, {"update_block." + k: v for k, v in sd.items()}, ml, mr, gvol, net, inp, d0
+
+
+def igev_at_size_case():
+    """BASELINE configs[4] at size (make_golden.gen_at_size): 136x240 quarter resolution, 96-channel matching features, 8 x 48 geometry volume."""
+    import torch
+    from openstereo_amd.utils.weights import synth_state_dict
+    from openstereo_amd.models.igev_update import IGEVRefiner
+    args = _Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2, SLOW_FAST_GRU=True)
+    ref = IGEVRefiner(args, hidden_dims=[128, 128, 128]).eval()
+    sd = synth_state_dict(ref.update_block, seed=11, gain=0.8)      # contractive recurrence, see make_golden.gen_at_size
+    ref.update_block.load_state_dict(sd)
+    H, W = 136, 240
+    ml, mr = rnd((1, 96, H, W), 192), rnd((1, 96, H, W), 193)
+    gvol = rnd((1, 8, 48, H, W), 194)
+    d0 = rnd((1, 1, H, W), 195).abs() * 3
+    net = [torch.tanh(rnd((1, 128, H >> i, W >> i), 170 + i)) for i in range(3)]
+    inp = [[rnd((1, 128, H >> i, W >> i), 180 + 3 * i + j) * 0.5 for j in range(3)] for i in range(3)]
+    return ref, ml, mr, gvol, net, inp, d0
+
+
+def stereobase_at_size_case():
+    """BASELINE configs[2] at the 320x736 training crop (make_golden.gen_at_size): quarter resolution 80x184, D/4 = 48."""
+    from openstereo_amd.utils.weights import synth_state_dict
+    from openstereo_amd.models.igev_style import StereoBaseCostStage
+    h, w = 80, 184
+    st = StereoBaseCostStage(max_disp=192, num_groups=8, concat_channels=8, backbone_channels=[48, 64, 192, 120])
+    st.load_state_dict(synth_state_dict(st, seed=8, head_gain=20.0))
+    x = (rnd((1, 96, h, w), 201), rnd((1, 96, h, w), 202), rnd((1, 8, h, w), 203), rnd((1, 8, h, w), 204))
+    feats = [None, rnd((1, 64, h // 2, w // 2), 205), rnd((1, 192, h // 4, w // 4), 206), rnd((1, 120, h // 8, w // 8), 207)]
+    return st.eval(), x, feats

@@ -172,3 +172,22 @@ def test_igev_refine_loop_against_reference():
     for k, v in (("disp", disp), ("mask", mask), ("net0", n[0])):
         ref = torch.from_numpy(g[k])
         assert (v - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_at_size_fixtures_against_reference():
+    """The oracle at BASELINE sizes (configs [2] and [4]): StereoBase cost stage at the 320x736 crop and the IGEV loop at 136x240
+    with 32 iterations, vs the outputs of the real reference's modules (tests/golden/*_at_size.npz)."""
+    from conftest import igev_at_size_case, stereobase_at_size_case
+    g = golden("stereobase_at_size.npz")
+    st, x, feats = stereobase_at_size_case()
+    with torch.no_grad():
+        d, prob, geo = O.stereobase_cost_stage(*x, feats, st.state_dict(), 192, 8)
+    assert (d - torch.from_numpy(g["init_disp"])).abs().max().item() <= 1e-5
+    assert (geo[:, :, ::4, ::4, ::4] - torch.from_numpy(g["geo_sub"])).abs().max().item() <= 1e-5 * float(np.abs(g["geo_sub"]).max())
+    g = golden("igev_at_size.npz")
+    ref, ml, mr, gvol, net, inp, d0 = igev_at_size_case()
+    sd = {"update_block." + k: v for k, v in ref.update_block.state_dict().items()}
+    with torch.no_grad():
+        disp, mask, n = O.igev_refine(ml, mr, gvol, net, inp, d0, sd, 32)
+    assert (disp - torch.from_numpy(g["disp"])).abs().max().item() <= 2e-4
+    assert (n[0][:, :, ::4, ::4] - torch.from_numpy(g["net0_sub"])).abs().max().item() <= 2e-4
