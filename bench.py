@@ -148,7 +148,7 @@ class IGEVRefine32:
     """BASELINE configs[4]: the IGEV refinement loop at SceneFlow size (quarter resolution 136x240), VALID_ITERS = 32
     (cfgs/igev/igev_sceneflow_amp.yaml:31; igev_stereo.py:181-203) + the final convex upsample."""
     metric = "stereo-pairs/s, IGEV GRU refinement x32 at 544x960"
-    scaling, graphable, training = "weak", False, False
+    scaling, graphable, training = "weak", True, False      # ~1500 launches per pair: launch-bound unless replayed as a hipGraph
 
     def __init__(self, args, dev, rank):
         from openstereo_amd.models.igev_update import IGEVRefiner
