@@ -88,13 +88,26 @@ struct LookupArgs {
     int Dl[4], Wl[4];
 };
 
-__device__ __forceinline__ float sample_row(const float* __restrict__ row, int n, float x) {
-    const float xf = floorf(x);
-    const int x0 = (int)xf;
-    const float w1 = x - xf;
-    const float a = (x0 >= 0 && x0 < n) ? row[x0] : 0.f;
-    const float b = (x0 + 1 >= 0 && x0 + 1 < n) ? row[x0 + 1] : 0.f;
-    return a * (1.f - w1) + b * w1;
+// Sampling position of one tap, with the reference's own float roundings: bilinear_sampler (igev/utils.py:61-79) maps the
+// pixel coordinate x to xgrid = 2 * x / (n - 1) - 1 and F.grid_sample(align_corners=True) maps it back with
+// ((xgrid + 1) / 2) * (n - 1); at n = 240 the round trip moves x by up to ~2e-5, which shifts the interpolation weights.
+// Reproducing the round trip keeps the lookup within a few 1e-6 of the reference at any width (-ffp-contract=off: no fma).
+struct Tap { int x0; float w0, w1; };
+__device__ __forceinline__ Tap tap_of(float x, int n) {
+    const float nm1 = (float)(n - 1);
+    const float g = 2.f * x / nm1 - 1.f;
+    const float ix = ((g + 1.f) / 2.f) * nm1;
+    const float xf = floorf(ix);
+    Tap t;
+    t.x0 = (int)xf;
+    t.w1 = ix - xf;
+    t.w0 = (xf + 1.f) - ix;
+    return t;
+}
+__device__ __forceinline__ float sample_row(const float* __restrict__ row, int n, const Tap t) {
+    const float a = (t.x0 >= 0 && t.x0 < n) ? row[t.x0] : 0.f;
+    const float b = (t.x0 + 1 >= 0 && t.x0 + 1 < n) ? row[t.x0 + 1] : 0.f;
+    return a * t.w0 + b * t.w1;
 }
 
 __global__ __launch_bounds__(256) void geo_lookup_kernel(const LookupArgs p) {
@@ -109,15 +122,16 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const LookupArgs p) {
     float scale = 1.f;
     for (int l = 0; l < p.levels; ++l, scale *= 0.5f) {
         const float* g = p.geo[l] + (size_t)i * p.C * p.Dl[l];
-        const float xg = d * scale, xc = cx * scale - d * scale;
-        for (int c = 0; c < p.C; ++c) {
-            const float* row = g + (size_t)c * p.Dl[l];
-            for (int k = 0; k < taps; ++k)
-                o[((size_t)l * per_level + c * taps + k) * HW] = sample_row(row, p.Dl[l], xg + (float)(k - p.radius));
-        }
         const float* crow = p.corr[l] + (size_t)i * p.Wl[l];
-        for (int k = 0; k < taps; ++k)
-            o[((size_t)l * per_level + p.C * taps + k) * HW] = sample_row(crow, p.Wl[l], xc + (float)(k - p.radius));
+        const float xg = d * scale, xc = cx * scale - d * scale;
+        for (int k = 0; k < taps; ++k) {                                    // tap position once, shared by the C volume rows
+            const float dx = (float)(k - p.radius);
+            const Tap tg = tap_of(dx + xg, p.Dl[l]);                        // geometry.py:36  x0 = dx + disp / 2^i
+            for (int c = 0; c < p.C; ++c)
+                o[((size_t)l * per_level + c * taps + k) * HW] = sample_row(g + (size_t)c * p.Dl[l], p.Dl[l], tg);
+            const Tap tc = tap_of(xc + dx, p.Wl[l]);                        // geometry.py:44  coords / 2^i - disp / 2^i + dx
+            o[((size_t)l * per_level + p.C * taps + k) * HW] = sample_row(crow, p.Wl[l], tc);
+        }
     }
 }
 

@@ -244,7 +244,8 @@ class PackedConv3d:
         if self.precision == "f16x3":
             # operand ranges (device-side): scale of x / residual / redir input, bound for a split output, and the
             # output's own running maximum
-            rng = _lib.F16x3Ranges(input_meta(x).data_ptr(), None if residual is None else input_meta(residual).data_ptr(),
+            need_res = residual is not None and (out_split or is_split(residual))    # its scale (split) / its share of the output bound
+            rng = _lib.F16x3Ranges(input_meta(x).data_ptr(), input_meta(residual).data_ptr() if need_res else None,
                                    None if redir is None else input_meta(redir[1]).data_ptr(), attach_meta(out, st).data_ptr(),
                                    self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):

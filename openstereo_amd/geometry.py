@@ -47,6 +47,11 @@ class CombinedGeoEncodingVolume:
         self._gl = (ctypes.c_int * L)(*[t.shape[-1] for t in self.geo_volume_pyramid])
         self._cl = (ctypes.c_int * L)(*[t.shape[-1] for t in self.init_corr_pyramid])
         self.shape = (B, H, W1)
+        # range block of every lookup result (f16x3 consumers): taps are convex combinations of volume entries or zero,
+        # the coarser pyramid levels are averages -> bounded by max |level 0|; measured once here, not once per iteration
+        from .ranges import new_meta
+        self.meta = new_meta(dev)
+        self.meta[0:1] = torch.maximum(rows.abs().amax(), corr.abs().amax()).reshape(1)
 
     def __call__(self, disp, coords):
         """disp [B,1,H,W] (quarter-res disparity), coords [B,H,W,1] (x coordinate grid) ->

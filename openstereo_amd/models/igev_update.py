@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from .. import _lib
 from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from ..ops import empty_cl, is_cl, on_engine, _stream
-from ..ranges import amax_of, attach_meta, ensure_meta, fold_amax, meta_of, new_meta
+from ..ranges import attach_meta, combine_meta, ensure_meta, fold_amax, inherit_meta, meta_of, new_meta
 from .lightstereo import nchw_to_cl, cl_to_nchw
 
 
@@ -44,17 +44,19 @@ def _as_cl(t4):
 
 
 def pool2x(x):
-    """update.py:99-100 on an engine tensor."""
-    return _as_cl(F.avg_pool2d(x[:, :, 0], 3, stride=2, padding=1))
+    """update.py:99-100 on an engine tensor (averages: x's range block stays valid)."""
+    return inherit_meta(_as_cl(F.avg_pool2d(x[:, :, 0], 3, stride=2, padding=1)), x)
 
 
 def interp(x, dest):
-    """update.py:107-109 (bilinear, align_corners=True) on engine tensors."""
-    return _as_cl(F.interpolate(x[:, :, 0], dest.shape[3:], mode="bilinear", align_corners=True))
+    """update.py:107-109 (bilinear, align_corners=True) on engine tensors (convex combinations: x's range block stays valid)."""
+    return inherit_meta(_as_cl(F.interpolate(x[:, :, 0], dest.shape[3:], mode="bilinear", align_corners=True)), x)
 
 
-def _cat_cl(parts, dev):
-    """Channel concatenation into one NHWC buffer (what torch.cat does for the reference)."""
+def _cat_cl(parts, dev, track=False):
+    """Channel concatenation into one NHWC buffer (what torch.cat does for the reference).  track (f16x3 chains): the result
+    gets a range block = slot-wise maximum of the parts' blocks; a part that has none yet (the static context inputs cz / cr / cq
+    ..., converted once per forward) is measured once and keeps its block, so the loop never reduces over data again."""
     B, _, _, H, W = parts[0].shape
     C = sum(p.shape[1] for p in parts)
     out = empty_cl(B, C, 1, H, W, dev)
@@ -63,11 +65,8 @@ def _cat_cl(parts, dev):
         assert p.shape[1] % 4 == 0, "engine tensors are channel-padded to 4: a part with padded channels would shift the next one"
         out[:, o:o + p.shape[1]] = p
         o += p.shape[1]
-    metas = [meta_of(p) for p in parts]
-    if all(m is not None for m in metas):        # f16x3 chains: max |.| of the concatenation = max over the parts (device side)
-        m = new_meta(dev)
-        m[0:1] = torch.cat([amax_of(t) for t in metas]).amax().reshape(1)
-        out._osa_meta = m
+    if track:
+        out._osa_meta = combine_meta(*[ensure_meta(p) for p in parts])
     return out
 
 
@@ -107,12 +106,13 @@ class ConvGRU(nn.Module):
                                                         PackedConv3d(self.convq, None, ACT_TANH)))
         hd = self.convz.out_channels
         assert hd % 4 == 0 and h.shape[1] == hd
-        hx = _cat_cl([h, *x_list], h.device)                   # [h | x]
+        f16 = pz.precision == "f16x3"
+        hx = _cat_cl([h, *x_list], h.device, track=f16)        # [h | x]
         z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
         rhx = hx.clone()                                       # [r*h | x]: the x part is shared, r*h overwrites the h slice
-        if pz.precision == "f16x3":                            # range block of [r*h | x]: that of [h | x] (|r*h| <= |h|); convr only
+        if f16:                                                # range block of [r*h | x]: that of [h | x] (|r*h| <= |h|); convr only
             rhx._osa_meta = new_meta(h.device)                 # folds its own slice in, the cloned x part would be missed
-            rhx._osa_meta.copy_(ensure_meta(hx))
+            rhx._osa_meta.copy_(meta_of(hx))
         pr(hx, residual=cr, gate=_nhwc(h), gate_raw=True, out=rhx, out_off=0)   # sigmoid(convr(hx) + cr) * h
         q = pq(rhx, residual=cq)                               # tanh(convq([r*h, x]) + cq)
         out = empty_cl(*h.shape, h.device)
@@ -257,6 +257,7 @@ class IGEVRefiner(nn.Module):
                 net = self.update_block.forward_cl(net, inp, iter16=True, iter08=False, iter04=False, update=False)
             if a.N_GRU_LAYERS >= 2 and a.SLOW_FAST_GRU:
                 net = self.update_block.forward_cl(net, inp, iter16=a.N_GRU_LAYERS == 3, iter08=True, iter04=False, update=False)
+            geo_feat._osa_meta = geo_fn.meta                  # lookups interpolate / zero-pad the volumes: bounded by their max |.|
             net, mask, delta = self.update_block.forward_cl(net, inp, c(geo_feat), c(disp),
                                                             iter16=a.N_GRU_LAYERS == 3, iter08=a.N_GRU_LAYERS >= 2)
             disp = disp + cl_to_nchw(delta, 1)

@@ -32,6 +32,8 @@ def nchw_to_cl(x):
     if Cp != C:
         out.zero_()
     out[:, :C, 0] = x.float()
+    if getattr(x, "_osa_meta", None) is not None:        # same values in another layout: the range block carries over
+        out._osa_meta = x._osa_meta
     return out
 
 

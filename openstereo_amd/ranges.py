@@ -87,3 +87,21 @@ def attach_meta(t, stream=None):
         m = new_meta(t.device, stream)
         t._osa_meta = m
     return m
+
+
+def combine_meta(*metas) -> torch.Tensor:
+    """Range block covering several tensors (a concatenation): slot-wise maximum -- one tiny elementwise kernel per pair,
+    no reduction over the data."""
+    out = metas[0]
+    for m in metas[1:]:
+        out = torch.maximum(out, m)
+    return out
+
+
+def inherit_meta(dst, src):
+    """`dst` holds convex combinations / copies of `src`'s values (pooling, bilinear resampling, layout change, clone):
+    max |dst| <= max |src|, so src's block is a valid (shared, read-only) range block for dst."""
+    m = getattr(src, "_osa_meta", None)
+    if m is not None:
+        dst._osa_meta = m
+    return dst
