@@ -218,18 +218,18 @@ def _graft_plan():
         (M + "gwcnet.gwcnet_backbone", {"feature_extraction": (GW._Features, ("forward_cl", "_pack"), False),
                                         "GwcNet": (GW.GwcBackbone, ("forward", "forward_cl", "use_engine"), False)}),  # :78-112
         (M + "gwcnet.gwcnet", {"GwcNet": (GW.GwcNet, ("forward", "reset_engine"), False)}),                     # gwcnet.py:27-39
-        (M + "psmnet.psmnet_cost_processor", {"Hourglass": (PSM.Hourglass, fwd, True),                          # :108-132
-                                              "PSMAggregator": (PSM.PSMAggregator, fwd + ("aggregate_cl",), True),   # :182-221
-                                              "PSMCostProcessor": (PSM.PSMCostProcessor, ("forward",), True)}),
+        (M + "psmnet.psmnet_cost_processor", {"Hourglass": (PSM.Hourglass, fwd, False),                         # :108-132
+                                              "PSMAggregator": (PSM.PSMAggregator, fwd + ("aggregate_cl", "aggregate_train"), False),   # :182-221
+                                              "PSMCostProcessor": (PSM.PSMCostProcessor, ("forward",), False)}),
         (M + "psmnet.psmnet_disp_processor", {"PSMDispProcessor": (PSM.PSMDispProcessor, ("forward",), False)}),
         (M + "psmnet.psmnet_backbone", {"PSMNet": (PSM.PSMBackbone, ("forward", "forward_cl", "_pack", "reset_engine", "use_engine"), False)}),
         (M + "stereobase.igev_blocks", {"FeatureAtt": (IG.FeatureAtt, ("logits",), False)}),
         (M + "stereobase.hourglass", {"Hourglass": (IG.Hourglass, fwd + ("gate_logits", "_unit_train"), False)}),   # hourglass.py:79-104
         (M + "igev.submodule", {"FeatureAtt": (IG.IGEVFeatureAtt, ("logits",), False)}),
         (M + "igev.igev_stereo", {"hourglass": (IG.hourglass, ("forward", "forward_cl", "_packed_layers", "reset_engine"), True)}),  # :51-76
-        (M + "lightstereo.aggregation", {c: (getattr(LS, c), fwd, True) for c in ("Aggregation", "MobileV2Residual", "AttentionModule")}),
-        (M + "igev.update", {c: (getattr(UP, c), fwd, True) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
-        (M + "stereobase.gru_blocks", {c: (getattr(UP, c), fwd, True) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
+        (M + "lightstereo.aggregation", {c: (getattr(LS, c), fwd, False) for c in ("Aggregation", "MobileV2Residual", "AttentionModule")}),
+        (M + "igev.update", {c: (getattr(UP, c), fwd, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
+        (M + "stereobase.gru_blocks", {c: (getattr(UP, c), fwd, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
     ]
 
 

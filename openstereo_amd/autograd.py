@@ -318,3 +318,77 @@ def conv_module(m, x):
     if isinstance(m, torch.nn.ConvTranspose3d):
         return conv_transpose3d(x, m.weight, m.bias, m.stride, m.padding, m.output_padding)
     return conv3d(x, m.weight, m.bias, m.stride, m.padding, m.dilation)
+
+
+# ----------------------------------------------------------------------------- 2-D convolutions and a module-level switch
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None):
+    """Differentiable F.conv2d (groups=1, stride 1) on the engine: the D = 1 case of conv3d (forward, dgrad and wgrad kernels)."""
+    p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    assert p2(stride) == (1, 1), "engine conv2d autograd: stride 1 (strided 2-D layers stay torch ops in training)"
+    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), precision or engine.get_precision())
+    y = y[:, :, 0]
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+def _eligible(m, x):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        return False
+    if m.groups != 1 or getattr(m, "padding_mode", "zeros") != "zeros" or isinstance(m.padding, str):
+        return False
+    if isinstance(m, torch.nn.Conv2d):
+        return tuple(m.stride) == (1, 1) and m.in_channels >= 4
+    if isinstance(m, torch.nn.ConvTranspose3d):
+        k, p, op = m.kernel_size, m.padding, m.output_padding
+        return tuple(m.stride) == (2, 2, 2) and tuple(m.dilation) == (1, 1, 1) and \
+            ((tuple(k), tuple(p), tuple(op)) in (((3, 3, 3), (1, 1, 1), (1, 1, 1)), ((4, 4, 4), (1, 1, 1), (0, 0, 0))))
+    if isinstance(m, torch.nn.Conv3d):
+        s = tuple(m.stride)
+        if s == (1, 1, 1):
+            return True
+        return s == (2, 2, 2) and tuple(m.kernel_size) == (3, 3, 3) and tuple(m.padding) == (1, 1, 1) and tuple(m.dilation) == (1, 1, 1) \
+            and all(d % 2 == 0 for d in x.shape[2:])
+    return False
+
+
+class engine_convs:
+    """Context manager: inside it every eligible nn.Conv3d / nn.ConvTranspose3d / nn.Conv2d forward -- and its backward -- runs on the
+    engine's kernels through the autograd Functions above; BatchNorm, activations, depthwise / strided 2-D convolutions, pooling and
+    everything else stay the torch modules they are, so batch statistics, SyncBN and DistributedDataParallel behave exactly as in the
+    reference.  This is the training path of modules that keep the reference's own forward (attach: train_fallback) and of the mirrors'
+    forward_train methods:
+
+        with openstereo_amd.autograd.engine_convs():
+            loss = model(batch)            # reference-built or mirror model, in train mode
+        loss.backward()                    # backward kernels run outside the context too (they belong to the recorded Functions)
+    """
+    _depth = 0
+    _saved = {}
+
+    def __enter__(self):
+        cls = engine_convs
+        if cls._depth == 0:
+            nn = torch.nn
+            for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d):
+                cls._saved[C] = C.forward
+            o2, o3, ot = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d]
+
+            def f2(m, x):
+                return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation).to(x.dtype) if _eligible(m, x) else o2(m, x)
+
+            def f3(m, x):
+                return conv_module(m, x).to(x.dtype) if _eligible(m, x) else o3(m, x)
+
+            def ft(m, x, output_size=None):
+                return conv_module(m, x).to(x.dtype) if (output_size is None and _eligible(m, x)) else ot(m, x, output_size)
+            nn.Conv2d.forward, nn.Conv3d.forward, nn.ConvTranspose3d.forward = f2, f3, ft
+        cls._depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        cls = engine_convs
+        cls._depth -= 1
+        if cls._depth == 0:
+            for C, f in cls._saved.items():
+                C.forward = f
+            cls._saved.clear()
+        return False

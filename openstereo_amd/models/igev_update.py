@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from .. import autograd as AG
 from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from ..ops import empty_cl, is_cl, on_engine, _stream
 from ..ranges import attach_meta, combine_meta, ensure_meta, fold_amax, inherit_meta, meta_of, new_meta
@@ -85,6 +86,9 @@ class DispHead(nn.Module):
         return e[1](e[0](x))
 
     def forward(self, x):
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):       # update.py:25-26, convs on the engine with autograd
+            with AG.engine_convs():
+                return self.conv2(self.relu(self.conv1(x)))
         return cl_to_nchw(self.forward_cl(nchw_to_cl(x)), self.conv2.out_channels)
 
 
@@ -121,7 +125,19 @@ class ConvGRU(nn.Module):
                   B * H * W, hd, z.shape[1], q.shape[1], h.shape[1], out.shape[1], attach_meta(out).data_ptr(), _stream())
         return out
 
+    def forward_train(self, h, cz, cr, cq, *x_list):
+        """update.py:36-45: the three 3x3 convolutions on the engine (forward, dgrad, wgrad), gating in torch."""
+        with AG.engine_convs():
+            x = torch.cat(x_list, dim=1)
+            hx = torch.cat([h, x], dim=1)
+            z = torch.sigmoid(self.convz(hx) + cz)
+            r = torch.sigmoid(self.convr(hx) + cr)
+            q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
+        return (1 - z) * h + z * q
+
     def forward(self, h, cz, cr, cq, *x_list):
+        if self.training or (torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(h, cz, cr, cq, *x_list)
         c = nchw_to_cl
         return cl_to_nchw(self.forward_cl(c(h), c(cz), c(cr), c(cq), *[c(x) for x in x_list]), self.convz.out_channels)
 
@@ -157,7 +173,17 @@ class BasicMotionEncoder(nn.Module):
             fold_amax(out, disp[:, 0])
         return out
 
+    def forward_train(self, disp, corr):
+        """update.py:83-92 (the 7x7 conv on the 1-channel disparity stays a torch op: fewer than 4 input channels)"""
+        with AG.engine_convs():
+            cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
+            d = F.relu(self.convd2(F.relu(self.convd1(disp))))
+            out = F.relu(self.conv(torch.cat([cor, d], dim=1)))
+        return torch.cat([out, disp], dim=1)
+
     def forward(self, disp, corr):
+        if self.training or (torch.is_grad_enabled() and (disp.requires_grad or corr.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(disp, corr)
         return cl_to_nchw(self.forward_cl(nchw_to_cl(disp), nchw_to_cl(corr)), 128)
 
 
@@ -204,9 +230,29 @@ class BasicMultiUpdateBlock(nn.Module):
         mask = cached_pack(self, "_mask", lambda: PackedConv3d(self.mask_feat_4[0], None, ACT_RELU), mods=(self.mask_feat_4,))
         return net, mask(net[0]), delta_disp
 
+    def forward_train(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+        """update.py:129-150 with differentiable sub-modules (their training paths); pool2x / interp are the reference's torch ops."""
+        n_gru = self.args.N_GRU_LAYERS if hasattr(self, "args") else self.n_gru_layers
+        p2 = lambda t: F.avg_pool2d(t, 3, stride=2, padding=1)
+        ip = lambda t, dest: F.interpolate(t, dest.shape[2:], mode="bilinear", align_corners=True)
+        net = list(net)
+        if iter16:
+            net[2] = self.gru16(net[2], *(inp[2]), p2(net[1]))
+        if iter08:
+            net[1] = self.gru08(net[1], *(inp[1]), p2(net[0]), ip(net[2], net[1])) if n_gru > 2 else self.gru08(net[1], *(inp[1]), p2(net[0]))
+        if iter04:
+            mf = self.encoder(disp, corr)
+            net[0] = self.gru04(net[0], *(inp[0]), mf, ip(net[1], net[0])) if n_gru > 1 else self.gru04(net[0], *(inp[0]), mf)
+        if not update:
+            return net
+        with AG.engine_convs():
+            return net, self.mask_feat_4(net[0]), self.disp_head(net[0])
+
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         if not on_engine(net[0]):
             raise RuntimeError("openstereo_amd BasicMultiUpdateBlock runs on the GPU engine only (no CPU path)")
+        if self.training or (torch.is_grad_enabled() and (net[0].requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(net, inp, corr, disp, iter04, iter08, iter16, update)
         c = nchw_to_cl
         net_cl = [c(t) for t in net]
         inp_cl = [[c(t) for t in ts] for ts in inp]

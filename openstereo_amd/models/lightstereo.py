@@ -19,7 +19,9 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import autograd as AG
 from ..engine import cached_pack, PackedConv3d, DepthwiseConv2d, ACT_NONE, ACT_RELU, ACT_RELU6
 from ..ops import empty_cl, is_cl, on_engine
 
@@ -67,7 +69,16 @@ class MobileV2Residual(nn.Module):
         pw, dw, pl = self._pack()
         return pl(dw(pw(x)), residual=x if self.use_res_connect else None)     # x + feat fused in the epilogue
 
+    def forward_train(self, x):
+        """aggregation.py:91-98 as a torch composition: the 1x1 convolutions run on the engine (forward, dgrad, wgrad) under
+        AG.engine_convs(); depthwise convolutions, BatchNorm (batch statistics) and ReLU6 are torch ops."""
+        with AG.engine_convs():
+            feat = self.pwliner(self.dwconv(self.pwconv(x)))
+        return x + feat if self.use_res_connect else feat
+
     def forward(self, x):
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x)
         return cl_to_nchw(self.forward_cl(nchw_to_cl(x)), self.pwliner[0].out_channels)
 
 
@@ -101,7 +112,16 @@ class AttentionModule(nn.Module):
         gate = cost.permute(0, 2, 3, 4, 1).reshape(B, H, W, C)  # NHWC view of the same memory
         return e["conv3"](s, gate=gate, gate_raw=True)         # conv3(attn) * cost
 
+    def forward_train(self, cost, x):
+        """aggregation.py:120-134 (1x1 convs on the engine, strip depthwise convs in torch)"""
+        with AG.engine_convs():
+            attn = self.conv0(x)
+            attn = attn + self.conv0_2(self.conv0_1(attn)) + self.conv1_2(self.conv1_1(attn)) + self.conv2_2(self.conv2_1(attn))
+            return self.conv3(attn) * cost
+
     def forward(self, cost, x):
+        if self.training or (torch.is_grad_enabled() and (cost.requires_grad or x.requires_grad)):
+            return self.forward_train(cost, x)
         return cl_to_nchw(self.forward_cl(nchw_to_cl(cost), nchw_to_cl(x)), self.conv3.out_channels)
 
 
@@ -164,9 +184,26 @@ class Aggregation(nn.Module):
         conv6 = d6(conv5, residual=self.redir1.forward_cl(x))         # relu(conv6(conv5) + redir1(x))
         return conv6
 
+    def forward_train(self, x, features_left):
+        """aggregation.py:44-60; sub-modules take their own training paths (engine 1x1 convs + torch depthwise / BN / ReLU6);
+        the two ConvTranspose2d are torch (MIOpen) ops in training."""
+        x = self.conv0(x)
+        if self.left_att:
+            x = self.att0(x, features_left[0])
+        conv2 = self.conv2(self.conv1(x))
+        if self.left_att:
+            conv2 = self.att2(conv2, features_left[1])
+        conv4 = self.conv4(self.conv3(conv2))
+        if self.left_att:
+            conv4 = self.att4(conv4, features_left[2])
+        conv5 = F.relu(self.conv5(conv4) + self.redir2(conv2))
+        return [F.relu(self.conv6(conv5) + self.redir1(x))]
+
     def forward(self, x, features_left):
         if not on_engine(x):
             raise RuntimeError("openstereo_amd Aggregation runs on the GPU engine only (no CPU path)")
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(x, features_left)
         out = self.forward_cl(nchw_to_cl(x), [nchw_to_cl(f) for f in features_left[:3]])
         return [cl_to_nchw(out, self.conv6[0].out_channels)]
 

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import autograd as AG
 from .. import ops, timing
 from ..engine import cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU, fold_amax
 
@@ -192,9 +193,20 @@ class Hourglass(nn.Module):
         post = p["c5"](out, residual=presqu if presqu is not None else pre)   # relu(conv5(out) + presqu|pre)
         return p["c6"](post, residual=out_residual), pre, post
 
+    def forward_train(self, x, presqu=None, postsqu=None):
+        """psmnet_cost_processor.py:108-132 as a torch composition; under AG.engine_convs() every Conv3d / ConvTranspose3d (forward,
+        dgrad, wgrad) runs on the engine, BatchNorm (batch statistics) / ReLU / adds are the reference's torch ops."""
+        with AG.engine_convs():
+            out = self.conv1(x)
+            pre = self.conv2(out)
+            pre = F.relu(pre + postsqu) if postsqu is not None else F.relu(pre)
+            out = self.conv4(self.conv3(pre))
+            post = F.relu(self.conv5(out) + (presqu if presqu is not None else pre))
+            return self.conv6(post), pre, post
+
     def forward(self, x, presqu=None, postsqu=None):
-        if self.training:
-            raise NotImplementedError("engine Hourglass: training-mode BatchNorm is not built yet")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            return self.forward_train(x, presqu, postsqu)
         cl = lambda t: None if t is None else ops.to_cl(t)
         out, pre, post = self.forward_cl(ops.to_cl(x), cl(presqu), cl(postsqu))
         return ops.to_ncdhw(out), ops.to_ncdhw(pre), ops.to_ncdhw(post)
@@ -243,10 +255,28 @@ class PSMAggregator(nn.Module):
         cost3 = p["k3b"](p["k3a"](out3), residual=cost2)
         return cost3, cost2, cost1
 
+    def aggregate_train(self, raw_cost):
+        """psmnet_cost_processor.py:182-198 -> low-resolution costs (cost3, cost2, cost1), differentiable on the engine."""
+        with AG.engine_convs():
+            cost0 = self.dres0(raw_cost)
+            cost0 = self.dres1(cost0) + cost0
+            out1, pre1, post1 = self.dres2.forward_train(cost0, None, None)
+            out1 = out1 + cost0
+            out2, pre2, post2 = self.dres3.forward_train(out1, pre1, post1)
+            out2 = out2 + cost0
+            out3, _, _ = self.dres4.forward_train(out2, pre2, post2)
+            out3 = out3 + cost0
+            cost1 = self.classif1(out1)
+            cost2 = self.classif2(out2) + cost1
+            cost3 = self.classif3(out3) + cost2
+        return cost3, cost2, cost1
+
     def forward(self, raw_cost):
-        if self.training:
-            raise NotImplementedError("engine PSMAggregator: training mode is not built yet")
         B, C, D, H, W = raw_cost.shape
+        if self.training or (torch.is_grad_enabled() and raw_cost.requires_grad):
+            # drop-in contract: full-resolution costs (:200-221); the engine model (PSMCostProcessor) keeps them low-res and fuses the upsample
+            return [F.interpolate(c, [self.max_disp, H * 4, W * 4], mode="trilinear", align_corners=True).squeeze(1)
+                    for c in self.aggregate_train(raw_cost)]
         lows = self.aggregate_cl(ops.to_cl(raw_cost))
         # drop-in contract: full-resolution costs (psmnet_cost_processor.py:200-221); torch does the upsample
         return [F.interpolate(c, [self.max_disp, H * 4, W * 4], mode="trilinear", align_corners=True).squeeze(1)
@@ -265,6 +295,10 @@ class PSMCostProcessor(nn.Module):
     def forward(self, inputs):
         """Engine path: keeps the three costs at 1/4 resolution (the fused heads upsample on the fly)."""
         l, r = inputs["ref_feature"], inputs["tgt_feature"]
+        if self.training or (torch.is_grad_enabled() and (l.requires_grad or r.requires_grad)):
+            vol = AG.build_concat_volume(l.float(), r.float(), int(self.aggregator.max_disp // 4))          # cat_fms, differentiable
+            cost3, cost2, cost1 = self.aggregator.aggregate_train(vol)
+            return {"cost1": cost1, "cost2": cost2, "cost3": cost3}
         vol = ops.build_cost_volume_cl(None, None, 0, l, r, maxdisp=int(self.aggregator.max_disp // 4))   # attribute the reference class has too
         cost3, cost2, cost1 = self.aggregator.aggregate_cl(vol)
         return {"cost1": cost1, "cost2": cost2, "cost3": cost3}
@@ -287,7 +321,9 @@ class PSMDispProcessor(nn.Module):
         out = []
         for k in ("cost1", "cost2", "cost3"):
             c = inputs[k]
-            if c.dim() == 5:
+            if c.dim() == 5 and torch.is_grad_enabled() and c.requires_grad:      # training: fused head with its backward kernel
+                out.append(AG.upsample_softargmin(c, self.disp_processor.max_disp, h, w, align_corners=True))
+            elif c.dim() == 5:
                 out.append(ops.upsample_softargmin(c, self.disp_processor.max_disp, h, w, align_corners=True))
             else:
                 out.append(self.disp_processor(c))
@@ -313,3 +349,12 @@ class PSMNet(nn.Module):
         inputs.update(self.CostProcessor(inputs))
         disp_out = self.DispProcessor(inputs)
         return {"disp_pred": disp_out[-1], "train_preds": disp_out}
+
+    def get_loss(self, model_preds, input_data):
+        """models/psmnet/psmnet.py:32-45"""
+        disp_gt = input_data["disp"]
+        mask = (disp_gt < self.maxdisp) & (disp_gt > 0)
+        loss = 0.0
+        for pred, weight in zip(model_preds["train_preds"], [0.5, 0.7, 1.0]):
+            loss = loss + weight * F.smooth_l1_loss(pred[mask], disp_gt[mask], reduction="mean")
+        return loss, {"scalar/train/loss_disp": loss.item()}

@@ -183,10 +183,43 @@ def gen_at_size():
     save("stereobase_at_size.npz", init_disp=init_disp, prob_sub=prob[:, :, ::4, ::4], geo_sub=geo[:, :, ::4, ::4, ::4])
 
 
+def gen_preprocess():
+    """Input pre-processing (8f #3): the reference's own transform classes, stereo/datasets/dataset_utils/stereo_trans.py --
+    RightTopPad (:243-267) -> TransposeImage (:22-29) -> ToTensor (:32-44) -> NormalizeImage (:48-56), composed as
+    cfgs/gwcnet/gwcnet_sceneflow.yaml:13-19 does for evaluation.  The module imports cv2 and torchvision at the top; neither is
+    installed here and only `torchvision.transforms.functional.normalize` is exercised by this chain, so both are stubbed and
+    normalize is restated with torchvision's semantics (float tensor, out = (x - mean[:, None, None]) / std[:, None, None])."""
+    import importlib.util
+
+    def tv_normalize(tensor, mean, std, inplace=False):
+        t = tensor.clone()
+        m = torch.as_tensor(mean, dtype=t.dtype).view(-1, 1, 1)
+        sd = torch.as_tensor(std, dtype=t.dtype).view(-1, 1, 1)
+        return t.sub_(m).div_(sd)
+    tv, tvt, tvf = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.transforms.functional")
+    tvf.normalize = tv_normalize
+    tvt.functional, tvt.ColorJitter = tvf, object
+    tv.transforms = tvt
+    for name, mod in (("cv2", types.ModuleType("cv2")), ("torchvision", tv), ("torchvision.transforms", tvt),
+                      ("torchvision.transforms.functional", tvf)):
+        sys.modules.setdefault(name, mod)
+    spec = importlib.util.spec_from_file_location("ref_stereo_trans", os.path.join(REF, "stereo/datasets/dataset_utils/stereo_trans.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    chain = st.Compose([st.RightTopPad(Cfg(SIZE=[32, 48])), st.TransposeImage(Cfg()), st.ToTensor(Cfg()),
+                        st.NormalizeImage(Cfg(MEAN=[0.485, 0.456, 0.406], STD=[0.229, 0.224, 0.225]))])
+    r = np.random.default_rng(12)
+    L = r.integers(0, 256, (27, 45, 3)).astype(np.uint8)
+    R = r.integers(0, 256, (27, 45, 3)).astype(np.uint8)
+    out = chain({"left": L.astype(np.float32), "right": R.astype(np.float32)})      # dataset readers hand float32 HWC arrays over
+    assert tuple(out["left"].shape) == (3, 32, 48)
+    save("preprocess.npz", left_u8=L, right_u8=R, left=out["left"], right=out["right"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -199,6 +232,9 @@ def main():
         return
     if args.only == "at_size":
         gen_at_size()
+        return
+    if args.only == "preprocess":
+        gen_preprocess()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -323,6 +359,7 @@ def main():
     gen_lightstereo()
     gen_igev_update()
     gen_at_size()
+    gen_preprocess()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

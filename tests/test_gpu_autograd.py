@@ -256,3 +256,142 @@ def test_ddp_wrapped_training_steps_reduce_loss():
         assert losses[-1] < losses[0], losses
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- round 2: training paths of the remaining module families
+def _freeze_bn(m):
+    for x in m.modules():
+        if isinstance(x, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            x.eval()
+    return m
+
+
+def _grad_check(params, sdr, keys, tol=3e-3):
+    for k in keys:
+        gr = sdr[k].grad
+        assert gr is not None and params[k].grad is not None, k
+        close(params[k].grad, gr, tol * (float(gr.abs().max()) + 1e-12), tol, f"grad {k}")
+
+
+def test_psm_aggregator_training_path_vs_oracle_autograd():
+    """PSMNet aggregation (psmnet_cost_processor.py:108-221) in training mode: volume, every Conv3d / ConvTranspose3d (forward, dgrad,
+    wgrad) and the fused upsample + soft-argmin heads on the engine; values and gradients vs torch-CPU autograd of the oracle."""
+    from openstereo_amd.models.psmnet import PSMCostProcessor, PSMDispProcessor
+    from oracle import torch_ref as O
+    cp = PSMCostProcessor(max_disp=32)
+    sd = synth_state_dict(cp, seed=21, head_gain=3.0)
+    cp.load_state_dict(sd)
+    fl, fr = rn((1, 32, 16, 24), 50), rn((1, 32, 16, 24), 51)
+    gy = rn((1, 64, 96), 52)
+    keys = ["aggregator.dres0.0.0.weight", "aggregator.dres3.conv5.0.weight", "aggregator.classif2.1.weight", "aggregator.dres2.conv1.0.weight"]
+    sdr = {"CostProcessor." + k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdr["CostProcessor." + k].requires_grad_()
+    flr, frr = fl.clone().requires_grad_(), fr.clone().requires_grad_()
+    vol = O.concat_volume(flr, frr, 8)
+    c3, c2, c1 = O.psm_aggregate(vol, sdr)
+    ref = sum(w * O.upsample_regression(c, 32, 64, 96, align_corners=True) for w, c in ((0.5, c1), (0.7, c2), (1.0, c3)))
+    (ref * gy).sum().backward()
+    cp = _freeze_bn(cp.to(DEV).train())
+    dp = PSMDispProcessor(max_disp=32).to(DEV)
+    fle, fre = fl.to(DEV).requires_grad_(), fr.to(DEV).requires_grad_()
+    inputs = {"ref_feature": fle, "tgt_feature": fre, "left": torch.zeros(1, 3, 64, 96, device=DEV)}
+    inputs.update(cp(inputs))
+    d1, d2, d3 = dp(inputs)
+    out = 0.5 * d1 + 0.7 * d2 + 1.0 * d3
+    close(out, ref, 5e-4, 5e-4, "PSM training-path disparities")
+    (out * gy.to(DEV)).sum().backward()
+    close(fle.grad, flr.grad, 3e-3 * float(flr.grad.abs().max()), 3e-3, "d left feature")
+    close(fre.grad, frr.grad, 3e-3 * float(frr.grad.abs().max()), 3e-3, "d right feature")
+    _grad_check(dict(cp.named_parameters()), {k[len("CostProcessor."):]: v for k, v in sdr.items()}, keys)
+
+
+def test_lightstereo_aggregation_training_path_vs_oracle_autograd():
+    """LightStereo Aggregation in training mode: 1x1 convolutions on the engine (forward + backward), depthwise / transposed convs,
+    BatchNorm, ReLU6 as torch ops -- vs torch-CPU autograd of the oracle."""
+    from conftest import lightstereo_case
+    from oracle import torch_ref as O
+    agg, sd, x, feats = lightstereo_case()
+    gy = rn((1, 48, 32, 64), 60)
+    keys = ["conv0.0.pwconv.0.weight", "conv3.pwliner.0.weight", "att2.conv3.weight", "att0.conv0.bias", "redir1.pwconv.0.weight"]
+    sdr = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_()
+    xr = x.clone().requires_grad_()
+    ref = O.lightstereo_aggregation(xr, feats, sdr)
+    (ref * gy).sum().backward()
+    agg = _freeze_bn(agg.to(DEV).train())
+    xe = x.to(DEV).requires_grad_()
+    out = agg(xe, [f.to(DEV) for f in feats])[0]
+    close(out, ref, 2e-4 * max(1.0, float(ref.abs().max())), 2e-4, "LightStereo aggregation (training path)")
+    (out * gy.to(DEV)).sum().backward()
+    close(xe.grad, xr.grad, 3e-3 * float(xr.grad.abs().max()), 3e-3, "d volume")
+    _grad_check(dict(agg.named_parameters()), sdr, keys)
+
+
+def test_igev_update_block_training_path_vs_oracle_autograd():
+    """IGEV BasicMultiUpdateBlock in training mode (ConvGRU convolutions, motion encoder, heads on the engine with autograd)."""
+    from conftest import igev_update_case
+    from oracle import torch_ref as O
+    blk, sd, net, inp, corr, disp = igev_update_case()
+    keys = ["gru04.convq.weight", "gru16.convz.bias", "encoder.convc2.weight", "disp_head.conv1.weight", "mask_feat_4.0.weight"]
+    sdr = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_()
+    n0 = net[0].clone().requires_grad_()
+    rn_, rm, rd = O.igev_update_block([n0, net[1], net[2]], inp, corr, disp, sdr)
+    (rd.sum() + rm.sum() * 0.01 + rn_[0].sum() * 0.1).backward()
+    blk = blk.to(DEV).train()
+    dv = lambda ts: [t.to(DEV) for t in ts]
+    n0e = net[0].to(DEV).requires_grad_()
+    n, mask, delta = blk([n0e, net[1].to(DEV), net[2].to(DEV)], [dv(ts) for ts in inp], corr.to(DEV), disp.to(DEV))
+    close(delta, rd, 2e-4, 2e-4, "delta disp (training path)")
+    (delta.sum() + mask.sum() * 0.01 + n[0].sum() * 0.1).backward()
+    close(n0e.grad, n0.grad, 3e-3 * float(n0.grad.abs().max()), 3e-3, "d hidden state")
+    _grad_check(dict(blk.named_parameters()), sdr, keys)
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from openstereo_amd.models.gwcnet import GwcNet
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # one GPU: RCCL refuses two ranks on a device; gloo carries the buckets
+    try:
+        net = GwcNet()
+        net.load_state_dict(synth_state_dict(net, seed=0))
+        net = net.to(DEV).train()
+        for m in net.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.eval()
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        L, R = synth_images(1, 64, 128, seed=1 + rank)                        # different pairs on the two ranks
+        gt = T(np.random.default_rng(8 + rank).uniform(1.0, 100.0, (1, 64, 128)).astype(np.float32)).to(DEV)
+        out = ddp({"left": L.to(DEV), "right": R.to(DEV)})
+        loss, _ = net.get_loss(out, {"disp": gt})
+        loss.backward()
+        g = net.DispProcessor.dres0[0][0].weight.grad.detach().cpu()
+        g2 = net.Backbone.feature_extraction.layer2[0].conv1[0][0].weight.grad.detach().cpu()
+        q.put((rank, float(loss.detach()), g, g2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_average_gradients_through_engine_functions():
+    """world_size 2 (two processes sharing the GPU): DistributedDataParallel's bucket hooks fire on the gradients the engine's autograd
+    Functions produce; both ranks end with the same, averaged gradients (data-parallel training)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, l0, g0, h0), (_, l1, g1, h1) = res
+    assert abs(l0 - l1) > 1e-6                                              # different data ...
+    assert torch.equal(g0, g1) and torch.equal(h0, h1)                      # ... identical (all-reduced) gradients
+    assert float(g0.abs().max()) > 0 and torch.isfinite(g0).all()

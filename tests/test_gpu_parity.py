@@ -420,6 +420,20 @@ def test_context_upsample_vs_reference_golden():
           g["out_s2"], atol=2e-5, what="scale 2")
 
 
+def test_preprocess_pair_vs_reference_golden():
+    """RightTopPad + transpose + /255 + normalise fused on device vs the output of the reference's own transform classes
+    (tests/golden/preprocess.npz, stereo_trans.py:22-56,243-267): uint8 and float32 HWC inputs, NCHW and NHWC4 outputs."""
+    from openstereo_amd import ops
+    g = golden("preprocess.npz")
+    for dt in (np.uint8, np.float32):
+        L, R = g["left_u8"].astype(dt), g["right_u8"].astype(dt)
+        l, rr = ops.preprocess_pair(T(L).to(DEV), T(R).to(DEV), (32, 48))
+        close(l[0], g["left"], atol=1e-6, rtol=1e-6, what=f"left {dt.__name__} vs reference transforms")
+        close(rr[0], g["right"], atol=1e-6, rtol=1e-6, what=f"right {dt.__name__} vs reference transforms")
+        cl = ops.preprocess_pair(T(L).to(DEV), T(R).to(DEV), (32, 48), channels_last=True)
+        close(cl[1, :3, 0], g["right"], atol=1e-6, rtol=1e-6, what="NHWC4 right")
+
+
 def test_preprocess_pair_vs_oracle():
     """RightTopPad + transpose + normalise fused on device vs the numpy/torch restatement of the transform chain."""
     from openstereo_amd import ops

@@ -191,3 +191,14 @@ def test_at_size_fixtures_against_reference():
         disp, mask, n = O.igev_refine(ml, mr, gvol, net, inp, d0, sd, 32)
     assert (disp - torch.from_numpy(g["disp"])).abs().max().item() <= 2e-4
     assert (n[0][:, :, ::4, ::4] - torch.from_numpy(g["net0_sub"])).abs().max().item() <= 2e-4
+
+
+def test_preprocess_against_reference_transforms():
+    """f3: the oracle's restatement of RightTopPad -> TransposeImage -> ToTensor -> NormalizeImage vs the output of the reference's own
+    transform classes (stereo_trans.py; fixture generated with cv2 / torchvision stubbed, see make_golden.gen_preprocess)."""
+    g = golden("preprocess.npz")
+    for side in ("left", "right"):
+        for img in (g[side + "_u8"], g[side + "_u8"].astype(np.float32)):
+            out = O.preprocess_image(img, (32, 48))
+            assert out.shape == (3, 32, 48)
+            assert (out - torch.from_numpy(g[side])).abs().max().item() <= 1e-6
