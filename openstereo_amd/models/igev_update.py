@@ -284,27 +284,31 @@ class IGEVRefiner(nn.Module):
         self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hidden_dims, cor_planes=cor_planes)
 
     def forward(self, match_left, match_right, geo_encoding_volume, net_list, inp_list, init_disp, iters):
-        from ..geometry import CombinedGeoEncodingVolume
-        if not on_engine(match_left):
-            raise RuntimeError("openstereo_amd IGEVRefiner runs on the GPU engine only (no CPU path)")
-        a = self.args
-        geo_fn = CombinedGeoEncodingVolume(match_left.float(), match_right.float(), geo_encoding_volume.float(),
-                                           radius=a.CORR_RADIUS, num_levels=a.CORR_LEVELS)
-        b, _, h, w = match_left.shape
-        coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
-        c = nchw_to_cl
-        net = [c(t) for t in net_list]
-        inp = [[c(t) for t in ts] for ts in inp_list]
-        disp = init_disp.float()
-        mask = None
-        for _ in range(iters):
-            geo_feat = geo_fn(disp, coords)
-            if a.N_GRU_LAYERS == 3 and a.SLOW_FAST_GRU:
-                net = self.update_block.forward_cl(net, inp, iter16=True, iter08=False, iter04=False, update=False)
-            if a.N_GRU_LAYERS >= 2 and a.SLOW_FAST_GRU:
-                net = self.update_block.forward_cl(net, inp, iter16=a.N_GRU_LAYERS == 3, iter08=True, iter04=False, update=False)
-            geo_feat._osa_meta = geo_fn.meta                  # lookups interpolate / zero-pad the volumes: bounded by their max |.|
-            net, mask, delta = self.update_block.forward_cl(net, inp, c(geo_feat), c(disp),
-                                                            iter16=a.N_GRU_LAYERS == 3, iter08=a.N_GRU_LAYERS >= 2)
-            disp = disp + cl_to_nchw(delta, 1)
-        return {"disp": disp, "mask_feat_4": cl_to_nchw(mask, 32), "net_list": [cl_to_nchw(t, r.shape[1]) for t, r in zip(net, net_list)]}
+        return run_refinement(self.update_block, self.args, match_left, match_right, geo_encoding_volume, net_list, inp_list, init_disp, iters)
+
+
+def run_refinement(update_block, a, match_left, match_right, geo_encoding_volume, net_list, inp_list, init_disp, iters):
+    """The loop of IGEVRefiner for any owner of an engine `update_block` (the end-to-end classes of stereo_models.py)."""
+    from ..geometry import CombinedGeoEncodingVolume
+    if not on_engine(match_left):
+        raise RuntimeError("openstereo_amd IGEVRefiner runs on the GPU engine only (no CPU path)")
+    geo_fn = CombinedGeoEncodingVolume(match_left.float(), match_right.float(), geo_encoding_volume.float(),
+                                       radius=a.CORR_RADIUS, num_levels=a.CORR_LEVELS)
+    b, _, h, w = match_left.shape
+    coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+    c = nchw_to_cl
+    net = [c(t) for t in net_list]
+    inp = [[c(t) for t in ts] for ts in inp_list]
+    disp = init_disp.float()
+    mask = None
+    for _ in range(iters):
+        geo_feat = geo_fn(disp, coords)
+        if a.N_GRU_LAYERS == 3 and a.SLOW_FAST_GRU:
+            net = update_block.forward_cl(net, inp, iter16=True, iter08=False, iter04=False, update=False)
+        if a.N_GRU_LAYERS >= 2 and a.SLOW_FAST_GRU:
+            net = update_block.forward_cl(net, inp, iter16=a.N_GRU_LAYERS == 3, iter08=True, iter04=False, update=False)
+        geo_feat._osa_meta = geo_fn.meta                  # lookups interpolate / zero-pad the volumes: bounded by their max |.|
+        net, mask, delta = update_block.forward_cl(net, inp, c(geo_feat), c(disp),
+                                                   iter16=a.N_GRU_LAYERS == 3, iter08=a.N_GRU_LAYERS >= 2)
+        disp = disp + cl_to_nchw(delta, 1)
+    return {"disp": disp, "mask_feat_4": cl_to_nchw(mask, 32), "net_list": [cl_to_nchw(t, r.shape[1]) for t, r in zip(net, net_list)]}

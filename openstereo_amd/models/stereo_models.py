@@ -1,0 +1,348 @@
+"""End-to-end model classes for BASELINE configs [2]-[4]: StereoBase, IGEVStereo, LightStereo.
+
+What is the engine's and what is not.  The hot path of SURVEY 8a -- cost volume, 3-D / 2-D aggregation, classifier,
+soft-argmin, geometry-encoding lookup, ConvGRU update block, convex (context) upsampling -- runs on the gfx950 engine
+through the stage modules of igev_style.py / lightstereo.py / igev_update.py, under the reference's attribute names
+(`cost_agg`, `classifier`, `corr_stem`, `corr_feature_att`, `update_block`), so those checkpoint keys load.
+
+The 2-D feature side is out of the path (SURVEY 8 "out of scope": timm MobileNetV2 / EfficientNet pyramids with
+pretrained weights, MultiBasicEncoder).  The small 2-D heads around it (stem_2, stem_4, conv, desc, concat_conv, spx*,
+context_zqr_convs, refine_*) are ordinary PyTorch-ROCm modules with the reference's names and shapes; the two large
+pieces -- `feature` / `backbone` (timm) and `cnet` -- are *injectable*: pass the reference's own module, or leave the
+default shape-compatible stand-ins (StubFeature, StubContext: strided conv pyramids with the documented channel counts and
+strides).  With the stand-ins the classes run offline end to end, which is what the tests and `bench.py` use; the
+numbers they produce are hot-path numbers, never accuracy claims.
+
+To accelerate the reference's *own* model objects (timm present), use `openstereo_amd.attach.patch_reference_modules()`
+instead: it grafts the same engine forwards onto the reference's classes.
+
+Reference: stereo/modeling/models/stereobase/stereobase_gru.py:14-213, models/igev/igev_stereo.py:78-218,
+models/lightstereo/lightstereo.py:13-71.
+"""
+from __future__ import annotations
+
+from functools import partial
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import on_engine
+from .igev_style import BasicConv2d, BasicConv, IGEVFeatureAtt, StereoBaseCostStage, hourglass, _pack_igev
+from .igev_update import BasicMultiUpdateBlock, run_refinement
+from .lightstereo import LightStereoCostStage
+from ..engine import cached_pack, SmallCoConv3d
+
+
+# ----------------------------------------------------------------------------- 2-D helper blocks (torch modules)
+class BasicDeconv2d(nn.Module):
+    """common/basic_block_2d.py:24-39"""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=False, norm_layer=None, act_layer=None, **kw):
+        super().__init__()
+        layers = [nn.ConvTranspose2d(cin, cout, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias, **kw)]
+        if norm_layer is not None:
+            layers.append(norm_layer(cout))
+        if act_layer is not None:
+            layers.append(act_layer())
+        self.block = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class Conv2xUp(nn.Module):
+    """stereobase/igev_blocks.py:10-32: deconv x2 -> concat with the skip -> 3x3 conv."""
+
+    def __init__(self, cin, cout, norm_layer, concat=True):
+        super().__init__()
+        self.concat = concat
+        self.conv1 = BasicDeconv2d(cin, cout, norm_layer=norm_layer, act_layer=nn.LeakyReLU, kernel_size=4, stride=2, padding=1)
+        self.conv2 = BasicConv2d(cout * 2, cout * 2, norm_layer=norm_layer, act_layer=nn.LeakyReLU, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x, rem):
+        x = self.conv1(x)
+        if x.shape != rem.shape:
+            x = F.interpolate(x, size=rem.shape[-2:], mode="nearest")
+        return self.conv2(torch.cat((x, rem), 1) if self.concat else x + rem)
+
+
+class FPNLayer(nn.Module):
+    """lightstereo/backbone.py:11-26"""
+
+    def __init__(self, chan_low, chan_high):
+        super().__init__()
+        act = partial(nn.LeakyReLU, negative_slope=0.2, inplace=True)
+        self.deconv = BasicDeconv2d(chan_low, chan_high, kernel_size=4, stride=2, padding=1, norm_layer=nn.BatchNorm2d, act_layer=act)
+        self.conv = BasicConv2d(chan_high * 2, chan_high, kernel_size=3, padding=1, norm_layer=nn.BatchNorm2d, act_layer=act)
+
+    def forward(self, low, high):
+        return self.conv(torch.cat([high, self.deconv(low)], 1))
+
+
+def _pyramid_step(cin, cout, stride):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class StubFeature(nn.Module):
+    """Shape-compatible stand-in for the timm feature pyramid (stereobase/igev `Feature`, lightstereo `Backbone`):
+    image [B,3,H,W] -> [1/4, 1/8, 1/16, 1/32] maps with `channels`.  NOT the reference's backbone (8 "out of scope")."""
+
+    def __init__(self, channels=(48, 64, 192, 160)):
+        super().__init__()
+        self.output_channels = list(channels)
+        self.stem = nn.Sequential(_pyramid_step(3, 16, 2), _pyramid_step(16, channels[0], 2))
+        self.down = nn.ModuleList([_pyramid_step(channels[i], channels[i + 1], 2) for i in range(3)])
+
+    def forward(self, x):
+        out = [self.stem(x)]
+        for d in self.down:
+            out.append(d(out[-1]))
+        return out
+
+
+class StubContext(nn.Module):
+    """Shape-compatible stand-in for MultiBasicEncoder (stereobase/gru_blocks.py, igev/extractor.py): image ->
+    [(net, inp)] at 1/4, 1/8, 1/16 with hidden_dims / context_dims channels.  `forward(x, num_layers)` like the reference."""
+
+    def __init__(self, hidden_dims=(128, 128, 128), context_dims=(128, 128, 128)):
+        super().__init__()
+        self.stem = nn.Sequential(_pyramid_step(3, 32, 2), _pyramid_step(32, 64, 2))
+        self.down = nn.ModuleList([_pyramid_step(64, 64, 2), _pyramid_step(64, 64, 2)])
+        # the reference orders hidden_dims coarse -> fine ([2] is the 1/4 level)
+        self.heads = nn.ModuleList([nn.ModuleList([nn.Conv2d(64, hidden_dims[2 - i], 3, padding=1), nn.Conv2d(64, context_dims[2 - i], 3, padding=1)])
+                                    for i in range(3)])
+
+    def forward(self, x, num_layers=3):
+        f = self.stem(x)
+        out = []
+        for i in range(num_layers):
+            if i:
+                f = self.down[i - 1](f)
+            out.append((self.heads[i][0](f), self.heads[i][1](f)))
+        return out
+
+
+def _context_lists(cnet, zqr_convs, image, n_layers):
+    """igev_stereo.py:175-179 / stereobase_gru.py:167-171"""
+    cnet_list = cnet(image, num_layers=n_layers)
+    net_list = [torch.tanh(x[0]) for x in cnet_list]
+    inp_list = [torch.relu(x[1]) for x in cnet_list]
+    inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1)) for i, conv in zip(inp_list, zqr_convs)]
+    return net_list, inp_list
+
+
+def _require_engine(x, who):
+    if not on_engine(x):
+        raise RuntimeError(f"openstereo_amd {who} runs on the GPU engine only (no CPU path)")
+
+
+# ----------------------------------------------------------------------------- StereoBase (BASELINE configs[2])
+class StereoBase(StereoBaseCostStage):
+    """stereobase_gru.py:14-213 (gwc [+ concat] volume configuration; USE_SUB_VOLUME / USE_INTERLACED_VOLUME are not built).
+
+    `cfgs`: attribute namespace with the reference's keys (MAX_DISP, NUM_GROUPS, USE_CONCAT_VOLUME, CONCAT_CHANNELS,
+    HIDDEN_DIMS, N_GRU_LAYERS, CORR_RADIUS, CORR_LEVELS, SLOW_FAST_GRU, EVAL_ITERS)."""
+
+    def __init__(self, cfgs, feature=None, cnet=None):
+        g = lambda k, d: getattr(cfgs, k, d)
+        if g("USE_SUB_VOLUME", False) or g("USE_INTERLACED_VOLUME", False) or not g("USE_GWC_VOLUME", True):
+            raise NotImplementedError("openstereo_amd StereoBase: only the gwc (+ concat) volume configuration is built")
+        self_concat = g("CONCAT_CHANNELS", 12) if g("USE_CONCAT_VOLUME", False) else 0
+        feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
+        bc = list(getattr(feature, "output_channels", (48, 64, 192, 160)))
+        bc[0] += 48
+        super().__init__(max_disp=cfgs.MAX_DISP, num_groups=g("NUM_GROUPS", 8), concat_channels=self_concat, backbone_channels=bc)
+        self.cfgs = cfgs
+        self.n_gru_layers, self.slow_fast_gru = cfgs.N_GRU_LAYERS, cfgs.SLOW_FAST_GRU
+        hd = list(cfgs.HIDDEN_DIMS)
+        volume_channel = self.num_groups + 2 * self_concat
+        IN, BN, LR = nn.InstanceNorm2d, nn.BatchNorm2d, nn.LeakyReLU
+        self.feature = feature
+        self.cnet = cnet if cnet is not None else StubContext(hd, hd)
+        args = SimpleNamespace(N_GRU_LAYERS=cfgs.N_GRU_LAYERS, CORR_LEVELS=cfgs.CORR_LEVELS, CORR_RADIUS=cfgs.CORR_RADIUS,
+                               SLOW_FAST_GRU=cfgs.SLOW_FAST_GRU)
+        self._loop_args = args
+        cor_planes = cfgs.CORR_LEVELS * (2 * cfgs.CORR_RADIUS + 1) * (volume_channel + 1)          # gru_blocks.py:236
+        self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hd, cor_planes=cor_planes)
+        self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hd[i], hd[i] * 3, 3, padding=1) for i in range(self.n_gru_layers)])
+        self.spx_2_gru = Conv2xUp(32, 32, norm_layer=BN)
+        self.spx_gru = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
+        self.stem_2 = nn.Sequential(BasicConv2d(3, 32, norm_layer=IN, act_layer=LR, kernel_size=3, stride=2, padding=1),
+                                    BasicConv2d(32, 32, norm_layer=IN, act_layer=nn.ReLU, kernel_size=3, stride=1, padding=1))
+        self.stem_4 = nn.Sequential(BasicConv2d(32, 48, norm_layer=IN, act_layer=LR, kernel_size=3, stride=2, padding=1),
+                                    BasicConv2d(48, 48, norm_layer=IN, act_layer=nn.ReLU, kernel_size=3, stride=1, padding=1))
+        self.spx = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
+        self.spx_2 = Conv2xUp(24, 32, norm_layer=IN, concat=True)
+        self.spx_4 = nn.Sequential(BasicConv2d(bc[0], 24, norm_layer=IN, act_layer=LR, kernel_size=3, stride=1, padding=1),
+                                   BasicConv2d(24, 24, norm_layer=IN, act_layer=nn.ReLU, kernel_size=3, stride=1, padding=1))
+        self.conv = BasicConv2d(bc[0], bc[0], norm_layer=IN, act_layer=LR, kernel_size=3, stride=1, padding=1)
+        self.desc = nn.Conv2d(bc[0], bc[0], kernel_size=1, padding=0, stride=1)
+        if self_concat:
+            self.concat_conv = nn.Sequential(BasicConv2d(bc[0], 32, norm_layer=BN, act_layer=nn.ReLU, kernel_size=3, stride=1, padding=1),
+                                             nn.Conv2d(32, self_concat, kernel_size=1, padding=0, stride=1, bias=False))
+
+    # -- 2-D side (torch modules): everything the hot path consumes ---------------------------------------------------
+    def side(self, image1, image2):
+        fl, fr = self.feature(image1), self.feature(image2)
+        stem_2x = self.stem_2(image1)
+        fl[0] = torch.cat((fl[0], self.stem_4(stem_2x)), 1)
+        fr[0] = torch.cat((fr[0], self.stem_4(self.stem_2(image2))), 1)
+        ml, mr = self.desc(self.conv(fl[0])), self.desc(self.conv(fr[0]))
+        cl = cr = None
+        if self.concat_channels:
+            cl, cr = self.concat_conv(ml), self.concat_conv(mr)
+        net_list, inp_list = _context_lists(self.cnet, self.context_zqr_convs, image1, self.n_gru_layers)
+        spx_logits = self.spx(self.spx_2(self.spx_4(fl[0]), stem_2x))
+        return dict(features_left=fl, match_left=ml, match_right=mr, concat_left=cl, concat_right=cr, stem_2x=stem_2x,
+                    net_list=net_list, inp_list=inp_list, spx_logits=spx_logits)
+
+    def upsample_disp(self, disp, mask_feat_4, stem_2x):
+        """stereobase_gru.py:114-119 with softmax, x4 gain and the 3x3 convex combination in one kernel."""
+        logits = self.spx_gru(self.spx_2_gru(mask_feat_4, stem_2x))
+        return ops.context_upsample(disp, logits, 4, softmax_weights=True, gain=4.0).unsqueeze(1)
+
+    def forward(self, data):
+        image1, image2 = data["left"], data["right"]
+        _require_engine(image1, "StereoBase")
+        if self.training:
+            raise NotImplementedError("openstereo_amd StereoBase: the end-to-end class is inference-only; the trainable pieces are "
+                                      "StereoBaseCostStage (volume -> aggregation -> regression) and BasicMultiUpdateBlock")
+        with torch.no_grad():
+            return self._infer(image1, image2)
+
+    def _infer(self, image1, image2):
+        s = self.side(image1, image2)
+        st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"])
+        r = run_refinement(self.update_block, self._loop_args, s["match_left"], s["match_right"], st["geo_encoding_volume"],
+                           s["net_list"], s["inp_list"], st["init_disp"], self.cfgs.EVAL_ITERS)
+        disp_up = self.upsample_disp(r["disp"], r["mask_feat_4"], s["stem_2x"])
+        init_up = ops.context_upsample(st["init_disp"], s["spx_logits"].float(), 4, softmax_weights=True, gain=4.0).unsqueeze(1)
+        # the reference also upsamples after every iteration (disp_preds, used by the training loss only)
+        return {"init_disp": init_up, "disp_preds": [disp_up], "disp_pred": disp_up}
+
+
+# ----------------------------------------------------------------------------- IGEV-Stereo (BASELINE configs[4])
+class IGEVCostStage(nn.Module):
+    """igev_stereo.py:158-168: gwc(8) volume -> corr_stem (Conv3d+BN+LeakyReLU) with the corr_feature_att gate fused into its
+    epilogue -> hourglass -> classifier -> softmax -> regression, reference attribute names."""
+
+    def __init__(self, max_disp=192):
+        super().__init__()
+        self.max_disp = max_disp
+        self.corr_stem = BasicConv(8, 8, is_3d=True, kernel_size=3, stride=1, padding=1)
+        self.corr_feature_att = IGEVFeatureAtt(8, 96)
+        self.cost_agg = hourglass(8)
+        self.classifier = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
+        self._stem = self._cls = None
+
+    def reset_engine(self):
+        self._stem = self._cls = None
+        self.cost_agg.reset_engine()
+
+    def cost_stage(self, match_left, match_right, features_left):
+        D4 = self.max_disp // 4
+        vol = ops.build_cost_volume_cl(match_left, match_right, 8, None, None, maxdisp=D4)
+        stem = cached_pack(self, "_stem", lambda: _pack_igev(self.corr_stem), mods=(self.corr_stem,))
+        vol = stem(vol, gate=self.corr_feature_att.logits(features_left[0]))
+        geo = self.cost_agg.forward_cl(vol, features_left)
+        cost = cached_pack(self, "_cls", lambda: SmallCoConv3d(self.classifier), mods=(self.classifier,))(geo)
+        init_disp, prob = ops.softmax_disparity_regression(cost[:, 0], D4, keepdim=True, return_prob=True)
+        return {"init_disp": init_disp, "prob": prob, "geo_encoding_volume": geo}
+
+    def forward(self, match_left, match_right, features_left):
+        _require_engine(match_left, "IGEVCostStage")
+        return self.cost_stage(match_left, match_right, features_left)
+
+
+class IGEVStereo(IGEVCostStage):
+    """igev_stereo.py:78-218, test mode.  `args`: MAX_DISP, HIDDEN_DIMS, N_GRU_LAYERS, CORR_RADIUS, CORR_LEVELS, SLOW_FAST_GRU,
+    VALID_ITERS.  The small 2-D heads use this package's block modules (`.block.N` keys, not the reference's `.conv/.IN`)."""
+
+    def __init__(self, args, feature=None, cnet=None):
+        super().__init__(max_disp=args.MAX_DISP)
+        self.args = args
+        hd = list(args.HIDDEN_DIMS)
+        IN, LR = nn.InstanceNorm2d, nn.LeakyReLU
+        self.feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
+        self.cnet = cnet if cnet is not None else StubContext(hd, hd)
+        self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hd)
+        self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hd[i], hd[i] * 3, 3, padding=1) for i in range(args.N_GRU_LAYERS)])
+        self.stem_2 = nn.Sequential(BasicConv2d(3, 32, norm_layer=IN, act_layer=LR, kernel_size=3, stride=2, padding=1),
+                                    nn.Conv2d(32, 32, 3, 1, 1, bias=False), IN(32), nn.ReLU())
+        self.stem_4 = nn.Sequential(BasicConv2d(32, 48, norm_layer=IN, act_layer=LR, kernel_size=3, stride=2, padding=1),
+                                    nn.Conv2d(48, 48, 3, 1, 1, bias=False), IN(48), nn.ReLU())
+        self.spx_2_gru = Conv2xUp(32, 32, norm_layer=nn.BatchNorm2d)
+        self.spx_gru = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
+        self.conv = BasicConv2d(96, 96, norm_layer=IN, act_layer=LR, kernel_size=3, padding=1, stride=1)
+        self.desc = nn.Conv2d(96, 96, kernel_size=1, padding=0, stride=1)
+
+    def side(self, image1, image2):
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()                    # igev_stereo.py:144-145
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        fl, fr = self.feature(image1), self.feature(image2)
+        stem_2x = self.stem_2(image1)
+        fl[0] = torch.cat((fl[0], self.stem_4(stem_2x)), 1)
+        fr[0] = torch.cat((fr[0], self.stem_4(self.stem_2(image2))), 1)
+        ml, mr = self.desc(self.conv(fl[0])), self.desc(self.conv(fr[0]))
+        net_list, inp_list = _context_lists(self.cnet, self.context_zqr_convs, image1, self.args.N_GRU_LAYERS)
+        return dict(features_left=fl, match_left=ml, match_right=mr, stem_2x=stem_2x, net_list=net_list, inp_list=inp_list)
+
+    def upsample_disp(self, disp, mask_feat_4, stem_2x):
+        logits = self.spx_gru(self.spx_2_gru(mask_feat_4, stem_2x))
+        return ops.context_upsample(disp, logits, 4, softmax_weights=True, gain=4.0).unsqueeze(1)
+
+    def forward(self, data):
+        image1, image2 = data["left"], data["right"]
+        _require_engine(image1, "IGEVStereo")
+        if self.training:
+            raise NotImplementedError("openstereo_amd IGEVStereo: the end-to-end class is inference-only (test mode, igev_stereo.py:206-207)")
+        with torch.no_grad():
+            return self._infer(image1, image2)
+
+    def _infer(self, image1, image2):
+        s = self.side(image1, image2)
+        st = self.cost_stage(s["match_left"], s["match_right"], s["features_left"])
+        r = run_refinement(self.update_block, self.args, s["match_left"], s["match_right"], st["geo_encoding_volume"],
+                           s["net_list"], s["inp_list"], st["init_disp"], self.args.VALID_ITERS)
+        return {"disp_pred": self.upsample_disp(r["disp"], r["mask_feat_4"], s["stem_2x"])}
+
+
+# ----------------------------------------------------------------------------- LightStereo (BASELINE configs[3])
+class LightStereo(LightStereoCostStage):
+    """lightstereo.py:13-71.  `cfgs`: MAX_DISP, LEFT_ATT, AGGREGATION_BLOCKS, EXPANSE_RATIO."""
+
+    def __init__(self, cfgs, backbone=None):
+        backbone = backbone if backbone is not None else StubFeature((24, 32, 96, 160))
+        oc = list(backbone.output_channels)
+        super().__init__(max_disp=cfgs.MAX_DISP, left_att=cfgs.LEFT_ATT, blocks=tuple(cfgs.AGGREGATION_BLOCKS),
+                         expanse_ratio=cfgs.EXPANSE_RATIO, backbone_channels=oc)
+        self.backbone = backbone
+        IN, BN, LR = nn.InstanceNorm2d, nn.BatchNorm2d, nn.LeakyReLU
+        self.refine_1 = nn.Sequential(BasicConv2d(oc[0], 24, kernel_size=3, stride=1, padding=1, norm_layer=IN, act_layer=LR),
+                                      BasicConv2d(24, 24, kernel_size=3, stride=1, padding=1, norm_layer=IN, act_layer=nn.ReLU))
+        self.stem_2 = nn.Sequential(BasicConv2d(3, 16, kernel_size=3, stride=2, padding=1, norm_layer=BN, act_layer=LR),
+                                    BasicConv2d(16, 16, kernel_size=3, stride=1, padding=1, norm_layer=BN, act_layer=nn.ReLU))
+        self.refine_2 = FPNLayer(24, 16)
+        self.refine_3 = BasicDeconv2d(16, 9, kernel_size=4, stride=2, padding=1)
+
+    def side(self, image1, image2):
+        fl, fr = self.backbone(image1), self.backbone(image2)
+        spx_logits = self.refine_3(self.refine_2(self.refine_1(fl[0]), self.stem_2(image1)))
+        return dict(features_left=fl, feature_right=fr[0], spx_logits=spx_logits)
+
+    def forward(self, data):
+        image1, image2 = data["left"], data["right"]
+        _require_engine(image1, "LightStereo")
+        if self.training:
+            raise NotImplementedError("openstereo_amd LightStereo: the end-to-end class is inference-only; Aggregation has a training path")
+        with torch.no_grad():
+            return self._infer(image1, image2)
+
+    def _infer(self, image1, image2):
+        s = self.side(image1, image2)
+        st = LightStereoCostStage.forward(self, s["features_left"], s["feature_right"])
+        disp = ops.context_upsample(st["init_disp"], s["spx_logits"].float(), 4, softmax_weights=True, gain=4.0).unsqueeze(1)
+        return {"disp_pred": disp}

@@ -347,6 +347,16 @@ def stereobase_cost_stage(match_l, match_r, cat_l, cat_r, features, sd, max_disp
     return disparity_regression(prob, D4, keepdim=True), prob, geo
 
 
+def igev_cost_stage(match_l, match_r, features, sd, max_disp):
+    """igev_stereo.py:158-168: gwc(8) volume -> corr_stem -> corr_feature_att -> cost_agg -> classifier -> softmax -> regression."""
+    D4 = max_disp // 4
+    vol = _unit3d(gwc_volume(match_l, match_r, D4, 8), sd, "corr_stem", "igev")
+    vol = _feature_att(vol, features[0], sd, "corr_feature_att", "igev")
+    geo = igev_style_hourglass(vol, features, sd, "cost_agg", "igev")
+    prob = F.softmax(F.conv3d(geo, sd["classifier.weight"], None, 1, 1).squeeze(1), dim=1)
+    return disparity_regression(prob, D4, keepdim=True), prob, geo
+
+
 # ============================================================================= refinement (a13)
 def context_upsample(disp_low, up_weights, scale_factor=4):
     """disp_refinement/disp_refinement.py:194-204 (== stereobase/igev_blocks.py:51-63, igev/submodule.py:253-265)."""

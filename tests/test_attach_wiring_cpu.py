@@ -188,3 +188,68 @@ def test_attach_gwcnet_shares_parameter_objects():
         ref.DispProcessor.dres0[0][0].weight.add_(1.0)
     assert torch.equal(eng.DispProcessor.dres0[0][0].weight, ref.DispProcessor.dres0[0][0].weight)
     assert not eng.training
+
+
+# ----------------------------------------------------------------------------- end-to-end classes: checkpoint-key compatibility
+def _ref_model_keys(modname, clsname, cfg, stub_names):
+    """Build the reference's model with its timm-backed pieces replaced by empty modules; return its parameter names + shapes."""
+    import sys
+    import types
+    from openstereo_amd import attach
+    attach.stub_reference_packages(REF)
+    if "timm" not in sys.modules:
+        sys.modules["timm"] = types.ModuleType("timm")
+    try:
+        mod = importlib.import_module(modname)
+    except Exception as ex:
+        pytest.skip(f"{modname} not importable here: {type(ex).__name__}: {ex}")
+    saved = {n: getattr(mod, n) for n in stub_names}
+
+    class Empty(torch.nn.Module):
+        output_channels = [24, 32, 96, 160]
+
+        def __init__(self, *a, **k):
+            super().__init__()
+    try:
+        for n in stub_names:
+            setattr(mod, n, Empty)
+        net = getattr(mod, clsname)(cfg)
+    finally:
+        for n, v in saved.items():
+            setattr(mod, n, v)
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}
+
+
+def _own_keys(model, drop):
+    return {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith(drop)}
+
+
+def test_stereobase_class_has_the_reference_checkpoint_keys():
+    from openstereo_amd.models.stereo_models import StereoBase
+    cfg = C(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
+            CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+            SLOW_FAST_GRU=False, TRAIN_ITERS=22, EVAL_ITERS=32)
+    ref = _ref_model_keys("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, ("Feature", "MultiBasicEncoder"))
+    own = _own_keys(StereoBase(cfg), ("feature.", "cnet."))
+    assert own == ref                                           # every key outside the injectable feature / cnet, same shapes
+
+
+def test_lightstereo_class_has_the_reference_checkpoint_keys():
+    from openstereo_amd.models.stereo_models import LightStereo
+    cfg = C(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4, BACKCONE="MobileNetv2")
+    ref = _ref_model_keys("stereo.modeling.models.lightstereo.lightstereo", "LightStereo", cfg, ("Backbone",))
+    own = _own_keys(LightStereo(cfg), ("backbone.",))
+    assert own == ref
+
+
+def test_igev_class_has_the_reference_hot_path_keys():
+    """IGEV's small 2-D heads use `.conv/.IN` unit names in the reference; the engine class keeps the reference's names for the
+    hot path (corr_stem, corr_feature_att, cost_agg, classifier, update_block, context_zqr_convs, desc, spx_gru)."""
+    from openstereo_amd.models.stereo_models import IGEVStereo
+    args = C(MAX_DISP=192, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+             SLOW_FAST_GRU=True, VALID_ITERS=32, TRAIN_ITERS=22)
+    ref = _ref_model_keys("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, ("Feature", "MultiBasicEncoder"))
+    own = _own_keys(IGEVStereo(args), ("feature.", "cnet."))
+    hot = ("corr_stem.", "corr_feature_att.", "cost_agg.", "classifier.", "update_block.", "context_zqr_convs.", "desc.", "spx_gru.")
+    pick = lambda d: {k: v for k, v in d.items() if k.startswith(hot)}
+    assert pick(own) == pick(ref) and len(pick(ref)) > 100
