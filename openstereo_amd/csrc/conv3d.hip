@@ -228,7 +228,10 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= cap) ++a.cps;
     }
     size_t lds = brick * a.cps;
-    const size_t epi = (size_t)(k.threads / 64) * 32 * 36 * sizeof(float);   // wave-private transpose tiles of the epilogue
+#ifndef OSA_TB
+#define OSA_TB 1
+#endif
+    const size_t epi = (size_t)(k.threads / 64) * OSA_TB * 32 * 36 * sizeof(float);   // wave-private transpose tiles of the epilogue
     if (lds < epi) lds = epi;
     { const size_t m = (size_t)exp_int("OSA_LDS_MIN", 0); if (m > lds) lds = m; }   // experiments: cap residency
     const long long nblk = (long long)a.B * a.tilesD * a.tilesH * a.tilesW;
@@ -818,3 +821,16 @@ static int small_co_impl(const float* x, const float* w_ref, bool packed, const 
     OSA_LAUNCH_CHECK("conv3d_small_co");
     return 0;
 }
+
+#ifdef OSA_TRACE_ON
+// -DOSA_TRACE_ON builds only: copy the in-kernel timeline (conv_kernel.h, OSA_DBG & 256) to the host and clear it
+extern "C" int osa_debug_trace_read(unsigned long long* dst, size_t n_words) {
+    const size_t have = (size_t)osa::TRACE_SLOTS * osa::TRACE_WAVES * osa::TRACE_EVENTS;
+    if (n_words > have) n_words = have;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(osa::g_trace), n_words * sizeof(unsigned long long)) != hipSuccess) return -1;
+    static unsigned long long zeros[osa::TRACE_SLOTS * osa::TRACE_WAVES * osa::TRACE_EVENTS];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(osa::g_trace), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    return (int)n_words;
+}
+#endif

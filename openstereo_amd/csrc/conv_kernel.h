@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
 namespace osa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -232,6 +234,17 @@ __device__ __forceinline__ void stage_brick_dma(const ConvArgs& p, float4* smem,
     }
 }
 
+// In-kernel timeline (build with -DOSA_EXPERIMENTS -DOSA_TRACE_ON, run with OSA_DBG & 256): wave `w` of every 97th workgroup stamps the 100 MHz wall clock at its
+// phase boundaries into g_trace[slot][wave][event]; tools/trace_conv.py reads it back (osa_debug_trace_read).
+#ifdef OSA_TRACE_ON
+constexpr int TRACE_SLOTS = 32, TRACE_WAVES = 4, TRACE_EVENTS = 40;
+static __device__ unsigned long long g_trace[TRACE_SLOTS * TRACE_WAVES * TRACE_EVENTS];
+#define OSA_TRACE(ev) do { if ((p.dbg & 256) && (tid & 63) == 0 && blockIdx.y == 0 && blockIdx.x % 97 == 0 && blockIdx.x / 97 < TRACE_SLOTS && (tid >> 6) < TRACE_WAVES && (ev) < TRACE_EVENTS) \
+    g_trace[((blockIdx.x / 97) * TRACE_WAVES + (tid >> 6)) * TRACE_EVENTS + (ev)] = wall_clock64(); } while (0)
+#else
+#define OSA_TRACE(ev) do {} while (0)
+#endif
+
 // CFG: MT m-tiles x NT n-tiles per wave, WM x WN waves, brick TD x TH x TW (TD derived)
 // NCLS = 1: ordinary (strided / dilated / 1x1x1) convolution.
 // NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
@@ -248,7 +261,11 @@ template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, in
 // (buffer_load ... lds) from a loader wave while the compute waves run the taps of the previous chunk, so staging
 // never waits (see the PIPE block below).  Split (OSA_IN_SPLIT) inputs, compact LDS image, unit input step; 2 workgroups
 // of NW + 1 waves per CU.
-#define OSA_MIN_BLOCKS (PIPE ? 3 : ((NCLS >= 4) ? 2 : ((MT == 2 && NT == 1 && WM * WN == 4) ? 4 : 1)))   // PIPE: 2 x 5 waves per CU = 3 on some SIMDs
+// Waves per SIMD every instantiation is compiled for (its accumulators set the scale: 16 registers per 32x32 tile).  Stated
+// explicitly: left to itself the compiler spends registers on scheduling freedom (the straight-line fast epilogue gives it
+// plenty) and silently drops a wave per SIMD, which costs more than any schedule gains.
+#define OSA_WAVES_PER_SIMD (PIPE ? 3 : ((NCLS == 8) ? 2 : ((NCLS >= 4) ? 3 : ((MT * NT == 1) ? 4 : ((MT * NT == 2) ? ((MT == 2) ? 4 : 3) : 2)))))
+#define OSA_MIN_BLOCKS OSA_WAVES_PER_SIMD          // HIP: the second __launch_bounds__ argument is waves per SIMD (execution unit)
 __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
@@ -482,9 +499,21 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
         }
     };
 
+#ifdef OSA_EXPERIMENTS
+    // experiment (OSA_DBG = 512 | us << 16): the second workgroup of every CU (ids 256..511 of the first dispatch round) starts `us`
+    // microseconds late, so the two co-resident workgroups -- and with them one half of the chip -- run their memory phase (epilogue)
+    // while the other half runs its taps
+    if ((p.dbg & 512) && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = wall_clock64(), ticks = (unsigned long long)(p.dbg >> 16) * 100ull;
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    OSA_TRACE(0);
+    [[maybe_unused]] int trace_ev = 1;
     if constexpr (!PIPE) {
     for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
         if (ch0) __syncthreads();
+        OSA_TRACE(trace_ev); ++trace_ev;                 // pass start (after the previous pass's readers are done)
         const int ncl = (p.nchunks - ch0 < p.cps) ? (p.nchunks - ch0) : p.cps;
         if (!(p.dbg & 1) && PREC == PREC_F16X3 && p.dma) {
             for (int cl = 0; cl < ncl; ++cl)
@@ -496,11 +525,14 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             if (cl < ncl)
                 stage_brick<NW * 64, PREC, 1>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
         }
+        OSA_TRACE(trace_ev); ++trace_ev;                 // own staging loads issued + written
         __syncthreads();
+        OSA_TRACE(trace_ev); ++trace_ev;                 // brick complete
         for (int cl = 0; cl < ncl; ++cl) {
             sm = smem + cl * brickQ;
             chunk_taps([]() {});
         }
+        OSA_TRACE(trace_ev); ++trace_ev;                 // taps done
     }
     }
 
@@ -532,6 +564,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
     }
     if (p.out_meta) amax_seen = amax_peek(p.out_meta);   // early: its latency hides behind the epilogue
     if constexpr (!PIPE) __syncthreads();              // everyone is done reading the input brick (PIPE: the chunk's end barrier)
+    OSA_TRACE(20);
     if (p.dbg & 8) {                                   // timing only: no epilogue (keeps the accumulators live)
         float s = 0.f;
 #pragma unroll
@@ -545,7 +578,10 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
         if (s == 12345.678f) p.y[0] = s;
         return;
     }
-    float* tb = tbase + wave * (32 * 36);
+#ifndef OSA_TB
+#define OSA_TB 1                                   // transpose buffers per wave (2: tile i+1's transpose may start while tile i is finalised)
+#endif
+    float* const tb0 = tbase + wave * (OSA_TB * 32 * 36);
     // per-batch-item base pointers (wave-uniform, 64-bit); everything per lane is a 32-bit element offset
     const size_t bvox = (size_t)b * p.Do * p.Ho * p.Wo;
     float* yb = p.y + bvox * p.yCs;
@@ -557,21 +593,48 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
     const int vsub = lane >> 3, cq = (lane & 7) * 4;   // voxel within a group of 8, channel quad
     const int actk = p.act & 15;
     const bool gate_raw = (p.act & OSA_GATE_RAW) != 0;
+    // ---- fast path.  Workgroups whose brick lies inside the tensor, with every channel of their N tiles present,
+    // 16-byte aligned rows, no gate and a cheap activation (none / ReLU / LeakyReLU / ReLU6) -- i.e. nearly all workgroups
+    // of a full-size layer -- finalise their tiles with STRAIGHT-LINE code (FULL = true below): no per-lane predicate, no
+    // branch around a load or a store.  This is not cosmetic: vmcnt retires in order, so the wait in front of tile i's
+    // residual / redir rows (requested PD tiles earlier) may leave the younger requests outstanding only if the compiler
+    // knows how many there are; one conditional memory operation in between and it has to emit vmcnt(0), which also
+    // waits for the stores of the previous tile and the prefetch just issued -- every tile then pays a full memory round
+    // trip (measured 3.7 us per tile in the fused transposed conv, 2 waves per SIMD).  A missing residual is handled
+    // without a branch: the loads go to one valid dummy address (offset masked to 0) and the value is discarded by a select.
+    const bool has_res = p.res != nullptr;
+    const float* const rbase = has_res ? resb : reinterpret_cast<const float*>(p.w);
+    const int rmask = has_res ? -1 : 0;
+    const float act_ns = (actk == OSA_ACT_NONE) ? 1.f : ((actk == OSA_ACT_LEAKY) ? p.slope : 0.f);    // slope for v < 0
+    const float act_hi = (actk == OSA_ACT_RELU6) ? 6.f : __builtin_inff();
+    auto act_cheap = [&](float v) { v = (v < 0.f) ? v * act_ns : v; return fminf(v, act_hi); };
+    // compiled for the f16x3 instantiations except (i) the 64-channel redir variant, which has no registers to spare, and (ii) the
+    // 256-voxel x 32-channel tile of the dominant 32 -> 32 layers: two tiles per wave and 4 waves per SIMD hide the waits anyway, and
+    // the second code path costs it 6 registers at its 128 cap (measured -1.5 % on that launch).  The f32 mode keeps the predicated
+    // code everywhere: its 4-waves-per-SIMD tiles would spill.
+    constexpr bool FASTC = (PREC == PREC_F16X3) && (REDIR != 2) && !(NCLS == 1 && MT == 2 && NT == 1);
+    const bool fast = FASTC && (a0d + TD <= p.Ad) && (a0h + TH <= p.Ah) && (a0w + TW <= p.Aw) && (n0 + WN * NT * 32 <= p.Co) &&
+                      vec4 && !p.gate && actk <= OSA_ACT_RELU6 && !(p.dbg & (32 | 64));
     // A wave finalises NI = MT*NCLS*NT tiles of 32 voxels x 32 channels one after the other.  The
     // residual rows of tile i+PD are requested before tile i is processed (rolling window of PD
     // tiles, static register sets), so the HBM round trip of a residual overlaps the LDS transposes,
     // arithmetic and stores of the PD-1 tiles in front of it -- the fused transposed conv has 8 tiles
     // per wave and spent half of its time waiting for them one by one.
     constexpr int NI = MT * NCLS * NT;
-    constexpr int PD = REDIR ? 2 : ((NCLS >= 4) ? 3 : ((NI < 2) ? NI : 2));
+#ifndef OSA_PD_REDIR
+#define OSA_PD_REDIR 2
+#endif
+    constexpr int PD = REDIR ? ((REDIR == 1) ? OSA_PD_REDIR : 2) : ((NCLS >= 4) ? ((PREC == PREC_F16X3 && NCLS == 8) ? 2 : 3) : ((NI < 2) ? NI : 2));
     // voxel bookkeeping of the 4 rows (vsub + 8k) this lane finalises in M tile m
-    auto rows_of = [&](int m, int (&v0)[4], int (&g0)[4], bool (&vok)[4]) {
+    auto rows_of = [&](auto F, int m, int (&v0)[4], int (&g0)[4], bool (&vok)[4]) {
+        constexpr bool FULL = decltype(F)::value;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int q = (wm * MT + m) * 32 + vsub + 8 * k;
             const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
-            vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
-            v0[k] = ((ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;      // voxel index inside batch item b (host: < 2^31 elements)
+            vok[k] = FULL || (ad < p.Ad && ah < p.Ah && aw < p.Aw);
+            const int os_ = (!FULL && (p.dbg & 64)) ? 1 : p.os;                // dbg 64: contiguous rows (timing only)
+            v0[k] = ((ad * os_) * p.Ho + ah * os_) * p.Wo + aw * os_;          // voxel index inside batch item b (host: < 2^31 elements)
             g0[k] = (ah * p.os) * p.Wo + aw * p.os;
         }
     };
@@ -579,17 +642,23 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
         const int ood = (NCLS == 1) ? p.ood : ((c >> 2) & 1), ooh = (NCLS == 1) ? p.ooh : ((c >> 1) & 1),
                   oow = (NCLS == 1) ? p.oow : (c & 1);
         coff = (ood * p.Ho + ooh) * p.Wo + oow;              // supported transposed convs: Do == 2*Di
+        if (p.dbg & 64) coff = ood * (p.Ad * p.Ho * p.Wo) + (ooh * 2 + oow) * TW;
         goff = ooh * p.Wo + oow;
     };
     // tile order: m outer, class, n inner
-    auto load_res = [&](int i, float4 (&rv)[4]) {
+    auto load_res = [&](auto F, int i, float4 (&rv)[4]) {
+        constexpr bool FULL = decltype(F)::value;
         const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
         int v0[4], g0[4], coff, goff; bool vok[4];
-        rows_of(m, v0, g0, vok);
+        rows_of(F, m, v0, g0, vok);
         class_off(c, coff, goff);
         const int co = n0 + (wn * NT + n) * 32 + cq;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            if constexpr (FULL) {                       // fp32 rows, 16-byte aligned (fast-path conditions); unconditional
+                rv[k] = *reinterpret_cast<const float4*>(rbase + (((v0[k] + coff) * p.rCs + co) & rmask));
+                continue;
+            }
             rv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.res && vok[k] && co < p.Co) {
                 const float* rp = resb + (v0[k] + coff) * p.rCs + co;
@@ -608,17 +677,19 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             }
         }
     };
-    auto finish = [&](int i, const float4 (&rv)[4]) {
+    auto finish = [&](auto F, int i, const float4 (&rv)[4]) {
+        constexpr bool FULL = decltype(F)::value;
         const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
         int v0[4], g0[4], coff, goff; bool vok[4];
-        rows_of(m, v0, g0, vok);
+        rows_of(F, m, v0, g0, vok);
         class_off(c, coff, goff);
         // registers -> LDS (tile[voxel row][channel])
+        float* const tb = tb0 + (i % OSA_TB) * (32 * 36);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
         const int co = n0 + (wn * NT + n) * 32 + cq;
-        const bool cok = co < p.Co;
+        const bool cok = FULL || co < p.Co;
         const float4 sc = scv[n], sh = shv[n];
         // LDS -> registers (4 voxels x 4 channels per lane); gate rows requested together
         float4 av[4], gv[4];
@@ -626,7 +697,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
         for (int k = 0; k < 4; ++k) {
             av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
             gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!REDIR && p.gate && vok[k] && cok) {
+            if (!FULL && !REDIR && p.gate && vok[k] && cok) {
                 const float* gp = gateb + (g0[k] + goff) * p.gCs + co;
                 if (vec4) gv[k] = *reinterpret_cast<const float4*>(gp);
                 else {
@@ -643,7 +714,8 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
             const float s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
             float4 rk = rv[k];
-            if (PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT) && p.res) {
+            if constexpr (FULL) rk = make_float4(has_res ? rk.x : 0.f, has_res ? rk.y : 0.f, has_res ? rk.z : 0.f, has_res ? rk.w : 0.f);
+            if (!FULL && PREC == PREC_F16X3 && (p.act & OSA_RES_SPLIT) && p.res) {
                 const uint4 b4 = __builtin_bit_cast(uint4, rv[k]);
                 rk = mul4(join_f16(make_uint2(b4.x, b4.y), make_uint2(b4.z, b4.w)), s_res_inv);
             }
@@ -651,6 +723,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
+                if constexpr (FULL) { o[e] = act_cheap(v); continue; }
                 if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
                 else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
@@ -659,7 +732,12 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
                 if (!REDIR && p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
                 o[e] = v;
             }
-            if (vok[k] && cok) {
+            if constexpr (FULL) {
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                *reinterpret_cast<float4*>(yb + (v0[k] + coff) * p.yCs + co) = make_float4(o[0], o[1], o[2], o[3]);
+                continue;
+            }
+            if (vok[k] && cok && !(p.dbg & 32)) {             // dbg 32: no stores (timing only)
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 float* yp = yb + (v0[k] + coff) * p.yCs + co;
                 if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
@@ -675,23 +753,32 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
     // hi halves and the lo halves of its 8 values are one 16-byte store each; a split residual is read the
     // same way (host: a split output takes a split residual, no gate).
     const int vs2 = lane >> 2, c8 = (lane & 3) * 8;
-    auto rows2 = [&](int m, int (&v0)[2], bool (&vok)[2]) {
+    auto rows2 = [&](auto F, int m, int (&v0)[2], bool (&vok)[2]) {
+        constexpr bool FULL = decltype(F)::value;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int q = (wm * MT + m) * 32 + vs2 + 16 * k;
             const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
-            vok[k] = ad < p.Ad && ah < p.Ah && aw < p.Aw;
-            v0[k] = ((ad * p.os) * p.Ho + ah * p.os) * p.Wo + aw * p.os;
+            vok[k] = FULL || (ad < p.Ad && ah < p.Ah && aw < p.Aw);
+            const int os_ = (!FULL && (p.dbg & 64)) ? 1 : p.os;
+            v0[k] = ((ad * os_) * p.Ho + ah * os_) * p.Wo + aw * os_;
         }
     };
-    auto load_res8 = [&](int i, float4 (&rv)[4]) {
+    auto load_res8 = [&](auto F, int i, float4 (&rv)[4]) {
+        constexpr bool FULL = decltype(F)::value;
         const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
         int v0[2], coff, goff; bool vok[2];
-        rows2(m, v0, vok);
+        rows2(F, m, v0, vok);
         class_off(c, coff, goff);
         const int co = n0 + (wn * NT + n) * 32 + c8;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if constexpr (FULL) {
+                const float* rs = rbase + (((v0[k] + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4) & rmask);
+                rv[2 * k] = *reinterpret_cast<const float4*>(rs);
+                rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);
+                continue;
+            }
             rv[2 * k] = make_float4(0.f, 0.f, 0.f, 0.f); rv[2 * k + 1] = rv[2 * k];
             if (p.res && vok[k] && co < p.Co) {
                 const float* rs = resb + (v0[k] + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
@@ -700,16 +787,18 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             }
         }
     };
-    auto finish8 = [&](int i, const float4 (&rv)[4], const float4 (&sc8)[2], const float4 (&sh8)[2]) {
+    auto finish8 = [&](auto F, int i, const float4 (&rv)[4], const float4 (&sc8)[2], const float4 (&sh8)[2]) {
+        constexpr bool FULL = decltype(F)::value;
         const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
         int v0[2], coff, goff; bool vok[2];
-        rows2(m, v0, vok);
+        rows2(F, m, v0, vok);
         class_off(c, coff, goff);
+        float* const tb = tb0 + (i % OSA_TB) * (32 * 36);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             tb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + col] = acc[c][m][n][r];
         const int co = n0 + (wn * NT + n) * 32 + c8;
-        const bool cok = co < p.Co;
+        const bool cok = FULL || co < p.Co;
         float4 av[2][2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -722,10 +811,11 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.res) {
+                if ((FULL && !REDIR) || p.res) {
                     const uint4 hb = __builtin_bit_cast(uint4, rv[2 * k]), lb = __builtin_bit_cast(uint4, rv[2 * k + 1]);
                     r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
                     r = mul4(r, s_res_inv);
+                    if constexpr (FULL) r = make_float4(has_res ? r.x : 0.f, has_res ? r.y : 0.f, has_res ? r.z : 0.f, has_res ? r.w : 0.f);
                 }
                 const float a4[4] = {av[k][h2].x, av[k][h2].y, av[k][h2].z, av[k][h2].w};
                 const float s4[4] = {sc8[h2].x, sc8[h2].y, sc8[h2].z, sc8[h2].w}, t4[4] = {sh8[h2].x, sh8[h2].y, sh8[h2].z, sh8[h2].w};
@@ -734,6 +824,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(a4[e], s4[e], t4[e]) + r4[e];
+                    if constexpr (FULL) { o[e] = act_cheap(v); continue; }
                     if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
                     else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
@@ -744,7 +835,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
                 if (vok[k] && cok) am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
             }
-            if (vok[k] && cok) {
+            if (FULL || (vok[k] && cok && !(p.dbg & 32))) {
                 float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
                 *reinterpret_cast<uint4*>(ys) = make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y);
                 *reinterpret_cast<uint4*>(ys + 8) = make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y);
@@ -778,11 +869,12 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             constexpr int RCH = RV / 2;                            // chunks of 16 redir input channels held per tile
             const int rch = (p.rCi + CC - 1) / CC;
             // x rows of tile i in MFMA A-operand order: lane (col, hh) -> voxel row `col`
-            auto load_x = [&](int i, float4 (&rv)[RV]) {
+            auto load_x = [&](auto F, int i, float4 (&rv)[RV]) {
+                constexpr bool FULL = decltype(F)::value;
                 const int c = (i / NT) % NCLS, m = i / (NT * NCLS);
                 const int q = (wm * MT + m) * 32 + col;
                 const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
-                const bool ok = ad < p.Ad && ah < p.Ah && aw < p.Aw;
+                const bool ok = FULL || (ad < p.Ad && ah < p.Ah && aw < p.Aw);
                 const int vox = ((ad * 2 + ((c >> 2) & 1)) * p.Ho + ah * 2 + ((c >> 1) & 1)) * p.Wo + aw * 2 + (c & 1);
 #pragma unroll
                 for (int k = 0; k < RV; ++k) {
@@ -792,19 +884,44 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
                     int cin = ch * CC + ((PREC == PREC_F32) ? (8 * j + 4 * hh) : (8 * hh + 4 * j));
                     // split redir input: j = 0 -> the lane's 8 hi halves, j = 1 -> its 8 lo halves (16 B each)
                     if (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) cin = ch * CC + 4 * hh + 8 * j;
-                    if (ok && ch < rch && ch * CC < p.rCi) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
+                    if (FULL || (ok && ch < rch && ch * CC < p.rCi)) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
                 }
             };
-            auto add_redir = [&](int i, const float4 (&rv)[RV]) {
+            // Tile-invariant operands of the branch, loaded ONCE: the stores of the tiles in between may alias them as far
+            // as the compiler knows, so left inside add_redir they are re-read from L2 for every tile with their latency
+            // exposed (2 waves per SIMD) -- measured 2.2 us per tile, most of the fused epilogue.  NT == 1 in every redir
+            // configuration.  REDIR == 2 (64 redir channels) has no registers left for the weights: it keeps the in-place loads.
+            static_assert(NT == 1, "fused redir configurations have one N tile per wave");
+            const float4* const rwp = p.rw + (size_t)hh * p.CoP + n0 + wn * 32 + col;
+            constexpr bool HOIST_W = (REDIR == 1);
+            float4 rwb[HOIST_W ? RCH : 1][2];
+            if constexpr (HOIST_W) {
+#pragma unroll
+                for (int ch = 0; ch < RCH; ++ch) {
+                    rwb[ch][0] = rwb[ch][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ch < rch) { rwb[ch][0] = rwp[ch * rtstep]; rwb[ch][1] = rwp[ch * rtstep + rbstep]; }
+                }
+            }
+            // per-lane (channel `col`) BN factors of both branches
+            const int cl = n0 + wn * 32 + col;
+            const bool lok = cl < p.Co;
+            float s6h = osc, t6h = 0.f, srh = rosc, trh = 0.f;
+            if constexpr (HOIST_W) {
+                s6h = (lok && p.scale) ? p.scale[cl] * osc : osc; t6h = (lok && p.shift) ? p.shift[cl] : 0.f;
+                srh = (lok && p.rscale) ? p.rscale[cl] * rosc : rosc; trh = (lok && p.rshift) ? p.rshift[cl] : 0.f;
+            }
+            auto add_redir = [&](auto F, int i, const float4 (&rv)[RV]) {
+                constexpr bool FULL = decltype(F)::value;
                 const int n = i % NT, c = (i / NT) % NCLS, m = i / (NT * NCLS);
-                const float4* rwp = p.rw + (size_t)hh * p.CoP + n0 + (wn * NT + n) * 32 + col;
                 f32x16 r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) r[e] = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < RCH; ++ch) {
-                    if (ch < rch) {
-                        const float4 b0 = rwp[ch * rtstep], b1 = rwp[ch * rtstep + rbstep];
+                    if (FULL || ch < rch) {
+                        float4 b0, b1;
+                        if constexpr (HOIST_W) { b0 = rwb[ch][0]; b1 = rwb[ch][1]; }
+                        else { b0 = rwp[ch * rtstep]; b1 = rwp[ch * rtstep + rbstep]; }
                         if constexpr (PREC == PREC_F32) {
                             const float4 a0 = rv[2 * ch], a1 = rv[2 * ch + 1];
                             r = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, r, 0, 0, 0);
@@ -833,11 +950,8 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
                         }
                     }
                 }
-                // per-lane (channel `col`) BN factors of both branches
-                const int cl = n0 + (wn * NT + n) * 32 + col;
-                const bool lok = cl < p.Co;
-                const float s6 = (lok && p.scale) ? p.scale[cl] * osc : osc, t6 = (lok && p.shift) ? p.shift[cl] : 0.f;
-                const float sr = (lok && p.rscale) ? p.rscale[cl] * rosc : rosc, tr = (lok && p.rshift) ? p.rshift[cl] : 0.f;
+                const float s6 = HOIST_W ? s6h : ((lok && p.scale) ? p.scale[cl] * osc : osc), t6 = HOIST_W ? t6h : ((lok && p.shift) ? p.shift[cl] : 0.f);
+                const float sr = HOIST_W ? srh : ((lok && p.rscale) ? p.rscale[cl] * rosc : rosc), tr = HOIST_W ? trh : ((lok && p.rshift) ? p.rshift[cl] : 0.f);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][m][n][e] = fmaf(acc[c][m][n][e], s6, t6) + fmaf(r[e], sr, tr);
             };
@@ -845,40 +959,60 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
             for (int n = 0; n < NT; ++n) { scv[n] = make_float4(1.f, 1.f, 1.f, 1.f); shv[n] = make_float4(0.f, 0.f, 0.f, 0.f); }
             const float4 zero4[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
                                      make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            // fast path also needs every redir chunk present (no conditional weight / x-row loads)
+            const bool fast_r = fast && rch == RCH && p.rCi == RCH * CC;
+            auto run = [&](auto F) {
 #pragma unroll
-            for (int i = 0; i < PD; ++i) load_x(i, rvb[i]);
+                for (int i = 0; i < PD; ++i) load_x(F, i, rvb[i]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                add_redir(i, rvb[i % PD]);
-                if (i + PD < NI) load_x(i + PD, rvb[i % PD]);
-                if constexpr (OUTS) {
-                    float4 sc8[2], sh8[2];
-                    bn8(i % NT, sc8, sh8);
-                    finish8(i, zero4, sc8, sh8);
-                } else finish(i, zero4);
-            }
+                for (int i = 0; i < NI; ++i) {
+                    add_redir(F, i, rvb[i % PD]);
+                    if (i + PD < NI) load_x(F, i + PD, rvb[i % PD]);
+                    if constexpr (OUTS) {
+                        float4 sc8[2], sh8[2];
+                        bn8(i % NT, sc8, sh8);
+                        finish8(F, i, zero4, sc8, sh8);
+                    } else finish(F, i, zero4);
+                    OSA_TRACE(21 + i);
+                    __builtin_amdgcn_sched_barrier(0);       // tiles are scheduled one at a time (the prefetch depth PD is explicit): bounds live ranges
+                }
+            };
+            if constexpr (FASTC) { if (fast_r) run(std::true_type{}); else run(std::false_type{}); }
+            else run(std::false_type{});
         }
     }
     if constexpr (!REDIR && OUTS) {
         float4 sc8[NT][2], sh8[NT][2];
 #pragma unroll
         for (int n = 0; n < NT; ++n) bn8(n, sc8[n], sh8[n]);
+        auto run = [&](auto F) {
 #pragma unroll
-        for (int i = 0; i < PD; ++i) load_res8(i, rvb[i]);
+            for (int i = 0; i < PD; ++i) load_res8(F, i, rvb[i]);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            finish8(i, rvb[i % PD], sc8[i % NT], sh8[i % NT]);
-            if (i + PD < NI) load_res8(i + PD, rvb[i % PD]);
-        }
+            for (int i = 0; i < NI; ++i) {
+                finish8(F, i, rvb[i % PD], sc8[i % NT], sh8[i % NT]);
+                if (i + PD < NI) load_res8(F, i + PD, rvb[i % PD]);
+                OSA_TRACE(21 + i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (FASTC) { if (fast) run(std::true_type{}); else run(std::false_type{}); }
+        else run(std::false_type{});
     }
     if constexpr (!REDIR && !OUTS) {
+        auto run = [&](auto F) {
 #pragma unroll
-        for (int i = 0; i < PD; ++i) load_res(i, rvb[i]);
+            for (int i = 0; i < PD; ++i) load_res(F, i, rvb[i]);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            finish(i, rvb[i % PD]);
-            if (i + PD < NI) load_res(i + PD, rvb[i % PD]);
-        }
+            for (int i = 0; i < NI; ++i) {
+                finish(F, i, rvb[i % PD]);
+                if (i + PD < NI) load_res(F, i + PD, rvb[i % PD]);
+                OSA_TRACE(21 + i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (FASTC) { if (fast && !(has_res && (p.act & OSA_RES_SPLIT))) run(std::true_type{}); else run(std::false_type{}); }
+        else run(std::false_type{});
     }
     };   // epilogue
 

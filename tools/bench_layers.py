@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
-from openstereo_amd import ops  # noqa: E402
+from openstereo_amd import ops, ranges  # noqa: E402
 from openstereo_amd.engine import PackedConv3d, SmallCoConv3d  # noqa: E402
 
 V0, V1, V2 = (48, 136, 240), (24, 68, 120), (12, 34, 60)
@@ -72,6 +72,7 @@ def main():
         m = m.to(dev)
         x = ops.empty_cl(nb, Ci, *dims, dev)
         x.normal_()
+        ranges.ensure_meta(x)          # one range reduction, not one per call
         layer = SmallCoConv3d(m) if kind == "small" else PackedConv3d(m, (nn.BatchNorm2d(Co) if kind == "conv2d" else nn.BatchNorm3d(Co)).to(dev).eval(), 1)
         od = layer.out_shape(*dims) if kind != "small" else dims
         macs = nb * Ci * Co * (k ** (2 if kind == "conv2d" else 3)) * (od[0] * od[1] * od[2]) / (8 if kind == "deconv" else 1)
