@@ -336,6 +336,37 @@ def gwcnet_rooflines(wl, args, eager_step, nrep):
     return out, per_step
 
 
+def generic_rooflines(wl, args, eager_step, nrep):
+    """Workloads other than GwcNet inference: instrumented replay, per-stage table, and a roofline record for the convolution launch
+    class that takes the most time (algorithmic flops / bytes of one launch are recorded by the engine next to each timed span)."""
+    from openstereo_amd import engine, timing
+    rec = engine.enable_timing()
+    for _ in range(nrep):
+        eager_step()
+    torch.cuda.synchronize()
+    stats = engine.collect_timing(rec)
+    per_step = {"/".join(map(str, k)): round(sum(v) / nrep, 4) for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1]))}
+    peak, why = PEAKS[args.precision]
+    convs = {k: v for k, v in stats.items() if k in timing.work and k[0] in ("conv3d", "deconv3d")}
+    out = []
+    for k, v in sorted(convs.items(), key=lambda kv: -sum(kv[1]))[:3]:
+        ms = sum(v) / len(v)
+        flops, nbytes = timing.work[k]
+        tf, gbs = flops / ms / 1e9, nbytes / ms / 1e6
+        mfma_bound = flops / (peak * 1e12) >= nbytes / (HBM_PEAK * 1e9)              # which roofline the launch sits under
+        kind, ci, co, kk, st, d, h, w = k
+        rec_ = {"kernel": "osa::conv_mfma_kernel<...> (tile picked per layer, csrc/conv3d.hip pick_cfg)",
+                "what": f"{kind} {ci}->{co} k{kk} stride {st} @ {d}x{h}x{w}, {len(v) // nrep} launches per step",
+                "bound": "mfma" if mfma_bound else "hbm", "avg_launch_ms": round(ms, 4), "traffic": None,
+                "algorithmic_gflop_per_launch": round(flops / 1e9, 3), "algorithmic_mb_per_launch": round(nbytes / 1e6, 2)}
+        if mfma_bound:
+            rec_.update({"achieved": round(tf, 2), "peak": round(peak, 1), "peak_note": why, "unit": "TFLOP/s", "frac": round(tf / peak, 4)})
+        else:
+            rec_.update({"achieved": round(gbs, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(gbs / HBM_PEAK, 4)})
+        out.append(rec_)
+    return out, per_step
+
+
 # ============================================================================================ CPU baseline (GwcNet)
 def gwcnet_cpu_baseline(wl, gpu_out):
     """SURVEY 8d procedure: the reference modules through the import shim when the checkout is mounted, else the oracle
@@ -524,6 +555,12 @@ def main():
         line["other_precision"] = alt
     elif rank == 0:
         line["roofline"], line["cpu_baseline"] = None, None
+        if not args.stub and not args.timed_only and dev.type == "cuda":
+            roofs, per_step = generic_rooflines(wl, args, eager_step, max(2, min(args.steps, 3)))
+            cfg["stage_ms_per_step"] = dict(list(per_step.items())[:14])
+            line["roofline"] = roofs[0] if roofs else None
+            line["rooflines"] = roofs[1:]
+            line["cpu_baseline_note"] = "the CPU leg runs with the default workload only (bench.py without --workload)"
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

@@ -84,8 +84,14 @@ static int pick_cfg(const ConvArgs& a, int stride) {
     if (flat) {
         // measured on MI355X (tools/bench_layers.py --set 2d, 1 and 2 pairs per step)
         if (stride == 2) return (a.CoP % 64 == 0) ? 14 : 12;
-        if (a.CoP % 128 == 0) return 9;                            // 128 pixels x 128 channels, 2x2 waves
-        return (a.CoP % 64 == 0) ? 13 : 12;                        // 128-pixel tiles
+        // Small maps (the 1/8 and 1/16 GRU levels of the update block: 2040 / 8160 pixels, LightStereo's 24x78 level): 128-pixel
+        // tiles leave most of the 256 CUs without a workgroup and every workgroup walks the whole K loop alone -- the 32- / 64-pixel
+        // tiles are 2.4x faster there (gru16 256->128 @34x60: 0.061 -> 0.025 ms, gru08 384->128 @68x120: 0.094 -> 0.038 ms,
+        // 768->192 1x1 @24x78: 0.045 -> 0.032 ms; tools/bench_layers.py --set gru)
+        const long long tiles128 = (vox + 127) / 128;
+        if (a.CoP % 128 == 0) return (tiles128 * (a.CoP / 128) < 128) ? 11 : 9;     // 32 or 128 pixels x 128 channels
+        if (a.CoP % 64 == 0) return (tiles128 * (a.CoP / 64) < 128) ? 14 : 13;       // 64 or 128 pixels x 64 channels
+        return 12;                                                                   // 128 pixels x 32 channels
     }
     if (stride == 2) return (a.CoP % 128 == 0) ? 6 : ((a.CoP % 64 == 0) ? 5 : 15);
     // measured on MI355X (tools/bench_layers.py): few-tap launches (1x1x1, transposed-conv parity

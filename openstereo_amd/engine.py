@@ -248,7 +248,11 @@ class PackedConv3d:
             rng = _lib.F16x3Ranges(input_meta(x).data_ptr(), input_meta(residual).data_ptr() if need_res else None,
                                    None if redir is None else input_meta(redir[1]).data_ptr(), attach_meta(out, st).data_ptr(),
                                    self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
-        with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W):
+        taps = self.k[0] * self.k[1] * self.k[2]
+        macs = B * Do * Ho * Wo * self.Ci * self.Co * taps / ((4 if self.flat_deconv else 8) if self.transposed else 1)
+        nbytes = 4 * B * (D * H * W * self.Ci + Do * Ho * Wo * self.Co * (1 + (residual is not None) + (redir is not None)))
+        with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W,
+                         flops=2 * macs, nbytes=nbytes):
             tail = (self.out_scale, rng, st) if self.precision == "f16x3" else (st,)
             sfx = "f16x3" if self.precision == "f16x3" else "f32"
             if redir is not None:

@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 
 _rec = None
+work = {}          # key -> (algorithmic flops, algorithmic bytes) of ONE launch with that key (filled while timing is enabled)
 
 
 def enable():
@@ -21,8 +22,10 @@ def disable():
 class span:
     __slots__ = ("key", "e0")
 
-    def __init__(self, *key):
+    def __init__(self, *key, flops=None, nbytes=None):
         self.key = key
+        if _rec is not None and flops is not None:
+            work[key] = (flops, nbytes)
 
     def __enter__(self):
         if _rec is not None:

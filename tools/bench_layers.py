@@ -44,21 +44,45 @@ LAYERS_2D = [
 ]
 
 
+# IGEV / StereoBase update block at 544x960 (one image per pair): 3x3 GRU gate convs on the 1/4, 1/8, 1/16 maps + the heads
+G4, G8, G16 = (1, 136, 240), (1, 68, 120), (1, 34, 60)
+LAYERS_GRU = [
+    ("gru16 256->128 @34x60", "conv2d", 256, 128, 3, 1, G16, 9 * 32, 1),
+    ("gru08 384->128 @68x120", "conv2d", 384, 128, 3, 1, G8, 6 * 32, 1),
+    ("gru04 384->128 @136x240", "conv2d", 384, 128, 3, 1, G4, 3 * 32, 1),
+    ("enc convc1 164->64 1x1", "conv2d", 164, 64, 1, 1, G4, 32, 1),
+    ("enc conv 128->127", "conv2d", 128, 127, 3, 1, G4, 32, 1),
+    ("head 128->256", "conv2d", 128, 256, 3, 1, G4, 32, 1),
+    ("mask 128->32", "conv2d", 128, 32, 3, 1, G4, 32, 1),
+    # LightStereo-S aggregation at 384x1248 (KITTI15): 1x1 expand / project convs of the MobileV2 blocks
+    ("ls 48->192 @96x312", "conv2d", 48, 192, 1, 1, (1, 96, 312), 3, 1),
+    ("ls 192->48 @96x312", "conv2d", 192, 48, 1, 1, (1, 96, 312), 3, 1),
+    ("ls 96->384 @48x156", "conv2d", 96, 384, 1, 1, (1, 48, 156), 3, 1),
+    ("ls 384->96 @48x156", "conv2d", 384, 96, 1, 1, (1, 48, 156), 3, 1),
+    ("ls 192->768 @24x78", "conv2d", 192, 768, 1, 1, (1, 24, 78), 3, 1),
+    ("ls 768->192 @24x78", "conv2d", 768, 192, 1, 1, (1, 24, 78), 3, 1),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfgs", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", default="")
-    ap.add_argument("--set", default="3d", choices=["3d", "2d"], help="2d: the feature extractor's layers (batch = 2 x --batch images)")
+    ap.add_argument("--set", default="3d", choices=["3d", "2d", "gru"], help="2d: the feature extractor's layers (batch = 2 x --batch images); gru: update-block layers")
+    ap.add_argument("--env", default="", help="extra experiment switches for every run, e.g. OSA_CPS=16,OSA_CPS_LDS=150000")
     ap.add_argument("--dbgs", default="", help="comma list of OSA_DBG masks to sweep (timing-only kernel ablations)")
     args = ap.parse_args()
     dev = "cuda:0"
+    for kv in args.env.split(","):
+        if "=" in kv:
+            os.environ[kv.split("=")[0]] = kv.split("=")[1]
     cfgs = [None] + [int(c) for c in args.cfgs.split(",") if c != ""]
     if args.dbgs:       # ablation sweep: reuse the cfg loop, value = -(mask) - 1
         cfgs = [None] + [-int(c) - 1 for c in args.dbgs.split(",")]
     total = {}
-    layers = [l + (1,) for l in LAYERS] if args.set == "3d" else LAYERS_2D
+    layers = [l + (1,) for l in LAYERS] if args.set == "3d" else (LAYERS_2D if args.set == "2d" else LAYERS_GRU)
     nb = args.batch * (2 if args.set == "2d" else 1)
     for name, kind, Ci, Co, k, s, dims, count, dil in layers:
         if args.only and args.only not in name:

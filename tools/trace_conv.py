@@ -40,7 +40,13 @@ def main():
     dev = "cuda:0"
     engine.set_precision("f16x3")
     V0, V1, V2 = (48, 136, 240), (24, 68, 120), (12, 34, 60)
-    if args.layer == "c32":
+    if args.layer in ("l1", "l2", "l3"):            # GwcNet backbone layers (D = 1), 2 images per pair, residual block tail
+        C, dims = {"l1": (32, (1, 272, 480)), "l2": (64, (1, 136, 240)), "l3": (128, (1, 136, 240))}[args.layer]
+        xs, _ = split_of(C, dims, 2 * args.batch, dev)
+        rs, _ = split_of(C, dims, 2 * args.batch, dev)
+        cv = PackedConv3d(nn.Conv2d(C, C, 3, 1, 1, bias=False).to(dev), nn.BatchNorm2d(C).to(dev).eval(), ACT_NONE)
+        fn = lambda: cv(xs, residual=rs, out_split=True)
+    elif args.layer == "c32":
         xs, _ = split_of(32, V0, args.batch, dev)
         cv = PackedConv3d(nn.Conv3d(32, 32, 3, 1, 1, bias=False).to(dev), nn.BatchNorm3d(32).to(dev).eval(), ACT_RELU)
         fn = lambda: cv(xs, out_split=True)
