@@ -12,6 +12,7 @@ struct KernelCfg {
     void (*fn[2])(const ConvArgs);      // [PREC_F32], [PREC_F16X3]
     void (*fn3[2])(const ConvArgs);     // same, B-ring pipeline (tap count a multiple of 3); may be null
     void (*fns[2])(const ConvArgs);     // f16x3 with split output (OUTS = 1): [ping-pong], [B ring or null]
+    int ks;                             // split-K groups inside the workgroup (0 / 1: none)
 };
 
 constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong pipeline
@@ -34,6 +35,22 @@ constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong p
         conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
       { nullptr, nullptr },                                                                  \
       { conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 1>, nullptr } }
+
+// split-K tiles for small maps (conv_kernel.h, KS): KS groups of WM x WN waves share a workgroup, each walks 1 / KS of the input chunks
+#define OSA_CFG_KS(MT, NT, WM, WN, TH, TW, KS)                                               \
+    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW "_ks" #KS, WM * MT * 32, WN * NT * 32,       \
+      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * KS * 64,                                   \
+      { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS>,    \
+        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS> },\
+      { conv_mfma_kernel<PREC_F32, 1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS>,                \
+        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS> },            \
+      { nullptr, nullptr }, KS }
+static const KernelCfg g_ks_cfgs[] = {
+    OSA_CFG_KS(1, 1, 1, 4, 4, 8, 4),     // 0: 32 pixels x 128 channels, 4 K groups (16 waves)
+    OSA_CFG_KS(1, 1, 2, 2, 4, 16, 4),    // 1: 64 pixels x  64 channels, 4 K groups
+    OSA_CFG_KS(1, 1, 1, 4, 4, 8, 2),     // 2: 32 pixels x 128 channels, 2 K groups
+    OSA_CFG_KS(1, 1, 2, 2, 4, 16, 2),    // 3: 64 pixels x  64 channels, 2 K groups
+};
 
 static const KernelCfg g_cfgs[] = {
     OSA_CFG_PINGPONG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
@@ -218,7 +235,17 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         for (int f : fallback)
             if (a.CoP % g_cfgs[f].N == 0 && brick_bytes(a, g_cfgs[f]) <= 160 * 1024) { ci = f; break; }
     }
-    const KernelCfg& k = forced ? *forced : g_cfgs[ci];
+    const KernelCfg* kp = forced ? forced : &g_cfgs[ci];
+    if (!forced && (ci == 11 || ci == 14) && a.Ad == 1 && !(a.act & OSA_OUT_SPLIT)) {
+        // small 2-D map on the 32- / 64-pixel tiles: still few workgroups, each alone with a long K loop -> split K inside the
+        // workgroup when the chunk count allows (4 groups from 16 chunks on, 2 groups from 8)
+        const int want = exp_int("OSA_KS", -1);
+        int ks = (a.nchunks % 4 == 0 && a.nchunks >= 16) ? 4 : ((a.nchunks % 2 == 0 && a.nchunks >= 8) ? 2 : 1);
+        if (want >= 0) ks = (want > 1 && a.nchunks % want == 0) ? want : 1;
+        if (ks == 4) kp = &g_ks_cfgs[ci == 11 ? 0 : 1];
+        else if (ks == 2) kp = &g_ks_cfgs[ci == 11 ? 2 : 3];
+    }
+    const KernelCfg& k = *kp;
     a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
     (void)brick_bytes(a, k);
     OSA_REQUIRE((long long)a.LD * a.LH * a.LW < 65536, "%s: LDS brick too large", what);
@@ -234,6 +261,12 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         while (a.cps < want && a.cps < a.nchunks && (size_t)(a.cps + 1) * brick <= cap) ++a.cps;
     }
     size_t lds = brick * a.cps;
+    if (k.ks > 1) {                                  // one chunk per group and pass; the partial tiles meet in the same LDS afterwards
+        a.cps = 1;
+        const size_t red = (size_t)(k.ks - 1) * (k.threads / k.ks / 64) * ((size_t)k.M * k.N / (k.threads / k.ks / 64) / 1024) * 16 * 64 * sizeof(float);
+        lds = brick * k.ks;
+        if (lds < red) lds = red;
+    }
 #ifndef OSA_TB
 #define OSA_TB 1
 #endif

@@ -250,13 +250,18 @@ static __device__ unsigned long long g_trace[TRACE_SLOTS * TRACE_WAVES * TRACE_E
 // NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
-template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0, int OUTS = 0, int PIPE = 0>
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0, int OUTS = 0, int PIPE = 0, int KS = 1>
 // OUTS = 1: the output is a split tensor (OSA_OUT_SPLIT) -- separate instantiation: a lane finalises 8
 // channels of 2 voxels (16-byte hi and lo stores) instead of 4 channels of 4 voxels.
 // Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
 // (MT = 2, NT = 1: the dominant 32 -> 32 layers) are held to 128 registers so that 4 workgroups
 // share a CU now that their compact LDS brick is 39 KB (measured +7 % on those layers; the same
 // limit costs the 64-channel tiles 5 %, so they keep the default).
+// KS > 1: split-K inside the workgroup, for small maps whose few workgroups would each walk the whole K loop alone (the 1/8 and 1/16
+// GRU levels of the update block: 16-24 input chunks, 16-255 workgroups).  The workgroup has KS groups of WM*WN waves; group g
+// owns the contiguous run of input chunks [g*cpg, (g+1)*cpg) -- its B stream is a contiguous piece of the ordinary packed
+// buffer -- stages its own chunk per pass and accumulates its own partial tiles; the partials meet in LDS and group 0 runs the
+// epilogue.  Host: nchunks % KS == 0, NCLS == 1.
 // PIPE = 1: persistent workgroups walking a list of bricks, the input brick double-buffered in LDS and fed by LDS-DMA
 // (buffer_load ... lds) from a loader wave while the compute waves run the taps of the previous chunk, so staging
 // never waits (see the PIPE block below).  Split (OSA_IN_SPLIT) inputs, compact LDS image, unit input step; 2 workgroups
@@ -266,7 +271,8 @@ template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, in
 // plenty) and silently drops a wave per SIMD, which costs more than any schedule gains.
 #define OSA_WAVES_PER_SIMD (PIPE ? 3 : ((NCLS == 8) ? 2 : ((NCLS >= 4) ? 3 : ((MT * NT == 1) ? 4 : ((MT * NT == 2) ? ((MT == 2) ? 4 : 3) : 2)))))
 #define OSA_MIN_BLOCKS OSA_WAVES_PER_SIMD          // HIP: the second __launch_bounds__ argument is waves per SIMD (execution unit)
-__global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM * WN * KS / 4) : OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
+    static_assert(KS == 1 || (NCLS == 1 && !PIPE && !REDIR), "split-K: plain convolutions");
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -274,7 +280,9 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = (KS > 1) ? wave_all / NW : 0;                 // K group of this wave (split-K), 0 otherwise
+    const int wave = (KS > 1) ? wave_all - kg * NW : wave_all;   // wave inside its group
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 31, hh = lane >> 5;
 
@@ -357,7 +365,8 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
     // carries a few tap steps of slack for the last prefetch.
     const size_t bstep = (size_t)2 * p.CoP;          // float4s per octet
     const size_t tstep = (p.dbg & 4) ? 0 : (size_t)JO * bstep;   // float4s per tap (dbg 4: stationary B stream, timing only)
-    const float4* const wp0 = p.w + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col;
+    const int cpg = (KS > 1) ? p.nchunks / KS : p.nchunks;     // chunks per K group
+    const float4* const wp0 = p.w + (size_t)hh * p.CoP + n0 + wn * (NT * 32) + col + (size_t)kg * cpg * p.T * tstep;
     const float4* wp = wp0;
     constexpr bool RING3 = (TU == 3);     // TU == 3 selects the 3-deep B ring (taps % 3 == 0, NCLS == 1)
     constexpr int TUA = RING3 ? 1 : TU;
@@ -510,7 +519,41 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
 #endif
     OSA_TRACE(0);
     [[maybe_unused]] int trace_ev = 1;
-    if constexpr (!PIPE) {
+    if constexpr (KS > 1) {
+        // split-K: pass i stages chunk kg*cpg + i of every group (each group with its own NW*64 threads, into its own LDS slot)
+        const int tid_g = tid - kg * (NW * 64);
+        for (int i = 0; i < cpg; ++i) {
+            if (i) __syncthreads();
+            if (!(p.dbg & 1)) stage_brick<NW * 64, PREC, 1>(p, smem + kg * brickQ, brickQ, b, (kg * cpg + i) * CC, g0d, g0h, g0w, tid_g, s_in);
+            __syncthreads();
+            sm = smem + kg * brickQ;
+            chunk_taps([]() {});
+        }
+        // partial tiles of groups 1 .. KS-1 -> LDS (lane-contiguous: [group][wave][tile][register][lane]); group 0 adds them up
+        __syncthreads();                                   // every group is done with the bricks
+        float* const red = reinterpret_cast<float*>(smem);
+        constexpr int NIK = MT * NT;
+        if (kg > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[(((((kg - 1) * NW + wave) * NIK + m * NT + n) * 16) + r) * 64 + lane] = acc[0][m][n][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+            for (int g = 0; g < KS - 1; ++g)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[0][m][n][r] += red[((((g * NW + wave) * NIK + m * NT + n) * 16) + r) * 64 + lane];
+        }
+    } else if constexpr (!PIPE) {
     for (int ch0 = 0; ch0 < p.nchunks; ch0 += p.cps) {
         if (ch0) __syncthreads();
         OSA_TRACE(trace_ev); ++trace_ev;                 // pass start (after the previous pass's readers are done)
@@ -565,6 +608,7 @@ __global__ __launch_bounds__(WM * WN * 64 + (PIPE ? 64 : 0), OSA_MIN_BLOCKS) voi
     if (p.out_meta) amax_seen = amax_peek(p.out_meta);   // early: its latency hides behind the epilogue
     if constexpr (!PIPE) __syncthreads();              // everyone is done reading the input brick (PIPE: the chunk's end barrier)
     OSA_TRACE(20);
+    if (KS > 1 && kg != 0) return;                     // split-K: group 0 holds the sums (the others rejoin at publish_amax)
     if (p.dbg & 8) {                                   // timing only: no epilogue (keeps the accumulators live)
         float s = 0.f;
 #pragma unroll

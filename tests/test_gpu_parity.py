@@ -728,8 +728,9 @@ def test_gwcnet_batch_invariance_and_odd_size(prec):
                 if prec == "f32":
                     assert torch.equal(both[i:i + 1], one), f"pair {i}: batched != single ({(both[i:i+1] - one).abs().max().item():.3e})"
                 else:       # f16x3: the operand scale is a power of two derived from the max over the WHOLE batch tensor, so elements below
-                    # 2^-18 of that maximum round differently when the batch changes: agreement to fp32 rounding, not bit for bit
-                    assert float((both[i:i + 1] - one).abs().max()) < 2e-4, f"pair {i}: {(both[i:i+1] - one).abs().max().item():.3e}"
+                    # 2^-18 of that maximum round differently when the batch changes, and the tile / split-K choice (summation order) follows
+                    # the pixel count of the batch: agreement to a few 1e-6 relative (disparities ~100 px), not bit for bit
+                    assert float((both[i:i + 1] - one).abs().max()) < 5e-4, f"pair {i}: {(both[i:i+1] - one).abs().max().item():.3e}"
         assert torch.isfinite(both).all() and both.std() > 1.0
     finally:
         engine.set_precision(old)
