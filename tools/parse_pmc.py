@@ -9,7 +9,7 @@ import sys
 
 out_dir = sys.argv[1]
 KERNELS = {   # key in traffic.json -> substring of the rocprof kernel name (+ optional grid filter)
-    "conv3d_32_32_V0_f16x3": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0>",
+    "conv3d_32_32_V0_f16x3": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
     "volume": "build_volume_quads_kernel<2, 8>",
     "head": "upsample4_softargmin_kernel",
     "classifier": "conv_small_co_tiled_kernel<1, true>",
