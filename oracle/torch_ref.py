@@ -72,7 +72,7 @@ def build_corr_volume(left, right, maxdisp):
 def disparity_regression(prob, maxdisp, keepdim=True):
     """disp_regression.py:8-12 (keepdim=True); gwcnet_disp_processor.py:22-26 (keepdim=False)."""
     assert prob.dim() == 4
-    d = torch.arange(0, maxdisp, dtype=prob.dtype).view(1, maxdisp, 1, 1)
+    d = torch.arange(0, maxdisp, dtype=prob.dtype, device=prob.device).view(1, maxdisp, 1, 1)
     return torch.sum(prob * d, 1, keepdim=keepdim)
 
 
