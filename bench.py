@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: 2 inference, 1 training)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: the best-throughput batch of the sweep in DESIGN.md 6 -- 8 GwcNet / LightStereo, 4 IGEV, 1 training; single-pair latency is reported next to it)")
     ap.add_argument("--workload", default="gwcnet",
                     choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "gwcnet_train"))
     ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
@@ -93,7 +93,7 @@ class GwcNetInference:
     def __init__(self, args, dev, rank):
         from openstereo_amd.models.gwcnet import GwcNet
         from openstereo_amd.utils.weights import synth_state_dict, synth_images
-        self.B = args.batch or 2
+        self.B = args.batch or 8
         net = GwcNet()
         self.sd = synth_state_dict(net, seed=0)
         net.load_state_dict(self.sd)
@@ -123,7 +123,7 @@ class LightStereoKitti15:
     def __init__(self, args, dev, rank):
         from openstereo_amd.models.lightstereo import LightStereoCostStage
         from openstereo_amd.utils.weights import synth_state_dict
-        self.B = B = args.batch or 2
+        self.B = B = args.batch or 8
         st = LightStereoCostStage(max_disp=192)
         st.load_state_dict(synth_state_dict(st, seed=9))
         self.st = st.to(dev).eval()
@@ -153,7 +153,7 @@ class IGEVRefine32:
     def __init__(self, args, dev, rank):
         from openstereo_amd.models.igev_update import IGEVRefiner
         from openstereo_amd.utils.weights import synth_state_dict
-        self.B = B = args.batch or 1
+        self.B = B = args.batch or 4
         a = _Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2, SLOW_FAST_GRU=True)
         ref = IGEVRefiner(a, hidden_dims=[128, 128, 128])
         ref.load_state_dict(synth_state_dict(ref, seed=11))

@@ -8,6 +8,7 @@ import os
 import sys
 
 out_dir = sys.argv[1]
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 8      # pairs per step of the profiled bench run (bench.py default)
 KERNELS = {   # key in traffic.json -> substring of the rocprof kernel name (+ optional grid filter)
     "conv3d_32_32_V0_f16x3": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
     "volume": "build_volume_quads_kernel<2, 8>",
@@ -27,8 +28,8 @@ def per_kernel(counter):
 
 
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
-res = {"_note": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes over `bench.py --timed-only --no-graph` "
-                "(f16x3, 2 pairs per step); per kernel instance, the LARGEST grid of that kernel (the 48x136x240 / full-size launches), averaged over "
+res = {"_note": f"HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes over `bench.py --timed-only --no-graph` "
+                f"(f16x3, {BATCH} pairs per step); per kernel instance, the LARGEST grid of that kernel (the 48x136x240 / full-size launches), averaged over "
                 "its dispatches.  The x2 on FETCH_SIZE is the guide's gfx950 correction, calibrated on wide coalesced streams (it reproduces the volume "
                 "builder's algorithmic bytes within 0.1 %); the conv / classifier staging reads 64-byte segments at a 128-byte stride, for which the "
                 "correction is uncalibrated -- _detail carries the undoubled figure too.  Source: profiles/round2/pmc_*.csv (tools/profile_round2.sh, "
@@ -48,7 +49,7 @@ for key, sub in KERNELS.items():
         f = [v for i, v in enumerate(f) if i % 4 in (1, 2)]
         w = [v for i, v in enumerate(w) if i % 4 in (1, 2)]
     fb, wb = sum(f) / len(f) * 1024.0, sum(w) / len(w) * 1024.0
-    res[key + "_B2"] = int(2 * fb + wb)
+    res[key + f"_B{BATCH}"] = int(2 * fb + wb)
     detail[key] = {"grid": g, "dispatches": len(f), "fetch_size_kib_avg": round(sum(f) / len(f), 1), "write_size_kib_avg": round(sum(w) / len(w), 1),
                    "bytes_if_fetch_size_is_not_doubled": int(fb + wb)}
 res["_detail"] = detail
