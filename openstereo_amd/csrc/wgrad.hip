@@ -11,6 +11,13 @@
 // Q operands per tap: v_mfma_f32_32x32x2_f32 with K = 2 positions per instruction, one accumulator
 // tile per tap kept in registers across ALL bricks of the strip, so only one round of float atomics
 // per workgroup reaches the [a][b][t] gradient buffer.
+//
+// Transposed convs (q = 2*pos + off_t) run in "class mode": a tap group is one output-parity class (pd, ph, pw) -- all taps whose
+// off_t has that parity, at most 2 x 2 x 2 = 8 -- and on the sub-lattice of that parity the access is unit stride,
+// q = 2*(pos + delta_t) + par, delta in {dmin, dmin + 1}.  The workgroup stages only the (TD+1) x (TH+1) x (TW+1) brick of that
+// sub-lattice (compact in LDS, stride-2 gather from HBM) instead of the full strided brick for every group of 9 taps: the k = 4
+// layers of the StereoBase / IGEV hourglasses staged 93 KB per 32 positions and 8 tap groups, i.e. 8x more bytes than they used
+// (3.65 ms per launch at the 320x736 training crop).
 #include "osa_common.h"
 #include <cstring>
 
@@ -34,7 +41,11 @@ struct WgradArgs {
     int LD, LH, LW;               // Q brick dims
     int dmin, hmin, wmin;
     int A, Bc;                    // number of a / b channels (dW is [A][Bc][kvol])
-    signed char od[64], oh[64], ow[64];  // per-tap Q offsets (k = 4 transposed convs have 64 taps)
+    signed char od[64], oh[64], ow[64];  // per-tap Q offsets (k = 4 transposed convs have 64 taps); class mode: delta_t on the class sub-lattice
+    // class mode (transposed convs): tap arrays are class-major, tapid maps back to the kernel index
+    int cls;
+    signed char tapid[64];
+    signed char g_t0[8], g_nt[8], g_par[8];   // first tap / tap count / parity bits (pd<<2 | ph<<1 | pw) of every class
 };
 
 template <int TD, int TH, int TW>     // position brick, TD*TH*TW = 256 (64 per wave) or 64 (16 per wave)
@@ -54,8 +65,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     int sidx = blockIdx.x / p.tgroups;
     const int atiles = (p.A + 31) / 32;
     const int a0 = (blockIdx.y % atiles) * 32, b0 = (blockIdx.y / atiles) * 32;
-    const int t0 = tg * WG_TAPS;
-    const int nt = (p.T - t0 < WG_TAPS) ? (p.T - t0) : WG_TAPS;
+    const int t0 = p.cls ? p.g_t0[tg] : tg * WG_TAPS;
+    const int nt = p.cls ? p.g_nt[tg] : ((p.T - t0 < WG_TAPS) ? (p.T - t0) : WG_TAPS);
+    // class mode: parity of the class and first delta per dimension (par 0: delta in {0, 1}; par 1: {-1, 0}); LDS brick unit stride
+    const int par = p.cls ? p.g_par[tg] : 0;
+    const int pard = (par >> 2) & 1, parh = (par >> 1) & 1, parw = par & 1;
+    const int dmin = p.cls ? -pard : p.dmin, hmin = p.cls ? -parh : p.hmin, wmin = p.cls ? -parw : p.wmin;
+    const int ls = p.cls ? 1 : p.s;                  // position step inside the LDS brick
     const int nstripsW = (p.tilesW + p.strip - 1) / p.strip;
     const int sw = sidx % nstripsW; sidx /= nstripsW;
     const int thi = sidx % p.tilesH; sidx /= p.tilesH;
@@ -85,11 +101,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             *reinterpret_cast<float4*>(Ps + q * WG_PS + c4 * 4) = v;
         }
         // ---- stage Q brick
-        const int q0d = p0d * p.s + p.dmin, q0h = p0h * p.s + p.hmin, q0w = p0w * p.s + p.wmin;
+        const int q0d = p0d * ls + dmin, q0h = p0h * ls + hmin, q0w = p0w * ls + wmin;
         for (int it = tid; it < nQ * 8; it += 256) {
             const int c4 = it & 7, v_ = it >> 3;
             const int lw = v_ % p.LW, lh = (v_ / p.LW) % p.LH, ld = v_ / (p.LW * p.LH);
-            const int gd = q0d + ld, gh = q0h + lh, gw = q0w + lw;
+            int gd = q0d + ld, gh = q0h + lh, gw = q0w + lw;
+            if (p.cls) { gd = 2 * gd + pard; gh = 2 * gh + parh; gw = 2 * gw + parw; }      // sub-lattice -> tensor coordinates
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh && (unsigned)gw < (unsigned)p.Qw) {
                 const float* src = p.Q + ((((size_t)b * p.Qd + gd) * p.Qh + gh) * p.Qw + gw) * p.QCs + b0 + c4 * 4;
@@ -107,13 +124,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const int q = wave * PER_WAVE + 2 * k + hh;
             areg[k] = Ps[q * WG_PS + col];
             const int pw = q % TW, ph = (q / TW) % TH, pd = q / (TW * TH);
-            qbase[k] = (((pd * p.s) * p.LH + ph * p.s) * p.LW + pw * p.s) * WG_PS + col;
+            qbase[k] = (((pd * ls) * p.LH + ph * ls) * p.LW + pw * ls) * WG_PS + col;
         }
 #pragma unroll
         for (int t = 0; t < WG_TAPS; ++t) {
             if (t < nt) {
                 const int tt = t0 + t;
-                const int toff = (((p.od[tt] - p.dmin) * p.LH + (p.oh[tt] - p.hmin)) * p.LW + (p.ow[tt] - p.wmin)) * WG_PS;
+                const int toff = (((p.od[tt] - dmin) * p.LH + (p.oh[tt] - hmin)) * p.LW + (p.ow[tt] - wmin)) * WG_PS;
 #pragma unroll
                 for (int k = 0; k < KSTEPS; ++k)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[k], Qs[qbase[k] + toff], acc[t], 0, 0, 0);
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int t = 0; t < WG_TAPS; ++t) {
         if (t < nt) {
-            const int tt = t0 + t;
+            const int tt = p.cls ? p.tapid[t0 + t] : t0 + t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int a = a0 + (r & 3) + 8 * (r >> 2) + 4 * hh, bb = b0 + col;
@@ -181,10 +198,39 @@ extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
         a.wmin = ow < a.wmin ? ow : a.wmin; wmax = ow > wmax ? ow : wmax;
     }
     a.tgroups = cdiv(T, WG_TAPS);
+    if (transposed) {
+        // class-major tap list: for parity (pd, ph, pw) every kernel index whose offset k - pad has that parity; delta = floor(off / 2)
+        a.cls = 1;
+        int n = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int par[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
+            const int kk[3] = {kd, kh, kw}, pd3[3] = {pad_d, pad_h, pad_w};
+            int idx[3][4], del[3][4], cnt[3];
+            for (int dim = 0; dim < 3; ++dim) {
+                cnt[dim] = 0;
+                for (int k = 0; k < kk[dim]; ++k) {
+                    const int off = k - pd3[dim];
+                    if (((off % 2) + 2) % 2 != par[dim]) continue;
+                    idx[dim][cnt[dim]] = k; del[dim][cnt[dim]] = (off - par[dim]) / 2; ++cnt[dim];      // off - par is even
+                }
+                for (int i = 0; i < cnt[dim]; ++i)
+                    OSA_REQUIRE(del[dim][i] == -par[dim] || del[dim][i] == 1 - par[dim], "conv3d_wgrad: transposed kernel %d / pad %d out of the supported range", kk[dim], pd3[dim]);
+            }
+            a.g_t0[c] = (signed char)n; a.g_par[c] = (signed char)c;
+            for (int i = 0; i < cnt[0]; ++i) for (int j = 0; j < cnt[1]; ++j) for (int l = 0; l < cnt[2]; ++l, ++n) {
+                a.od[n] = (signed char)del[0][i]; a.oh[n] = (signed char)del[1][j]; a.ow[n] = (signed char)del[2][l];
+                a.tapid[n] = (signed char)((idx[0][i] * kh + idx[1][j]) * kw + idx[2][l]);
+            }
+            a.g_nt[c] = (signed char)(n - a.g_t0[c]);
+            OSA_REQUIRE(a.g_nt[c] <= WG_TAPS, "conv3d_wgrad: %d taps in one parity class", (int)a.g_nt[c]);
+        }
+        OSA_REQUIRE(n == T, "conv3d_wgrad: class decomposition covers %d of %d taps", n, T);
+        a.tgroups = 8;
+    }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.A * a.Bc * T * sizeof(float), st);
     OSA_REQUIRE(e == hipSuccess, "conv3d_wgrad: memset failed: %s", hipGetErrorString(e));
-    const bool small = (a.s == 2);
+    const bool small = (a.s == 2) && !transposed;        // strided convs: strided Q bricks; transposed convs: compact class bricks
     int TD = small ? 2 : 4, TH = small ? 4 : 8;
     const int TW = 8;
     // k = 4 transposed convs: the strided Q brick of a 2x4x8 position tile does not fit -> 2x2x8
@@ -194,6 +240,7 @@ extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
     a.LD = (TD - 1) * a.s + (dmax - a.dmin) + 1;
     a.LH = (TH - 1) * a.s + (hmax - a.hmin) + 1;
     a.LW = (TW - 1) * a.s + (wmax - a.wmin) + 1;
+    if (transposed) { a.LD = TD + 1; a.LH = TH + 1; a.LW = TW + 1; }      // class sub-lattice: delta in {dmin, dmin + 1}
     a.tilesD = cdiv(a.Pd, TD); a.tilesH = cdiv(a.Ph, TH); a.tilesW = cdiv(a.Pw, TW);
     a.strip = a.tilesW;                                       // a whole row of bricks per workgroup
     const size_t lds = ((size_t)TD * TH * TW + (size_t)a.LD * a.LH * a.LW) * WG_PS * sizeof(float);
