@@ -212,6 +212,19 @@ def _out(n, k, p, d, s):
     return (n + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed):
+    """Weight gradient, two-stage form (osa_conv3d_wgrad_ws_f32): partial tiles in a scratch tensor from the caching allocator, summed
+    in a fixed order -- deterministic, and free of the contended float atomics of the one-stage form."""
+    dims = (B, D, H, W, Ci, Do, Ho, Wo, Co, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed)
+    need = _lib.load().osa_conv3d_wgrad_workspace_bytes(*dims)
+    if need == 0:
+        raise _lib.EngineError("osa_conv3d_wgrad_workspace_bytes: unsupported layer " + str(dims))
+    ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
+    _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
+              Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+              ws.data_ptr(), need, _stream())
+
+
 class _Conv3d(torch.autograd.Function):
     """y = conv3d(x, w) (no bias).  x: logical [B,Ci,D,H,W] (any strides); y: NDHWC-strided [B,Co,...]."""
 
@@ -253,9 +266,7 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
-            _lib.call("osa_conv3d_wgrad_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
-                      Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2],
-                      dil[0], dil[1], dil[2], 0, _stream())
+            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0)
         return dx, dw, None, None, None, None
 
 
@@ -289,8 +300,7 @@ class _ConvTranspose3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
-            _lib.call("osa_conv3d_wgrad_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
-                      Do, Ho, Wo, Co, dyc.shape[1], k, k, k, 2, pad, pad, pad, 1, 1, 1, 1, _stream())
+            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, (k, k, k), 2, (pad, pad, pad), (1, 1, 1), 1)
         return dx, dw, None, None, None
 
 

@@ -30,6 +30,7 @@ constexpr int WG_PS = 36;         // LDS row stride (floats) of a 32-channel vox
 
 struct WgradArgs {
     const float* P; const float* Q; float* dW;
+    float* ws;                    // partial tiles [workgroup][WG_TAPS][16][64] (two-stage reduction) or NULL (float atomics)
     int B;
     int Pd, Ph, Pw, PC, PCs;      // P tensor dims (positions) / channels / voxel stride
     int Qd, Qh, Qw, QC, QCs;      // Q tensor
@@ -137,6 +138,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             }
         }
     }
+    if (p.ws) {
+        // ---- partial tiles to the workspace (lane-contiguous, plain stores); wgrad_reduce_kernel adds them up.  Float atomics on the
+        // 27-64 K words of dW from every workgroup serialise in L2 (measured 4.5 G atomics/s: 0.5 ms per workgroup once a few thousand
+        // of them contend) and make the gradient depend on the arrival order; this path is deterministic.
+        float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WG_TAPS * 1024) + lane;
+        // every wave holds a partial sum over its quarter of the positions: add the 4 waves up through LDS first, tap by tap
+        // (3 x 16 x 64 floats = 12 KB at a time)
+        __syncthreads();
+        float* red = smem;
+#pragma unroll
+        for (int t = 0; t < WG_TAPS; ++t) {
+            if (t < nt) {
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[t][r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dst[(t * 16 + r) * 64] = acc[t][r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     // ---- one round of atomics: dW[a][b][tap]
 #pragma unroll
     for (int t = 0; t < WG_TAPS; ++t) {
@@ -151,24 +179,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// Second stage: dW[a][b][tap] = sum over the workgroups (position strips) of one (tile, tap group).  One thread per (tap, tile element).
+struct WgradReduceArgs {
+    const float* ws; float* dW;
+    int gx, tgroups, nstrips;     // workspace layout: workgroup = y * gx + strip * tgroups + tg
+    int A, Bc, kvol, atiles, T, cls;
+    signed char tapid[64], g_t0[8], g_nt[8];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;            // (t, r, lane) inside one workgroup record
+    const int tg = blockIdx.y, y = blockIdx.z;
+    const int t = e >> 10, r = (e >> 6) & 15, lane = e & 63;
+    const int t0 = p.cls ? p.g_t0[tg] : tg * WG_TAPS;
+    const int nt = p.cls ? p.g_nt[tg] : ((p.T - t0 < WG_TAPS) ? (p.T - t0) : WG_TAPS);
+    if (t >= nt) return;
+    const int a = (y % p.atiles) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), b = (y / p.atiles) * 32 + (lane & 31);
+    if (a >= p.A || b >= p.Bc) return;
+    const float* src = p.ws + ((size_t)y * p.gx + tg) * (WG_TAPS * 1024) + e;
+    const size_t step = (size_t)p.tgroups * (WG_TAPS * 1024);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;            // fixed association order: deterministic
+    int i = 0;
+    for (; i + 4 <= p.nstrips; i += 4) {
+        s0 += src[(size_t)i * step]; s1 += src[(size_t)(i + 1) * step]; s2 += src[(size_t)(i + 2) * step]; s3 += src[(size_t)(i + 3) * step];
+    }
+    for (; i < p.nstrips; ++i) s0 += src[(size_t)i * step];
+    const int tt = p.cls ? p.tapid[t0 + t] : t0 + t;
+    p.dW[((size_t)a * p.Bc + b) * p.kvol + tt] = (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace osa
 
 using namespace osa;
 
 // conv:   P = dy [B,Do,Ho,Wo,Co]  Q = x  [B,Di,Hi,Wi,Ci]  dW [Co][Ci][k]   (transposed = 0)
 // deconv: P = x  [B,Di,Hi,Wi,Ci]  Q = dy [B,Do,Ho,Wo,Co]  dW [Ci][Co][k]   (transposed = 1, stride 2, off = t - pad)
-extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
-                                    int B, int Di, int Hi, int Wi, int Ci, int xCs,
-                                    int Do, int Ho, int Wo, int Co, int dyCs,
-                                    int kd, int kh, int kw, int stride,
-                                    int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
-                                    int transposed, void* stream) {
-    OSA_REQUIRE(x && dy && dw, "conv3d_wgrad: NULL pointer");
+// query != nullptr: only compute the workspace size of the two-stage form for these dimensions (no pointer is touched)
+static int wgrad_impl(const float* x, const float* dy, float* dw,
+                      int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                      int Do, int Ho, int Wo, int Co, int dyCs,
+                      int kd, int kh, int kw, int stride,
+                      int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                      int transposed, float* ws, size_t ws_bytes, size_t* query, void* stream) {
+    if (!query) OSA_REQUIRE(x && dy && dw, "conv3d_wgrad: NULL pointer");
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= 64, "conv3d_wgrad: %d taps unsupported", T);
     OSA_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride %d unsupported", stride);
-    OSA_REQUIRE(xCs % 4 == 0 && dyCs % 4 == 0 && (((size_t)x | (size_t)dy) & 15) == 0,
-                "conv3d_wgrad: tensors must be 16-byte aligned with voxel strides %% 4 == 0");
+    if (!query) OSA_REQUIRE(xCs % 4 == 0 && dyCs % 4 == 0 && (((size_t)x | (size_t)dy) & 15) == 0,
+                            "conv3d_wgrad: tensors must be 16-byte aligned with voxel strides %% 4 == 0");
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.kh = kh; a.kw = kw; a.kvol = T;
@@ -198,18 +255,19 @@ extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
         a.wmin = ow < a.wmin ? ow : a.wmin; wmax = ow > wmax ? ow : wmax;
     }
     a.tgroups = cdiv(T, WG_TAPS);
-    if (transposed) {
-        // class-major tap list: for parity (pd, ph, pw) every kernel index whose offset k - pad has that parity; delta = floor(off / 2)
+    if (a.s == 2) {
+        // class-major tap list (transposed convs AND stride-2 convs: both read Q at 2*pos + off): for parity (pd, ph, pw) every kernel
+        // index whose offset has that parity; delta = floor(off / 2)
         a.cls = 1;
         int n = 0;
         for (int c = 0; c < 8; ++c) {
             const int par[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
-            const int kk[3] = {kd, kh, kw}, pd3[3] = {pad_d, pad_h, pad_w};
+            const int kk[3] = {kd, kh, kw}, pd3[3] = {pad_d, pad_h, pad_w}, dl3[3] = {transposed ? 1 : dil_d, transposed ? 1 : dil_h, transposed ? 1 : dil_w};
             int idx[3][4], del[3][4], cnt[3];
             for (int dim = 0; dim < 3; ++dim) {
                 cnt[dim] = 0;
                 for (int k = 0; k < kk[dim]; ++k) {
-                    const int off = k - pd3[dim];
+                    const int off = k * dl3[dim] - pd3[dim];
                     if (((off % 2) + 2) % 2 != par[dim]) continue;
                     idx[dim][cnt[dim]] = k; del[dim][cnt[dim]] = (off - par[dim]) / 2; ++cnt[dim];      // off - par is even
                 }
@@ -228,37 +286,94 @@ extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
         a.tgroups = 8;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.A * a.Bc * T * sizeof(float), st);
-    OSA_REQUIRE(e == hipSuccess, "conv3d_wgrad: memset failed: %s", hipGetErrorString(e));
-    const bool small = (a.s == 2) && !transposed;        // strided convs: strided Q bricks; transposed convs: compact class bricks
-    int TD = small ? 2 : 4, TH = small ? 4 : 8;
-    const int TW = 8;
-    // k = 4 transposed convs: the strided Q brick of a 2x4x8 position tile does not fit -> 2x2x8
-    const bool tiny = small && ((size_t)(TD * TH * TW + ((TD - 1) * 2 + (dmax - a.dmin) + 1) * ((TH - 1) * 2 + (hmax - a.hmin) + 1) *
-                                         ((TW - 1) * 2 + (wmax - a.wmin) + 1)) * WG_PS * sizeof(float) > 160 * 1024);
-    if (tiny) TH = 2;
+    const bool two_stage = query || ws;
+    if (!two_stage) {
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.A * a.Bc * T * sizeof(float), st);
+        OSA_REQUIRE(e == hipSuccess, "conv3d_wgrad: memset failed: %s", hipGetErrorString(e));
+    }
+    // Position brick: 4x8x8 (256 positions, 1 workgroup per CU with its ~95-122 KB of LDS) or 2x8x8 (128 positions, 2 per CU: the
+    // staging of one overlaps the MFMAs of the other).  `OSA_WGRAD_TD` (experiments build) forces one.
+    const int TW = 8, TH = 8;
+    int TD = exp_int("OSA_WGRAD_TD", 4);
+    if (TD != 2 && TD != 4) TD = 4;
     a.LD = (TD - 1) * a.s + (dmax - a.dmin) + 1;
     a.LH = (TH - 1) * a.s + (hmax - a.hmin) + 1;
     a.LW = (TW - 1) * a.s + (wmax - a.wmin) + 1;
-    if (transposed) { a.LD = TD + 1; a.LH = TH + 1; a.LW = TW + 1; }      // class sub-lattice: delta in {dmin, dmin + 1}
+    if (a.cls) { a.LD = TD + 1; a.LH = TH + 1; a.LW = TW + 1; }          // class sub-lattice: delta in {dmin, dmin + 1}
     a.tilesD = cdiv(a.Pd, TD); a.tilesH = cdiv(a.Ph, TH); a.tilesW = cdiv(a.Pw, TW);
-    a.strip = a.tilesW;                                       // a whole row of bricks per workgroup
     const size_t lds = ((size_t)TD * TH * TW + (size_t)a.LD * a.LH * a.LW) * WG_PS * sizeof(float);
     OSA_REQUIRE(lds <= 160 * 1024, "conv3d_wgrad: %zu B of LDS needed", lds);
-    const long long gx = (long long)B * a.tilesD * a.tilesH * cdiv(a.tilesW, a.strip) * a.tgroups;
     const int gy = cdiv(a.A, 32) * cdiv(a.Bc, 32);
+    // Strip = consecutive w-bricks one workgroup accumulates before it hands its partial tiles over.  Atomics form: a whole row per
+    // workgroup (every extra workgroup costs a round of ~9 K contended float atomics).  Two-stage form: the hand-over is 36 KB of plain
+    // stores, so the strip is chosen for load balance -- the one that minimises rounds x (strip + 1), the serial brick count of the
+    // busiest CU (a whole row left e.g. 288 workgroups for 256 CUs: two rounds, the second nearly empty).
+    a.strip = a.tilesW;
+    if (two_stage) {
+        const long long rows = (long long)B * a.tilesD * a.tilesH * a.tgroups * gy;
+        const long long slots = 256ll * ((lds <= 80 * 1024) ? 2 : 1);
+        long long best = -1; int best_strip = a.tilesW;
+        for (int strip = a.tilesW; strip >= 1; --strip) {
+            const long long wgs = rows * cdiv(a.tilesW, strip);
+            const long long cost = (long long)cdiv(wgs, slots) * (strip + 1);    // + 1: the atomics round of a workgroup costs about one brick
+            if (best < 0 || cost < best) { best = cost; best_strip = strip; }
+        }
+        a.strip = exp_int("OSA_WGRAD_STRIP", best_strip);
+        if (a.strip < 1 || a.strip > a.tilesW) a.strip = best_strip;
+    }
+    const long long gx = (long long)B * a.tilesD * a.tilesH * cdiv(a.tilesW, a.strip) * a.tgroups;
     OSA_REQUIRE(gx < (1ll << 31) && gy <= 65535, "conv3d_wgrad: grid too large");
+    const size_t need = (size_t)gx * gy * WG_TAPS * 1024 * sizeof(float);
+    if (query) { *query = need; return 0; }
+    if (ws) OSA_REQUIRE(ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad: workspace of %zu B needed (got %zu)", need, ws_bytes);
+    a.ws = ws;
     dim3 grid((unsigned)gx, gy), block(256);
-    if (tiny) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wgrad_kernel<2, 2, 8>), grid, block, lds, st, a);
-    } else if (small) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wgrad_kernel<2, 4, 8>), grid, block, lds, st, a);
+    if (TD == 2) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<2, 8, 8>), grid, block, lds, st, a);
     } else {
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<4, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((wgrad_kernel<4, 8, 8>), grid, block, lds, st, a);
     }
     OSA_LAUNCH_CHECK("conv3d_wgrad");
+    if (ws) {
+        WgradReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        r.ws = ws; r.dW = dw; r.gx = (int)gx; r.tgroups = a.tgroups; r.nstrips = (int)(gx / a.tgroups);
+        r.A = a.A; r.Bc = a.Bc; r.kvol = T; r.atiles = cdiv(a.A, 32); r.T = T; r.cls = a.cls;
+        memcpy(r.tapid, a.tapid, sizeof(r.tapid)); memcpy(r.g_t0, a.g_t0, sizeof(r.g_t0)); memcpy(r.g_nt, a.g_nt, sizeof(r.g_nt));
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_TAPS * 1024 / 256, a.tgroups, gy), dim3(256), 0, st, r);
+        OSA_LAUNCH_CHECK("conv3d_wgrad_reduce");
+    }
     return 0;
+}
+
+extern "C" int osa_conv3d_wgrad_f32(const float* x, const float* dy, float* dw,
+                                    int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                    int Do, int Ho, int Wo, int Co, int dyCs,
+                                    int kd, int kh, int kw, int stride,
+                                    int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                                    int transposed, void* stream) {
+    return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
+                      dil_d, dil_h, dil_w, transposed, nullptr, 0, nullptr, stream);
+}
+
+extern "C" size_t osa_conv3d_wgrad_workspace_bytes(int B, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co,
+                                                   int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w,
+                                                   int dil_d, int dil_h, int dil_w, int transposed) {
+    size_t need = 0;
+    if (wgrad_impl(nullptr, nullptr, nullptr, B, Di, Hi, Wi, Ci, 4, Do, Ho, Wo, Co, 4, kd, kh, kw, stride, pad_d, pad_h, pad_w,
+                   dil_d, dil_h, dil_w, transposed, nullptr, 0, &need, nullptr)) return 0;
+    return need;
+}
+
+extern "C" int osa_conv3d_wgrad_ws_f32(const float* x, const float* dy, float* dw,
+                                       int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                       int Do, int Ho, int Wo, int Co, int dyCs,
+                                       int kd, int kh, int kw, int stride,
+                                       int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                                       int transposed, float* workspace, size_t workspace_bytes, void* stream) {
+    OSA_REQUIRE(workspace, "conv3d_wgrad_ws: NULL workspace (osa_conv3d_wgrad_workspace_bytes gives its size)");
+    return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
+                      dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream);
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# build_variant.sh NAME [extra hipcc flags]: conv3d.hip / conv_pipe.hip / volume.hip compiled with extra flags (e.g.
+# build_variant.sh NAME [extra hipcc flags]: conv3d.hip / conv_pipe.hip / volume.hip / wgrad.hip compiled with extra flags (e.g.
 # -DOSA_EXPERIMENTS: the measurement switches of osa_common.h), linked with the
 # regular objects into openstereo_amd/lib/variants/NAME.so (A/B experiments via OSA_LIB_PATH)
 set -e
@@ -7,11 +7,11 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p openstereo_amd/lib/variants
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off"
-for f in conv3d conv_pipe volume; do
+for f in conv3d conv_pipe volume wgrad; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c openstereo_amd/csrc/$f.hip -o openstereo_amd/lib/variants/$NAME.$f.o &
 done
 wait
-OBJS=$(ls openstereo_amd/lib/obj/*.o | grep -v "/conv3d.o\|/conv_pipe.o\|/volume.o")
+OBJS=$(ls openstereo_amd/lib/obj/*.o | grep -v "/conv3d.o\|/conv_pipe.o\|/volume.o\|/wgrad.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o openstereo_amd/lib/variants/$NAME.so openstereo_amd/lib/variants/$NAME.*.o $OBJS
 rm openstereo_amd/lib/variants/$NAME.*.o
 echo openstereo_amd/lib/variants/$NAME.so
