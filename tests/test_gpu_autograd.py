@@ -373,7 +373,7 @@ def _ddp_worker(rank, world, port, q):
         loss.backward()
         g = net.DispProcessor.dres0[0][0].weight.grad.detach().cpu()
         g2 = net.Backbone.feature_extraction.layer2[0].conv1[0][0].weight.grad.detach().cpu()
-        q.put((rank, float(loss.detach()), g, g2))
+        q.put((rank, float(loss.detach()), g.numpy(), g2.numpy()))     # by value: tensors travel as fds the exiting child may close first
     finally:
         dist.destroy_process_group()
 
@@ -391,7 +391,7 @@ def test_ddp_two_ranks_average_gradients_through_engine_functions():
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
     [p.join(120) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
-    (_, l0, g0, h0), (_, l1, g1, h1) = res
+    (_, l0, g0, h0), (_, l1, g1, h1) = [(r, l, torch.from_numpy(a), torch.from_numpy(b)) for r, l, a, b in res]
     assert abs(l0 - l1) > 1e-6                                              # different data ...
     assert torch.equal(g0, g1) and torch.equal(h0, h1)                      # ... identical (all-reduced) gradients
     assert float(g0.abs().max()) > 0 and torch.isfinite(g0).all()
