@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: the best-throughput batch of the sweep in DESIGN.md 6 -- 8 GwcNet / LightStereo, 4 IGEV, 1 training; single-pair latency is reported next to it)")
     ap.add_argument("--workload", default="gwcnet",
-                    choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "gwcnet_train"))
+                    choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "stereobase_e2e_train", "gwcnet_train"))
     ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
@@ -222,6 +222,51 @@ class StereoBaseTrain:
                             "maps stand in for the timm backbone"}
 
 
+class StereoBaseE2ETrain:
+    """BASELINE configs[2], whole model: openstereo_amd.models.stereo_models.StereoBase in training mode at the SceneFlow crop 320x736
+    (cfgs/stereobase/stereobase_sceneflow.yaml) -- volumes, hourglass, classifier, regression, geometry-encoding lookup and 22 GRU iterations
+    (TRAIN_ITERS) with convex upsampling after each, the loss of stereobase_gru.py:215-243, backward, AdamW step; frozen BN.  The timm
+    pyramid / context encoder are the shape-compatible stand-ins (torch modules, trained along)."""
+    metric = "training stereo-pairs/s, StereoBase (stand-in backbone) at 320x736 crop, 22 GRU iterations"
+    scaling, graphable, training = "weak", False, True
+
+    def __init__(self, args, dev, rank):
+        import numpy as np
+        from types import SimpleNamespace
+        from openstereo_amd.models.stereo_models import StereoBase
+        from openstereo_amd.utils.weights import synth_state_dict, synth_images
+        self.B = B = args.batch or 1
+        cfg = SimpleNamespace(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                              N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=32, TRAIN_ITERS=22)
+        net = StereoBase(cfg)
+        net.load_state_dict(synth_state_dict(net, seed=41, head_gain=20.0, gain=0.9))
+        net = net.to(dev).train()
+        for m in net.modules():                                   # FREEZE_BN: true
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+                m.eval()
+        self.raw = net
+        self.model = net
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            self.model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
+        self.opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5, eps=1e-8)
+        L, R = synth_images(B, 320, 736, seed=20 + rank)
+        self.L, self.R = L.to(dev), R.to(dev)
+        self.gt = torch.from_numpy(np.random.default_rng(rank).uniform(1, 100, (B, 320, 736)).astype("float32")).to(dev)
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model({"left": self.L, "right": self.R})
+        loss, _ = self.raw.get_loss(out, {"disp": self.gt})
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(self.raw.parameters(), 1.0)          # CLIP_GRAD: value 1.0
+        self.opt.step()
+        return loss.detach()
+
+    def config(self, args):
+        return {"workload": "StereoBase training step, whole model with stand-in 2-D backbone (cost stage + geometry lookup + 22 GRU iterations + convex "
+                            "upsampling; fwd + bwd + AdamW, frozen BN, grad clip), SceneFlow crop 320x736, 1 pair per GPU (BASELINE configs[2])"}
+
+
 class GwcNetTrain:
     metric = "training stereo-pairs/s, GwcNet at 256x512 crop"
     scaling, graphable, training = "weak", False, True
@@ -276,7 +321,7 @@ class _Cfg(dict):
 
 
 WORKLOADS = {"gwcnet": GwcNetInference, "lightstereo_kitti15": LightStereoKitti15, "igev_refine32": IGEVRefine32,
-             "stereobase_train": StereoBaseTrain, "gwcnet_train": GwcNetTrain}
+             "stereobase_train": StereoBaseTrain, "stereobase_e2e_train": StereoBaseE2ETrain, "gwcnet_train": GwcNetTrain}
 
 
 # ============================================================================================ rooflines (GwcNet)

@@ -394,6 +394,13 @@ int osa_geo_lookup_f32(const float* const* geo_levels, const float* const* corr_
                        const int* geo_len, const int* corr_len, int levels,
                        const float* disp, const float* coords_x, float* out,
                        int B, int H, int W, int C, int radius, void* stream);
+/* Gradient of osa_geo_lookup_f32 with respect to the pyramid levels (the disparity is detached in the reference's loop,
+ * models/igev/igev_stereo.py:190): dgeo_levels / dcorr_levels have the shapes of geo_levels / corr_levels, are zero-filled and then
+ * accumulated without atomics (every pixel owns its rows).  dout: [B,(C+1)*(2r+1)*levels,H,W]. */
+int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* dcorr_levels,
+                           const int* geo_len, const int* corr_len, int levels,
+                           const float* disp, const float* coords_x, const float* dout,
+                           int B, int H, int W, int C, int radius, void* stream);
 
 /* ---- input pre-processing on device ------------------------- */
 /* RightTopPad(edge) + HWC->CHW + /255 + (x-mean)/std for the left and right image in one launch

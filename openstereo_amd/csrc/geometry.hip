@@ -135,9 +135,68 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const LookupArgs p) {
     }
 }
 
+// Backward of the lookup w.r.t. the pyramid levels (the disparity is detached in the reference, igev_stereo.py:190): every pixel owns
+// its rows of every level, so a thread adds its taps into its own (zero-filled) rows -- no atomics, deterministic.
+struct LookupBwdArgs {
+    float* dgeo[4]; float* dcorr[4];
+    const float* disp; const float* coords; const float* dout;
+    int B, H, W, C, levels, radius;
+    int Dl[4], Wl[4];
+};
+__device__ __forceinline__ void scatter_row(float* __restrict__ row, int n, const Tap t, float g) {
+    if (t.x0 >= 0 && t.x0 < n) row[t.x0] += g * t.w0;
+    if (t.x0 + 1 >= 0 && t.x0 + 1 < n) row[t.x0 + 1] += g * t.w1;
+}
+__global__ __launch_bounds__(256) void geo_lookup_bwd_kernel(const LookupBwdArgs p) {
+    const long long HW = (long long)p.H * p.W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.B * HW) return;
+    const long long b = i / HW, hw = i - b * HW;
+    const int taps = 2 * p.radius + 1;
+    const int per_level = (p.C + 1) * taps;
+    const float d = p.disp[i], cx = p.coords[i];
+    const float* o = p.dout + (size_t)b * per_level * p.levels * HW + hw;
+    float scale = 1.f;
+    for (int l = 0; l < p.levels; ++l, scale *= 0.5f) {
+        float* g = p.dgeo[l] + (size_t)i * p.C * p.Dl[l];
+        float* crow = p.dcorr[l] + (size_t)i * p.Wl[l];
+        const float xg = d * scale, xc = cx * scale - d * scale;
+        for (int k = 0; k < taps; ++k) {
+            const float dx = (float)(k - p.radius);
+            const Tap tg = tap_of(dx + xg, p.Dl[l]);
+            for (int c = 0; c < p.C; ++c)
+                scatter_row(g + (size_t)c * p.Dl[l], p.Dl[l], tg, o[((size_t)l * per_level + c * taps + k) * HW]);
+            const Tap tc = tap_of(xc + dx, p.Wl[l]);
+            scatter_row(crow, p.Wl[l], tc, o[((size_t)l * per_level + p.C * taps + k) * HW]);
+        }
+    }
+}
+
 }  // namespace osa
 
 using namespace osa;
+
+extern "C" int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* dcorr_levels,
+                                      const int* geo_len, const int* corr_len, int levels,
+                                      const float* disp, const float* coords_x, const float* dout,
+                                      int B, int H, int W, int C, int radius, void* stream) {
+    OSA_REQUIRE(dgeo_levels && dcorr_levels && geo_len && corr_len && disp && coords_x && dout, "geo_lookup_bwd: NULL pointer");
+    OSA_REQUIRE(levels >= 1 && levels <= 4, "geo_lookup_bwd: %d levels unsupported (1..4)", levels);
+    LookupBwdArgs a;
+    const long long total = (long long)B * H * W;
+    for (int l = 0; l < levels; ++l) {
+        OSA_REQUIRE(dgeo_levels[l] && dcorr_levels[l] && geo_len[l] > 0 && corr_len[l] > 0, "geo_lookup_bwd: level %d missing", l);
+        a.dgeo[l] = dgeo_levels[l]; a.dcorr[l] = dcorr_levels[l]; a.Dl[l] = geo_len[l]; a.Wl[l] = corr_len[l];
+        hipError_t e = hipMemsetAsync(a.dgeo[l], 0, (size_t)total * C * geo_len[l] * sizeof(float), (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemsetAsync(a.dcorr[l], 0, (size_t)total * corr_len[l] * sizeof(float), (hipStream_t)stream);
+        OSA_REQUIRE(e == hipSuccess, "geo_lookup_bwd: memset failed: %s", hipGetErrorString(e));
+    }
+    a.disp = disp; a.coords = coords_x; a.dout = dout;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.levels = levels; a.radius = radius;
+    hipLaunchKernelGGL(geo_lookup_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("geo_lookup_bwd");
+    return 0;
+}
 
 extern "C" int osa_allpairs_corr_f32(const float* fmap1, const float* fmap2, float* corr,
                                      int B, int C, int H, int W1, int W2, void* stream) {

@@ -16,10 +16,63 @@ from . import _lib, ops, timing
 from .ops import _f32c, _stream, is_cl
 
 
+class _Lookup(torch.autograd.Function):
+    """out = lookup(disp, coords; geo levels, corr levels) with gradients for the levels (osa_geo_lookup_bwd_f32).  The disparity is
+    detached in the reference's loop (igev_stereo.py:190, stereobase_gru.py:186), so it gets none."""
+
+    @staticmethod
+    def forward(ctx, d, cx, C, radius, *levels):
+        L = len(levels) // 2
+        geo, corr = levels[:L], levels[L:]
+        B, H, W = d.shape
+        out = torch.empty((B, (C + 1) * (2 * radius + 1) * L, H, W), device=d.device, dtype=torch.float32)
+        gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in geo])
+        cp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in corr])
+        gl = (ctypes.c_int * L)(*[t.shape[-1] for t in geo])
+        cl = (ctypes.c_int * L)(*[t.shape[-1] for t in corr])
+        _lib.call("osa_geo_lookup_f32", gp, cp, gl, cl, L, d.data_ptr(), cx.data_ptr(), out.data_ptr(), B, H, W, C, radius, _stream())
+        ctx.save_for_backward(d, cx)
+        ctx.meta = (C, radius, L, [tuple(t.shape) for t in levels])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d, cx = ctx.saved_tensors
+        C, radius, L, shapes = ctx.meta
+        B, H, W = d.shape
+        grads = [torch.empty(s, device=d.device, dtype=torch.float32) for s in shapes]
+        gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads[:L]])
+        cp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads[L:]])
+        gl = (ctypes.c_int * L)(*[s[-1] for s in shapes[:L]])
+        cl = (ctypes.c_int * L)(*[s[-1] for s in shapes[L:]])
+        _lib.call("osa_geo_lookup_bwd_f32", gp, cp, gl, cl, L, d.data_ptr(), cx.data_ptr(), _f32c(dout).data_ptr(),
+                  B, H, W, C, radius, _stream())
+        return (None, None, None, None, *grads)
+
+
 class CombinedGeoEncodingVolume:
     def __init__(self, init_fmap1, init_fmap2, geo_volume, num_levels=2, radius=4):
         assert 1 <= num_levels <= 4
         self.num_levels, self.radius = num_levels, radius
+        self.train_path = torch.is_grad_enabled() and any(t.requires_grad for t in (init_fmap1, init_fmap2, geo_volume))
+        if self.train_path:
+            # Training: the pyramid is built from differentiable torch ops (a permutation, an einsum, two average pools: once per
+            # forward), the per-iteration lookup and its gradient run on the engine (_Lookup).
+            import torch.nn.functional as F
+            f1, f2, gv = init_fmap1.float(), init_fmap2.float(), geo_volume.float()
+            B, C, D, H, W1 = gv.shape
+            self.C, self.shape = C, (B, H, W1)
+            rows = gv.permute(0, 3, 4, 1, 2).contiguous()                                 # [B,H,W,C,D]
+            corr = torch.einsum("aijk,aijh->ajkh", f1, f2).contiguous()                   # [B,H,W1,W2]
+            self.geo_volume_pyramid, self.init_corr_pyramid = [rows], [corr]
+            for _ in range(num_levels - 1):
+                g, c = self.geo_volume_pyramid[-1], self.init_corr_pyramid[-1]
+                self.geo_volume_pyramid.append(F.avg_pool1d(g.reshape(-1, 1, g.shape[-1]), 2, 2).reshape(*g.shape[:-1], g.shape[-1] // 2))
+                self.init_corr_pyramid.append(F.avg_pool1d(c.reshape(-1, 1, c.shape[-1]), 2, 2).reshape(*c.shape[:-1], c.shape[-1] // 2))
+            from .ranges import new_meta
+            self.meta = new_meta(rows.device)
+            self.meta[0:1] = torch.maximum(rows.detach().abs().amax(), corr.detach().abs().amax()).reshape(1)
+            return
         f1, f2 = _f32c(init_fmap1), _f32c(init_fmap2)
         B, Cf, H, W1 = f1.shape
         W2 = f2.shape[3]
@@ -58,6 +111,8 @@ class CombinedGeoEncodingVolume:
         [B,(C+1)*(2r+1)*levels,H,W] float32."""
         B, H, W = self.shape
         d, cx = _f32c(disp).reshape(B, H, W), _f32c(coords).reshape(B, H, W)
+        if self.train_path:
+            return _Lookup.apply(d.detach(), cx.detach(), self.C, self.radius, *self.geo_volume_pyramid, *self.init_corr_pyramid)
         out = torch.empty((B, (self.C + 1) * (2 * self.radius + 1) * self.num_levels, H, W), device=d.device, dtype=torch.float32)
         with timing.span("geo_lookup", self.C, self.num_levels, self.radius, H, W):
             _lib.call("osa_geo_lookup_f32", self._gp, self._cp, self._gl, self._cl, self.num_levels,

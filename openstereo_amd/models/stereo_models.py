@@ -144,7 +144,7 @@ class StereoBase(StereoBaseCostStage):
     """stereobase_gru.py:14-213 (gwc [+ concat] volume configuration; USE_SUB_VOLUME / USE_INTERLACED_VOLUME are not built).
 
     `cfgs`: attribute namespace with the reference's keys (MAX_DISP, NUM_GROUPS, USE_CONCAT_VOLUME, CONCAT_CHANNELS,
-    HIDDEN_DIMS, N_GRU_LAYERS, CORR_RADIUS, CORR_LEVELS, SLOW_FAST_GRU, EVAL_ITERS)."""
+    HIDDEN_DIMS, N_GRU_LAYERS, CORR_RADIUS, CORR_LEVELS, SLOW_FAST_GRU, EVAL_ITERS, TRAIN_ITERS)."""
 
     def __init__(self, cfgs, feature=None, cnet=None):
         g = lambda k, d: getattr(cfgs, k, d)
@@ -208,10 +208,52 @@ class StereoBase(StereoBaseCostStage):
         image1, image2 = data["left"], data["right"]
         _require_engine(image1, "StereoBase")
         if self.training:
-            raise NotImplementedError("openstereo_amd StereoBase: the end-to-end class is inference-only; the trainable pieces are "
-                                      "StereoBaseCostStage (volume -> aggregation -> regression) and BasicMultiUpdateBlock")
+            return self._train(image1, image2)
         with torch.no_grad():
             return self._infer(image1, image2)
+
+    def _train(self, image1, image2):
+        """stereobase_gru.py:121-213, training mode: every hot-path op forward AND backward on the engine -- volumes, hourglass convs,
+        classifier, fused softmax regression (StereoBaseCostStage.forward_train), geometry-encoding lookup (geometry._Lookup), update
+        block convs (BasicMultiUpdateBlock.forward_train); BatchNorm / activations / the small 2-D heads are torch modules."""
+        from ..attach import context_upsample as ctx_up              # differentiable form (torch composition when gradients flow)
+        from ..geometry import CombinedGeoEncodingVolume
+        s = self.side(image1, image2)
+        st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"])
+        init_disp, geo = st["init_disp"], st["geo_encoding_volume"]
+        geo_fn = CombinedGeoEncodingVolume(s["match_left"].float(), s["match_right"].float(), geo.float(),
+                                           radius=self.cfgs.CORR_RADIUS, num_levels=self.cfgs.CORR_LEVELS)
+        b, _, h, w = s["match_left"].shape
+        coords = torch.arange(w, device=image1.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+        net_list, inp_list = s["net_list"], s["inp_list"]
+        n3, n2 = self.n_gru_layers == 3, self.n_gru_layers >= 2
+        disp, disp_preds = init_disp, []
+        for _ in range(self.cfgs.TRAIN_ITERS):
+            disp = disp.detach()
+            geo_feat = geo_fn(disp, coords)
+            if n3 and self.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter16=True, iter08=False, iter04=False, update=False)
+            if n2 and self.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter16=n3, iter08=True, iter04=False, update=False)
+            net_list, mask_feat_4, delta_disp = self.update_block(net_list, inp_list, geo_feat, disp, iter16=n3, iter08=n2)
+            disp = disp + delta_disp
+            spx = F.softmax(self.spx_gru(self.spx_2_gru(mask_feat_4, s["stem_2x"])), 1)
+            disp_preds.append(ctx_up(disp * 4.0, spx).unsqueeze(1))
+        init_up = ctx_up(init_disp * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
+        return {"init_disp": init_up, "disp_preds": disp_preds, "disp_pred": disp_preds[-1]}
+
+    def get_loss(self, model_pred, input_data):
+        """stereobase_gru.py:215-243: smooth-L1 on the initial disparity + gamma-weighted L1 over the GRU predictions."""
+        disp_gt = input_data["disp"]
+        valid = ((disp_gt < self.max_disp) & (disp_gt > 0)).unsqueeze(1)
+        disp_gt = disp_gt.unsqueeze(1)
+        loss = F.smooth_l1_loss(model_pred["init_disp"][valid], disp_gt[valid], reduction="mean")
+        preds = model_pred["disp_preds"]
+        n = len(preds)
+        for i, pr in enumerate(preds):
+            gamma = 0.9 ** (15 / (n - 1)) if n > 1 else 1.0
+            loss = loss + gamma ** (n - i - 1) * (pr - disp_gt).abs()[valid].mean()
+        return loss, {"scalar/train/loss_disp": float(loss.detach())}
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)

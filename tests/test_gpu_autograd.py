@@ -395,3 +395,68 @@ def test_ddp_two_ranks_average_gradients_through_engine_functions():
     assert abs(l0 - l1) > 1e-6                                              # different data ...
     assert torch.equal(g0, g1) and torch.equal(h0, h1)                      # ... identical (all-reduced) gradients
     assert float(g0.abs().max()) > 0 and torch.isfinite(g0).all()
+
+
+def test_geo_lookup_gradients_vs_oracle_autograd():
+    """Geometry-encoding lookup (a5) in training: engine forward + backward (osa_geo_lookup_bwd_f32) vs torch-CPU autograd of the oracle's
+    grid_sample composition -- gradients w.r.t. the geometry volume and both matching feature maps, two lookups with different disparities
+    accumulated like two GRU iterations."""
+    from openstereo_amd.geometry import CombinedGeoEncodingVolume
+    from oracle import torch_ref as O
+    g = torch.Generator().manual_seed(21)
+    r = lambda *s: torch.randn(*s, generator=g)
+    B, C, D, H, W, Cf = 2, 8, 12, 8, 24, 16
+    f1, f2, gv = r(B, Cf, H, W) * 0.5, r(B, Cf, H, W) * 0.5, r(B, C, D, H, W)
+    disps = [r(B, 1, H, W).abs() * 3, r(B, 1, H, W).abs() * 6]
+    wts = [r(B, (C + 1) * 9 * 2, H, W) for _ in disps]
+    coords = torch.arange(W).float().reshape(1, 1, W, 1).repeat(B, H, 1, 1)
+
+    def run(dev, cls, kw):
+        a, b_, v = (t.clone().to(dev).requires_grad_() for t in (f1, f2, gv))
+        fn = cls(a, b_, v, **kw)
+        outs = [fn(d.to(dev), coords.to(dev)) for d in disps]
+        loss = sum((o.reshape(wt.shape) * wt.to(dev)).sum() for o, wt in zip(outs, wts))
+        loss.backward()
+        return [o.detach().cpu().reshape(wts[0].shape) for o in outs], [t.grad.cpu() for t in (a, b_, v)]
+
+    outs_e, grads_e = run(DEV, CombinedGeoEncodingVolume, dict(num_levels=2, radius=4))
+    outs_o, grads_o = run("cpu", O.GeoEncodingVolume, dict(num_levels=2, radius=4))
+    for oe, oo in zip(outs_e, outs_o):
+        torch.testing.assert_close(oe, oo, rtol=1e-5, atol=2e-5)
+    for ge, go, name in zip(grads_e, grads_o, ("fmap1", "fmap2", "geo_volume")):
+        assert float(go.abs().max()) > 0, name
+        torch.testing.assert_close(ge, go, rtol=1e-4, atol=1e-4 * float(go.abs().max()), msg=lambda m: f"{name}: {m}")
+
+
+def test_stereobase_end_to_end_training_step():
+    """The end-to-end StereoBase class in training mode (BASELINE configs[2]): cost stage + 3 GRU iterations + convex upsampling, loss of
+    stereobase_gru.py:215-243, backward through every engine op; gradients reach the volume stage, the hourglass, the update block and
+    the 2-D heads, and one SGD step lowers the loss."""
+    from types import SimpleNamespace
+    from openstereo_amd.models.stereo_models import StereoBase
+    cfg = SimpleNamespace(MAX_DISP=64, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                          N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=4, TRAIN_ITERS=3)
+    m = StereoBase(cfg)
+    m.load_state_dict(synth_state_dict(m, seed=41, head_gain=20.0, gain=0.9))
+    m = m.to(DEV).train()
+    for mod in m.modules():                                   # FREEZE_BN (cfgs/stereobase/stereobase_sceneflow.yaml:48)
+        if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            mod.eval()
+    L, R = synth_images(1, 64, 128, seed=31, max_shift=12.0)
+    gt = T(np.random.default_rng(3).uniform(1.0, 30.0, (1, 64, 128)).astype(np.float32)).to(DEV)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-5)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = m({"left": L.to(DEV), "right": R.to(DEV)})
+        assert len(out["disp_preds"]) == 3 and out["disp_pred"].shape == (1, 1, 64, 128)
+        loss, _ = m.get_loss(out, {"disp": gt})
+        loss.backward()
+        if not losses:
+            for name in ("cost_agg.conv1.0.block.0.weight", "classifier.weight", "update_block.gru04.convz.weight",
+                         "update_block.encoder.convc1.weight", "desc.weight", "spx_gru.0.weight", "concat_conv.1.weight"):
+                gr = dict(m.named_parameters())[name].grad
+                assert gr is not None and torch.isfinite(gr).all() and float(gr.abs().max()) > 0, name
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[1] < losses[0], losses
