@@ -88,6 +88,13 @@ int osa_build_volume_nhwc_f32(const float* left_gwc, const float* right_gwc, int
                               const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                               float* vol, int vol_channels, int c_off,
                               int B, int H, int W, int maxdisp, int mask_left_concat, float* vol_meta, void* stream);
+/* Dormant volume variants of cost_volume.py (no shipped config enables them), NCHW in, NCDHW out:
+ *   mode 0  CoExCostVolume.forward (:17-29): out[B,groups,planes,H,W] = sum over the group's channels of x[w] * y[w-d], planes = maxdisp + 1
+ *   mode 1  compute_volume(side='left')  (:44-56): out[B,C,planes,H,W] = reference[w] - target[w-d]   (w >= d, else 0)
+ *   mode 2  compute_volume(side='right'):          out[B,C,planes,H,W] = target[w+d] - reference[w]   (w < W-d; plane 0: reference - target)
+ *   mode 3  build_sub_volume (:108-117):           out[B,planes,H,W]   = sum_c |l[w] - r[w-d]| (w >= d), sum_c |l[w]| (w < d) */
+int osa_pair_volume_f32(const float* left, const float* right, float* out,
+                        int B, int C, int groups, int H, int W, int planes, int mode, void* stream);
 
 /* correlation layer: vol[b,d,h,w] = mean_c L[b,c,h,w]*R[b,c,h,w-d], 0 for w<d. vol is [B,D,H,W]. */
 int osa_corr_volume_f32(const float* left, const float* right, float* vol,

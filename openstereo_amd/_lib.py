@@ -78,6 +78,7 @@ SIGNATURES = {
                                        c_fp, c_i,
                                        c_i, c_f, c_f, c_rng, c_st]),
     "osa_conv3d_pack_ex": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
+    "osa_pair_volume_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_conv3d_wgrad_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_conv3d_wgrad_workspace_bytes": (C.c_size_t, [c_i] * 20),

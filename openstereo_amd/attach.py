@@ -104,6 +104,19 @@ def context_upsample(disp_low, up_weights, scale_factor=4):
     return ops.context_upsample(disp_low, up_weights, scale_factor)
 
 
+def _dormant(name):
+    """Engine version of a dormant volume helper for inference; with gradients required it defers to the function it replaced."""
+    def fn(*a, **k):
+        if _needs_grad(*[t for t in a if isinstance(t, torch.Tensor)]):
+            for mod, attr, old in _saved:
+                if attr == name and callable(old) and mod.__name__.endswith("cost_volume.cost_volume"):
+                    return old(*a, **k)
+            raise NotImplementedError(f"openstereo_amd: {name} has no autograd path on the engine")
+        return getattr(ops, name)(*a, **k)
+    fn.__name__ = name
+    return fn
+
+
 # (module, attribute, replacement)
 def _targets():
     igev_concat = lambda l, r, d: build_concat_volume(l, r, d, mask_left=False)   # igev/submodule.py:216-227
@@ -113,6 +126,9 @@ def _targets():
     return [
         (cv, "build_gwc_volume", build_gwc_volume), (cv, "build_concat_volume", build_concat_volume),
         (cv, "correlation_volume", correlation_volume), (cv, "build_corr_volume", build_corr_volume),
+        # dormant variants (inference; no autograd path): engine versions fall back to the reference's own code when gradients are needed
+        (cv, "compute_volume", _dormant("compute_volume")), (cv, "build_sub_volume", _dormant("build_sub_volume")),
+        ("stereo.modeling.models.stereobase.stereobase_gru", "build_sub_volume", _dormant("build_sub_volume")),
         ("stereo.modeling.disp_pred.disp_regression", "disparity_regression", reg_keep),
         ("stereo.modeling.disp_refinement.disp_refinement", "context_upsample", context_upsample),
         # names already imported into model namespaces

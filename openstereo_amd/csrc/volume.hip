@@ -361,9 +361,64 @@ __global__ __launch_bounds__(256) void build_volume_ncdhw_kernel(const VolNArgs 
     p.vol[((((size_t)b * p.VC + p.coff + c) * p.D + d) * plane) + hw] = v;
 }
 
+// ------------------------------------------------------------------ dormant variants (cost_volume.py:9-29, 44-56, 108-117) ----
+// No shipped config enables them (StereoBase USE_SUB_VOLUME / CoEx-style heads); plain one-thread-per-element kernels, NCDHW like the
+// reference, w fastest.  mode 0: CoEx correlation (sum over the channels of a group, D = maxdisp + 1 planes);
+// mode 1 / 2: difference volume of compute_volume, side left / right; mode 3: L1 "sub" volume.
+struct PairArgs {
+    const float* l; const float* r; float* out;
+    int B, C, G, H, W, D, mode;
+};
+__global__ __launch_bounds__(256) void pair_volume_kernel(const PairArgs p) {
+    const int oc = blockIdx.y;                              // output channel (group / channel / 0)
+    const int bd = blockIdx.z;
+    const int b = bd / p.D, d = bd - b * p.D;
+    const int hw = blockIdx.x * 256 + threadIdx.x;
+    if (hw >= p.H * p.W) return;
+    const int w = hw % p.W;
+    const size_t plane = (size_t)p.H * p.W;
+    const float* lb = p.l + (size_t)b * p.C * plane + hw;
+    const float* rb = p.r + (size_t)b * p.C * plane + hw;
+    float v = 0.f;
+    int OC = 1;
+    if (p.mode == 0) {                                      // cost[b,g,d,h,w] = sum_k x[g,k,h,w] * y[g,k,h,w-d]
+        OC = p.G;
+        const int K = p.C / p.G;
+        if (w >= d)
+            for (int k = 0; k < K; ++k) v += lb[(size_t)(oc * K + k) * plane] * rb[(size_t)(oc * K + k) * plane - d];   // torch's sum(2): ascending k
+    } else if (p.mode == 1) {                               // reference[w] - target[w-d]   (w >= d)
+        OC = p.C;
+        if (w >= d) v = lb[(size_t)oc * plane] - rb[(size_t)oc * plane - d];
+    } else if (p.mode == 2) {                               // target[w+d] - reference[w]   (w < W-d); d = 0: reference - target
+        OC = p.C;
+        if (d == 0) v = lb[(size_t)oc * plane] - rb[(size_t)oc * plane];
+        else if (w < p.W - d) v = rb[(size_t)oc * plane + d] - lb[(size_t)oc * plane];
+    } else {                                                // w < d: sum_c |l|;  else: sum_c |l[w] - r[w-d]|
+        for (int c = 0; c < p.C; ++c) {
+            const float a = lb[(size_t)c * plane];
+            v += (w >= d) ? fabsf(a - rb[(size_t)c * plane - d]) : fabsf(a);
+        }
+    }
+    p.out[(((size_t)b * OC + oc) * p.D + d) * plane + hw] = v;
+}
+
 }  // namespace osa
 
 using namespace osa;
+
+extern "C" int osa_pair_volume_f32(const float* left, const float* right, float* out,
+                                   int B, int C, int groups, int H, int W, int planes, int mode, void* stream) {
+    OSA_REQUIRE(left && right && out, "pair_volume: NULL pointer");
+    OSA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && planes > 0, "pair_volume: bad dims");
+    OSA_REQUIRE(mode >= 0 && mode <= 3, "pair_volume: mode %d (0 coex correlation, 1 / 2 difference left / right, 3 L1 sub volume)", mode);
+    if (mode == 0) OSA_REQUIRE(groups > 0 && C % groups == 0, "pair_volume: C=%d not divisible by groups=%d", C, groups);
+    PairArgs a{left, right, out, B, C, mode == 0 ? groups : 1, H, W, planes, mode};
+    const int oc = (mode == 0) ? groups : ((mode == 3) ? 1 : C);
+    OSA_REQUIRE((long long)B * planes <= 65535 && oc <= 65535, "pair_volume: grid too large");
+    hipLaunchKernelGGL(pair_volume_kernel, dim3(cdiv((long long)H * W, 256), oc, B * planes), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("pair_volume");
+    return 0;
+}
 
 static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                              const float* left_cat, const float* right_cat, int Cc, int cat_stride,

@@ -149,7 +149,8 @@ class StereoBase(StereoBaseCostStage):
     def __init__(self, cfgs, feature=None, cnet=None):
         g = lambda k, d: getattr(cfgs, k, d)
         if g("USE_SUB_VOLUME", False) or g("USE_INTERLACED_VOLUME", False) or not g("USE_GWC_VOLUME", True):
-            raise NotImplementedError("openstereo_amd StereoBase: only the gwc (+ concat) volume configuration is built")
+            raise NotImplementedError("openstereo_amd StereoBase: only the gwc (+ concat) volume configuration is built (build_sub_volume exists "
+                                      "as an engine op, ops.build_sub_volume, but is not wired into the fused NDHWC volume; InterlacedVolume is not built)")
         self_concat = g("CONCAT_CHANNELS", 12) if g("USE_CONCAT_VOLUME", False) else 0
         feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
         bc = list(getattr(feature, "output_channels", (48, 64, 192, 160)))

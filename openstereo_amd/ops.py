@@ -163,6 +163,38 @@ def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
                   _f32c(_chk(target_fm, "target_fm", 4)), max_disp, NCDHW)
 
 
+def _pair_volume(left, right, planes, mode, groups=1):
+    l, r = _f32c(_chk(left, "left", 4)), _f32c(_chk(right, "right", 4))
+    assert l.shape == r.shape, "feature maps must have the same shape"
+    B, C, H, W = l.shape
+    shape = (B, groups, planes, H, W) if mode == 0 else ((B, planes, H, W) if mode == 3 else (B, C, planes, H, W))
+    out = torch.empty(shape, device=l.device, dtype=torch.float32)
+    _lib.call("osa_pair_volume_f32", l.data_ptr(), r.data_ptr(), out.data_ptr(), B, C, groups, H, W, planes, mode, _stream())
+    return out if left.dtype == torch.float32 else out.to(left.dtype)
+
+
+def compute_volume(reference_embedding, target_embedding, maxdisp, side="left"):
+    """cost_volume.py:44-56 (difference volume, [B,C,maxdisp,H,W])."""
+    assert side in ("left", "right")
+    return _pair_volume(reference_embedding, target_embedding, maxdisp, 1 if side == "left" else 2)
+
+
+def build_sub_volume(feat_l, feat_r, maxdisp):
+    """cost_volume.py:108-117 (L1 volume, [B,maxdisp,H,W])."""
+    return _pair_volume(feat_l, feat_r, maxdisp, 3)
+
+
+class CoExCostVolume(torch.nn.Module):
+    """cost_volume.py:9-29: correlation summed over the channels of each group, maxdisp + 1 planes, [B,group,maxdisp+1,H,W]."""
+
+    def __init__(self, maxdisp, group=1):
+        super().__init__()
+        self.maxdisp, self.group = maxdisp + 1, group
+
+    def forward(self, x, y):
+        return _pair_volume(x, y, self.maxdisp, 0, self.group)
+
+
 def build_cost_volume_cl(gwc_left, gwc_right, num_groups, cat_left=None, cat_right=None, maxdisp=48,
                          mask_left=True):
     """Fused gwc(+concat) volume written straight into one NDHWC buffer

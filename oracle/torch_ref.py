@@ -357,6 +357,42 @@ def igev_cost_stage(match_l, match_r, features, sd, max_disp):
     return disparity_regression(prob, D4, keepdim=True), prob, geo
 
 
+# ============================================================================= dormant volume variants
+def coex_cost_volume(x, y, maxdisp, group=1):
+    """cost_volume.py:9-29 (CoExCostVolume.forward): cost[b,g,d,h,w] = sum_k x[g,k,h,w] * y[g,k,h,w-d], d = 0..maxdisp."""
+    b, c, h, w = x.shape
+    xg, yg = x.reshape(b, group, c // group, h, w), y.reshape(b, group, c // group, h, w)
+    out = x.new_zeros(b, group, maxdisp + 1, h, w)
+    for d in range(maxdisp + 1):
+        if d < w:
+            out[:, :, d, :, d:] = (xg[..., d:] * yg[..., :w - d]).sum(2)
+    return out
+
+
+def compute_volume(reference, target, maxdisp, side="left"):
+    """cost_volume.py:44-56 (the reference hard-codes device='cuda': restated, parity unpinned)."""
+    b, c, h, w = reference.shape
+    cost = reference.new_zeros(b, c, maxdisp, h, w)
+    cost[:, :, 0] = reference - target
+    for i in range(1, min(maxdisp, w)):
+        if side == "left":
+            cost[:, :, i, :, i:] = reference[..., i:] - target[..., :-i]
+        else:
+            cost[:, :, i, :, :-i] = target[..., i:] - reference[..., :-i]
+    return cost
+
+
+def build_sub_volume(feat_l, feat_r, maxdisp):
+    """cost_volume.py:108-117 (device='cuda' hard-coded in the reference: restated, parity unpinned)."""
+    b, c, h, w = feat_l.shape
+    cost = feat_l.new_zeros(b, maxdisp, h, w)
+    for i in range(maxdisp):
+        cost[:, i, :, :i] = feat_l[..., :i].abs().sum(1)
+        if i < w:
+            cost[:, i, :, i:] = (feat_l[..., i:] - (feat_r[..., :w - i] if i else feat_r)).abs().sum(1)
+    return cost
+
+
 # ============================================================================= refinement (a13)
 def context_upsample(disp_low, up_weights, scale_factor=4):
     """disp_refinement/disp_refinement.py:194-204 (== stereobase/igev_blocks.py:51-63, igev/submodule.py:253-265)."""

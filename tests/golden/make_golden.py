@@ -216,10 +216,21 @@ def gen_preprocess():
     save("preprocess.npz", left_u8=L, right_u8=R, left=out["left"], right=out["right"])
 
 
+def gen_dormant():
+    """Dormant volume variants: CoExCostVolume (cost_volume.py:9-29) is CPU-runnable -> pinned here.  compute_volume / build_sub_volume
+    (:44-56, :108-117) hard-code device='cuda' and cannot run in this container: their oracle restatements stay unpinned."""
+    from stereo.modeling.cost_volume import cost_volume as cv
+    x, y = rnd((2, 8, 5, 20), 301), rnd((2, 8, 5, 20), 302)
+    out = {"x": x.numpy(), "y": y.numpy()}
+    for grp in (1, 4):
+        out[f"coex_g{grp}"] = cv.CoExCostVolume(6, grp)(x, y).numpy()
+    save("dormant_volumes.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -235,6 +246,9 @@ def main():
         return
     if args.only == "preprocess":
         gen_preprocess()
+        return
+    if args.only == "dormant":
+        gen_dormant()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -360,6 +374,7 @@ def main():
     gen_igev_update()
     gen_at_size()
     gen_preprocess()
+    gen_dormant()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from conftest import golden
+from conftest import golden, rnd
 from openstereo_amd.utils.weights import synth_state_dict, synth_images, synth_tensor
 
 pytestmark = pytest.mark.gpu
@@ -863,3 +863,21 @@ def test_pipelined_conv_on_split_inputs_vs_torch(case):
         eye.weight.data = torch.eye(Co).reshape(Co, Co, 1, 1, 1).clone()
         y = PackedConv3d(eye.to(DEV), None, 0, precision="f16x3")(y)
     close(y[:, :Co], ref, atol=3e-5, rtol=3e-5, what=f"pipelined conv {name}")
+
+
+def test_dormant_volume_variants():
+    """CoExCostVolume / compute_volume / build_sub_volume (cost_volume.py:9-29, 44-56, 108-117) on the engine vs the oracle restatements
+    (CoEx also vs the reference's own output), incl. maxdisp > W and a ragged width."""
+    from openstereo_amd import ops
+    from oracle import torch_ref as R
+    g = golden("dormant_volumes.npz")
+    x, y = T(g["x"]), T(g["y"])
+    for grp in (1, 4):
+        got = ops.CoExCostVolume(6, grp)(x.to(DEV), y.to(DEV)).cpu()
+        torch.testing.assert_close(got, T(g[f"coex_g{grp}"]), rtol=1e-5, atol=1e-6)
+    for (B, C, H, W, D) in ((2, 12, 5, 37, 9), (1, 8, 3, 6, 10)):
+        l, r = rnd((B, C, H, W), 311), rnd((B, C, H, W), 312)
+        for side in ("left", "right"):
+            assert torch.equal(ops.compute_volume(l.to(DEV), r.to(DEV), D, side).cpu(), R.compute_volume(l, r, D, side)), side
+        torch.testing.assert_close(ops.build_sub_volume(l.to(DEV), r.to(DEV), D).cpu(), R.build_sub_volume(l, r, D), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(ops.CoExCostVolume(D - 1, 4)(l.to(DEV), r.to(DEV)).cpu(), R.coex_cost_volume(l, r, D - 1, 4), rtol=1e-5, atol=1e-6)

@@ -202,3 +202,23 @@ def test_preprocess_against_reference_transforms():
             out = O.preprocess_image(img, (32, 48))
             assert out.shape == (3, 32, 48)
             assert (out - torch.from_numpy(g[side])).abs().max().item() <= 1e-6
+
+
+def test_dormant_volume_variants_oracle():
+    """CoExCostVolume restatement vs the reference's class (golden); compute_volume / build_sub_volume are CUDA-only in the reference
+    (device='cuda' hard-coded): checked here against their definitions on a tiny case written out by hand."""
+    import torch
+    from oracle import torch_ref as R
+    g = golden("dormant_volumes.npz")
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for grp in (1, 4):
+        torch.testing.assert_close(R.coex_cost_volume(x, y, 6, grp), torch.from_numpy(g[f"coex_g{grp}"]), rtol=1e-5, atol=1e-6)
+    l = torch.tensor([[[[1.0, 2.0, 4.0]]], ]).repeat(1, 2, 1, 1); l[:, 1] *= -1          # [1,2,1,3]
+    r = torch.tensor([[[[0.5, 1.0, 3.0]]], ]).repeat(1, 2, 1, 1)
+    cv = R.compute_volume(l, r, 2, "left")
+    assert cv.shape == (1, 2, 2, 1, 3) and cv[0, 0, 1, 0].tolist() == [0.0, 1.5, 3.0] and cv[0, 0, 0, 0].tolist() == [0.5, 1.0, 1.0]
+    cvr = R.compute_volume(l, r, 2, "right")
+    assert cvr[0, 0, 1, 0].tolist() == [0.0, 1.0, 0.0]                                   # target[w+1] - reference[w] for w < W-1
+    sv = R.build_sub_volume(l, r, 2)
+    assert sv.shape == (1, 2, 1, 3) and sv[0, 0, 0].tolist() == [2.0, 4.0, 8.0]          # |1-.5|+|-1-.5|, |2-1|+|-2-1|, |4-3|+|-4-3|
+    assert sv[0, 1, 0].tolist() == [2.0, 4.0, 8.0]                                       # w<1: |1|+|-1|; |2-.5|+|-2-.5|; |4-1|+|-4-1|
