@@ -460,3 +460,27 @@ def test_stereobase_end_to_end_training_step():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[1] < losses[0], losses
+
+
+def test_gwcnet_training_batchnorm_statistics_follow_the_reference_call_pattern():
+    """Non-frozen BN (FREEZE_BN: false, the GwcNet / PSMNet default): the reference runs feature_extraction on the left and the right
+    batch SEPARATELY (gwcnet_backbone.py:108-109), so one training forward makes two momentum updates with per-call batch statistics.
+    The engine model must leave the same running statistics as that call pattern executed with plain torch modules."""
+    import copy
+    from openstereo_amd.models.gwcnet import GwcNet
+    net = GwcNet()
+    net.load_state_dict(synth_state_dict(net, seed=0))
+    net = net.to(DEV).train()
+    ref_fe = copy.deepcopy(net.Backbone.feature_extraction).train()
+    L, R = synth_images(2, 64, 128, seed=3)
+    L, R = L.to(DEV), R.to(DEV)
+    net({"left": L, "right": R})
+    with torch.no_grad():
+        ref_fe(L); ref_fe(R)
+    bns = [(n, m) for n, m in net.Backbone.feature_extraction.named_modules() if isinstance(m, nn.BatchNorm2d)]
+    assert bns
+    refs = dict(ref_fe.named_modules())
+    for n, m in bns:
+        assert int(m.num_batches_tracked) == 2, n
+        torch.testing.assert_close(m.running_mean, refs[n].running_mean, rtol=1e-5, atol=1e-6, msg=lambda s: f"{n}: {s}")
+        torch.testing.assert_close(m.running_var, refs[n].running_var, rtol=1e-5, atol=1e-6, msg=lambda s: f"{n}: {s}")
