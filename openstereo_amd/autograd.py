@@ -152,12 +152,48 @@ def _pow2_scale(w):
     return 2.0 ** max(-14, min(k, 40))
 
 
-def _pack(w, Ci, Co, k, mode, precision):
-    """mode: 'fwd' | 'dgrad_s1' (role swap + flip) | 'dgrad_of_deconv' (role swap) | 'deconv' (k^3 parity packing)."""
+def _wcache(w):
+    """Per-weight pack cache: a dict that lives ON the weight tensor object (the nn.Parameter the caller holds), so it dies with the
+    model -- a process-wide table keyed on data_ptr would serve a freed model's packs to the next one the allocator places there."""
+    c = getattr(w, "_osa_packs", None)
+    if c is None:
+        try:
+            w._osa_packs = c = {}
+        except Exception:                               # tensor subclasses without a __dict__
+            c = None
+    return c
+
+
+def _pack(w, Ci, Co, k, mode, precision, cache=None):
+    """Packed image of a weight for one role, memoised per weight object and version: a layer that runs many times between two
+    optimizer steps -- the update block: 22 GRU iterations, forward and data gradient each -- is packed (and its power-of-two scale
+    measured, a host sync) once per role and step instead of once per call."""
+    if cache is None:
+        return _pack_now(w, Ci, Co, k, mode, precision)
+    ver = w._version
+    if cache.get("version") != ver:
+        cache.clear()
+        cache["version"] = ver
+    key = (tuple(w.shape), mode, precision)
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = _pack_now(w, Ci, Co, k, mode, precision)
+    return hit
+
+
+def _pack_now(w, Ci, Co, k, mode, precision):
+    """mode: 'fwd' | 'dgrad_s1' (role swap + flip) | 'dgrad_of_deconv' (role swap) | 'deconv' / 'deconv2d' (parity-class packing)."""
     f16 = precision == "f16x3"
     ws = _pow2_scale(w) if f16 else 1.0
     lib = _lib.load()
-    if mode == "deconv":
+    if mode == "deconv2d":
+        n = lib.osa_deconv2d_packed_floats(Ci, Co, k[0])
+        buf = torch.zeros(n, device=w.device, dtype=torch.float32)
+        if f16:
+            _lib.call("osa_deconv2d_pack_f16x3", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, ws, _stream())
+        else:
+            _lib.call("osa_deconv2d_pack_f32", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
+    elif mode == "deconv":
         n = lib.osa_deconv3d_packed_floats(Ci, Co, k[0])
         buf = torch.zeros(n, device=w.device, dtype=torch.float32)
         if f16:
@@ -229,18 +265,19 @@ class _Conv3d(torch.autograd.Function):
     """y = conv3d(x, w) (no bias).  x: logical [B,Ci,D,H,W] (any strides); y: NDHWC-strided [B,Co,...]."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad, dil, precision):
+    def forward(ctx, x, w, stride, pad, dil, precision, cache=None):
         xc = to_cl(x)                               # NDHWC, channels padded to a multiple of 4 with zeros
         wf = _f32c(w)
         Co, Ci = wf.shape[:2]
         k = tuple(wf.shape[2:])
-        packed, osc = _pack(wf, Ci, Co, k, "fwd", precision)
+        packed, osc = _pack(wf, Ci, Co, k, "fwd", precision, cache)
         B, _, D, H, W = xc.shape
         sd = 1 if (D == 1 and k[0] == 1) else stride
         oshape = (_out(D, k[0], pad[0], dil[0], sd), _out(H, k[1], pad[1], dil[1], stride), _out(W, k[2], pad[2], dil[2], stride))
         y = _run_conv(xc, packed, osc, Ci, Co, k, stride, pad, dil, precision, oshape)
         ctx.save_for_backward(xc, wf)
         ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
+        ctx.cache = cache
         return y[:, :Co]
 
     @staticmethod
@@ -254,31 +291,32 @@ class _Conv3d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if stride == 1:
-                packed, osc = _pack(wf, Co, Ci, k, "dgrad_s1", precision)
+                packed, osc = _pack(wf, Co, Ci, k, "dgrad_s1", precision, ctx.cache)
                 p2 = tuple(dil[i] * (k[i] - 1) - pad[i] for i in range(3))
                 dxc = _run_conv(dyc, packed, osc, Co, Ci, k, 1, p2, dil, precision, (D, H, W))
             else:
                 assert k == (3, 3, 3) and pad == (1, 1, 1) and dil == (1, 1, 1) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0, \
                     "stride-2 data gradient: 3x3x3, pad 1, even input dims (what the aggregation networks use)"
-                packed, osc = _pack(wf, Co, Ci, k, "deconv", precision)       # w [Co][Ci][k] == transposed-conv layout [Cin_t][Cout_t]
+                packed, osc = _pack(wf, Co, Ci, k, "deconv", precision, ctx.cache)       # w [Co][Ci][k] == transposed-conv layout [Cin_t][Cout_t]
                 dxc = _run_deconv(dyc, packed, osc, Co, Ci, 3, 1, 1, precision)
             dx = dxc[:, :Ci].to(xdt)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
             _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 class _ConvTranspose3d(torch.autograd.Function):
     """y = conv_transpose3d(x, w[Ci][Co][k], stride 2); k3/p1/op1 or k4/p1/op0."""
 
     @staticmethod
-    def forward(ctx, x, w, pad, opad, precision):
+    def forward(ctx, x, w, pad, opad, precision, cache=None):
         xc = to_cl(x)
         wf = _f32c(w)
         Ci, Co, k = wf.shape[0], wf.shape[1], wf.shape[2]
-        packed, osc = _pack(wf, Ci, Co, (k, k, k), "deconv", precision)
+        packed, osc = _pack(wf, Ci, Co, (k, k, k), "deconv", precision, cache)
+        ctx.cache = cache
         y = _run_deconv(xc, packed, osc, Ci, Co, k, pad, opad, precision)
         ctx.save_for_backward(xc, wf)
         ctx.meta = (pad, opad, precision, x.dtype)
@@ -294,14 +332,68 @@ class _ConvTranspose3d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             # dx = conv(dy, w) with stride 2: w read as [Cout'=Ci][Cin'=Co][k]
-            packed, osc = _pack(wf, Co, Ci, (k, k, k), "dgrad_of_deconv", precision)
+            packed, osc = _pack(wf, Co, Ci, (k, k, k), "dgrad_of_deconv", precision, ctx.cache)
             dxc = _run_conv(dyc, packed, osc, Co, Ci, (k, k, k), 2, (pad,) * 3, (1, 1, 1), precision, (D, H, W))
             dx = dxc[:, :Ci].to(xdt)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
             _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, (k, k, k), 2, (pad, pad, pad), (1, 1, 1), 1)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
+
+
+class _ConvTranspose2d(torch.autograd.Function):
+    """y = conv_transpose2d(x, w[Ci][Co][k][k], stride 2); k3/p1/op1 or k4/p1/op0: the D = 1 case (4 output-parity classes in one launch).
+    The k = 4 upsampling heads of StereoBase / IGEV (spx_2_gru, spx_gru) run 22 times per training step; PyTorch-ROCm executes them as
+    GEMM + col2im (5 ms per call at the 320x736 crop)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad, opad, precision, cache=None):
+        xc = to_cl(x.unsqueeze(2))
+        ctx.cache = cache
+        wf = _f32c(w)
+        Ci, Co, k = wf.shape[0], wf.shape[1], wf.shape[2]
+        packed, osc = _pack(wf, Ci, Co, (k, k), "deconv2d", precision, cache)
+        B, Cs, _, H, W = xc.shape
+        CoS = (Co + 3) // 4 * 4
+        od = lambda n: (n - 1) * 2 - 2 * pad + k + opad
+        y = empty_cl(B, CoS, 1, od(H), od(W), xc.device)
+        if CoS != Co:
+            y.zero_()
+        Ci4 = (Ci + 3) // 4 * 4
+        sfx, tail = ("f16x3", (osc, _ranges(xc, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+        _lib.call("osa_deconv2d_nhwc_" + sfx, xc.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+                  B, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
+        ctx.save_for_backward(xc, wf)
+        ctx.meta = (pad, opad, precision, x.dtype)
+        return y[:, :Co, 0]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wf = ctx.saved_tensors
+        pad, opad, precision, xdt = ctx.meta
+        Ci, Co, k = wf.shape[0], wf.shape[1], wf.shape[2]
+        dyc = to_cl(dy.unsqueeze(2))
+        B, _, _, H, W = xc.shape
+        dx = dw = None
+        w5 = wf.unsqueeze(2)                                               # [Ci][Co][1][k][k]
+        if ctx.needs_input_grad[0]:
+            packed, osc = _pack(w5, Co, Ci, (1, k, k), "dgrad_of_deconv", precision, ctx.cache)
+            dxc = _run_conv(dyc, packed, osc, Co, Ci, (1, k, k), 2, (0, pad, pad), (1, 1, 1), precision, (1, H, W))
+            dx = dxc[:, :Ci, 0].to(xdt)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w5)
+            Ho, Wo = dyc.shape[3:]
+            _wgrad(xc, dyc, dw, B, 1, H, W, Ci, 1, Ho, Wo, Co, (1, k, k), 2, (0, pad, pad), (1, 1, 1), 1)
+            dw = dw[:, :, 0]
+        return dx, dw, None, None, None, None
+
+
+def conv_transpose2d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
+    p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    assert p2(stride) == (2, 2)
+    y = _ConvTranspose2d.apply(x, weight, p2(padding)[0], p2(output_padding)[0], precision or engine.get_precision(), _wcache(weight))
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
 def _t3(v):
@@ -312,14 +404,14 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv3d (groups=1, isotropic stride 1|2) on the engine; output is NDHWC-strided."""
     s = _t3(stride)
     assert s[0] == s[1] == s[2]
-    y = _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), precision or engine.get_precision())
+    y = _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), precision or engine.get_precision(), _wcache(weight))
     return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
 
 
 def conv_transpose3d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
     assert _t3(stride) == (2, 2, 2)
     p, op = _t3(padding)[0], _t3(output_padding)[0]
-    y = _ConvTranspose3d.apply(x, weight, p, op, precision or engine.get_precision())
+    y = _ConvTranspose3d.apply(x, weight, p, op, precision or engine.get_precision(), _wcache(weight))
     return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
 
 
@@ -335,7 +427,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv2d (groups=1, stride 1) on the engine: the D = 1 case of conv3d (forward, dgrad and wgrad kernels)."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (1, 1), "engine conv2d autograd: stride 1 (strided 2-D layers stay torch ops in training)"
-    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), precision or engine.get_precision())
+    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), precision or engine.get_precision(), _wcache(weight))
     y = y[:, :, 0]
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
@@ -347,6 +439,10 @@ def _eligible(m, x):
         return False
     if isinstance(m, torch.nn.Conv2d):
         return tuple(m.stride) == (1, 1) and m.in_channels >= 4
+    if isinstance(m, torch.nn.ConvTranspose2d):
+        k, p, op = m.kernel_size, m.padding, m.output_padding
+        return tuple(m.stride) == (2, 2) and tuple(m.dilation) == (1, 1) and m.in_channels >= 4 and \
+            ((tuple(k), tuple(p), tuple(op)) in (((3, 3), (1, 1), (1, 1)), ((4, 4), (1, 1), (0, 0))))
     if isinstance(m, torch.nn.ConvTranspose3d):
         k, p, op = m.kernel_size, m.padding, m.output_padding
         return tuple(m.stride) == (2, 2, 2) and tuple(m.dilation) == (1, 1, 1) and \
@@ -378,9 +474,14 @@ class engine_convs:
         cls = engine_convs
         if cls._depth == 0:
             nn = torch.nn
-            for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d):
+            for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d):
                 cls._saved[C] = C.forward
-            o2, o3, ot = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d]
+            o2, o3, ot, ot2 = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d], cls._saved[nn.ConvTranspose2d]
+
+            def ft2(m, x, output_size=None):
+                if output_size is None and _eligible(m, x):
+                    return conv_transpose2d(x, m.weight, m.bias, m.stride, m.padding, m.output_padding).to(x.dtype)
+                return ot2(m, x, output_size)
 
             def f2(m, x):
                 return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation).to(x.dtype) if _eligible(m, x) else o2(m, x)
@@ -390,7 +491,7 @@ class engine_convs:
 
             def ft(m, x, output_size=None):
                 return conv_module(m, x).to(x.dtype) if (output_size is None and _eligible(m, x)) else ot(m, x, output_size)
-            nn.Conv2d.forward, nn.Conv3d.forward, nn.ConvTranspose3d.forward = f2, f3, ft
+            nn.Conv2d.forward, nn.Conv3d.forward, nn.ConvTranspose3d.forward, nn.ConvTranspose2d.forward = f2, f3, ft, ft2
         cls._depth += 1
         return self
 

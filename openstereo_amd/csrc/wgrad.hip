@@ -293,9 +293,12 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
     }
     // Position brick: 4x8x8 (256 positions, 1 workgroup per CU with its ~95-122 KB of LDS) or 2x8x8 (128 positions, 2 per CU: the
     // staging of one overlaps the MFMAs of the other).  `OSA_WGRAD_TD` (experiments build) forces one.
-    const int TW = 8, TH = 8;
-    int TD = exp_int("OSA_WGRAD_TD", 4);
-    if (TD != 2 && TD != 4) TD = 4;
+    // Flat (D = 1) layers -- the 2-D convs of the update block and of the upsampling heads -- take a 1x16x16 brick: a 4x8x8 one would
+    // spend three of its four planes on padding.
+    const bool flat = (a.Pd == 1 && kd == 1);
+    const int TW = flat ? 16 : 8, TH = flat ? 16 : 8;
+    int TD = flat ? 1 : exp_int("OSA_WGRAD_TD", 4);
+    if (!flat && TD != 2 && TD != 4) TD = 4;
     a.LD = (TD - 1) * a.s + (dmax - a.dmin) + 1;
     a.LH = (TH - 1) * a.s + (hmax - a.hmin) + 1;
     a.LW = (TW - 1) * a.s + (wmax - a.wmin) + 1;
@@ -328,7 +331,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
     if (ws) OSA_REQUIRE(ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad: workspace of %zu B needed (got %zu)", need, ws_bytes);
     a.ws = ws;
     dim3 grid((unsigned)gx, gy), block(256);
-    if (TD == 2) {
+    if (flat) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<1, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<1, 16, 16>), grid, block, lds, st, a);
+    } else if (TD == 2) {
         (void)hipFuncSetAttribute((const void*)wgrad_kernel<2, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((wgrad_kernel<2, 8, 8>), grid, block, lds, st, a);
     } else {

@@ -218,6 +218,7 @@ class StereoBase(StereoBaseCostStage):
         classifier, fused softmax regression (StereoBaseCostStage.forward_train), geometry-encoding lookup (geometry._Lookup), update
         block convs (BasicMultiUpdateBlock.forward_train); BatchNorm / activations / the small 2-D heads are torch modules."""
         from ..attach import context_upsample as ctx_up              # differentiable form (torch composition when gradients flow)
+        from .. import autograd as AG
         from ..geometry import CombinedGeoEncodingVolume
         s = self.side(image1, image2)
         st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"])
@@ -238,7 +239,8 @@ class StereoBase(StereoBaseCostStage):
                 net_list = self.update_block(net_list, inp_list, iter16=n3, iter08=True, iter04=False, update=False)
             net_list, mask_feat_4, delta_disp = self.update_block(net_list, inp_list, geo_feat, disp, iter16=n3, iter08=n2)
             disp = disp + delta_disp
-            spx = F.softmax(self.spx_gru(self.spx_2_gru(mask_feat_4, s["stem_2x"])), 1)
+            with AG.engine_convs():              # the k = 4 ConvTranspose2d heads: engine deconv / strided conv / class-mode wgrad
+                spx = F.softmax(self.spx_gru(self.spx_2_gru(mask_feat_4, s["stem_2x"])), 1)
             disp_preds.append(ctx_up(disp * 4.0, spx).unsqueeze(1))
         init_up = ctx_up(init_disp * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
         return {"init_disp": init_up, "disp_preds": disp_preds, "disp_pred": disp_preds[-1]}

@@ -37,6 +37,11 @@ def new_meta(device, stream=None) -> torch.Tensor:
     return a[0][i * META_FLOATS:(i + 1) * META_FLOATS]
 
 
+def _amax_into(slot0, t):
+    """max |t| -> the 0-dim view `slot0` with ONE reduction kernel (no abs() temporary, no copy): the infinity norm."""
+    torch.linalg.vector_norm(t.detach(), float("inf"), dtype=torch.float32 if t.dtype != torch.float32 else None, out=slot0)   # all dims, no reshape (no copy of strided tensors)
+
+
 def meta_of(t):
     return None if t is None else getattr(t, "_osa_meta", None)
 
@@ -49,7 +54,7 @@ def input_meta(t) -> torch.Tensor:
     m = getattr(t, "_osa_meta", None)
     if m is None:
         m = new_meta(t.device)
-        m[0:1] = t.detach().abs().amax().reshape(1).float()
+        _amax_into(m[0], t)
     return m
 
 
@@ -59,7 +64,7 @@ def ensure_meta(t) -> torch.Tensor:
     m = getattr(t, "_osa_meta", None)
     if m is None:
         m = new_meta(t.device)
-        m[0:1] = t.detach().abs().amax().reshape(1).float()
+        _amax_into(m[0], t)
         t._osa_meta = m
     return m
 

@@ -484,3 +484,29 @@ def test_gwcnet_training_batchnorm_statistics_follow_the_reference_call_pattern(
         assert int(m.num_batches_tracked) == 2, n
         torch.testing.assert_close(m.running_mean, refs[n].running_mean, rtol=1e-5, atol=1e-6, msg=lambda s: f"{n}: {s}")
         torch.testing.assert_close(m.running_var, refs[n].running_var, rtol=1e-5, atol=1e-6, msg=lambda s: f"{n}: {s}")
+
+
+@pytest.mark.parametrize("k,p,op,Ci,Co", [(4, 1, 0, 32, 32), (4, 1, 0, 64, 9), (3, 1, 1, 16, 24)])
+def test_conv_transpose2d_forward_and_gradients(k, p, op, Ci, Co):
+    """nn.ConvTranspose2d (stride 2) through autograd.engine_convs(): flat 4-class deconv forward, strided-conv data gradient, parity-class
+    weight gradient -- vs torch-CPU autograd.  (4,1,0) 64 -> 9 is StereoBase / IGEV's spx_gru head."""
+    from openstereo_amd import autograd as AG
+    g = torch.Generator().manual_seed(k * 100 + Co)
+    m = nn.ConvTranspose2d(Ci, Co, k, stride=2, padding=p, output_padding=op)
+    with torch.no_grad():
+        m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.2); m.bias.copy_(torch.randn(Co, generator=g) * 0.1)
+    x = torch.randn(2, Ci, 10, 22, generator=g)
+    wt = torch.randn(2, Co, (10 - 1) * 2 - 2 * p + k + op, (22 - 1) * 2 - 2 * p + k + op, generator=g)
+
+    def run(mod, xin, ctx):
+        xin = xin.clone().requires_grad_()
+        with ctx:
+            y = mod(xin)
+        (y * wt.to(y.device)).sum().backward()
+        return y.detach().cpu(), xin.grad.cpu(), mod.weight.grad.cpu(), mod.bias.grad.cpu()
+
+    import contextlib, copy
+    want = run(copy.deepcopy(m), x, contextlib.nullcontext())
+    got = run(copy.deepcopy(m).to(DEV), x.to(DEV), AG.engine_convs())
+    for a, b, name in zip(got, want, ("y", "dx", "dw", "db")):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max())), msg=lambda s: f"{name}: {s}")
