@@ -72,7 +72,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: the best-throughput batch of the sweep in DESIGN.md 6 -- 8 GwcNet / LightStereo, 4 IGEV, 1 training; single-pair latency is reported next to it)")
     ap.add_argument("--workload", default="gwcnet",
-                    choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "stereobase_e2e_train", "gwcnet_train"))
+                    choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "stereobase_e2e_train", "gwcnet_train",
+                             "stereobase_e2e", "igev_e2e", "lightstereo_e2e"))
     ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
@@ -222,6 +223,74 @@ class StereoBaseTrain:
                             "maps stand in for the timm backbone"}
 
 
+class _E2EInference:
+    """Whole-model inference of the end-to-end classes of openstereo_amd/models/stereo_models.py (stand-in 2-D backbone: torch modules;
+    everything from the volume to the full-resolution disparity on the engine)."""
+    scaling, graphable, training = "weak", True, False
+    H, W = 544, 960
+
+    def _finish(self, net, args, dev, rank, seed, scale255=False):
+        from openstereo_amd.utils.weights import synth_state_dict, synth_images
+        net.load_state_dict(synth_state_dict(net, seed=seed, head_gain=20.0, gain=0.9))
+        self.net = net.to(dev).eval()
+        L, R = synth_images(self.B, self.H, self.W, seed=30 + rank)
+        if scale255:
+            L, R = (L * 40 + 128).clamp(0, 255), (R * 40 + 128).clamp(0, 255)
+        self.L, self.R = L.to(dev), R.to(dev)
+
+    def step(self):
+        with torch.no_grad():
+            return self.net({"left": self.L, "right": self.R})["disp_pred"]
+
+
+class StereoBaseE2E(_E2EInference):
+    metric = "stereo-pairs/s, StereoBase (stand-in backbone) at 544x960 D=192, 32 GRU iterations"
+
+    def __init__(self, args, dev, rank):
+        from types import SimpleNamespace
+        from openstereo_amd.models.stereo_models import StereoBase
+        self.B = args.batch or 2
+        cfg = SimpleNamespace(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                              N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=32, TRAIN_ITERS=22)
+        self._finish(StereoBase(cfg), args, dev, rank, 41)
+
+    def config(self, args):
+        return {"workload": "StereoBase inference, whole model with stand-in 2-D backbone (gwc + concat volume -> hourglass -> classifier -> regression -> "
+                            "geometry lookup + 32 GRU iterations -> convex upsampling), 544x960 D=192 (cfgs/stereobase/stereobase_sceneflow.yaml, EVAL_ITERS 32)"}
+
+
+class IGEVE2E(_E2EInference):
+    metric = "stereo-pairs/s, IGEV-Stereo (stand-in backbone) at 544x960 D=192, 32 GRU iterations"
+
+    def __init__(self, args, dev, rank):
+        from types import SimpleNamespace
+        from openstereo_amd.models.stereo_models import IGEVStereo
+        self.B = args.batch or 2
+        a = SimpleNamespace(MAX_DISP=192, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=True,
+                            VALID_ITERS=32, N_DOWNSAMPLE=2)
+        self._finish(IGEVStereo(a), args, dev, rank, 43, scale255=True)
+
+    def config(self, args):
+        return {"workload": "IGEV-Stereo inference, whole model with stand-in 2-D backbone (gwc volume -> corr_stem + FeatureAtt -> hourglass -> classifier -> "
+                            "regression -> geometry lookup + 32 slow-fast GRU iterations -> convex upsampling), 544x960 D=192 (BASELINE configs[4])"}
+
+
+class LightStereoE2E(_E2EInference):
+    metric = "stereo-pairs/s, LightStereo-S (stand-in backbone) at 384x1248 D=192"
+    H, W = 384, 1248
+
+    def __init__(self, args, dev, rank):
+        from types import SimpleNamespace
+        from openstereo_amd.models.stereo_models import LightStereo
+        self.B = args.batch or 8
+        cfg = SimpleNamespace(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)
+        self._finish(LightStereo(cfg), args, dev, rank, 47)
+
+    def config(self, args):
+        return {"workload": "LightStereo-S inference, whole model with stand-in 2-D backbone (correlation volume -> 2-D aggregation -> regression -> convex "
+                            "upsampling), KITTI15 375x1242 padded to 384x1248 (BASELINE configs[3])"}
+
+
 class StereoBaseE2ETrain:
     """BASELINE configs[2], whole model: openstereo_amd.models.stereo_models.StereoBase in training mode at the SceneFlow crop 320x736
     (cfgs/stereobase/stereobase_sceneflow.yaml) -- volumes, hourglass, classifier, regression, geometry-encoding lookup and 22 GRU iterations
@@ -321,7 +390,8 @@ class _Cfg(dict):
 
 
 WORKLOADS = {"gwcnet": GwcNetInference, "lightstereo_kitti15": LightStereoKitti15, "igev_refine32": IGEVRefine32,
-             "stereobase_train": StereoBaseTrain, "stereobase_e2e_train": StereoBaseE2ETrain, "gwcnet_train": GwcNetTrain}
+             "stereobase_train": StereoBaseTrain, "stereobase_e2e_train": StereoBaseE2ETrain, "gwcnet_train": GwcNetTrain,
+             "stereobase_e2e": StereoBaseE2E, "igev_e2e": IGEVE2E, "lightstereo_e2e": LightStereoE2E}
 
 
 # ============================================================================================ rooflines (GwcNet)
