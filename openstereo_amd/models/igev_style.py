@@ -313,7 +313,31 @@ class hourglass(nn.Module):
                      g8u=self.feature_att_up_8.logits(features[1]))
         return hourglass_forward_cl(self._packed_layers(), x, gates)
 
+    @staticmethod
+    def _unit_train(m, x):
+        """BasicConv (submodule.py:6-32) in training mode: the convolution on the engine through autograd, BatchNorm3d / LeakyReLU as torch ops."""
+        from .. import autograd as A
+        x = A.conv_module(m.conv, x)
+        if m.use_bn:
+            x = m.bn(x)
+        return nn.functional.leaky_relu(x, 0.01) if m.relu else x
+
+    def forward_train(self, x, features):
+        """igev_stereo.py:51-76 with differentiable engine convolutions; FeatureAtt gates, concatenations, BatchNorm and activations are
+        torch ops (batch statistics, SyncBN and DDP behave like the reference)."""
+        u = self._unit_train
+        seq = lambda mods, t: [t := u(m, t) for m in mods][-1]
+        att = lambda fa, cv, feat: torch.sigmoid(fa.feat_att(feat).unsqueeze(2)) * cv
+        conv1 = att(self.feature_att_8, seq(self.conv1, x), features[1])
+        conv2 = att(self.feature_att_16, seq(self.conv2, conv1), features[2])
+        conv3 = att(self.feature_att_32, seq(self.conv3, conv2), features[3])
+        conv2 = torch.cat((u(self.conv3_up, conv3), conv2), dim=1)
+        conv2 = att(self.feature_att_up_16, seq(self.agg_0, conv2), features[2])
+        conv1 = torch.cat((u(self.conv2_up, conv2), conv1), dim=1)
+        conv1 = att(self.feature_att_up_8, seq(self.agg_1, conv1), features[1])
+        return u(self.conv1_up, conv1)
+
     def forward(self, x, features):
-        if self.training:
-            raise NotImplementedError("engine hourglass: training-mode BatchNorm is not built yet")
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.forward_train(x, features)
         return ops.to_ncdhw(self.forward_cl(ops.to_cl(x), features), channels=8)

@@ -134,6 +134,46 @@ def _context_lists(cnet, zqr_convs, image, n_layers):
     return net_list, inp_list
 
 
+def _gru_train_loop(model, a, s, init_disp, geo, iters, n_layers, slow_fast):
+    """The GRU loop of stereobase_gru.py:177-203 / igev_stereo.py:181-208 in training mode: lookup (forward + backward on the engine),
+    update block (engine convs through autograd), convex upsampling of every iteration's disparity (the loss needs them all)."""
+    from ..attach import context_upsample as ctx_up              # differentiable form (torch composition when gradients flow)
+    from ..geometry import CombinedGeoEncodingVolume
+    from .. import autograd as AG
+    geo_fn = CombinedGeoEncodingVolume(s["match_left"].float(), s["match_right"].float(), geo.float(), radius=a.CORR_RADIUS, num_levels=a.CORR_LEVELS)
+    b, _, h, w = s["match_left"].shape
+    coords = torch.arange(w, device=init_disp.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+    net_list, inp_list = s["net_list"], s["inp_list"]
+    n3, n2 = n_layers == 3, n_layers >= 2
+    disp, disp_preds = init_disp, []
+    for _ in range(iters):
+        disp = disp.detach()
+        geo_feat = geo_fn(disp, coords)
+        if n3 and slow_fast:
+            net_list = model.update_block(net_list, inp_list, iter16=True, iter08=False, iter04=False, update=False)
+        if n2 and slow_fast:
+            net_list = model.update_block(net_list, inp_list, iter16=n3, iter08=True, iter04=False, update=False)
+        net_list, mask_feat_4, delta_disp = model.update_block(net_list, inp_list, geo_feat, disp, iter16=n3, iter08=n2)
+        disp = disp + delta_disp
+        with AG.engine_convs():              # the k = 4 ConvTranspose2d heads: engine deconv / strided conv / class-mode wgrad
+            spx = F.softmax(model.spx_gru(model.spx_2_gru(mask_feat_4, s["stem_2x"])), 1)
+        disp_preds.append(ctx_up(disp * 4.0, spx).unsqueeze(1))
+    return disp_preds
+
+
+def _sequence_loss(model_pred, disp_gt, max_disp):
+    """stereobase_gru.py:215-243 == igev_stereo.py:209-240: smooth-L1 on the initial disparity + gamma-weighted L1 over the GRU predictions."""
+    valid = ((disp_gt < max_disp) & (disp_gt > 0)).unsqueeze(1)
+    disp_gt = disp_gt.unsqueeze(1)
+    loss = F.smooth_l1_loss(model_pred["init_disp"][valid], disp_gt[valid], reduction="mean")
+    preds = model_pred["disp_preds"]
+    n = len(preds)
+    for i, pr in enumerate(preds):
+        gamma = 0.9 ** (15 / (n - 1)) if n > 1 else 1.0
+        loss = loss + gamma ** (n - i - 1) * (pr - disp_gt).abs()[valid].mean()
+    return loss, {"scalar/train/loss_disp": float(loss.detach())}
+
+
 def _require_engine(x, who):
     if not on_engine(x):
         raise RuntimeError(f"openstereo_amd {who} runs on the GPU engine only (no CPU path)")
@@ -217,46 +257,16 @@ class StereoBase(StereoBaseCostStage):
         """stereobase_gru.py:121-213, training mode: every hot-path op forward AND backward on the engine -- volumes, hourglass convs,
         classifier, fused softmax regression (StereoBaseCostStage.forward_train), geometry-encoding lookup (geometry._Lookup), update
         block convs (BasicMultiUpdateBlock.forward_train); BatchNorm / activations / the small 2-D heads are torch modules."""
-        from ..attach import context_upsample as ctx_up              # differentiable form (torch composition when gradients flow)
-        from .. import autograd as AG
-        from ..geometry import CombinedGeoEncodingVolume
+        from ..attach import context_upsample as ctx_up
         s = self.side(image1, image2)
         st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"])
-        init_disp, geo = st["init_disp"], st["geo_encoding_volume"]
-        geo_fn = CombinedGeoEncodingVolume(s["match_left"].float(), s["match_right"].float(), geo.float(),
-                                           radius=self.cfgs.CORR_RADIUS, num_levels=self.cfgs.CORR_LEVELS)
-        b, _, h, w = s["match_left"].shape
-        coords = torch.arange(w, device=image1.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
-        net_list, inp_list = s["net_list"], s["inp_list"]
-        n3, n2 = self.n_gru_layers == 3, self.n_gru_layers >= 2
-        disp, disp_preds = init_disp, []
-        for _ in range(self.cfgs.TRAIN_ITERS):
-            disp = disp.detach()
-            geo_feat = geo_fn(disp, coords)
-            if n3 and self.slow_fast_gru:
-                net_list = self.update_block(net_list, inp_list, iter16=True, iter08=False, iter04=False, update=False)
-            if n2 and self.slow_fast_gru:
-                net_list = self.update_block(net_list, inp_list, iter16=n3, iter08=True, iter04=False, update=False)
-            net_list, mask_feat_4, delta_disp = self.update_block(net_list, inp_list, geo_feat, disp, iter16=n3, iter08=n2)
-            disp = disp + delta_disp
-            with AG.engine_convs():              # the k = 4 ConvTranspose2d heads: engine deconv / strided conv / class-mode wgrad
-                spx = F.softmax(self.spx_gru(self.spx_2_gru(mask_feat_4, s["stem_2x"])), 1)
-            disp_preds.append(ctx_up(disp * 4.0, spx).unsqueeze(1))
-        init_up = ctx_up(init_disp * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
+        disp_preds = _gru_train_loop(self, self.cfgs, s, st["init_disp"], st["geo_encoding_volume"], self.cfgs.TRAIN_ITERS,
+                                     self.n_gru_layers, self.slow_fast_gru)
+        init_up = ctx_up(st["init_disp"] * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
         return {"init_disp": init_up, "disp_preds": disp_preds, "disp_pred": disp_preds[-1]}
 
     def get_loss(self, model_pred, input_data):
-        """stereobase_gru.py:215-243: smooth-L1 on the initial disparity + gamma-weighted L1 over the GRU predictions."""
-        disp_gt = input_data["disp"]
-        valid = ((disp_gt < self.max_disp) & (disp_gt > 0)).unsqueeze(1)
-        disp_gt = disp_gt.unsqueeze(1)
-        loss = F.smooth_l1_loss(model_pred["init_disp"][valid], disp_gt[valid], reduction="mean")
-        preds = model_pred["disp_preds"]
-        n = len(preds)
-        for i, pr in enumerate(preds):
-            gamma = 0.9 ** (15 / (n - 1)) if n > 1 else 1.0
-            loss = loss + gamma ** (n - i - 1) * (pr - disp_gt).abs()[valid].mean()
-        return loss, {"scalar/train/loss_disp": float(loss.detach())}
+        return _sequence_loss(model_pred, input_data["disp"], self.max_disp)
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)
@@ -297,8 +307,22 @@ class IGEVCostStage(nn.Module):
         init_disp, prob = ops.softmax_disparity_regression(cost[:, 0], D4, keepdim=True, return_prob=True)
         return {"init_disp": init_disp, "prob": prob, "geo_encoding_volume": geo}
 
+    def cost_stage_train(self, match_left, match_right, features_left):
+        """igev_stereo.py:158-168 with differentiable engine ops (volume, convolutions, fused softmax regression)."""
+        from .. import autograd as A
+        D4 = self.max_disp // 4
+        vol = A.build_gwc_volume(match_left, match_right, D4, 8)
+        vol = self.cost_agg._unit_train(self.corr_stem, vol)
+        vol = torch.sigmoid(self.corr_feature_att.feat_att(features_left[0]).unsqueeze(2)) * vol
+        geo = self.cost_agg.forward_train(vol, features_left)
+        cost = A.conv_module(self.classifier, geo).squeeze(1)
+        init_disp = A.softmax_disparity_regression(cost, keepdim=True)
+        return {"init_disp": init_disp, "prob": torch.softmax(cost, dim=1), "geo_encoding_volume": geo}
+
     def forward(self, match_left, match_right, features_left):
         _require_engine(match_left, "IGEVCostStage")
+        if self.training or (torch.is_grad_enabled() and (match_left.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return self.cost_stage_train(match_left, match_right, features_left)
         return self.cost_stage(match_left, match_right, features_left)
 
 
@@ -321,6 +345,10 @@ class IGEVStereo(IGEVCostStage):
                                     nn.Conv2d(48, 48, 3, 1, 1, bias=False), IN(48), nn.ReLU())
         self.spx_2_gru = Conv2xUp(32, 32, norm_layer=nn.BatchNorm2d)
         self.spx_gru = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
+        self.spx = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))      # init_disp head (training only)
+        self.spx_2 = Conv2xUp(24, 32, norm_layer=IN, concat=True)
+        self.spx_4 = nn.Sequential(BasicConv2d(96, 24, norm_layer=IN, act_layer=LR, kernel_size=3, stride=1, padding=1),
+                                   nn.Conv2d(24, 24, 3, 1, 1, bias=False), IN(24), nn.ReLU())
         self.conv = BasicConv2d(96, 96, norm_layer=IN, act_layer=LR, kernel_size=3, padding=1, stride=1)
         self.desc = nn.Conv2d(96, 96, kernel_size=1, padding=0, stride=1)
 
@@ -343,9 +371,23 @@ class IGEVStereo(IGEVCostStage):
         image1, image2 = data["left"], data["right"]
         _require_engine(image1, "IGEVStereo")
         if self.training:
-            raise NotImplementedError("openstereo_amd IGEVStereo: the end-to-end class is inference-only (test mode, igev_stereo.py:206-207)")
+            return self._train(image1, image2)
         with torch.no_grad():
             return self._infer(image1, image2)
+
+    def _train(self, image1, image2):
+        """igev_stereo.py:139-218, training mode (TRAIN_ITERS iterations, every prediction upsampled, init_disp through spx_4 / spx_2 / spx)."""
+        from ..attach import context_upsample as ctx_up
+        s = self.side(image1, image2)
+        st = self.cost_stage_train(s["match_left"], s["match_right"], s["features_left"])
+        disp_preds = _gru_train_loop(self, self.args, s, st["init_disp"], st["geo_encoding_volume"], self.args.TRAIN_ITERS,
+                                     self.args.N_GRU_LAYERS, self.args.SLOW_FAST_GRU)
+        spx_pred = F.softmax(self.spx(self.spx_2(self.spx_4(s["features_left"][0]), s["stem_2x"])), 1)
+        init_up = ctx_up(st["init_disp"] * 4.0, spx_pred.float()).unsqueeze(1)
+        return {"init_disp": init_up, "disp_preds": disp_preds, "disp_pred": disp_preds[-1]}
+
+    def get_loss(self, model_pred, input_data):
+        return _sequence_loss(model_pred, input_data["disp"], self.max_disp)
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)
@@ -382,9 +424,32 @@ class LightStereo(LightStereoCostStage):
         image1, image2 = data["left"], data["right"]
         _require_engine(image1, "LightStereo")
         if self.training:
-            raise NotImplementedError("openstereo_amd LightStereo: the end-to-end class is inference-only; Aggregation has a training path")
+            return self._train(image1, image2)
         with torch.no_grad():
             return self._infer(image1, image2)
+
+    def _train(self, image1, image2):
+        """lightstereo.py:44-71, training mode: correlation volume, aggregation convs and the fused softmax regression forward and backward on
+        the engine; disp_4 (bilinear x4 of the quarter-resolution disparity) for the auxiliary loss."""
+        from ..attach import context_upsample as ctx_up
+        from .. import autograd as A
+        s = self.side(image1, image2)
+        D4 = self.max_disp // 4
+        vol = A.correlation_volume(s["features_left"][0], s["feature_right"], D4)
+        enc = self.cost_agg(vol, s["features_left"])[0]
+        cost = enc.reshape(enc.size(0), -1, enc.size(2), enc.size(3))
+        init_disp = A.softmax_disparity_regression(cost, keepdim=True)
+        disp_pred = ctx_up(init_disp * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
+        disp_4 = F.interpolate(init_disp, image1.shape[2:], mode="bilinear", align_corners=False) * 4
+        return {"disp_pred": disp_pred, "disp_4": disp_4}
+
+    def get_loss(self, model_pred, input_data):
+        """lightstereo.py:72-85"""
+        disp_gt = input_data["disp"].unsqueeze(1)
+        mask = (disp_gt < self.max_disp) & (disp_gt > 0)
+        loss = F.smooth_l1_loss(model_pred["disp_pred"][mask], disp_gt[mask], reduction="mean") \
+            + 0.3 * F.smooth_l1_loss(model_pred["disp_4"][mask], disp_gt[mask], reduction="mean")
+        return loss, {"scalar/train/loss_disp": float(loss.detach())}
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)
