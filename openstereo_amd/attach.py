@@ -242,7 +242,7 @@ def _graft_plan():
         (M + "stereobase.igev_blocks", {"FeatureAtt": (IG.FeatureAtt, ("logits",), False)}),
         (M + "stereobase.hourglass", {"Hourglass": (IG.Hourglass, fwd + ("gate_logits", "_unit_train"), False)}),   # hourglass.py:79-104
         (M + "igev.submodule", {"FeatureAtt": (IG.IGEVFeatureAtt, ("logits",), False)}),
-        (M + "igev.igev_stereo", {"hourglass": (IG.hourglass, ("forward", "forward_cl", "_packed_layers", "reset_engine"), True)}),  # :51-76
+        (M + "igev.igev_stereo", {"hourglass": (IG.hourglass, ("forward", "forward_cl", "forward_train", "_unit_train", "_packed_layers", "reset_engine"), False)}),  # :51-76
         (M + "lightstereo.aggregation", {c: (getattr(LS, c), fwd, False) for c in ("Aggregation", "MobileV2Residual", "AttentionModule")}),
         (M + "igev.update", {c: (getattr(UP, c), fwd, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
         (M + "stereobase.gru_blocks", {c: (getattr(UP, c), fwd, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
