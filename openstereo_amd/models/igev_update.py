@@ -114,9 +114,8 @@ class ConvGRU(nn.Module):
         hx = _cat_cl([h, *x_list], h.device, track=f16)        # [h | x]
         z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
         rhx = hx.clone()                                       # [r*h | x]: the x part is shared, r*h overwrites the h slice
-        if f16:                                                # range block of [r*h | x]: that of [h | x] (|r*h| <= |h|); convr only
-            rhx._osa_meta = new_meta(h.device)                 # folds its own slice in, the cloned x part would be missed
-            rhx._osa_meta.copy_(meta_of(hx))
+        if f16:                                                # range block of [r*h | x]: that of [h | x] itself (|r*h| <= |h|) -- shared,
+            rhx._osa_meta = meta_of(hx)                        # not copied: convr folding max |r*h| into it changes nothing
         pr(hx, residual=cr, gate=_nhwc(h), gate_raw=True, out=rhx, out_off=0)   # sigmoid(convr(hx) + cr) * h
         q = pq(rhx, residual=cq)                               # tanh(convq([r*h, x]) + cq)
         out = empty_cl(*h.shape, h.device)
