@@ -168,12 +168,15 @@ struct VolQArgs {
     int dbg;               // timing experiments only (OSA_VOL_DBG): 1 = no stores, 2 = no dot products, 4 = no window staging
 };
 
-template <int QG, int NWV>     // NWV waves per workgroup (4 or 8): a wider pixel tile amortises the right window
+// PX2: a lane owns TWO pixels, w and w + vpw.  out(w, d) and out(w + vpw, d + vpw) read the same right vector R[w - d], so walking the
+// window once serves both: the kernel is bound by LDS reads (8 float4 per lane and (w, d): 983 KB per workgroup for 196 KB of output),
+// and this cuts them by DCH / (DCH + vpw) * 2 = 1.7x at the price of a second set of left registers.  Stores stay 1 KB contiguous.
+template <int QG, int NWV, bool PX2 = false>     // NWV waves per workgroup (4 or 8): a wider pixel tile amortises the right window
 __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQArgs q) {
     extern __shared__ __attribute__((aligned(16))) float4 smq[];
     const VolArgs& p = q.v;
     constexpr int NTHR = NWV * 64;
-    const int vpw = 64 >> q.lgNQ, WT = NWV * vpw;
+    const int vpw = 64 >> q.lgNQ, WT = NWV * vpw * (PX2 ? 2 : 1);
     const int NPXR = WT + q.DCH - 1;
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -194,35 +197,39 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
     // latency overlaps the staging of the right window
     const int lane = tid & 63, wave = tid >> 6;
     const int cq = lane & (q.NQ - 1), wsub = lane >> q.lgNQ;
-    const int w = w0 + wave * vpw + wsub;
+    const int w = w0 + wave * vpw * (PX2 ? 2 : 1) + wsub;          // PX2: the lane's first pixel; the second is w + vpw
     const bool wlive = w < p.W;
     const int role = (cq < G4) ? 0 : ((cq < G4 + nq_c) ? 1 : 2);   // gwc quad / left concat quad / right concat quad
-    float4 Lr[4 * QG];
-    float4 lcat = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 Lr[4 * QG], Lr2[PX2 ? 4 * QG : 1];
+    float4 lcat = make_float4(0.f, 0.f, 0.f, 0.f), lcat2 = lcat;
+    auto load_left = [&](int wp, float4* L, float4& lc) {
 #pragma unroll
-    for (int i = 0; i < 4 * QG; ++i) Lr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wlive && role == 0) {
+        for (int i = 0; i < 4 * QG; ++i) L[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wp < p.W && role == 0) {
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
+            for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-            for (int kq = 0; kq < QG; ++kq) {
-                const int g = cq * 4 + gi;
-                if (p.gstride) Lr[gi * QG + kq] = *reinterpret_cast<const float4*>(p.lg + (rowpix + w) * p.gstride + g * p.K + kq * 4);
-                else {
-                    const float* src = p.lg + ((size_t)b * p.C + (size_t)g * p.K + kq * 4) * plane + (size_t)h * p.W + w;
-                    Lr[gi * QG + kq] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+                for (int kq = 0; kq < QG; ++kq) {
+                    const int g = cq * 4 + gi;
+                    if (p.gstride) L[gi * QG + kq] = *reinterpret_cast<const float4*>(p.lg + (rowpix + wp) * p.gstride + g * p.K + kq * 4);
+                    else {
+                        const float* src = p.lg + ((size_t)b * p.C + (size_t)g * p.K + kq * 4) * plane + (size_t)h * p.W + wp;
+                        L[gi * QG + kq] = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
+                    }
                 }
+        } else if (wp < p.W && role == 1) {
+            const int qc = cq - G4;
+            if (p.cstride) {
+                const float* src = p.lc + (rowpix + wp) * p.cstride + qc * 4;
+                lc = make_float4(src[0], src[1], src[2], src[3]);
+            } else {
+                const float* src = p.lc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + wp;
+                lc = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
             }
-    } else if (wlive && role == 1) {
-        const int qc = cq - G4;
-        if (p.cstride) {
-            const float* src = p.lc + (rowpix + w) * p.cstride + qc * 4;
-            lcat = make_float4(src[0], src[1], src[2], src[3]);
-        } else {
-            const float* src = p.lc + ((size_t)b * p.Cc + qc * 4) * plane + (size_t)h * p.W + w;
-            lcat = make_float4(src[0], src[plane], src[2 * plane], src[3 * plane]);
         }
-    }
+    };
+    load_left(w, Lr, lcat);
+    if constexpr (PX2) load_left(w + vpw, Lr2, lcat2);
     // ---- right window -> LDS.  Source quad (g, kq) goes to slot (g&3)*QG*G4 + kq*G4 + (g>>2).
     // Item = (pixel, quad); the fast index follows the feature layout (NHWC: quads of a pixel, NCHW:
     // pixels of a quad).  A thread walks its items with a carry instead of dividing, and keeps 4
@@ -289,6 +296,48 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
     float* vout = p.vol + p.coff + cq * 4;
     float am = 0.f;
     const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
+    // one output quad of pixel wp at disparity d from the window row rrow (R[wp - d])
+    auto emit = [&](int wp, int d, const float4* rrow, const float4* L, const float4& lc) {
+        const bool valid = (wp >= d);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (role == 0 && !(q.dbg & 2)) {
+            float sv[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int kq = 0; kq < QG; ++kq) {
+                    const float4 r = rrow[(gi * QG + kq) * G4 + cq];
+                    const float4 l = L[gi * QG + kq];
+                    s_ = fmaf(l.x, r.x, s_); s_ = fmaf(l.y, r.y, s_);
+                    s_ = fmaf(l.z, r.z, s_); s_ = fmaf(l.w, r.w, s_);
+                }
+                sv[gi] = valid ? (kpow2 ? s_ * Kinv : s_ / Kf) : 0.f;
+            }
+            o = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        } else if (role == 1) {
+            if (valid || !p.mask_left) o = lc;
+        } else {
+            if (valid) o = rrow[rq];
+        }
+        if (wp < p.W && (!(q.dbg & 1) || o.x == 12345.678f)) {
+            const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + wp;
+            *reinterpret_cast<float4*>(vout + vox * p.VC) = o;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        }
+    };
+    if constexpr (PX2) {
+        // t walks the window rows both pixels need: row(t) = R[(w + vpw) - (d0 + t)] serves pixel w + vpw at dd = t and pixel w at dd = t - vpw
+        const int c2 = wave * vpw * 2 + wsub + vpw;             // window column of the second pixel
+#pragma unroll 4
+        for (int t = 0; t < q.DCH + vpw; ++t) {
+            const float4* rrow = smq + (size_t)(c2 + q.DCH - 1 - t) * q.RSq;
+            if (t < q.DCH && d0 + t < p.D) emit(w + vpw, d0 + t, rrow, Lr2, lcat2);
+            if (t >= vpw && d0 + t - vpw < p.D) emit(w, d0 + t - vpw, rrow, Lr, lcat);
+        }
+        if (p.meta) publish_amax(p.meta, am, am_seen, reinterpret_cast<float*>(smq));
+        return;
+    }
 #pragma unroll 4
     for (int dd = 0; dd < q.DCH; ++dd) {
         const int d = d0 + dd;
@@ -493,12 +542,15 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             // 8 waves per workgroup when the map is wide enough (amortises the right window over 2x the pixels)
             int nwv = (W >= 8 * (64 / nq4) * 2) ? 8 : 4;
             { const int e = exp_int("OSA_VOL_WAVES", 0); if (e == 4 || e == 8) nwv = e; }
-            const int WT = nwv * (64 / nq4);
+            // two pixels per lane (PX2): the same pixel tile from half the waves
+            const bool px2 = exp_int("OSA_VOL_PX2", 0) != 0 && nwv == 8;
+            if (px2) nwv = 4;
+            const int WT = nwv * (64 / nq4) * (px2 ? 2 : 1);
             qa.RSq = ((G > 0) ? QG * G : 0) + Cc / 4;
             if (qa.RSq % 16 > 6) qa.RSq += 16 - qa.RSq % 16;     // keeps the lanes of two neighbouring voxels on distinct 16-byte slots
             // disparity chunk: D split evenly into the fewest chunks whose right window fits ~52 KiB of
             // LDS (3 workgroups per CU); very wide feature vectors may use up to the whole 160 KiB
-            size_t budget = (nwv == 8) ? 78 * 1024 : 52 * 1024;   // 2 x 8 waves or 3 x 4 waves per CU
+            size_t budget = (nwv == 8 || px2) ? 78 * 1024 : 52 * 1024;   // 2 x 8 waves (or 2 x 4 two-pixel waves) or 3 x 4 waves per CU
             { const int e = exp_int("OSA_VOL_LDS", 0); if (e > 0) budget = (size_t)e; }
             int nchunk = 1;
             while (nchunk < maxdisp && (size_t)(WT + cdiv(maxdisp, nchunk) - 1) * qa.RSq * 16 > budget) ++nchunk;
@@ -518,7 +570,15 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
                 hipLaunchKernelGGL((build_volume_quads_kernel<Q, NWV>), grid, block, lds, st, qa);  \
             } while (0)
-#define OSA_VOLQ_LAUNCH(Q) do { if (nwv == 8) OSA_VOLQ_LAUNCH1(Q, 8); else OSA_VOLQ_LAUNCH1(Q, 4); } while (0)
+#define OSA_VOLQ_LAUNCH1P(Q, NWV)                                                                   \
+            do {                                                                                    \
+                if (lds > 64 * 1024)                                                                \
+                    (void)hipFuncSetAttribute((const void*)build_volume_quads_kernel<Q, NWV, true>, \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);\
+                hipLaunchKernelGGL((build_volume_quads_kernel<Q, NWV, true>), grid, block, lds, st, qa); \
+            } while (0)
+#define OSA_VOLQ_LAUNCH(Q) do { if (px2) { if (nwv == 8) OSA_VOLQ_LAUNCH1P(Q, 8); else OSA_VOLQ_LAUNCH1P(Q, 4); }    \
+                                else if (nwv == 8) OSA_VOLQ_LAUNCH1(Q, 8); else OSA_VOLQ_LAUNCH1(Q, 4); } while (0)
             switch (QG) {
                 case 1: OSA_VOLQ_LAUNCH(1); break;
                 case 2: OSA_VOLQ_LAUNCH(2); break;
@@ -526,6 +586,7 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
                 default: OSA_VOLQ_LAUNCH(4); break;
             }
 #undef OSA_VOLQ_LAUNCH1
+#undef OSA_VOLQ_LAUNCH1P
 #undef OSA_VOLQ_LAUNCH
             OSA_LAUNCH_CHECK("build_volume_quads");
             return 0;
