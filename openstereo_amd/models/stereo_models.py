@@ -82,6 +82,41 @@ class FPNLayer(nn.Module):
         return self.conv(torch.cat([high, self.deconv(low)], 1))
 
 
+class BasicConvIN(nn.Module):
+    """models/igev/submodule.py:83-110 (`.conv` / `.IN` unit names; InstanceNorm2d without affine parameters, LeakyReLU(0.01))."""
+
+    def __init__(self, cin, cout, deconv=False, IN=True, relu=True, **kw):
+        super().__init__()
+        self.relu, self.use_in = relu, IN
+        self.conv = (nn.ConvTranspose2d if deconv else nn.Conv2d)(cin, cout, bias=False, **kw)
+        self.IN = nn.InstanceNorm2d(cout)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.use_in:
+            x = self.IN(x)
+        return F.leaky_relu(x, 0.01) if self.relu else x
+
+
+class Conv2xIGEV(nn.Module):
+    """models/igev/submodule.py:35-78 (`Conv2x`, norm="bn") and :113-157 (`Conv2x_IN`, norm="in") in the one configuration IGEV-Stereo
+    uses for its upsampling heads (igev_stereo.py:104,112): deconv k4 s2 p1 -> concat with the skip -> 3x3 conv keeping 2 x cout channels.
+    Unit names `.conv1.conv` / `.conv1.bn|IN` / `.conv2.conv` / `.conv2.bn|IN` as in the reference's checkpoints."""
+
+    def __init__(self, cin, cout, norm="bn"):
+        super().__init__()
+        unit = BasicConv if norm == "bn" else BasicConvIN
+        self.concat = True
+        self.conv1 = unit(cin, cout, deconv=True, kernel_size=4, stride=2, padding=1)
+        self.conv2 = unit(cout * 2, cout * 2, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x, rem):
+        x = self.conv1(x)
+        if x.shape != rem.shape:
+            x = F.interpolate(x, size=rem.shape[-2:], mode="nearest")
+        return self.conv2(torch.cat((x, rem), 1))
+
+
 def _pyramid_step(cin, cout, stride):
     return nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
 
@@ -328,7 +363,8 @@ class IGEVCostStage(nn.Module):
 
 class IGEVStereo(IGEVCostStage):
     """igev_stereo.py:78-218, test mode.  `args`: MAX_DISP, HIDDEN_DIMS, N_GRU_LAYERS, CORR_RADIUS, CORR_LEVELS, SLOW_FAST_GRU,
-    VALID_ITERS.  The small 2-D heads use this package's block modules (`.block.N` keys, not the reference's `.conv/.IN`)."""
+    VALID_ITERS, TRAIN_ITERS.  Every parameter / buffer outside `feature.` / `cnet.` has the reference's name and shape (the small 2-D heads are
+    the reference's `.conv` / `.IN` / `.bn` units, igev/submodule.py:6-157), so an IGEV-Stereo checkpoint loads completely."""
 
     def __init__(self, args, feature=None, cnet=None):
         super().__init__(max_disp=args.MAX_DISP)
@@ -339,17 +375,17 @@ class IGEVStereo(IGEVCostStage):
         self.cnet = cnet if cnet is not None else StubContext(hd, hd)
         self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hd)
         self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hd[i], hd[i] * 3, 3, padding=1) for i in range(args.N_GRU_LAYERS)])
-        self.stem_2 = nn.Sequential(BasicConv2d(3, 32, norm_layer=IN, act_layer=LR, kernel_size=3, stride=2, padding=1),
+        self.stem_2 = nn.Sequential(BasicConvIN(3, 32, kernel_size=3, stride=2, padding=1),
                                     nn.Conv2d(32, 32, 3, 1, 1, bias=False), IN(32), nn.ReLU())
-        self.stem_4 = nn.Sequential(BasicConv2d(32, 48, norm_layer=IN, act_layer=LR, kernel_size=3, stride=2, padding=1),
+        self.stem_4 = nn.Sequential(BasicConvIN(32, 48, kernel_size=3, stride=2, padding=1),
                                     nn.Conv2d(48, 48, 3, 1, 1, bias=False), IN(48), nn.ReLU())
-        self.spx_2_gru = Conv2xUp(32, 32, norm_layer=nn.BatchNorm2d)
+        self.spx_2_gru = Conv2xIGEV(32, 32, norm="bn")
         self.spx_gru = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))
         self.spx = nn.Sequential(nn.ConvTranspose2d(2 * 32, 9, kernel_size=4, stride=2, padding=1))      # init_disp head (training only)
-        self.spx_2 = Conv2xUp(24, 32, norm_layer=IN, concat=True)
-        self.spx_4 = nn.Sequential(BasicConv2d(96, 24, norm_layer=IN, act_layer=LR, kernel_size=3, stride=1, padding=1),
+        self.spx_2 = Conv2xIGEV(24, 32, norm="in")
+        self.spx_4 = nn.Sequential(BasicConvIN(96, 24, kernel_size=3, stride=1, padding=1),
                                    nn.Conv2d(24, 24, 3, 1, 1, bias=False), IN(24), nn.ReLU())
-        self.conv = BasicConv2d(96, 96, norm_layer=IN, act_layer=LR, kernel_size=3, padding=1, stride=1)
+        self.conv = BasicConvIN(96, 96, kernel_size=3, padding=1, stride=1)
         self.desc = nn.Conv2d(96, 96, kernel_size=1, padding=0, stride=1)
 
     def side(self, image1, image2):

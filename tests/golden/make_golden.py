@@ -227,10 +227,157 @@ def gen_dormant():
     save("dormant_volumes.npz", **out)
 
 
+def _reference_model(modname, clsname, cfg, stand_ins):
+    """Construct the reference's OWN model class with its timm-backed pieces (`Feature` / `Backbone`, `MultiBasicEncoder`: SURVEY 8 "out
+    of scope", timm + pretrained weights are not available offline) replaced by the stand-in modules the engine classes inject by default
+    (openstereo_amd.models.stereo_models.StubFeature / StubContext: plain torch conv pyramids).  Everything else -- __init__, forward,
+    the 2-D heads, the iteration schedule, the final upsampling -- is the reference's code."""
+    import importlib
+    sys.modules.setdefault("timm", types.ModuleType("timm"))
+    mod = importlib.import_module(modname)
+    saved = {n: getattr(mod, n) for n in stand_ins}
+    try:
+        for n, f in stand_ins.items():
+            setattr(mod, n, f)
+        return getattr(mod, clsname)(cfg).eval()
+    finally:
+        for n, v in saved.items():
+            setattr(mod, n, v)
+
+
+def gen_e2e(full=True):
+    """Whole-model forwards of the reference's StereoBase / IGEVStereo / LightStereo classes (stereobase_gru.py:121-213,
+    igev_stereo.py:139-218, lightstereo.py:44-71) -- VERDICT r2 row h: the end-to-end classes of openstereo_amd/models/stereo_models.py
+    are pinned against THESE outputs, not against an assembly of oracle stages.  128x256, MAX_DISP 64, 4 GRU iterations; plus IGEV-Stereo
+    at 544x960, MAX_DISP 192, 32 iterations (contractive update-block weights as in gen_at_size), sub-sampled.
+    Inputs / parameters: synth_images(seed=31) and synth_state_dict(seed, head_gain=20, gain=0.9), regenerated by the tests."""
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    from openstereo_amd.models.stereo_models import StubFeature, StubContext
+    H, W, MAXD = 128, 256, 64
+    feat = lambda *a, **k: StubFeature((48, 64, 192, 160))
+    cnet = lambda output_dim, norm_fn="batch", downsample=2: StubContext(list(output_dim[0]), list(output_dim[1]))
+    L, R = synth_images(1, H, W, seed=31, max_shift=12.0)
+    out = {}
+
+    def load(net, seed, gru_gain=None):
+        sd = synth_state_dict(net, seed=seed, head_gain=20.0, gain=0.9)
+        if gru_gain is not None:
+            sd.update({k: v for k, v in synth_state_dict(net, seed=seed, head_gain=20.0, gain=gru_gain).items() if k.startswith("update_block.")})
+        net.load_state_dict(sd)
+
+    cfg = Cfg(MAX_DISP=MAXD, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
+              CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+              SLOW_FAST_GRU=False, TRAIN_ITERS=4, EVAL_ITERS=4)
+    sb = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, {"Feature": feat, "MultiBasicEncoder": cnet})
+    load(sb, 41)
+    r = sb({"left": L, "right": R})
+    assert len(r["disp_preds"]) == 4
+    out.update(stereobase_disp=r["disp_pred"], stereobase_init=r["init_disp"], stereobase_it1=r["disp_preds"][0])
+    print("StereoBase e2e: disp range", r["disp_pred"].min().item(), r["disp_pred"].max().item(), "std", r["disp_pred"].std().item())
+    # slow-fast schedule too (cfgs/stereobase: SLOW_FAST_GRU false; the code path exists, stereobase_gru.py:184-196)
+    cfg2 = Cfg(cfg, SLOW_FAST_GRU=True)
+    sb2 = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg2, {"Feature": feat, "MultiBasicEncoder": cnet})
+    load(sb2, 41)
+    out["stereobase_slowfast_disp"] = sb2({"left": L, "right": R})["disp_pred"]
+
+    args = Cfg(MAX_DISP=MAXD, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+               SLOW_FAST_GRU=True, VALID_ITERS=4, TRAIN_ITERS=4)
+    ig = _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat, "MultiBasicEncoder": cnet})
+    load(ig, 43)
+    L255, R255 = (L * 40 + 128).clamp(0, 255), (R * 40 + 128).clamp(0, 255)
+    r = ig({"left": L255, "right": R255})
+    out["igev_disp"] = r["disp_pred"]
+    print("IGEV e2e: disp range", r["disp_pred"].min().item(), r["disp_pred"].max().item(), "std", r["disp_pred"].std().item())
+
+    # the reference hard-codes the aggregation's in_channels = 48 = 192 / 4 (lightstereo.py:23): MAX_DISP must be 192
+    lcfg = Cfg(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)
+    ls = _reference_model("stereo.modeling.models.lightstereo.lightstereo", "LightStereo", lcfg,
+                          {"Backbone": lambda *a, **k: StubFeature((24, 32, 96, 160))})
+    load(ls, 47)
+    r = ls({"left": L, "right": R})
+    out["lightstereo_disp"] = r["disp_pred"]
+    print("LightStereo e2e: disp range", r["disp_pred"].min().item(), r["disp_pred"].max().item(), "std", r["disp_pred"].std().item())
+
+    if full:
+        # BASELINE configs[4] at size: cfgs/igev/igev_sceneflow_amp.yaml (MAX_DISP 192, VALID_ITERS 32), 544x960 (540 padded to /32)
+        args = Cfg(args, MAX_DISP=192, VALID_ITERS=32)
+        ig = _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat, "MultiBasicEncoder": cnet})
+        load(ig, 43, gru_gain=0.8)
+        Lf, Rf = synth_images(1, 544, 960, seed=31)
+        t = time.time()
+        r = ig({"left": (Lf * 40 + 128).clamp(0, 255), "right": (Rf * 40 + 128).clamp(0, 255)})
+        print(f"IGEV e2e 544x960 x32: {time.time() - t:.1f} s, disp range {r['disp_pred'].min().item():.2f}..{r['disp_pred'].max().item():.2f}"
+              f" std {r['disp_pred'].std().item():.2f}")
+        out["igev_full_disp_sub"] = r["disp_pred"][:, :, ::4, ::4]
+    save("e2e_reference.npz", **out)
+    gen_e2e_train(feat, cnet)
+
+
+E2E_TRAIN_KEYS = {
+    "stereobase": ("classifier.weight", "cost_agg.conv1.0.block.0.weight", "cost_agg.conv3_up.block.0.weight", "cost_agg.agg_0.1.block.0.weight",
+                   "update_block.gru04.convz.weight", "update_block.gru16.convq.weight", "update_block.disp_head.conv2.weight",
+                   "update_block.encoder.convc1.weight", "desc.weight", "concat_conv.1.weight", "spx_gru.0.weight", "spx.0.weight",
+                   "context_zqr_convs.0.weight", "feature.stem.0.0.weight", "cnet.heads.0.0.weight"),
+    "igev": ("classifier.weight", "corr_stem.conv.weight", "cost_agg.conv1.0.conv.weight", "cost_agg.conv2_up.conv.weight",
+             "corr_feature_att.feat_att.1.weight", "update_block.gru08.convr.weight", "update_block.gru16.convq.weight",
+             "update_block.disp_head.conv2.weight", "update_block.mask_feat_4.0.weight", "desc.weight", "conv.conv.weight",
+             "spx_2_gru.conv1.conv.weight", "spx_gru.0.weight", "spx.0.weight", "stem_2.0.conv.weight", "feature.stem.0.0.weight"),
+    "lightstereo": ("cost_agg.conv0.0.pwconv.0.weight", "cost_agg.conv6.0.weight", "cost_agg.conv1.dwconv.0.weight", "cost_agg.att0.conv1_2.weight",
+                    "refine_3.block.0.weight", "refine_1.0.block.0.weight", "stem_2.0.block.0.weight", "backbone.stem.0.0.weight"),
+}
+
+
+def gen_e2e_train(feat, cnet):
+    """Training-mode forward + the reference's own get_loss + CPU autograd of the reference's model classes (frozen BatchNorm, i.e. the
+    `freeze_bn` semantics of igev_stereo.py:121-124 applied to every BN so the fixture does not depend on batch statistics of one image):
+    loss and the gradients of selected parameters across all stages (the end-to-end training tests used to assert only
+    that the loss goes down).  64x128, 3 GRU iterations."""
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    from openstereo_amd.models.stereo_models import StubFeature
+    import torch.nn as nn
+    H, W = 64, 128
+    L, R = synth_images(1, H, W, seed=31, max_shift=12.0)
+    gt = torch.from_numpy(np.random.default_rng(3).uniform(1.0, 30.0, (1, H, W)).astype(np.float32))
+    out = {}
+
+    def run(tag, net, seed, left, right):
+        net.load_state_dict(synth_state_dict(net, seed=seed, head_gain=20.0, gain=0.9))
+        net.train()
+        for m in net.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.eval()
+        with torch.enable_grad():
+            pred = net({"left": left, "right": right})
+            loss, _ = net.get_loss(pred, {"disp": gt})
+            loss.backward()
+        params = dict(net.named_parameters())
+        out[f"{tag}_loss"] = loss.detach()
+        out[f"{tag}_disp"] = pred["disp_pred"].detach()
+        for k in E2E_TRAIN_KEYS[tag]:
+            g = params[k].grad
+            assert g is not None and float(g.abs().max()) > 0, (tag, k)
+            out[f"{tag}_grad::{k}"] = g.reshape(-1)[:20000].clone()
+        print(f"{tag} training step (reference autograd): loss {loss.item():.4f}")
+
+    cfg = Cfg(MAX_DISP=64, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
+              CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+              SLOW_FAST_GRU=False, TRAIN_ITERS=3, EVAL_ITERS=4)
+    run("stereobase", _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg,
+                                       {"Feature": feat, "MultiBasicEncoder": cnet}), 41, L, R)
+    args = Cfg(MAX_DISP=64, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+               SLOW_FAST_GRU=True, VALID_ITERS=4, TRAIN_ITERS=3)
+    run("igev", _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat, "MultiBasicEncoder": cnet}),
+        43, (L * 40 + 128).clamp(0, 255), (R * 40 + 128).clamp(0, 255))
+    lcfg = Cfg(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)
+    run("lightstereo", _reference_model("stereo.modeling.models.lightstereo.lightstereo", "LightStereo", lcfg,
+                                        {"Backbone": lambda *a, **k: StubFeature((24, 32, 96, 160))}), 47, L, R)
+    save("e2e_reference_train.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -249,6 +396,9 @@ def main():
         return
     if args.only == "dormant":
         gen_dormant()
+        return
+    if args.only == "e2e":
+        gen_e2e()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -375,6 +525,7 @@ def main():
     gen_at_size()
     gen_preprocess()
     gen_dormant()
+    gen_e2e()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

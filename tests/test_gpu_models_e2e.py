@@ -120,6 +120,152 @@ def test_lightstereo_end_to_end():
     torch.testing.assert_close(out["disp_pred"].cpu(), want, rtol=1e-4, atol=2e-3)
 
 
+# ----------------------------------------------------------------------------- pinned against the REFERENCE's own forward
+# tests/golden/e2e_reference.npz = outputs of the reference's StereoBase / IGEVStereo / LightStereo classes (make_golden.gen_e2e: the
+# reference's __init__ + forward with only the timm-backed `Feature` / `Backbone` / `MultiBasicEncoder` replaced by the same stand-in
+# modules the engine classes inject).  Same name-keyed synthetic parameters on both sides; the engine classes must reproduce the
+# reference's whole composition -- stem reuse, iteration schedule, disp * 4 / mask order, final convex upsampling.
+def _with_precision(prec, fn):
+    from openstereo_amd import engine
+    old = engine.get_precision()
+    engine.set_precision(prec)
+    try:
+        return fn()
+    finally:
+        engine.set_precision(old)
+
+
+def _epe(a, b):
+    return float((a.float().cpu() - torch.from_numpy(b)).abs().mean())
+
+
+def _ref_golden():
+    from conftest import golden
+    return golden("e2e_reference.npz")
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("slow_fast", [False, True])
+def test_stereobase_matches_reference_forward(prec, slow_fast):
+    from openstereo_amd.models.stereo_models import StereoBase
+    g = _ref_golden()
+    cfg = SimpleNamespace(MAX_DISP=MAXD, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                          N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=slow_fast, EVAL_ITERS=4, TRAIN_ITERS=4)
+    m = StereoBase(cfg).eval()
+    _load(m, 41)
+    m = m.cuda()
+    L, Rr = _images("cuda")
+    out = _with_precision(prec, lambda: m({"left": L, "right": Rr}))
+    if slow_fast:
+        want = g["stereobase_slowfast_disp"]
+    else:
+        want = g["stereobase_disp"]
+        assert _epe(out["init_disp"], g["stereobase_init"]) < 1e-3
+        torch.testing.assert_close(out["init_disp"].cpu(), torch.from_numpy(g["stereobase_init"]), rtol=1e-4, atol=5e-3)
+    assert want.std() > 0.5
+    assert _epe(out["disp_pred"], want) < 1e-3, _epe(out["disp_pred"], want)
+    torch.testing.assert_close(out["disp_pred"].cpu(), torch.from_numpy(want), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_igev_matches_reference_forward(prec):
+    from openstereo_amd.models.stereo_models import IGEVStereo
+    g = _ref_golden()
+    args = SimpleNamespace(MAX_DISP=MAXD, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+                           SLOW_FAST_GRU=True, VALID_ITERS=4, TRAIN_ITERS=4, N_DOWNSAMPLE=2)
+    m = IGEVStereo(args).eval()
+    _load(m, 43)
+    m = m.cuda()
+    L, Rr = _images("cuda", scale255=True)
+    out = _with_precision(prec, lambda: m({"left": L, "right": Rr}))
+    assert g["igev_disp"].std() > 0.5
+    assert _epe(out["disp_pred"], g["igev_disp"]) < 1e-3, _epe(out["disp_pred"], g["igev_disp"])
+    torch.testing.assert_close(out["disp_pred"].cpu(), torch.from_numpy(g["igev_disp"]), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_igev_full_size_32_iterations_matches_reference_forward(prec):
+    """BASELINE configs[4] at size: 544x960, MAX_DISP 192, VALID_ITERS 32 (cfgs/igev/igev_sceneflow_amp.yaml), the reference's own
+    IGEVStereo.forward; update-block weights at the contractive gain of the at-size fixture (make_golden.gen_at_size)."""
+    from openstereo_amd.models.stereo_models import IGEVStereo
+    g = _ref_golden()
+    args = SimpleNamespace(MAX_DISP=192, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+                           SLOW_FAST_GRU=True, VALID_ITERS=32, TRAIN_ITERS=22, N_DOWNSAMPLE=2)
+    m = IGEVStereo(args).eval()
+    sd = synth_state_dict(m, seed=43, head_gain=20.0, gain=0.9)
+    sd.update({k: v for k, v in synth_state_dict(m, seed=43, head_gain=20.0, gain=0.8).items() if k.startswith("update_block.")})
+    m.load_state_dict(sd)
+    m = m.cuda()
+    L, Rr = synth_images(1, 544, 960, seed=31)
+    L, Rr = (L * 40 + 128).clamp(0, 255).cuda(), (Rr * 40 + 128).clamp(0, 255).cuda()
+    out = _with_precision(prec, lambda: m({"left": L, "right": Rr}))
+    got = out["disp_pred"][:, :, ::4, ::4]
+    want = g["igev_full_disp_sub"]
+    assert want.std() > 2.0
+    assert _epe(got, want) < 1e-3, _epe(got, want)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_lightstereo_matches_reference_forward(prec):
+    from openstereo_amd.models.stereo_models import LightStereo
+    g = _ref_golden()
+    cfg = SimpleNamespace(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)       # reference: in_channels 48 = 192 / 4
+    m = LightStereo(cfg).eval()
+    _load(m, 47)
+    m = m.cuda()
+    L, Rr = _images("cuda")
+    out = _with_precision(prec, lambda: m({"left": L, "right": Rr}))
+    assert g["lightstereo_disp"].std() > 0.5
+    assert _epe(out["disp_pred"], g["lightstereo_disp"]) < 1e-3, _epe(out["disp_pred"], g["lightstereo_disp"])
+    torch.testing.assert_close(out["disp_pred"].cpu(), torch.from_numpy(g["lightstereo_disp"]), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("which", ["stereobase", "igev", "lightstereo"])
+def test_training_step_matches_reference_autograd(which):
+    """Training-mode forward, the reference's loss and the gradients of parameters in every stage (2-D heads, volume / aggregation,
+    classifier, update block, upsampling heads, stand-in backbone) vs CPU autograd of the REFERENCE's own model class
+    (tests/golden/e2e_reference_train.npz, make_golden.gen_e2e_train; frozen BatchNorm).  64x128, 3 GRU iterations."""
+    import numpy as np
+    import torch.nn as nn
+    from conftest import golden
+    from openstereo_amd.models.stereo_models import StereoBase, IGEVStereo, LightStereo
+    g = golden("e2e_reference_train.npz")
+    if which == "stereobase":
+        m, seed = StereoBase(SimpleNamespace(MAX_DISP=64, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                                             N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=4, TRAIN_ITERS=3)), 41
+    elif which == "igev":
+        m, seed = IGEVStereo(SimpleNamespace(MAX_DISP=64, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+                                             SLOW_FAST_GRU=True, VALID_ITERS=4, TRAIN_ITERS=3, N_DOWNSAMPLE=2)), 43
+    else:
+        m, seed = LightStereo(SimpleNamespace(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)), 47
+    _load(m, seed)
+    m = m.cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            mod.eval()
+    L, Rr = synth_images(1, 64, 128, seed=31, max_shift=12.0)
+    if which == "igev":
+        L, Rr = (L * 40 + 128).clamp(0, 255), (Rr * 40 + 128).clamp(0, 255)
+    gt = torch.from_numpy(np.random.default_rng(3).uniform(1.0, 30.0, (1, 64, 128)).astype(np.float32)).cuda()
+    out = m({"left": L.cuda(), "right": Rr.cuda()})
+    loss, _ = m.get_loss(out, {"disp": gt})
+    loss.backward()
+    want_loss = float(g[f"{which}_loss"])
+    assert abs(float(loss.detach()) - want_loss) < 2e-4 * abs(want_loss), (float(loss.detach()), want_loss)
+    assert _epe(out["disp_pred"].detach(), g[f"{which}_disp"]) < 1e-3
+    params = dict(m.named_parameters())
+    keys = [k.split("::", 1)[1] for k in g.files if k.startswith(f"{which}_grad::")]
+    assert len(keys) >= 7
+    worst = {}
+    for k in keys:
+        want = torch.from_numpy(g[f"{which}_grad::{k}"])
+        got = params[k].grad.detach().reshape(-1)[:want.numel()].cpu()
+        worst[k] = float((got - want).abs().max() / (want.abs().max() + 1e-20))
+    print({k: f"{v:.1e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v < 5e-4}
+    assert not bad, bad                    # whole-model gradient error <= 5e-4 of max |grad| per tensor
+
+
 def test_end_to_end_classes_refuse_cpu():
     """No CPU path: CPU tensors are refused loudly (training mode is covered by tests/test_gpu_autograd.py)."""
     from openstereo_amd.models.stereo_models import LightStereo
