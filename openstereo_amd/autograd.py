@@ -15,17 +15,26 @@ unchanged (one process per GPU).
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 
-from . import _lib, engine, ops
+from . import _lib, amp, engine, ops
 from .ops import _f32c, _p, _stream, empty_cl, is_cl, to_cl
 from .ranges import input_meta, attach_meta
+
+
+# Every Function runs its forward with autocast switched off and floating inputs cast to fp32 (torch.amp.custom_fwd): the kernels compute
+# in fp32-class arithmetic whatever the surrounding region says; the callers below cast the result to the dtype the reference's op would
+# have produced there (openstereo_amd/amp.py).  Backward runs under the same (disabled) autocast state (custom_bwd).
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
 
 
 # ----------------------------------------------------------------------------- volumes
 class _GwcVolume(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, left, right, maxdisp, num_groups):
         l, r = _f32c(left), _f32c(right)
         ctx.save_for_backward(l, r)
@@ -33,6 +42,7 @@ class _GwcVolume(torch.autograd.Function):
         return ops._build(l, r, num_groups, None, None, maxdisp, ops.NCDHW)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dvol):
         l, r = ctx.saved_tensors
         maxdisp, G, dt = ctx.meta
@@ -46,12 +56,14 @@ class _GwcVolume(torch.autograd.Function):
 
 class _ConcatVolume(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, left, right, maxdisp, mask_left):
         l, r = _f32c(left), _f32c(right)
         ctx.meta = (maxdisp, mask_left, left.dtype, tuple(l.shape))
         return ops._build(None, None, 0, l, r, maxdisp, ops.NCDHW, mask_left=mask_left)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dvol):
         maxdisp, mask_left, dt, (B, C, H, W) = ctx.meta
         dv = _f32c(dvol)
@@ -78,11 +90,13 @@ def correlation_volume(left_feature, right_feature, max_disp):
 # ----------------------------------------------------------------------------- regression
 class _SoftArgmin(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, prob):
         ctx.shape = tuple(prob.shape)
         return ops.disparity_regression(prob, prob.shape[1], keepdim=False)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         B, D, H, W = ctx.shape
         g = _f32c(dout)
@@ -93,12 +107,14 @@ class _SoftArgmin(torch.autograd.Function):
 
 class _SoftmaxSoftArgmin(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, cost):
         c = _f32c(cost)
         ctx.save_for_backward(c)
         return ops.softmax_disparity_regression(c, keepdim=False)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         (c,) = ctx.saved_tensors
         B, D, H, W = c.shape
@@ -110,6 +126,7 @@ class _SoftmaxSoftArgmin(torch.autograd.Function):
 
 class _UpsampleSoftArgmin(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, cost_low, maxdisp, h, w, align_corners):
         c = _f32c(cost_low)
         ctx.save_for_backward(c)
@@ -117,6 +134,7 @@ class _UpsampleSoftArgmin(torch.autograd.Function):
         return ops.upsample_softargmin(c, maxdisp, h, w, align_corners)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         (c,) = ctx.saved_tensors
         maxdisp, h, w, align = ctx.meta
@@ -153,31 +171,38 @@ def _pow2_scale(w):
 
 
 def _wcache(w):
-    """Per-weight pack cache: a dict that lives ON the weight tensor object (the nn.Parameter the caller holds), so it dies with the
-    model -- a process-wide table keyed on data_ptr would serve a freed model's packs to the next one the allocator places there."""
+    """Per-weight pack cache handle `(dict, stamp)`.  The dict lives ON the weight tensor object (the nn.Parameter the caller holds), so
+    it dies with the model -- a process-wide table keyed on data_ptr would serve a freed model's packs to the next one the allocator
+    places there.  The stamp identifies the CONTENT the packs were built from and is read from the caller's tensor itself --
+    (_version, data_ptr, device, dtype) of the Parameter, not of the fp32-contiguous working copy `_f32c` may have to make (a fresh
+    copy always has version 0: with channels_last / fp16 / bf16 parameters the memo would never invalidate after an optimizer step;
+    ADVICE r2).  `.to(other device)`, `.double()`, `load_state_dict` and every in-place update through autograd-visible ops change the
+    stamp.  Not covered: writes through `.data` / raw pointers, which leave `_version` untouched -- call `engine.reset_engine(model)`
+    or `weight._osa_packs.clear()` after such an update."""
     c = getattr(w, "_osa_packs", None)
     if c is None:
         try:
             w._osa_packs = c = {}
         except Exception:                               # tensor subclasses without a __dict__
-            c = None
-    return c
+            return None
+    return c, (w._version, w.data_ptr(), str(w.device), w.dtype)
 
 
 def _pack(w, Ci, Co, k, mode, precision, cache=None):
-    """Packed image of a weight for one role, memoised per weight object and version: a layer that runs many times between two
+    """Packed image of a weight for one role, memoised per weight object and content stamp: a layer that runs many times between two
     optimizer steps -- the update block: 22 GRU iterations, forward and data gradient each -- is packed (and its power-of-two scale
-    measured, a host sync) once per role and step instead of once per call."""
+    measured, a host sync) once per role and step instead of once per call.  `w` is the fp32-contiguous working tensor, `cache` the
+    `_wcache` handle of the tensor it came from."""
     if cache is None:
         return _pack_now(w, Ci, Co, k, mode, precision)
-    ver = w._version
-    if cache.get("version") != ver:
-        cache.clear()
-        cache["version"] = ver
+    memo, stamp = cache
+    if memo.get("stamp") != stamp:
+        memo.clear()
+        memo["stamp"] = stamp
     key = (tuple(w.shape), mode, precision)
-    hit = cache.get(key)
+    hit = memo.get(key)
     if hit is None:
-        hit = cache[key] = _pack_now(w, Ci, Co, k, mode, precision)
+        hit = memo[key] = _pack_now(w, Ci, Co, k, mode, precision)
     return hit
 
 
@@ -265,6 +290,7 @@ class _Conv3d(torch.autograd.Function):
     """y = conv3d(x, w) (no bias).  x: logical [B,Ci,D,H,W] (any strides); y: NDHWC-strided [B,Co,...]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, w, stride, pad, dil, precision, cache=None):
         xc = to_cl(x)                               # NDHWC, channels padded to a multiple of 4 with zeros
         wf = _f32c(w)
@@ -281,6 +307,7 @@ class _Conv3d(torch.autograd.Function):
         return y[:, :Co]
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy):
         xc, wf = ctx.saved_tensors
         stride, pad, dil, precision, xshape, xdt = ctx.meta
@@ -311,6 +338,7 @@ class _ConvTranspose3d(torch.autograd.Function):
     """y = conv_transpose3d(x, w[Ci][Co][k], stride 2); k3/p1/op1 or k4/p1/op0."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, w, pad, opad, precision, cache=None):
         xc = to_cl(x)
         wf = _f32c(w)
@@ -323,6 +351,7 @@ class _ConvTranspose3d(torch.autograd.Function):
         return y[:, :Co]
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy):
         xc, wf = ctx.saved_tensors
         pad, opad, precision, xdt = ctx.meta
@@ -348,6 +377,7 @@ class _ConvTranspose2d(torch.autograd.Function):
     GEMM + col2im (5 ms per call at the 320x736 crop)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, w, pad, opad, precision, cache=None):
         xc = to_cl(x.unsqueeze(2))
         ctx.cache = cache
@@ -369,6 +399,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         return y[:, :Co, 0]
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy):
         xc, wf = ctx.saved_tensors
         pad, opad, precision, xdt = ctx.meta
@@ -432,11 +463,46 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
+def _wgrad_ok(m, x):
+    """Preconditions of the backward kernels for module m on input x, checked BEFORE the forward is routed to the engine (a
+    dilated 3x3 conv whose weight-gradient brick exceeds the 160 KB of LDS used to pass `_eligible` and raise inside backward()).  Only
+    consulted when a gradient can actually be asked for."""
+    if not (torch.is_grad_enabled() and (m.weight.requires_grad or x.requires_grad)):
+        return True
+    nn = torch.nn
+    tr = isinstance(m, (nn.ConvTranspose2d, nn.ConvTranspose3d))
+    flat = isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))
+    lift = (lambda v, unit: (unit,) + tuple(v)) if flat else (lambda v, unit: tuple(v))      # 2-D layer = the D = 1 case
+    k, s, p, d = lift(m.kernel_size, 1), lift(m.stride, 1), lift(m.padding, 0), lift(m.dilation, 1)
+    sp = ((1,) + tuple(x.shape[2:])) if flat else tuple(x.shape[2:])
+    if len(sp) != 3 or any(v <= 0 for v in sp):
+        return False
+    st = max(s)
+    if tr:
+        op = lift(m.output_padding, 0)
+        out = tuple((sp[i] - 1) * s[i] - 2 * p[i] + d[i] * (k[i] - 1) + op[i] + 1 for i in range(3))
+        Ci, Co = m.in_channels, m.out_channels
+    else:
+        out = tuple((sp[i] + 2 * p[i] - d[i] * (k[i] - 1) - 1) // s[i] + 1 for i in range(3))
+        Ci, Co = m.in_channels, m.out_channels
+        if st == 2 and not flat and any(v % 2 for v in sp):            # stride-2 data gradient runs as the fused transposed conv: even dims
+            return False
+    if any(v <= 0 for v in out):
+        return False
+    need = _lib.load().osa_conv3d_wgrad_workspace_bytes(int(x.shape[0]), sp[0], sp[1], sp[2], Ci, out[0], out[1], out[2], Co,
+                                                        k[0], k[1], k[2], st, p[0], p[1], p[2], d[0], d[1], d[2], 1 if tr else 0)
+    return need != 0
+
+
 def _eligible(m, x):
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16)):
         return False
     if m.groups != 1 or getattr(m, "padding_mode", "zeros") != "zeros" or isinstance(m.padding, str):
         return False
+    return _shape_eligible(m, x) and _wgrad_ok(m, x)
+
+
+def _shape_eligible(m, x):
     if isinstance(m, torch.nn.Conv2d):
         return tuple(m.stride) == (1, 1) and m.in_channels >= 4
     if isinstance(m, torch.nn.ConvTranspose2d):
@@ -467,39 +533,50 @@ class engine_convs:
             loss = model(batch)            # reference-built or mirror model, in train mode
         loss.backward()                    # backward kernels run outside the context too (they belong to the recorded Functions)
     """
-    _depth = 0
+    _depth = 0                      # number of threads x nesting levels currently inside (guarded by _lock)
     _saved = {}
+    _lock = threading.RLock()
+    _tls = threading.local()        # .depth: nesting level of THIS thread; the patched forwards reroute only when it is > 0
+
+    @classmethod
+    def active(cls) -> bool:
+        return getattr(cls._tls, "depth", 0) > 0
 
     def __enter__(self):
         cls = engine_convs
-        if cls._depth == 0:
-            nn = torch.nn
-            for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d):
-                cls._saved[C] = C.forward
-            o2, o3, ot, ot2 = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d], cls._saved[nn.ConvTranspose2d]
+        with cls._lock:
+            if cls._depth == 0:
+                nn = torch.nn
+                for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d):
+                    cls._saved[C] = C.forward
+                o2, o3, ot, ot2 = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d], cls._saved[nn.ConvTranspose2d]
+                on = cls.active             # other threads (a validation thread, DataParallel replicas) keep the original forwards
 
-            def ft2(m, x, output_size=None):
-                if output_size is None and _eligible(m, x):
-                    return conv_transpose2d(x, m.weight, m.bias, m.stride, m.padding, m.output_padding).to(x.dtype)
-                return ot2(m, x, output_size)
+                def ft2(m, x, output_size=None):
+                    if on() and output_size is None and _eligible(m, x):
+                        return conv_transpose2d(x, m.weight, m.bias, m.stride, m.padding, m.output_padding).to(amp.conv_out_dtype(x))
+                    return ot2(m, x, output_size)
 
-            def f2(m, x):
-                return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation).to(x.dtype) if _eligible(m, x) else o2(m, x)
+                def f2(m, x):
+                    return conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation).to(amp.conv_out_dtype(x)) if (on() and _eligible(m, x)) else o2(m, x)
 
-            def f3(m, x):
-                return conv_module(m, x).to(x.dtype) if _eligible(m, x) else o3(m, x)
+                def f3(m, x):
+                    return conv_module(m, x).to(amp.conv_out_dtype(x)) if (on() and _eligible(m, x)) else o3(m, x)
 
-            def ft(m, x, output_size=None):
-                return conv_module(m, x).to(x.dtype) if (output_size is None and _eligible(m, x)) else ot(m, x, output_size)
-            nn.Conv2d.forward, nn.Conv3d.forward, nn.ConvTranspose3d.forward, nn.ConvTranspose2d.forward = f2, f3, ft, ft2
-        cls._depth += 1
+                def ft(m, x, output_size=None):
+                    return conv_module(m, x).to(amp.conv_out_dtype(x)) if (on() and output_size is None and _eligible(m, x)) else ot(m, x, output_size)
+                nn.Conv2d.forward, nn.Conv3d.forward, nn.ConvTranspose3d.forward, nn.ConvTranspose2d.forward = f2, f3, ft, ft2
+            cls._depth += 1
+        cls._tls.depth = getattr(cls._tls, "depth", 0) + 1
         return self
 
     def __exit__(self, *exc):
         cls = engine_convs
-        cls._depth -= 1
-        if cls._depth == 0:
-            for C, f in cls._saved.items():
-                C.forward = f
-            cls._saved.clear()
+        cls._tls.depth = getattr(cls._tls, "depth", 1) - 1
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0:         # the last thread out restores the class attributes
+                for C, f in cls._saved.items():
+                    C.forward = f
+                cls._saved.clear()
         return False

@@ -18,10 +18,14 @@ from .ops import _f32c, _stream, is_cl
 
 class _Lookup(torch.autograd.Function):
     """out = lookup(disp, coords; geo levels, corr levels) with gradients for the levels (osa_geo_lookup_bwd_f32).  The disparity is
-    detached in the reference's loop (igev_stereo.py:190, stereobase_gru.py:186), so it gets none."""
+    detached in the reference's loop (igev_stereo.py:190, stereobase_gru.py:186), so it gets none.
+    The kernels take fp32 rows: inside an autocast region the levels arrive cast to fp32 (custom_fwd) and every tensor is passed through
+    `_f32c` -- handing the raw pointer of an fp16 pyramid level to the kernel reads past its end (found by tests/test_gpu_autocast.py)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, d, cx, C, radius, *levels):
+        d, cx, levels = _f32c(d), _f32c(cx), tuple(_f32c(t) for t in levels)
         L = len(levels) // 2
         geo, corr = levels[:L], levels[L:]
         B, H, W = d.shape
@@ -36,6 +40,7 @@ class _Lookup(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dout):
         d, cx = ctx.saved_tensors
         C, radius, L, shapes = ctx.meta
@@ -58,17 +63,22 @@ class CombinedGeoEncodingVolume:
         if self.train_path:
             # Training: the pyramid is built from differentiable torch ops (a permutation, an einsum, two average pools: once per
             # forward), the per-iteration lookup and its gradient run on the engine (_Lookup).
-            import torch.nn.functional as F
-            f1, f2, gv = init_fmap1.float(), init_fmap2.float(), geo_volume.float()
-            B, C, D, H, W1 = gv.shape
-            self.C, self.shape = C, (B, H, W1)
-            rows = gv.permute(0, 3, 4, 1, 2).contiguous()                                 # [B,H,W,C,D]
-            corr = torch.einsum("aijk,aijh->ajkh", f1, f2).contiguous()                   # [B,H,W1,W2]
-            self.geo_volume_pyramid, self.init_corr_pyramid = [rows], [corr]
-            for _ in range(num_levels - 1):
-                g, c = self.geo_volume_pyramid[-1], self.init_corr_pyramid[-1]
-                self.geo_volume_pyramid.append(F.avg_pool1d(g.reshape(-1, 1, g.shape[-1]), 2, 2).reshape(*g.shape[:-1], g.shape[-1] // 2))
-                self.init_corr_pyramid.append(F.avg_pool1d(c.reshape(-1, 1, c.shape[-1]), 2, 2).reshape(*c.shape[:-1], c.shape[-1] // 2))
+            # fp32 throughout, whatever autocast region surrounds the call: the reference casts its inputs to fp32 here too
+            # (`match_left.float()`, igev_stereo.py:184) but its einsum / pooling still run in the autocast dtype; the engine keeps the
+            # pyramid in fp32 -- no fp16 overflow of the 96-term correlation sums, and the levels are what _Lookup's kernels read.
+            # The pooling is written as a strided add (exactly F.avg_pool2d(x, [1, 2], stride=[1, 2]): (a + b) / 2, a trailing odd
+            # element dropped) instead of F.avg_pool1d: PyTorch 2.10 + ROCm 7.0 faults in that op for fp16 rows (tools/diag_lookup_ac.py).
+            with torch.autocast("cuda", enabled=False):
+                f1, f2, gv = init_fmap1.float(), init_fmap2.float(), geo_volume.float()
+                B, C, D, H, W1 = gv.shape
+                self.C, self.shape = C, (B, H, W1)
+                rows = gv.permute(0, 3, 4, 1, 2).contiguous()                                 # [B,H,W,C,D]
+                corr = torch.einsum("aijk,aijh->ajkh", f1, f2).contiguous()                   # [B,H,W1,W2]
+                self.geo_volume_pyramid, self.init_corr_pyramid = [rows], [corr]
+                half = lambda t: ((t[..., 0:t.shape[-1] // 2 * 2:2] + t[..., 1::2]) * 0.5).contiguous()
+                for _ in range(num_levels - 1):
+                    self.geo_volume_pyramid.append(half(self.geo_volume_pyramid[-1]))
+                    self.init_corr_pyramid.append(half(self.init_corr_pyramid[-1]))
             from .ranges import new_meta
             self.meta = new_meta(rows.device)
             self.meta[0:1] = torch.maximum(rows.detach().abs().amax(), corr.detach().abs().amax()).reshape(1)

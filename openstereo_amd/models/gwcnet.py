@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import autograd as AG
-from .. import ops, timing
+from .. import amp, ops, timing
 from ..engine import is_split, cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
 
 
@@ -157,6 +157,7 @@ class GwcBackbone(nn.Module):
         self.concat_channels = concat_channels if use_concat_volume else 0
         self.feature_extraction = _Features(use_concat_volume, self.concat_channels)
 
+    @amp.contract("cast")
     def forward(self, inputs):
         """Reference contract: NCHW feature dicts.  engine=True (default on GPU in eval mode) runs the
         extractor on the engine's conv kernel and converts at the boundary; GwcNet.forward skips
@@ -200,6 +201,7 @@ class GwcVolumeCostProcessor(nn.Module):
     def build_concat_volume(self, refimg_fea, targetimg_fea):
         return ops.build_concat_volume(refimg_fea, targetimg_fea, self.maxdisp // self.downsample)
 
+    @amp.contract("volume")
     def forward(self, inputs):
         l, r = inputs["ref_feature"], inputs["tgt_feature"]
         cat = self.use_concat_volume
@@ -276,6 +278,7 @@ class Hourglass(nn.Module):
         c5 = F.relu(run_train(self.conv5, c4) + run_train(self.redir2, c2))
         return F.relu(run_train(self.conv6, c5) + run_train(self.redir1, x))
 
+    @amp.contract("cast")
     def forward(self, x):
         """Drop-in: NCDHW in -> NCDHW out.  Gradients required or training mode -> autograd path."""
         if self.training or (torch.is_grad_enabled() and x.requires_grad):

@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import amp, ops
 from ..engine import cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_LEAKY
 from ..ops import empty_cl
 
@@ -183,6 +183,7 @@ class Hourglass(nn.Module):
         conv = self._unit_train(self.conv1_up, conv1)
         return [conv, conv1, conv2] if return_multi else conv
 
+    @amp.contract("cast")
     def forward(self, x, features, return_multi=False):
         """Drop-in: NCDHW in -> NCDHW out.  Training mode (or grad-requiring inputs) takes the autograd path."""
         if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
@@ -337,6 +338,7 @@ class hourglass(nn.Module):
         conv1 = att(self.feature_att_up_8, seq(self.agg_1, conv1), features[1])
         return u(self.conv1_up, conv1)
 
+    @amp.contract("cast")
     def forward(self, x, features):
         if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.forward_train(x, features)

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, amp
 from .. import autograd as AG
 from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from ..ops import empty_cl, is_cl, on_engine, _stream
@@ -85,6 +85,7 @@ class DispHead(nn.Module):
         e = cached_pack(self, "_eng", lambda: (PackedConv3d(self.conv1, None, ACT_RELU), PackedConv3d(self.conv2)))
         return e[1](e[0](x))
 
+    @amp.contract("cast")
     def forward(self, x):
         if self.training or (torch.is_grad_enabled() and x.requires_grad):       # update.py:25-26, convs on the engine with autograd
             with AG.engine_convs():
@@ -134,6 +135,7 @@ class ConvGRU(nn.Module):
             q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
         return (1 - z) * h + z * q
 
+    @amp.contract("gru")
     def forward(self, h, cz, cr, cq, *x_list):
         if self.training or (torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.forward_train(h, cz, cr, cq, *x_list)
@@ -180,6 +182,7 @@ class BasicMotionEncoder(nn.Module):
             out = F.relu(self.conv(torch.cat([cor, d], dim=1)))
         return torch.cat([out, disp], dim=1)
 
+    @amp.contract("enc")
     def forward(self, disp, corr):
         if self.training or (torch.is_grad_enabled() and (disp.requires_grad or corr.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.forward_train(disp, corr)
@@ -232,7 +235,11 @@ class BasicMultiUpdateBlock(nn.Module):
     def forward_train(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         """update.py:129-150 with differentiable sub-modules (their training paths); pool2x / interp are the reference's torch ops."""
         n_gru = self.args.N_GRU_LAYERS if hasattr(self, "args") else self.n_gru_layers
-        p2 = lambda t: F.avg_pool2d(t, 3, stride=2, padding=1)
+        # .contiguous(): PyTorch 2.10 + ROCm 7.0 computes a WRONG avg_pool2d gradient for a channels-last input (aten.avg_pool2d_backward
+        # with NHWC `self`: 0.9 of max |grad| off vs CPU, tools/diag_cl_ops2.py; the forward is right).  The engine's conv outputs are
+        # channels-last, so the hidden states arriving here are too; found by pinning the whole-model training gradients to the reference's
+        # CPU autograd (tests/test_gpu_models_e2e.py::test_training_step_matches_reference_autograd: 2-5 % error upstream of the GRUs).
+        p2 = lambda t: F.avg_pool2d(t.contiguous(), 3, stride=2, padding=1)
         ip = lambda t, dest: F.interpolate(t, dest.shape[2:], mode="bilinear", align_corners=True)
         net = list(net)
         if iter16:
@@ -247,6 +254,7 @@ class BasicMultiUpdateBlock(nn.Module):
         with AG.engine_convs():
             return net, self.mask_feat_4(net[0]), self.disp_head(net[0])
 
+    @amp.contract("update")
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         if not on_engine(net[0]):
             raise RuntimeError("openstereo_amd BasicMultiUpdateBlock runs on the GPU engine only (no CPU path)")
@@ -295,6 +303,23 @@ def run_refinement(update_block, a, match_left, match_right, geo_encoding_volume
                                        radius=a.CORR_RADIUS, num_levels=a.CORR_LEVELS)
     b, _, h, w = match_left.shape
     coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+    wants_grad = torch.is_grad_enabled() and (update_block.training or any(
+        t.requires_grad for t in (match_left, match_right, geo_encoding_volume, init_disp, *net_list, *[x for ts in inp_list for x in ts])))
+    if wants_grad:
+        # training mode / gradient-requiring inputs: the differentiable loop (geometry lookup with its backward kernel, update block
+        # through its forward_train path) -- the non-recording forward_cl kernels below would hand back tensors with no graph and the
+        # update block would silently receive no gradients.  igev_stereo.py:181-203: disp is detached every iteration.
+        net, disp, mask = list(net_list), init_disp.float(), None
+        for _ in range(iters):
+            disp = disp.detach()
+            geo_feat = geo_fn(disp, coords)
+            if a.N_GRU_LAYERS == 3 and a.SLOW_FAST_GRU:
+                net = update_block(net, inp_list, iter16=True, iter08=False, iter04=False, update=False)
+            if a.N_GRU_LAYERS >= 2 and a.SLOW_FAST_GRU:
+                net = update_block(net, inp_list, iter16=a.N_GRU_LAYERS == 3, iter08=True, iter04=False, update=False)
+            net, mask, delta = update_block(net, inp_list, geo_feat, disp, iter16=a.N_GRU_LAYERS == 3, iter08=a.N_GRU_LAYERS >= 2)
+            disp = disp + delta
+        return {"disp": disp, "mask_feat_4": mask, "net_list": list(net)}
     c = nchw_to_cl
     net = [c(t) for t in net_list]
     inp = [[c(t) for t in ts] for ts in inp_list]

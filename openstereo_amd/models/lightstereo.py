@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import amp
 from .. import autograd as AG
 from ..engine import cached_pack, PackedConv3d, DepthwiseConv2d, ACT_NONE, ACT_RELU, ACT_RELU6
 from ..ops import empty_cl, is_cl, on_engine
@@ -76,6 +77,7 @@ class MobileV2Residual(nn.Module):
             feat = self.pwliner(self.dwconv(self.pwconv(x)))
         return x + feat if self.use_res_connect else feat
 
+    @amp.contract("res")
     def forward(self, x):
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
             return self.forward_train(x)
@@ -119,6 +121,7 @@ class AttentionModule(nn.Module):
             attn = attn + self.conv0_2(self.conv0_1(attn)) + self.conv1_2(self.conv1_1(attn)) + self.conv2_2(self.conv2_1(attn))
             return self.conv3(attn) * cost
 
+    @amp.contract("gru")                 # conv3(attn) * cost: promoted against the cost's dtype (aggregation.py:45)
     def forward(self, cost, x):
         if self.training or (torch.is_grad_enabled() and (cost.requires_grad or x.requires_grad)):
             return self.forward_train(cost, x)
@@ -199,6 +202,7 @@ class Aggregation(nn.Module):
         conv5 = F.relu(self.conv5(conv4) + self.redir2(conv2))
         return [F.relu(self.conv6(conv5) + self.redir1(x))]
 
+    @amp.contract("gru")                 # relu(conv6(conv5) + redir1(x)): redir1 is a skip block -> promoted against x's dtype (aggregation.py:58-60)
     def forward(self, x, features_left):
         if not on_engine(x):
             raise RuntimeError("openstereo_amd Aggregation runs on the GPU engine only (no CPU path)")

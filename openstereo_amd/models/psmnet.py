@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import autograd as AG
-from .. import ops, timing
+from .. import amp, ops, timing
 from ..engine import cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU, fold_amax
 
 
@@ -135,6 +135,7 @@ class PSMBackbone(nn.Module):
         l0, l1 = pk["last"]
         return l1(l0(cat))
 
+    @amp.contract("cast")
     def forward(self, inputs):
         left, right = inputs["left"], inputs["right"]
         B = left.shape[0]
@@ -204,6 +205,7 @@ class Hourglass(nn.Module):
             post = F.relu(self.conv5(out) + (presqu if presqu is not None else pre))
             return self.conv6(post), pre, post
 
+    @amp.contract("cast")
     def forward(self, x, presqu=None, postsqu=None):
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
             return self.forward_train(x, presqu, postsqu)
@@ -271,6 +273,7 @@ class PSMAggregator(nn.Module):
             cost3 = self.classif3(out3) + cost2
         return cost3, cost2, cost1
 
+    @amp.contract("cast")
     def forward(self, raw_cost):
         B, C, D, H, W = raw_cost.shape
         if self.training or (torch.is_grad_enabled() and raw_cost.requires_grad):
@@ -292,6 +295,7 @@ class PSMCostProcessor(nn.Module):
     def cat_func(self, left, right):
         return ops.cat_fms(left, right, max_disp=int(self.max_disp // 4), start_disp=0, dilation=1)
 
+    @amp.contract("cast")
     def forward(self, inputs):
         """Engine path: keeps the three costs at 1/4 resolution (the fused heads upsample on the fly)."""
         l, r = inputs["ref_feature"], inputs["tgt_feature"]

@@ -57,6 +57,17 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _sum_dtype(*ts):
+    """dtype of `torch.sum(a * b ...)` as the reference writes it (disp_regression.py:11, disp_refinement.py:203): the promoted input
+    dtype -- except inside a CUDA autocast region, where `sum` is on the fp32 list (openstereo_amd/amp.py)."""
+    if torch.is_autocast_enabled("cuda"):
+        return torch.float32
+    dt = ts[0].dtype
+    for t in ts[1:]:
+        dt = torch.promote_types(dt, t.dtype)
+    return dt
+
+
 # --------------------------------------------------------------------------- layouts
 def empty_cl(B, C, D, H, W, device, dtype=torch.float32) -> torch.Tensor:
     """Logical [B,C,D,H,W] tensor stored NDHWC (torch.channels_last_3d strides)."""
@@ -253,7 +264,7 @@ def disparity_regression(x, maxdisp, keepdim=True):
     xs = _f32c(x)
     out = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
     _lib.call("osa_softargmin_f32", xs.data_ptr(), out.data_ptr(), B, D, H, W, _stream())
-    out = out if x.dtype == torch.float32 else out.to(x.dtype)
+    out = out if _sum_dtype(x) == torch.float32 else out.to(x.dtype)
     return out.unsqueeze(1) if keepdim else out
 
 
@@ -302,7 +313,8 @@ def context_upsample(disp_low, up_weights, scale_factor=4, softmax_weights=False
     with timing.span("context_upsample", h, w, scale_factor):
         _lib.call("osa_context_upsample_f32", d.data_ptr(), wt.data_ptr(), out.data_ptr(), b, h, w, int(scale_factor),
                   1 if softmax_weights else 0, float(gain), _stream())
-    return out if disp_low.dtype == torch.float32 else out.to(disp_low.dtype)
+    od = _sum_dtype(disp_low, up_weights)
+    return out if od == torch.float32 else out.to(od)
 
 
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
