@@ -50,6 +50,10 @@ enum { OSA_ACT_NONE = 0, OSA_ACT_RELU = 1, OSA_ACT_LEAKY = 2, OSA_ACT_RELU6 = 3,
 /* OR'ed into `act`: the gate tensor is a plain multiplier (LightStereo AttentionModule, attn * cost,
  * models/lightstereo/aggregation.py:134) instead of logits passed through a sigmoid */
 enum { OSA_GATE_RAW = 16 };
+/* OR'ed into `act`: the gate multiplies output channels [0, n) only (n a multiple of 4; 0 = all of them).  One launch can then
+ * produce [r * h | z] for ConvGRU (update.py:38-39: z and r convolve the same [h | x]): the weights of convr and convz
+ * concatenated, the hidden state as raw gate of the first half. */
+#define OSA_GATE_CHANNELS(n) ((int)((unsigned)(n) << 16))
 /* OR'ed into `act` of the f16x3 conv / deconv calls: "split" activation tensors.  Same bytes per voxel as
  * fp32 NDHWC, but every 16-channel chunk is stored as [16 x fp16 hi | 16 x fp16 lo] (x = hi + lo, the
  * image the kernels stage into LDS), so a consumer copies instead of splitting and a producer splits each
@@ -295,6 +299,21 @@ int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
  */
 int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
                         long long npix, int C, int zCs, int qCs, int hCs, int oCs, float* out_meta, void* stream);
+
+/*
+ * Resampling of the GRU hidden states between the 1/4, 1/8 and 1/16 levels (models/igev/update.py:99-109,
+ * models/stereobase/gru_blocks.py pool2x / interp), NHWC with channel strides so that source and destination can be
+ * channel slices of the per-level [h | x | r*h | z] state buffers (no torch.cat, no copies):
+ *   osa_pool2x_nhwc_f32          F.avg_pool2d(x, 3, stride=2, padding=1)  (count_include_pad: the sum of the 3x3 window / 9)
+ *                                -> [B, floor((H - 1) / 2) + 1, floor((W - 1) / 2) + 1, C]
+ *   osa_resize_bilinear_nhwc_f32 F.interpolate(x, (Ho, Wo), mode='bilinear', align_corners=True)
+ * C, xCs, yCs multiples of 4.  x_meta / y_meta (optional): f16x3 range blocks -- both results are convex combinations of
+ * inputs (or of inputs and zeros), so max |x| is folded into y's block without a reduction over the data.
+ */
+int osa_pool2x_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int xCs, int yCs,
+                        const float* x_meta, float* y_meta, void* stream);
+int osa_resize_bilinear_nhwc_f32(const float* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int xCs, int yCs,
+                                 const float* x_meta, float* y_meta, void* stream);
 
 /* Packing for backward passes.  Ci/Co are the roles of the convolution that will be EXECUTED with the
  * packed buffer; src_transposed=1 reads w_ref as [Ci][Co][k] (instead of [Co][Ci][k]); flip=1 mirrors taps.

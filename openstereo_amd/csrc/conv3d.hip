@@ -69,6 +69,10 @@ static const KernelCfg g_cfgs[] = {
     OSA_CFG(1, 2, 4, 1, 8, 16),  // 13: 128 vox x 64 ch   brick 1x8x16
     OSA_CFG(1, 1, 2, 2, 4, 16),  // 14:  64 vox x 64 ch   brick 1x4x16  (2-D stride-2 layers)
     OSA_CFG(1, 1, 2, 1, 4, 8),   // 15:  64 vox x 32 ch   brick 2x4x8   (stride-2 layers with <= 32 outputs; 2 waves)
+#ifdef OSA_EXPERIMENTS
+    OSA_CFG_PINGPONG(2, 1, 8, 1, 8, 8),   // 16: 512 vox x 32 ch  brick 8x8x8, 8 waves (halo amplification 1.95x instead of 2.34x)
+    OSA_CFG(2, 2, 8, 1, 8, 8),            // 17: 512 vox x 64 ch  brick 8x8x8, 8 waves
+#endif
 };
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -220,6 +224,46 @@ static int launch_conv_pipe(ConvArgs& a, int stride, int prec, hipStream_t st, c
 
 #endif   // OSA_EXPERIMENTS
 
+// Start-up stagger of the first dispatch wave (conv_kernel.h).  slots = workgroups that share a CU (LDS and wave limits), period =
+// what one workgroup lasts when it has the CU to itself in every phase -- modelled from the launch geometry, not measured:
+//   taps   : MFMAs per wave x 32 (f16x3: 3 per product, 8 passes x 4 cycles) or x 64 (f32: 32x32x2, 16 passes) cycles
+//   memory : bytes the workgroup moves (staged brick x chunks + output tile + residual) at its share of ~4 TB/s
+// Slot s starts s * period / slots late.  Launches that do not fill the chip twice over gain nothing and are left alone.
+static int resident_workgroups(void (*fn)(const ConvArgs), int threads, size_t lds) {
+    // what the hardware will co-schedule on one CU (registers, LDS, wave slots), memoised per (kernel, LDS size)
+    struct Key { const void* f; size_t l; int n; };
+    static Key cache[64]; static int used = 0;
+    for (int i = 0; i < used; ++i) if (cache[i].f == (const void*)fn && cache[i].l == lds) return cache[i].n;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fn, threads, lds) != hipSuccess) { (void)hipGetLastError(); n = 1; }
+    if (used < 64) cache[used++] = Key{(const void*)fn, lds, n};
+    return n;
+}
+
+static void set_stagger(ConvArgs& a, const KernelCfg& k, void (*fn)(const ConvArgs), size_t lds, long long nwg, bool deconv, int prec) {
+    a.stag_ticks = 0; a.stag_n = 0; a.stag_cus = 256;
+    const int mode = exp_int("OSA_STAG", 0);      // measured neutral (profiles/round3/stagger_sweep_B8.txt): experiments build only
+    if (!mode) return;
+    const int waves = k.threads / 64;
+    int slots = resident_workgroups(fn, k.threads, lds);
+    { const int o = exp_int("OSA_STAG_K", 0); if (o) slots = o; }
+    if (slots < 2 || nwg < (long long)2 * slots * 256) return;
+    // period model (cycles at ~2 GHz -> 10 ns ticks)
+    const double mfma_per_wave = (double)a.nchunks * a.T * ((double)k.M * k.N / 1024.0 / waves) * (prec == PREC_F16X3 ? 3.0 : 8.0);
+    const double tap_us = mfma_per_wave * (prec == PREC_F16X3 ? 32.0 : 64.0) / 2000.0;
+    const double bytes = (double)a.LD * a.LH * a.LW * 64.0 * a.nchunks + (double)k.M * (deconv ? 8 : 1) * k.N * 4.0 * (a.res || a.rx ? 2 : 1);
+    const double mem_us = bytes / (4.0e6 / 256.0);         // 4 TB/s over 256 CUs = 15.6 KB/us per CU
+    // de-phased steady state: the CU's matrix pipes need slots * tap_us per round of its workgroups, its memory share slots * mem_us,
+    // and a single workgroup cannot finish faster than tap_us + mem_us  ->  consecutive slots start max(...) / slots apart
+    double step_us = tap_us > mem_us ? tap_us : mem_us;
+    if ((tap_us + mem_us) / slots > step_us) step_us = (tap_us + mem_us) / slots;
+    { const int o = exp_int("OSA_STAG_PCT", 100); step_us *= o / 100.0; }
+    { const int o = exp_int("OSA_STAG_US10", 0); if (o) step_us = o / 10.0; }
+    a.stag_ticks = (int)(step_us * 100.0 + 0.5);
+    a.stag_n = slots * 256; a.stag_cus = 256;
+    if (exp_int("OSA_STAG_PRINT", 0)) fprintf(stderr, "[stagger] %s slots %d tap %.2f us mem %.2f us step %.2f us\n", k.name, slots, tap_us, mem_us, step_us);
+}
+
 static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what,
                        const KernelCfg* forced = nullptr) {
 #ifdef OSA_EXPERIMENTS
@@ -291,9 +335,9 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
                                                           "%s: split residual needs Co, rCs %% 16 == 0", what);
         if ((a.act & OSA_REDIR_SPLIT) && a.rx) OSA_REQUIRE(a.rCi % 16 == 0, "%s: split redir input needs channels %% 16 == 0", what);
     }
-    // LDS-DMA staging of split inputs: measured throughput-neutral at 4 workgroups per CU (block-level overlap
-    // already hides the staging), so it is opt-in (OSA_DMA=1) until the tap loop is pipelined across barriers
-    a.dma = (exp_int("OSA_DMA", 0) && prec == PREC_F16X3 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0;
+    // LDS-DMA staging of split inputs (one global_load_lds_dwordx4 per brick row, no VGPR round trip): +1 % on the whole GwcNet step
+    // (interleaved A/B, profiles/round3/ab_dma_s2u.txt); OSA_DMA=0 in the experiments build switches it off
+    a.dma = (exp_int("OSA_DMA", 1) && prec == PREC_F16X3 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0;
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = exp_set("OSA_NORING");
     void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];
@@ -304,6 +348,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
+    set_stagger(a, k, fn, lds, (long long)grid.x * grid.y, forced != nullptr, prec);
     hipLaunchKernelGGL(fn, grid, block, lds, st, a);
     OSA_LAUNCH_CHECK(what);
     return 0;

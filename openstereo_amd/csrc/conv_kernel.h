@@ -76,6 +76,7 @@ struct ConvArgs {
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
     unsigned magicH;              // ceil(2^32/LH)
     int dma;                      // 1: split input + compact LDS image -> stage rows by LDS-DMA (global_load_lds_dwordx4)
+    int stag_ticks, stag_n, stag_cus;   // start-up stagger: workgroups with linear id < stag_n wait (id / stag_cus) * stag_ticks 10-ns ticks (0: off)
     // f16x3 range tracking (see osa_f16x3_ranges in the header); every pointer may be NULL.  A "meta" block is
     // OSA_META_FLOATS floats of device memory per tensor: running max |value| in 8 slots (osa_common.h),
     // [1] = power-of-two scale of the stored hi/lo halves when the tensor is a split tensor.
@@ -139,13 +140,13 @@ __device__ __forceinline__ float4 join_f16(const uint2 hi, const uint2 lo) {
 __device__ __forceinline__ int split_off_hi(int c) { return (c >> 4) * 16 + ((c & 15) >> 2) * 2; }
 __device__ __forceinline__ int split_off_lo(int c) { return split_off_hi(c) + 8; }
 
-template <int NTHR, int PREC, int NCL>
-__device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
-                                            int g0d, int g0h, int g0w, int tid, float s_in = 1.f) {
 #ifndef OSA_STAGE_U
 #define OSA_STAGE_U 4
 #endif
-    constexpr int U = (NCL == 1) ? OSA_STAGE_U : OSA_STAGE_U / 2;
+template <int NTHR, int PREC, int NCL, int SU = OSA_STAGE_U>
+__device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
+                                            int g0d, int g0h, int g0w, int tid, float s_in = 1.f) {
+    constexpr int U = (NCL == 1) ? SU : SU / 2;
     const int total = p.LD * p.LH * p.LW * (CC / 4);
     const int LHW = p.LH * p.LW;
     // wave-uniform 64-bit base of batch item b / chunk c0; per-lane offsets are 32-bit (host checks < 2^31 elements)
@@ -269,7 +270,15 @@ template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, in
 // Waves per SIMD every instantiation is compiled for (its accumulators set the scale: 16 registers per 32x32 tile).  Stated
 // explicitly: left to itself the compiler spends registers on scheduling freedom (the straight-line fast epilogue gives it
 // plenty) and silently drops a wave per SIMD, which costs more than any schedule gains.
-#define OSA_WAVES_PER_SIMD (PIPE ? 3 : ((NCLS == 8) ? 2 : ((NCLS >= 4) ? 3 : ((MT * NT == 1) ? 4 : ((MT * NT == 2) ? ((MT == 2) ? 4 : 3) : 2)))))
+// Stride-2 tiles (64-voxel bricks 2x4x8 of two M-tile waves: configurations 5, 6, 15): the strided input brick is 5x9x17 voxels = 63 KB per
+// chunk, so two workgroups share a CU whatever the registers allow -- the launch is bound by the latency of its staging loads (12 per
+// thread and chunk at 4 in flight = 3 HBM round trips per pass).  They are compiled for 2 waves per SIMD and keep a whole chunk's loads in
+// flight (OSA_S2_U).
+#ifndef OSA_S2_U
+#define OSA_S2_U 12
+#endif
+#define OSA_S2TILE (NCLS == 1 && WM == 2 && TH == 4 && TW == 8 && !PIPE && KS == 1)
+#define OSA_WAVES_PER_SIMD (PIPE ? 3 : ((NCLS == 8) ? 2 : ((NCLS >= 4) ? 3 : ((OSA_S2TILE && OSA_S2_U > 4) ? 2 : ((MT * NT == 1) ? 4 : ((MT * NT == 2) ? ((MT == 2) ? 4 : 3) : 2))))))
 #define OSA_MIN_BLOCKS OSA_WAVES_PER_SIMD          // HIP: the second __launch_bounds__ argument is waves per SIMD (execution unit)
 __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM * WN * KS / 4) : OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(KS == 1 || (NCLS == 1 && !PIPE && !REDIR), "split-K: plain convolutions");
@@ -508,15 +517,22 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         }
     };
 
-#ifdef OSA_EXPERIMENTS
-    // experiment (OSA_DBG = 512 | us << 16): the second workgroup of every CU (ids 256..511 of the first dispatch round) starts `us`
-    // microseconds late, so the two co-resident workgroups -- and with them one half of the chip -- run their memory phase (epilogue)
-    // while the other half runs its taps
-    if ((p.dbg & 512) && blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t0 = wall_clock64(), ticks = (unsigned long long)(p.dbg >> 16) * 100ull;
-        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    // ---- start-up stagger (de-phasing).  Every workgroup of a launch does the same work in the same time, so the workgroups that
+    // share a CU -- and with them the whole chip -- march through "stage (HBM) -> taps (MFMA) -> epilogue (HBM)" in lock step: the
+    // matrix pipes idle while everybody stages or stores, HBM idles while everybody runs taps, and the launch costs the SUM of
+    // its phases although 2-4 workgroups per CU could overlap them (in-kernel timeline, profiles/round2/deconv_epilogue.txt).  The
+    // workgroups of the first dispatch wave that land in residency slot s of their CU (dispatch order: slot = linear id / #CUs)
+    // start s * stag_ticks later (100 MHz wall clock); their successors inherit the phase because every workgroup lasts equally long.
+    if (p.stag_ticks) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if (lin < (unsigned)p.stag_n) {
+            const unsigned slot = lin / (unsigned)p.stag_cus;
+            if (slot) {
+                const unsigned long long t0 = wall_clock64(), ticks = (unsigned long long)slot * (unsigned)p.stag_ticks;
+                while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+            }
+        }
     }
-#endif
     OSA_TRACE(0);
     [[maybe_unused]] int trace_ev = 1;
     if constexpr (KS > 1) {
@@ -562,11 +578,12 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             for (int cl = 0; cl < ncl; ++cl)
                 stage_brick_dma<NW * 64>(p, smem + cl * brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
         } else if (!(p.dbg & 1)) {
+            constexpr int SU = OSA_S2TILE ? OSA_S2_U : OSA_STAGE_U;
             int cl = 0;
             for (; cl + 2 <= ncl; cl += 2)
-                stage_brick<NW * 64, PREC, 2>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
+                stage_brick<NW * 64, PREC, 2, SU>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
             if (cl < ncl)
-                stage_brick<NW * 64, PREC, 1>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
+                stage_brick<NW * 64, PREC, 1, SU>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
         }
         OSA_TRACE(trace_ev); ++trace_ev;                 // own staging loads issued + written
         __syncthreads();
@@ -637,6 +654,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
     const int vsub = lane >> 3, cq = (lane & 7) * 4;   // voxel within a group of 8, channel quad
     const int actk = p.act & 15;
     const bool gate_raw = (p.act & OSA_GATE_RAW) != 0;
+    const int gate_co = ((unsigned)p.act >> 16) ? (int)((unsigned)p.act >> 16) : 0x7fffffff;   // OSA_GATE_CHANNELS(n): gate output channels < n only
     // ---- fast path.  Workgroups whose brick lies inside the tensor, with every channel of their N tiles present,
     // 16-byte aligned rows, no gate and a cheap activation (none / ReLU / LeakyReLU / ReLU6) -- i.e. nearly all workgroups
     // of a full-size layer -- finalise their tiles with STRAIGHT-LINE code (FULL = true below): no per-lane predicate, no
@@ -741,7 +759,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         for (int k = 0; k < 4; ++k) {
             av[k] = *reinterpret_cast<const float4*>(tb + (vsub + 8 * k) * 36 + cq);
             gv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!FULL && !REDIR && p.gate && vok[k] && cok) {
+            if (!FULL && !REDIR && p.gate && vok[k] && cok && co < gate_co) {
                 const float* gp = gateb + (g0[k] + goff) * p.gCs + co;
                 if (vec4) gv[k] = *reinterpret_cast<const float4*>(gp);
                 else {
@@ -773,7 +791,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
                 else if (actk == OSA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
                 else if (actk == OSA_ACT_TANH) v = tanhf(v);
-                if (!REDIR && p.gate) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
+                if (!REDIR && p.gate && co < gate_co) v *= gate_raw ? g4[e] : 1.0f / (1.0f + expf(-g4[e]));
                 o[e] = v;
             }
             if constexpr (FULL) {

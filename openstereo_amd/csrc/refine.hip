@@ -130,8 +130,10 @@ extern "C" int osa_preprocess_pair_f32(const void* left_hwc, const void* right_h
 
 // ------------------------------------------------------------------ ConvGRU state update --
 namespace osa {
+// h and out may be the same buffer (the hidden state is updated in place inside its level's state buffer): element-wise, every
+// thread reads its own quad before it writes it
 __global__ __launch_bounds__(256) void gru_combine_kernel(const float* __restrict__ z, const float* __restrict__ q,
-                                                          const float* __restrict__ h, float* __restrict__ out,
+                                                          const float* h, float* out,
                                                           long long total, int nq, int zCs, int qCs, int hCs, int oCs, float* meta) {
     __shared__ float red[4];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -164,5 +166,107 @@ extern "C" int osa_gru_combine_f32(const float* z, const float* q, const float* 
     hipLaunchKernelGGL(osa::gru_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        z, q, h, out, total, C / 4, zCs, qCs, hCs, oCs, out_meta);
     OSA_LAUNCH_CHECK("gru_combine");
+    return 0;
+}
+
+
+// ------------------------------------------------------------------ hidden-state resampling (update.py:99-109) --
+namespace osa {
+// y's range block >= x's: one thread folds max |x| (read from x's block) into slot 0 of y's
+__device__ __forceinline__ void inherit_amax(const float* xmeta, float* ymeta) {
+    if (xmeta && ymeta && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(ymeta), __builtin_bit_cast(unsigned, amax_read(xmeta)));
+}
+
+// F.avg_pool2d(x, 3, stride=2, padding=1), count_include_pad=True: (sum over the window, zeros outside) / 9; one thread = one
+// output pixel x 4 channels, window rows outer / columns inner like ATen's kernel
+__global__ __launch_bounds__(256) void pool2x_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                          int C4, int xCs, int yCs, long long total, const float* xmeta, float* ymeta) {
+    inherit_amax(xmeta, ymeta);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4) * 4;
+    long long px = i / C4;
+    const int wo = (int)(px % Wo); px /= Wo;
+    const int ho = (int)(px % Ho);
+    const long long b = px / Ho;
+    const float* xb = x + b * (long long)H * W * xCs + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((long long)hi * W + wi) * xCs);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((b * Ho + ho) * Wo + wo) * yCs + c) = make_float4(s.x / 9.f, s.y / 9.f, s.z / 9.f, s.w / 9.f);
+}
+
+// F.interpolate(mode='bilinear', align_corners=True): source index = dst * (in - 1) / (out - 1), ATen's upsample_bilinear2d
+// arithmetic (h1 = (int)h1r, lambda1 = h1r - h1, lambda0 = 1 - lambda1; out = l0h * (l0w * v00 + l1w * v01) + l1h * (l0w * v10 + l1w * v11))
+__global__ __launch_bounds__(256) void resize_bilinear_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
+                                                                   int C4, int xCs, int yCs, float rh, float rw, long long total,
+                                                                   const float* xmeta, float* ymeta) {
+    inherit_amax(xmeta, ymeta);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4) * 4;
+    long long px = i / C4;
+    const int wo = (int)(px % Wo); px /= Wo;
+    const int ho = (int)(px % Ho);
+    const long long b = px / Ho;
+    const float h1r = rh * ho, w1r = rw * wo;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = (h1 < Hi - 1) ? 1 : 0, w1p = (w1 < Wi - 1) ? 1 : 0;
+    const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+    const float* xb = x + b * (long long)Hi * Wi * xCs + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(xb + ((long long)h1 * Wi + w1) * xCs);
+    const float4 v01 = *reinterpret_cast<const float4*>(xb + ((long long)h1 * Wi + w1 + w1p) * xCs);
+    const float4 v10 = *reinterpret_cast<const float4*>(xb + ((long long)(h1 + h1p) * Wi + w1) * xCs);
+    const float4 v11 = *reinterpret_cast<const float4*>(xb + ((long long)(h1 + h1p) * Wi + w1 + w1p) * xCs);
+    float4 o;
+    o.x = h0l * (w0l * v00.x + w1l * v01.x) + h1l * (w0l * v10.x + w1l * v11.x);
+    o.y = h0l * (w0l * v00.y + w1l * v01.y) + h1l * (w0l * v10.y + w1l * v11.y);
+    o.z = h0l * (w0l * v00.z + w1l * v01.z) + h1l * (w0l * v10.z + w1l * v11.z);
+    o.w = h0l * (w0l * v00.w + w1l * v01.w) + h1l * (w0l * v10.w + w1l * v11.w);
+    *reinterpret_cast<float4*>(y + ((b * Ho + ho) * Wo + wo) * yCs + c) = o;
+}
+}  // namespace osa
+
+static int check_nhwc(const char* what, const float* x, float* y, int C, int xCs, int yCs) {
+    OSA_REQUIRE(x && y, "%s: NULL pointer", what);
+    OSA_REQUIRE(C > 0 && C % 4 == 0 && xCs >= C && yCs >= C && ((xCs | yCs) & 3) == 0, "%s: C=%d xCs=%d yCs=%d must be multiples of 4, strides >= C", what, C, xCs, yCs);
+    OSA_REQUIRE((((size_t)x | (size_t)y) & 15) == 0, "%s: pointers must be 16-byte aligned", what);
+    return 0;
+}
+
+extern "C" int osa_pool2x_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int xCs, int yCs,
+                                   const float* x_meta, float* y_meta, void* stream) {
+    if (check_nhwc("pool2x", x, y, C, xCs, yCs)) return -1;
+    OSA_REQUIRE(B > 0 && H > 0 && W > 0, "pool2x: bad dims");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    OSA_REQUIRE((total + 255) / 256 < (1ll << 31), "pool2x: grid too large");
+    hipLaunchKernelGGL(osa::pool2x_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, H, W, Ho, Wo, C / 4, xCs, yCs, total, x_meta, y_meta);
+    OSA_LAUNCH_CHECK("pool2x");
+    return 0;
+}
+
+extern "C" int osa_resize_bilinear_nhwc_f32(const float* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int xCs, int yCs,
+                                            const float* x_meta, float* y_meta, void* stream) {
+    if (check_nhwc("resize_bilinear", x, y, C, xCs, yCs)) return -1;
+    OSA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "resize_bilinear: bad dims");
+    const float rh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, rw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    OSA_REQUIRE((total + 255) / 256 < (1ll << 31), "resize_bilinear: grid too large");
+    hipLaunchKernelGGL(osa::resize_bilinear_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, Hi, Wi, Ho, Wo, C / 4, xCs, yCs, rh, rw, total, x_meta, y_meta);
+    OSA_LAUNCH_CHECK("resize_bilinear");
     return 0;
 }
