@@ -300,6 +300,13 @@ int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
 int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
                         long long npix, int C, int zCs, int qCs, int hCs, int oCs, float* out_meta, void* stream);
 
+/* Disparity update of the GRU loop (igev_stereo.py:201 `disp = disp + delta_disp`) with the copies its consumers read:
+ *   disp [npix] += delta[p * delta_cs] (delta NULL: unchanged);  disp_nhwc4 [npix][4] = (disp, 0, 0, 0) (input of the motion encoder's
+ *   7x7 convd1, update.py:87);  slot[p * slot_cs] = disp (the `torch.cat([out, disp])` channel of the 1/4 level, update.py:92).
+ *   Optional range blocks of the two NHWC destinations receive max |disp|.  Any of disp_nhwc4 / slot may be NULL. */
+int osa_disp_update_f32(float* disp, const float* delta, int delta_cs, float* disp_nhwc4, float* slot, int slot_cs,
+                        long long npix, float* disp4_meta, float* slot_meta, void* stream);
+
 /*
  * Resampling of the GRU hidden states between the 1/4, 1/8 and 1/16 levels (models/igev/update.py:99-109,
  * models/stereobase/gru_blocks.py pool2x / interp), NHWC with channel strides so that source and destination can be
@@ -420,6 +427,12 @@ int osa_geo_lookup_f32(const float* const* geo_levels, const float* const* corr_
                        const int* geo_len, const int* corr_len, int levels,
                        const float* disp, const float* coords_x, float* out,
                        int B, int H, int W, int C, int radius, void* stream);
+/* The same lookup, channels-last: out [B,H,W,out_cs], channel index as above, channels beyond (C+1)*(2r+1)*levels zero-filled --
+ * the layout the update block's motion encoder (1x1 convc1, update.py:85) reads, so the GRU loop needs no transpose per iteration. */
+int osa_geo_lookup_nhwc_f32(const float* const* geo_levels, const float* const* corr_levels,
+                            const int* geo_len, const int* corr_len, int levels,
+                            const float* disp, const float* coords_x, float* out, int out_cs,
+                            int B, int H, int W, int C, int radius, void* stream);
 /* Gradient of osa_geo_lookup_f32 with respect to the pyramid levels (the disparity is detached in the reference's loop,
  * models/igev/igev_stereo.py:190): dgeo_levels / dcorr_levels have the shapes of geo_levels / corr_levels, are zero-filled and then
  * accumulated without atomics (every pixel owns its rows).  dout: [B,(C+1)*(2r+1)*levels,H,W]. */

@@ -125,6 +125,7 @@ SIGNATURES = {
                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                     c_i, c_fp, c_st]),
     "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
+    "osa_disp_update_f32": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_ll, c_fp, c_fp, c_st]),
     "osa_pool2x_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_resize_bilinear_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_context_upsample_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
@@ -133,6 +134,8 @@ SIGNATURES = {
     "osa_avgpool_rows_f32": (c_i, [c_fp, c_fp, c_ll, c_i, c_st]),
     "osa_geo_lookup_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
                                  c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_geo_lookup_nhwc_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
+                                      c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_geo_lookup_bwd_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
                                      c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_preprocess_pair_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_fp, c_i, c_st]),

@@ -226,6 +226,7 @@ M = "stereo.modeling.models."
 def _graft_plan():
     from .models import gwcnet as GW, psmnet as PSM, igev_style as IG, lightstereo as LS, igev_update as UP
     fwd = ("forward", "forward_cl", "forward_train", "_pack", "reset_engine")
+    gru = ("_packs", "new_level", "step", "_levels")          # per-level state buffers of the update block (igev_update.py)
     return [
         # (reference module, {reference class: (mirror class, methods, keep the reference forward for training)})
         (M + "gwcnet.hourglass", {"Hourglass": (GW.Hourglass, fwd, False)}),                                   # hourglass.py:46-56
@@ -244,8 +245,8 @@ def _graft_plan():
         (M + "igev.submodule", {"FeatureAtt": (IG.IGEVFeatureAtt, ("logits",), False)}),
         (M + "igev.igev_stereo", {"hourglass": (IG.hourglass, ("forward", "forward_cl", "forward_train", "_unit_train", "_packed_layers", "reset_engine"), False)}),  # :51-76
         (M + "lightstereo.aggregation", {c: (getattr(LS, c), fwd, False) for c in ("Aggregation", "MobileV2Residual", "AttentionModule")}),
-        (M + "igev.update", {c: (getattr(UP, c), fwd, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
-        (M + "stereobase.gru_blocks", {c: (getattr(UP, c), fwd, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
+        (M + "igev.update", {c: (getattr(UP, c), fwd + gru, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
+        (M + "stereobase.gru_blocks", {c: (getattr(UP, c), fwd + gru, False) for c in ("ConvGRU", "BasicMotionEncoder", "DispHead", "BasicMultiUpdateBlock")}),
     ]
 
 

@@ -109,8 +109,11 @@ static int pick_cfg(const ConvArgs& a, int stride) {
         // tiles leave most of the 256 CUs without a workgroup and every workgroup walks the whole K loop alone -- the 32- / 64-pixel
         // tiles are 2.4x faster there (gru16 256->128 @34x60: 0.061 -> 0.025 ms, gru08 384->128 @68x120: 0.094 -> 0.038 ms,
         // 768->192 1x1 @24x78: 0.045 -> 0.032 ms; tools/bench_layers.py --set gru)
+        // r3 (tools/bench_gru_cfgs.sh, 4 pairs per launch, profiles/round3/gru_tile_sweep_B4.txt): the 32-pixel tile wins until the
+        // 128-pixel grid has ~3 workgroups per CU -- gru08 r|z 384->256 @68x120 (510 workgroups): 0.224 -> 0.197 ms, gru08 q (255): 0.148 ->
+        // 0.100 ms, gru16 r|z: 0.073 -> 0.054 ms; from 1020 workgroups on (gru04 q) the 128-pixel tile is 20 % faster
         const long long tiles128 = (vox + 127) / 128;
-        if (a.CoP % 128 == 0) return (tiles128 * (a.CoP / 128) < 128) ? 11 : 9;     // 32 or 128 pixels x 128 channels
+        if (a.CoP % 128 == 0) return (tiles128 * (a.CoP / 128) < 768) ? 11 : 9;     // 32 or 128 pixels x 128 channels
         if (a.CoP % 64 == 0) return (tiles128 * (a.CoP / 64) < 128) ? 14 : 13;       // 64 or 128 pixels x 64 channels
         return 12;                                                                   // 128 pixels x 32 channels
     }
@@ -283,8 +286,13 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     if (!forced && (ci == 11 || ci == 14) && a.Ad == 1 && !(a.act & OSA_OUT_SPLIT)) {
         // small 2-D map on the 32- / 64-pixel tiles: still few workgroups, each alone with a long K loop -> split K inside the
         // workgroup when the chunk count allows (4 groups from 16 chunks on, 2 groups from 8)
+        // ... and only while the grid is still small: with >= 192 workgroups (gru16 at 4 pairs per launch: 255) the plain 32-pixel tile is
+        // faster than any split (0.035 vs 0.037 / 0.045 ms for 2 / 4 groups), below ~96 workgroups four groups pay (one pair per launch)
         const int want = exp_int("OSA_KS", -1);
+        const long long nwg = (((long long)a.B * a.Ad * a.Ah * a.Aw + g_cfgs[ci].M - 1) / g_cfgs[ci].M) * (a.CoP / g_cfgs[ci].N);
         int ks = (a.nchunks % 4 == 0 && a.nchunks >= 16) ? 4 : ((a.nchunks % 2 == 0 && a.nchunks >= 8) ? 2 : 1);
+        if (nwg >= 192) ks = 1;
+        else if (nwg >= 96 && ks == 4) ks = 2;
         if (want >= 0) ks = (want > 1 && a.nchunks % want == 0) ? want : 1;
         if (ks == 4) kp = &g_ks_cfgs[ci == 11 ? 0 : 1];
         else if (ks == 2) kp = &g_ks_cfgs[ci == 11 ? 2 : 3];

@@ -135,6 +135,56 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const LookupArgs p) {
     }
 }
 
+// Channels-last form for the engine's GRU loop: out [B,H,W,Cs] (Cs >= channels, the padding zero-filled), i.e. what the update
+// block's 1x1 convc1 reads -- the NCHW result of the kernel above had to be transposed every iteration (85 MB at 4 pairs).  One thread =
+// one (pixel, row): row j < levels * (C + 1) is geometry row c of level l or that level's correlation row, and produces the 2r + 1 taps of
+// its row = 2r + 1 consecutive output channels, so the threads of a pixel write its channel vector contiguously; 18x the threads of the
+// per-pixel kernel and 18 loads per thread instead of 324.  Same tap arithmetic (tap_of / sample_row), same values.
+template <int TAPS>      // TAPS = 2 * radius + 1 known at compile time (9 in every shipped config), 0 = generic
+__global__ __launch_bounds__(256) void geo_lookup_nhwc_kernel(const LookupArgs p, int Cs) {
+    const int rows_per_px = p.levels * (p.C + 1);
+    const unsigned npix = (unsigned)p.B * p.H * p.W;                // host: B*H*W*rows < 2^31
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= npix * (unsigned)rows_per_px) return;
+    const unsigned i = t / (unsigned)rows_per_px;
+    const int j = (int)(t - i * (unsigned)rows_per_px);
+    const int l = j / (p.C + 1), c = j - l * (p.C + 1);
+    const int taps = TAPS ? TAPS : 2 * p.radius + 1;
+    const float scale = 1.f / (float)(1 << l);                     // exact: the per-pixel kernel multiplies 0.5f l times
+    const float d = p.disp[i], cx = p.coords[i];
+    float* o = p.out + (size_t)i * Cs + (size_t)j * taps;
+    const bool is_corr = (c == p.C);
+    const int n = is_corr ? p.Wl[l] : p.Dl[l];
+    const float* row = is_corr ? p.corr[l] + (size_t)i * p.Wl[l] : p.geo[l] + ((size_t)i * p.C + c) * p.Dl[l];
+    const float x = is_corr ? (cx * scale - d * scale) : d * scale;
+    if constexpr (TAPS > 0) {
+        // all loads first, unconditionally (index clamped into the row, the value dropped by a select): 2 * TAPS independent requests
+        // in flight per thread instead of a branch and a wait per tap
+        Tap tp[TAPS]; float a[TAPS], b[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const float dx = (float)(k - TAPS / 2);
+            tp[k] = tap_of(is_corr ? x + dx : dx + x, n);           // operand order of geometry.py:36 / :44
+            const int i0 = tp[k].x0 < 0 ? 0 : (tp[k].x0 > n - 1 ? n - 1 : tp[k].x0);
+            const int i1 = tp[k].x0 + 1 < 0 ? 0 : (tp[k].x0 + 1 > n - 1 ? n - 1 : tp[k].x0 + 1);
+            a[k] = row[i0]; b[k] = row[i1];
+        }
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+            const float av = (tp[k].x0 >= 0 && tp[k].x0 < n) ? a[k] : 0.f;
+            const float bv = (tp[k].x0 + 1 >= 0 && tp[k].x0 + 1 < n) ? b[k] : 0.f;
+            o[k] = av * tp[k].w0 + bv * tp[k].w1;                   // == sample_row
+        }
+    } else {
+        for (int k = 0; k < taps; ++k) {
+            const float dx = (float)(k - p.radius);
+            o[k] = sample_row(row, n, tap_of(is_corr ? x + dx : dx + x, n));
+        }
+    }
+    if (j == rows_per_px - 1)
+        for (int k = rows_per_px * taps; k < Cs; ++k) p.out[(size_t)i * Cs + k] = 0.f;
+}
+
 // Backward of the lookup w.r.t. the pyramid levels (the disparity is detached in the reference, igev_stereo.py:190): every pixel owns
 // its rows of every level, so a thread adds its taps into its own (zero-filled) rows -- no atomics, deterministic.
 struct LookupBwdArgs {
@@ -227,6 +277,28 @@ extern "C" int osa_avgpool_rows_f32(const float* x, float* y, long long rows, in
     const long long total = rows * (n / 2);
     hipLaunchKernelGGL(avgpool_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, rows, n);
     OSA_LAUNCH_CHECK("avgpool_rows");
+    return 0;
+}
+
+extern "C" int osa_geo_lookup_nhwc_f32(const float* const* geo_levels, const float* const* corr_levels,
+                                       const int* geo_len, const int* corr_len, int levels,
+                                       const float* disp, const float* coords_x, float* out, int out_cs,
+                                       int B, int H, int W, int C, int radius, void* stream) {
+    OSA_REQUIRE(geo_levels && corr_levels && geo_len && corr_len && disp && coords_x && out, "geo_lookup_nhwc: NULL pointer");
+    OSA_REQUIRE(levels >= 1 && levels <= 4, "geo_lookup_nhwc: %d levels unsupported (1..4)", levels);
+    OSA_REQUIRE(out_cs >= levels * (C + 1) * (2 * radius + 1), "geo_lookup_nhwc: channel stride %d < %d channels", out_cs, levels * (C + 1) * (2 * radius + 1));
+    LookupArgs a;
+    for (int l = 0; l < levels; ++l) {
+        OSA_REQUIRE(geo_levels[l] && corr_levels[l] && geo_len[l] > 0 && corr_len[l] > 0, "geo_lookup_nhwc: level %d missing", l);
+        a.geo[l] = geo_levels[l]; a.corr[l] = corr_levels[l]; a.Dl[l] = geo_len[l]; a.Wl[l] = corr_len[l];
+    }
+    a.disp = disp; a.coords = coords_x; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.levels = levels; a.radius = radius;
+    const long long total = (long long)B * H * W * levels * (C + 1);
+    OSA_REQUIRE(total < (1ll << 31), "geo_lookup_nhwc: more than 2^31 (pixel, row) pairs");
+    if (radius == 4) hipLaunchKernelGGL(geo_lookup_nhwc_kernel<9>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, out_cs);
+    else hipLaunchKernelGGL(geo_lookup_nhwc_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, out_cs);
+    OSA_LAUNCH_CHECK("geo_lookup_nhwc");
     return 0;
 }
 

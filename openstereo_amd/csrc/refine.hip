@@ -270,3 +270,39 @@ extern "C" int osa_resize_bilinear_nhwc_f32(const float* x, float* y, int B, int
     OSA_LAUNCH_CHECK("resize_bilinear");
     return 0;
 }
+
+
+// ------------------------------------------------------------------ disparity update of the GRU loop (igev_stereo.py:201) --
+namespace osa {
+// disp += delta (delta: channel 0 of an NHWC tensor, may be NULL = 0), and the copies the next iteration's consumers read: the NCHW
+// [B,1,H,W] map itself (geometry lookup), an NHWC [B,H,W,4] map with the disparity in channel 0 and zeros behind it (7x7 convd1 of the motion
+// encoder) and one channel of the 1/4 GRU level's state buffer (`torch.cat([out, disp])`, update.py:92).  max |disp| is folded into the
+// range blocks of the two NHWC destinations.
+__global__ __launch_bounds__(256) void disp_update_kernel(float* disp, const float* __restrict__ delta, int dCs, float* __restrict__ disp4,
+                                                          float* __restrict__ slot, int sCs, long long n, float* meta4, float* meta_slot) {
+    __shared__ float red[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned seen4 = meta4 ? amax_peek(meta4) : 0u, seen_s = meta_slot ? amax_peek(meta_slot) : 0u;
+    float am = 0.f;
+    if (i < n) {
+        const float v = disp[i] + (delta ? delta[i * dCs] : 0.f);
+        disp[i] = v;
+        if (disp4) *reinterpret_cast<float4*>(disp4 + i * 4) = make_float4(v, 0.f, 0.f, 0.f);
+        if (slot) slot[i * sCs] = v;
+        am = fabsf(v);
+    }
+    if (meta4) publish_amax(meta4, am, seen4, red);
+    if (meta_slot) publish_amax(meta_slot, am, seen_s, red);
+}
+}  // namespace osa
+
+extern "C" int osa_disp_update_f32(float* disp, const float* delta, int delta_cs, float* disp_nhwc4, float* slot, int slot_cs,
+                                   long long npix, float* disp4_meta, float* slot_meta, void* stream) {
+    OSA_REQUIRE(disp && npix > 0, "disp_update: bad arguments");
+    OSA_REQUIRE(!disp_nhwc4 || (((size_t)disp_nhwc4) & 15) == 0, "disp_update: the NHWC map must be 16-byte aligned");
+    OSA_REQUIRE((npix + 255) / 256 < (1ll << 31), "disp_update: grid too large");
+    hipLaunchKernelGGL(osa::disp_update_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       disp, delta, delta_cs, disp_nhwc4, slot, slot_cs, npix, disp4_meta, slot_meta);
+    OSA_LAUNCH_CHECK("disp_update");
+    return 0;
+}

@@ -197,12 +197,13 @@ class PackedConv3d:
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
     def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False, redir=None,
-                 out_split=False):
+                 out_split=False, gate_channels=0):
         """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
         Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
         multiplied by sigmoid(gate) broadcast over D (FeatureAtt); gate_raw=True multiplies by the
-        gate itself (LightStereo AttentionModule: attn * cost).  redir=(layer, t): a transposed conv adds
+        gate itself (LightStereo AttentionModule: attn * cost); gate_channels=n gates output channels [0, n) only
+        (OSA_GATE_CHANNELS: the fused ConvGRU r|z launch).  redir=(layer, t): a transposed conv adds
         layer(t) -- a 1x1x1 PackedConv3d (+BN) on the output-resolution tensor t (<= 64 channels) -- inside
         its epilogue (GwcNet hourglass conv6 + redir1); replaces `residual`.  out_split=True (f16x3 only)
         writes the output as a split tensor (see IN_SPLIT ...); split inputs / residuals are recognised by
@@ -231,6 +232,9 @@ class PackedConv3d:
         xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
         rp = None if residual is None else residual.data_ptr() + 4 * res_off
         act = self.act | (GATE_RAW if (gate is not None and gate_raw) else 0)
+        if gate_channels:
+            assert gate is not None and gate_channels % 4 == 0 and 0 < gate_channels <= self.Co
+            act |= gate_channels << 16
         fmt = (IN_SPLIT if is_split(x) else 0) | (OUT_SPLIT if out_split else 0) | (RES_SPLIT if is_split(residual) else 0) \
             | (REDIR_SPLIT if (redir is not None and is_split(redir[1])) else 0)
         if fmt:

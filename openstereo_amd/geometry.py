@@ -129,6 +129,22 @@ class CombinedGeoEncodingVolume:
                       d.data_ptr(), cx.data_ptr(), out.data_ptr(), B, H, W, self.C, self.radius, _stream())
         return out
 
+    def lookup_cl(self, disp, coords):
+        """The same lookup as an NHWC engine tensor [B, Cpad4, 1, H, W] (padding channels zero) for the engine's GRU loop
+        (osa_geo_lookup_nhwc_f32): what the motion encoder's convc1 reads, without the per-iteration NCHW -> NHWC transpose.
+        disp / coords: fp32, [B,1,H,W] / [B,H,W,1] (or any shape with B*H*W elements), contiguous.  Inference path only."""
+        assert not self.train_path
+        B, H, W = self.shape
+        nch = (self.C + 1) * (2 * self.radius + 1) * self.num_levels
+        out = ops.empty_cl(B, (nch + 3) // 4 * 4, 1, H, W, disp.device)
+        d, cx = _f32c(disp), _f32c(coords)
+        assert d.numel() == B * H * W and cx.numel() == B * H * W
+        with timing.span("geo_lookup", self.C, self.num_levels, self.radius, H, W):
+            _lib.call("osa_geo_lookup_nhwc_f32", self._gp, self._cp, self._gl, self._cl, self.num_levels,
+                      d.data_ptr(), cx.data_ptr(), out.data_ptr(), out.shape[1], B, H, W, self.C, self.radius, _stream())
+        out._osa_meta = self.meta                  # taps interpolate / zero-pad the volumes: bounded by their max |.|
+        return out
+
     @staticmethod
     def corr(fmap1, fmap2):
         """einsum('aijk,aijh->ajkh') -> [B,H,W1,1,W2] (gru_blocks.py:221-229)."""

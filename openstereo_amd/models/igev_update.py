@@ -7,12 +7,13 @@ state_dict keys; forward on the engine with NHWC tensors:
 
   * every Conv2d (3x3, 1x1, 7x7, with bias) is the MFMA conv kernel with D = 1; inputs that the
     reference concatenates (`torch.cat([h, x...])`) are channel slices of one buffer,
-  * ConvGRU: z = sigmoid(convz(hx) + cz) and q = tanh(convq([r*h, x]) + cq) are fused epilogues
-    (residual = cz / cq, OSA_ACT_SIGMOID / OSA_ACT_TANH); r*h = sigmoid(convr(hx) + cr) * h comes out of
-    convr's epilogue with h as a raw gate, written straight into the [r*h | x] buffer;
-    h' = (1-z)*h + z*q is `osa_gru_combine_f32`,
-  * pool2x / interp (avg_pool2d, bilinear align_corners=True) stay PyTorch-ROCm ops on NHWC views
-    (tiny maps, feature side).
+  * ConvGRU (r3): every level keeps ONE state buffer [h | x | r*h | z] per forward (`_GruLevel`).  The producers of x -- pool2x /
+    interp of the neighbouring levels' hidden states (`osa_pool2x_nhwc_f32`, `osa_resize_bilinear_nhwc_f32`) and the motion encoder's
+    last conv -- write their channel slice in place; ONE launch computes convr and convz (they read the same [h | x]: the brick is
+    staged once, twice the workgroups on the small 1/8 and 1/16 maps) with the sigmoid, the `+ cr / + cz` and `r * h` (h as raw gate of
+    the first half, OSA_GATE_CHANNELS) in its epilogue and stores [r*h | z] next to x; convq reads [x | r*h] in place (its input
+    channels permuted when the weights are packed) with tanh / `+ cq` fused; h' = (1-z)*h + z*q (`osa_gru_combine_f32`) updates h in
+    place.  No torch.cat, no clone, no copy per call: three launches per GRU.
 
 forward() takes and returns the reference's NCHW tensors; forward_cl() is the channels-last entry.
 """
@@ -44,20 +45,77 @@ def _as_cl(t4):
     return nchw_to_cl(t4)
 
 
+def _fold_meta(dst, src):
+    """dst's range block (f16x3 chains) must cover values copied / resampled from src: slot-wise maximum, one tiny kernel."""
+    m = meta_of(dst)
+    if m is not None:
+        torch.maximum(m, ensure_meta(src), out=m)
+
+
+class _GruLevel:
+    """State of one ConvGRU level for the duration of a forward: T = [h (hd) | x (cx) | r*h (hd) | z (hd)] NHWC, plus the static
+    context terms: crz = [cr | cz] (residual of the fused r|z launch) and cq."""
+    __slots__ = ("T", "hd", "cx", "B", "H", "W", "crz", "cq", "q")
+
+    def __init__(self, h, cx, cz, cr, cq, track):
+        B, hd, _, H, W = h.shape
+        self.hd, self.cx, self.B, self.H, self.W = hd, cx, B, H, W
+        self.T = empty_cl(B, 3 * hd + cx, 1, H, W, h.device)      # the r*h | z slots are written by the first r|z launch before anything reads them
+        if track:
+            attach_meta(self.T)
+        self.set_h(h)
+        self.crz = _cat_cl([cr, cz], h.device)
+        self.cq = cq
+        self.q = empty_cl(B, hd, 1, H, W, h.device)
+
+    def set_h(self, h):
+        self.T[:, :self.hd] = h[:, :self.hd]
+        _fold_meta(self.T, h)
+
+    def write_x(self, off, part):
+        """copy an engine tensor into x channels [off, off + C) (standalone ConvGRU calls; the update block's producers write in place)"""
+        C = part.shape[1]
+        self.T[:, self.hd + off:self.hd + off + C] = part
+        _fold_meta(self.T, part)
+
+    def h_out(self):
+        return self.T                                   # consumers read channels [0, hd) (PackedConv3d takes Cs >= Ci; cl_to_nchw slices)
+
+
+def _resample_into(kind, src, C, dst, off):
+    """pool2x (update.py:99-100) or interp (:107-109, bilinear align_corners=True) of channels [0, C) of `src` into channels [off, off + C) of
+    the level buffer `dst`, both NHWC engine tensors; the destination's range block inherits the source's maximum in-kernel."""
+    B, sCs, _, H, W = src.shape
+    _, dCs, _, Hd, Wd = dst.shape
+    sm, dm = meta_of(src), meta_of(dst)
+    xm = None if (sm is None or dm is None) else sm.data_ptr()
+    ym = None if xm is None else dm.data_ptr()
+    if kind == "pool":
+        assert (Hd, Wd) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1), ((H, W), (Hd, Wd))
+        _lib.call("osa_pool2x_nhwc_f32", src.data_ptr(), dst.data_ptr() + 4 * off, B, H, W, C, sCs, dCs, xm, ym, _stream())
+    else:
+        _lib.call("osa_resize_bilinear_nhwc_f32", src.data_ptr(), dst.data_ptr() + 4 * off, B, H, W, Hd, Wd, C, sCs, dCs, xm, ym, _stream())
+
+
 def pool2x(x):
-    """update.py:99-100 on an engine tensor (averages: x's range block stays valid)."""
-    return inherit_meta(_as_cl(F.avg_pool2d(x[:, :, 0], 3, stride=2, padding=1)), x)
+    """update.py:99-100 on an engine tensor -> new engine tensor (averages: x's range block stays valid)."""
+    B, C, _, H, W = x.shape
+    out = inherit_meta(empty_cl(B, C, 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.device), x)
+    _resample_into("pool", x, C, out, 0)
+    return out
 
 
 def interp(x, dest):
     """update.py:107-109 (bilinear, align_corners=True) on engine tensors (convex combinations: x's range block stays valid)."""
-    return inherit_meta(_as_cl(F.interpolate(x[:, :, 0], dest.shape[3:], mode="bilinear", align_corners=True)), x)
+    B, C, _, _, _ = x.shape
+    out = inherit_meta(empty_cl(B, C, 1, dest.shape[3], dest.shape[4], x.device), x)
+    _resample_into("interp", x, C, out, 0)
+    return out
 
 
 def _cat_cl(parts, dev, track=False):
     """Channel concatenation into one NHWC buffer (what torch.cat does for the reference).  track (f16x3 chains): the result
-    gets a range block = slot-wise maximum of the parts' blocks; a part that has none yet (the static context inputs cz / cr / cq
-    ..., converted once per forward) is measured once and keeps its block, so the loop never reduces over data again."""
+    gets a range block = slot-wise maximum of the parts' blocks; a part that has none yet is measured once and keeps its block."""
     B, _, _, H, W = parts[0].shape
     C = sum(p.shape[1] for p in parts)
     out = empty_cl(B, C, 1, H, W, dev)
@@ -105,25 +163,49 @@ class ConvGRU(nn.Module):
         self.hidden_dim = hidden_dim
         self._eng = None
 
+    def _packs(self):
+        """(fused r|z launch, q launch): convr and convz stacked on the output axis (update.py:38-39 read the same hx); convq with its input
+        channels rotated from [r*h | x] to [x | r*h], the order in which the level buffer holds them."""
+        def build():
+            hd = self.convz.out_channels
+            k, pd = self.convz.kernel_size, self.convz.padding
+            with torch.no_grad():
+                rz = nn.Conv2d(self.convz.in_channels, 2 * hd, k, padding=pd).to(self.convz.weight.device)
+                rz.weight.copy_(torch.cat([self.convr.weight, self.convz.weight], 0)); rz.bias.copy_(torch.cat([self.convr.bias, self.convz.bias], 0))
+                q = nn.Conv2d(self.convq.in_channels, hd, k, padding=pd).to(self.convq.weight.device)
+                q.weight.copy_(torch.cat([self.convq.weight[:, hd:], self.convq.weight[:, :hd]], 1)); q.bias.copy_(self.convq.bias)
+            return PackedConv3d(rz, None, ACT_SIGMOID), PackedConv3d(q, None, ACT_TANH)
+        return cached_pack(self, "_eng", build)
+
+    def new_level(self, h, cz, cr, cq, cx):
+        prz, _ = self._packs()
+        assert self.convz.out_channels % 4 == 0 and h.shape[1] >= self.convz.out_channels and cx % 4 == 0
+        return _GruLevel(h, cx, cz, cr, cq, track=prz.precision == "f16x3")
+
+    def step(self, lv):
+        """One GRU update of a level whose x slots are filled: 3 launches, h updated in place (update.py:36-45)."""
+        prz, pq = self._packs()
+        hd, cx, T = lv.hd, lv.cx, lv.T
+        assert prz.Ci == hd + cx, (prz.Ci, hd, cx)
+        prz(T, residual=lv.crz, gate=_nhwc(T), gate_raw=True, gate_channels=hd, out=T, out_off=hd + cx)    # [sigmoid(convr+cr)*h | sigmoid(convz+cz)]
+        pq(T, x_off=hd, residual=lv.cq, out=lv.q)                                                           # tanh(convq([r*h, x]) + cq)
+        zoff = 4 * (2 * hd + cx)
+        _lib.call("osa_gru_combine_f32", T.data_ptr() + zoff, lv.q.data_ptr(), T.data_ptr(), T.data_ptr(), lv.B * lv.H * lv.W, hd,
+                  T.shape[1], lv.q.shape[1], T.shape[1], T.shape[1], None if meta_of(T) is None else meta_of(T).data_ptr(), _stream())
+
     def forward_cl(self, h, cz, cr, cq, *x_list):
-        pz, pr, pq = cached_pack(self, "_eng", lambda: (PackedConv3d(self.convz, None, ACT_SIGMOID),
-                                                        PackedConv3d(self.convr, None, ACT_SIGMOID),
-                                                        PackedConv3d(self.convq, None, ACT_TANH)))
-        hd = self.convz.out_channels
-        assert hd % 4 == 0 and h.shape[1] == hd
-        f16 = pz.precision == "f16x3"
-        hx = _cat_cl([h, *x_list], h.device, track=f16)        # [h | x]
-        z = pz(hx, residual=cz)                                # sigmoid(convz(hx) + cz)
-        rhx = hx.clone()                                       # [r*h | x]: the x part is shared, r*h overwrites the h slice
-        if f16:                                                # range block of [r*h | x]: that of [h | x] itself (|r*h| <= |h|) -- shared,
-            rhx._osa_meta = meta_of(hx)                        # not copied: convr folding max |r*h| into it changes nothing
-        pr(hx, residual=cr, gate=_nhwc(h), gate_raw=True, out=rhx, out_off=0)   # sigmoid(convr(hx) + cr) * h
-        q = pq(rhx, residual=cq)                               # tanh(convq([r*h, x]) + cq)
+        """Stand-alone call on engine tensors (the update block drives `step` on persistent levels instead)."""
+        lv = self.new_level(h, cz, cr, cq, sum(x.shape[1] for x in x_list))
+        off = 0
+        for x in x_list:
+            lv.write_x(off, x)
+            off += x.shape[1]
+        self.step(lv)
         out = empty_cl(*h.shape, h.device)
-        B, _, _, H, W = h.shape
-        _lib.call("osa_gru_combine_f32", z.data_ptr(), q.data_ptr(), h.data_ptr(), out.data_ptr(),
-                  B * H * W, hd, z.shape[1], q.shape[1], h.shape[1], out.shape[1], attach_meta(out).data_ptr(), _stream())
-        return out
+        out[:, :lv.hd] = lv.T[:, :lv.hd]
+        if h.shape[1] > lv.hd:
+            out[:, lv.hd:] = 0.0
+        return inherit_meta(out, lv.T)
 
     def forward_train(self, h, cz, cr, cq, *x_list):
         """update.py:36-45: the three 3x3 convolutions on the engine (forward, dgrad, wgrad), gating in torch."""
@@ -158,8 +240,10 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 64, 128 - 1, 3, padding=1)
         self._eng = None
 
-    def forward_cl(self, disp, corr):
-        """disp: engine tensor with the disparity in channel 0 (channels 1..3 zero); corr: engine tensor."""
+    def forward_cl(self, disp, corr, out=None, out_off=0, disp_in_place=False):
+        """disp: engine tensor with the disparity in channel 0 (channels 1..3 zero); corr: engine tensor.  out / out_off: write the 128
+        motion-feature channels into a channel slice of `out` (the 1/4 GRU level's x slot) instead of a new tensor; disp_in_place: the
+        caller has already written the disparity into channel out_off + 127 (osa_disp_update_f32)."""
         R = lambda m: PackedConv3d(m, None, ACT_RELU)
         e = cached_pack(self, "_eng", lambda: dict(c1=R(self.convc1), c2=R(self.convc2), d1=R(self.convd1), d2=R(self.convd2),
                                                    conv=R(self.conv)))
@@ -167,11 +251,13 @@ class BasicMotionEncoder(nn.Module):
         cor_disp = empty_cl(B, 128, 1, H, W, disp.device)      # [cor | disp_]
         e["c2"](e["c1"](corr), out=cor_disp, out_off=0)
         e["d2"](e["d1"](disp), out=cor_disp, out_off=64)
-        out = empty_cl(B, 128, 1, H, W, disp.device)           # [conv(cor_disp) (127) | disp]
-        e["conv"](cor_disp, out=out, out_off=0)
-        out[:, 127] = disp[:, 0]
-        if meta_of(out) is not None:
-            fold_amax(out, disp[:, 0])
+        if out is None:
+            out = empty_cl(B, 128, 1, H, W, disp.device)       # [conv(cor_disp) (127) | disp]
+        e["conv"](cor_disp, out=out, out_off=out_off)
+        if not disp_in_place:
+            out[:, out_off + 127] = disp[:, 0]
+            if meta_of(out) is not None:
+                fold_amax(out, disp[:, 0])
         return out
 
     def forward_train(self, disp, corr):
@@ -206,31 +292,60 @@ class BasicMultiUpdateBlock(nn.Module):
 
     def reset_engine(self):
         self._mask = None
+        self.__dict__.pop("_lv", None)
         for m in self.modules():
             if hasattr(m, "_eng"):
                 m._eng = None
 
-    def forward_cl(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
-        """Engine tensors everywhere; `net` (list) is updated in place like the reference does."""
+    def _levels(self, net, inp, n_gru):
+        """Per-level state buffers, kept across the calls of one forward: `net[i]` handed back by the previous call IS level i's buffer
+        (identity), anything else (first call, a caller that replaced a hidden state) is copied in.  A new set of context tensors
+        (`inp`) starts a new forward."""
+        ctx = [t for ts in inp[:n_gru] for t in ts]     # the state holds these references, so identity is a safe key (no id() reuse)
+        shapes = [tuple(t.shape[2:]) for t in net[:n_gru]]
+        st = self.__dict__.get("_lv")
+        if st is None or st[0][1] != shapes or len(st[0][0]) != len(ctx) or any(a is not b for a, b in zip(st[0][0], ctx)):
+            key = (ctx, shapes)
+            hd = [g.convz.out_channels for g in (self.gru04, self.gru08, self.gru16)]
+            cx = [128 + (hd[1] if n_gru > 1 else 0), hd[0] + (hd[2] if n_gru > 2 else 0), hd[1]]
+            lv = [g.new_level(net[i], inp[i][0], inp[i][1], inp[i][2], cx[i]) if i < n_gru else None
+                  for i, g in enumerate((self.gru04, self.gru08, self.gru16))]
+            st = (key, lv)
+            object.__setattr__(self, "_lv", st)
+            return st[1]
+        for i, lv in enumerate(st[1]):
+            if lv is not None and net[i] is not lv.T:
+                lv.set_h(net[i])
+        return st[1]
+
+    def forward_cl(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True, want_mask=True, disp_in_place=False):
+        """Engine tensors everywhere.  Returns `net` as the per-level state buffers (channels [0, hidden) are the hidden state): hand them
+        back unchanged for the next call, or read them with cl_to_nchw(t, hidden).  want_mask=False skips mask_feat_4 (returns None for it):
+        in test mode only the last iteration's mask features are used (igev_stereo.py:203-207)."""
         n_gru = self.args.N_GRU_LAYERS if hasattr(self, "args") else self.n_gru_layers    # igev/update.py vs stereobase/gru_blocks.py
+        lv = self._levels(net, inp, n_gru)
+        l4, l8, l16 = lv[0], (lv[1] if n_gru > 1 else None), (lv[2] if n_gru > 2 else None)
         if iter16:
-            net[2] = self.gru16.forward_cl(net[2], *(inp[2]), pool2x(net[1]))
+            _resample_into("pool", l8.T, l8.hd, l16.T, l16.hd)                         # x = pool2x(net[1])
+            self.gru16.step(l16)
         if iter08:
+            _resample_into("pool", l4.T, l4.hd, l8.T, l8.hd)                           # x = [pool2x(net[0]) | interp(net[2], net[1])]
             if n_gru > 2:
-                net[1] = self.gru08.forward_cl(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
-            else:
-                net[1] = self.gru08.forward_cl(net[1], *(inp[1]), pool2x(net[0]))
+                _resample_into("interp", l16.T, l16.hd, l8.T, l8.hd + l4.hd)
+            self.gru08.step(l8)
         if iter04:
-            motion_features = self.encoder.forward_cl(disp, corr)
+            self.encoder.forward_cl(disp, corr, out=l4.T, out_off=l4.hd, disp_in_place=disp_in_place)   # x = [motion features | interp(net[1], net[0])]
             if n_gru > 1:
-                net[0] = self.gru04.forward_cl(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
-            else:
-                net[0] = self.gru04.forward_cl(net[0], *(inp[0]), motion_features)
+                _resample_into("interp", l8.T, l8.hd, l4.T, l4.hd + 128)
+            self.gru04.step(l4)
+        out_net = [l.T for l in lv if l is not None] + list(net[n_gru:])
         if not update:
-            return net
-        delta_disp = self.disp_head.forward_cl(net[0])
+            return out_net
+        delta_disp = self.disp_head.forward_cl(l4.T)
+        if not want_mask:
+            return out_net, None, delta_disp
         mask = cached_pack(self, "_mask", lambda: PackedConv3d(self.mask_feat_4[0], None, ACT_RELU), mods=(self.mask_feat_4,))
-        return net, mask(net[0]), delta_disp
+        return out_net, mask(l4.T), delta_disp
 
     def forward_train(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         """update.py:129-150 with differentiable sub-modules (their training paths); pool2x / interp are the reference's torch ops."""
@@ -323,16 +438,32 @@ def run_refinement(update_block, a, match_left, match_right, geo_encoding_volume
     c = nchw_to_cl
     net = [c(t) for t in net_list]
     inp = [[c(t) for t in ts] for ts in inp_list]
-    disp = init_disp.float()
+    n_gru = a.N_GRU_LAYERS
+    # The disparity lives in three places the loop's kernels read: the NCHW map (lookup), an NHWC [disp, 0, 0, 0] map (the motion encoder's
+    # 7x7 convd1) and channel 127 of the 1/4 level's x slot (update.py:92); osa_disp_update_f32 advances all of them with one launch.
+    disp = init_disp.float().contiguous().clone()
+    disp4 = empty_cl(b, 4, 1, h, w, disp.device)
+    if iters < 1:
+        raise ValueError("run_refinement: at least one GRU iteration (the reference's loop defines its outputs inside the loop)")
+    lvs = update_block._levels(net, inp, n_gru)
+    lv4 = lvs[0]
+    net = [l.T for l in lvs if l is not None] + net[n_gru:]
+    m4 = attach_meta(disp4).data_ptr() if meta_of(lv4.T) is not None else None
+    ms = None if meta_of(lv4.T) is None else meta_of(lv4.T).data_ptr()
+    slot = lv4.T.data_ptr() + 4 * (lv4.hd + 127)
+
+    def advance(delta):
+        _lib.call("osa_disp_update_f32", disp.data_ptr(), None if delta is None else delta.data_ptr(), 0 if delta is None else delta.shape[1],
+                  disp4.data_ptr(), slot, lv4.T.shape[1], b * h * w, m4, ms, _stream())
+    advance(None)
     mask = None
-    for _ in range(iters):
-        geo_feat = geo_fn(disp, coords)
-        if a.N_GRU_LAYERS == 3 and a.SLOW_FAST_GRU:
+    for it in range(iters):
+        geo_feat = geo_fn.lookup_cl(disp, coords)
+        if n_gru == 3 and a.SLOW_FAST_GRU:
             net = update_block.forward_cl(net, inp, iter16=True, iter08=False, iter04=False, update=False)
-        if a.N_GRU_LAYERS >= 2 and a.SLOW_FAST_GRU:
-            net = update_block.forward_cl(net, inp, iter16=a.N_GRU_LAYERS == 3, iter08=True, iter04=False, update=False)
-        geo_feat._osa_meta = geo_fn.meta                  # lookups interpolate / zero-pad the volumes: bounded by their max |.|
-        net, mask, delta = update_block.forward_cl(net, inp, c(geo_feat), c(disp),
-                                                   iter16=a.N_GRU_LAYERS == 3, iter08=a.N_GRU_LAYERS >= 2)
-        disp = disp + cl_to_nchw(delta, 1)
+        if n_gru >= 2 and a.SLOW_FAST_GRU:
+            net = update_block.forward_cl(net, inp, iter16=n_gru == 3, iter08=True, iter04=False, update=False)
+        net, mask, delta = update_block.forward_cl(net, inp, geo_feat, disp4, iter16=n_gru == 3, iter08=n_gru >= 2,
+                                                   want_mask=it == iters - 1, disp_in_place=True)
+        advance(delta)
     return {"disp": disp, "mask_feat_4": cl_to_nchw(mask, 32), "net_list": [cl_to_nchw(t, r.shape[1]) for t, r in zip(net, net_list)]}

@@ -881,3 +881,28 @@ def test_dormant_volume_variants():
             assert torch.equal(ops.compute_volume(l.to(DEV), r.to(DEV), D, side).cpu(), R.compute_volume(l, r, D, side)), side
         torch.testing.assert_close(ops.build_sub_volume(l.to(DEV), r.to(DEV), D).cpu(), R.build_sub_volume(l, r, D), rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(ops.CoExCostVolume(D - 1, 4)(l.to(DEV), r.to(DEV)).cpu(), R.coex_cost_volume(l, r, D - 1, 4), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 17, 30), (1, 128, 34, 60), (1, 64, 8, 9)])
+def test_hidden_state_resampling_kernels(shape):
+    """pool2x / interp of the update block (update.py:99-109) on NHWC engine tensors, channel-sliced source and destination, vs torch."""
+    import torch.nn.functional as F
+    from openstereo_amd import ops
+    from openstereo_amd.models.igev_update import _resample_into, pool2x, interp
+    from openstereo_amd.models.lightstereo import nchw_to_cl, cl_to_nchw
+    B, C, H, W = shape
+    x = rnd(shape, 71)
+    src = ops.empty_cl(B, C + 64, 1, H, W, DEV)
+    src.normal_()
+    src[:, :C] = nchw_to_cl(x.to(DEV))[:, :C]
+    want_p = F.avg_pool2d(x, 3, stride=2, padding=1)
+    dst = ops.empty_cl(B, 32 + C + 12, 1, want_p.shape[2], want_p.shape[3], DEV)
+    dst.fill_(7.0)
+    _resample_into("pool", src, C, dst, 32)
+    close(cl_to_nchw(dst[:, 32:32 + C]), want_p, 1e-6, 1e-6, "pool2x")
+    assert float(dst[:, :32].min()) == 7.0 and float(dst[:, 32 + C:].max()) == 7.0          # neighbours untouched
+    close(cl_to_nchw(pool2x(nchw_to_cl(x.to(DEV)))), want_p, 1e-6, 1e-6, "pool2x (new tensor)")
+    for (Ho, Wo) in ((2 * H, 2 * W), (2 * H - 1, 2 * W + 1), (H, W)):
+        want_i = F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)
+        dest = ops.empty_cl(B, C, 1, Ho, Wo, DEV)
+        close(cl_to_nchw(interp(nchw_to_cl(x.to(DEV)), dest)), want_i, 2e-6, 1e-6, f"interp -> {Ho}x{Wo}")

@@ -50,6 +50,9 @@ LAYERS_GRU = [
     ("gru16 256->128 @34x60", "conv2d", 256, 128, 3, 1, G16, 9 * 32, 1),
     ("gru08 384->128 @68x120", "conv2d", 384, 128, 3, 1, G8, 6 * 32, 1),
     ("gru04 384->128 @136x240", "conv2d", 384, 128, 3, 1, G4, 3 * 32, 1),
+    ("gru16 r|z 256->256 @34x60", "conv2d", 256, 256, 3, 1, G16, 3 * 32, 1),
+    ("gru08 r|z 384->256 @68x120", "conv2d", 384, 256, 3, 1, G8, 2 * 32, 1),
+    ("gru04 r|z 384->256 @136x240", "conv2d", 384, 256, 3, 1, G4, 32, 1),
     ("enc convc1 164->64 1x1", "conv2d", 164, 64, 1, 1, G4, 32, 1),
     ("enc conv 128->127", "conv2d", 128, 127, 3, 1, G4, 32, 1),
     ("head 128->256", "conv2d", 128, 256, 3, 1, G4, 32, 1),
