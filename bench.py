@@ -78,7 +78,8 @@ def parse():
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (default workload) / the same-GPU PyTorch-ROCm eager leg (training workloads)")
+    ap.add_argument("--no-workloads", action="store_true", help="default workload: skip the compact measurements of the other BASELINE configs (`workloads`)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs: nothing but warm-up + the timed configuration (no other-precision leg, no B=1 loop, no CPU leg)")
     ap.add_argument("--stub", action="store_true",
@@ -462,15 +463,20 @@ def generic_rooflines(wl, args, eager_step, nrep):
     stats = engine.collect_timing(rec)
     per_step = {"/".join(map(str, k)): round(sum(v) / nrep, 4) for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1]))}
     peak, why = PEAKS[args.precision]
-    convs = {k: v for k, v in stats.items() if k in timing.work and k[0] in ("conv3d", "deconv3d")}
+    convs = {k: v for k, v in stats.items() if k in timing.work and k[0] in ("conv3d", "deconv3d", "wgrad")}
     out = []
     for k, v in sorted(convs.items(), key=lambda kv: -sum(kv[1]))[:3]:
         ms = sum(v) / len(v)
         flops, nbytes = timing.work[k]
         tf, gbs = flops / ms / 1e9, nbytes / ms / 1e6
+        kind, ci, co, kk, st, d, h, w = k[:8]
+        if kind == "wgrad":                                  # weight gradients are exact-fp32 MFMA in both modes (csrc/wgrad.hip)
+            peak, why = PEAKS["f32"]
+        else:
+            peak, why = PEAKS[args.precision]
         mfma_bound = flops / (peak * 1e12) >= nbytes / (HBM_PEAK * 1e9)              # which roofline the launch sits under
-        kind, ci, co, kk, st, d, h, w = k
-        rec_ = {"kernel": "osa::conv_mfma_kernel<...> (tile picked per layer, csrc/conv3d.hip pick_cfg)",
+        rec_ = {"kernel": "osa::wgrad_kernel<...> + osa::wgrad_reduce_kernel (csrc/wgrad.hip)" if kind == "wgrad" else
+                          "osa::conv_mfma_kernel<...> (tile picked per layer, csrc/conv3d.hip pick_cfg)",
                 "what": f"{kind} {ci}->{co} k{kk} stride {st} @ {d}x{h}x{w}, {len(v) // nrep} launches per step",
                 "bound": "mfma" if mfma_bound else "hbm", "avg_launch_ms": round(ms, 4), "traffic": None,
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 3), "algorithmic_mb_per_launch": round(nbytes / 1e6, 2)}
@@ -480,6 +486,115 @@ def generic_rooflines(wl, args, eager_step, nrep):
             rec_.update({"achieved": round(gbs, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(gbs / HBM_PEAK, 4)})
         out.append(rec_)
     return out, per_step
+
+
+# ============================================================================================ same-GPU eager baseline + secondary workloads
+class _eager_torch_mode:
+    """Baseline leg only: inside this context the engine's autograd entry points are rebound to the plain torch ops the reference's own
+    code executes (the oracle restatements / torch.nn.functional), so the SAME workload classes measure what stock PyTorch-ROCm eager
+    (MIOpen / rocBLAS) does on this GPU -- training included.  Never active in a timed engine region, never shipped behaviour."""
+
+    def __enter__(self):
+        import contextlib
+        import torch.nn.functional as F
+        from oracle import torch_ref as O                 # baseline leg only
+        from openstereo_amd import autograd as AG, geometry as GEO
+        self.saved = [(AG, n, getattr(AG, n)) for n in ("engine_convs", "conv_module", "conv3d", "conv2d", "conv_transpose3d", "conv_transpose2d",
+                                                         "build_gwc_volume", "build_concat_volume", "correlation_volume", "disparity_regression",
+                                                         "softmax_disparity_regression", "upsample_softargmin")]
+        self.saved.append((GEO, "CombinedGeoEncodingVolume", GEO.CombinedGeoEncodingVolume))
+        AG.engine_convs = contextlib.nullcontext
+        AG.conv_module = lambda m, x: m(x)
+        AG.conv3d = lambda x, w, b=None, stride=1, padding=0, dilation=1, precision=None: F.conv3d(x, w, b, stride, padding, dilation)
+        AG.conv2d = lambda x, w, b=None, stride=1, padding=0, dilation=1, precision=None: F.conv2d(x, w, b, stride, padding, dilation)
+        AG.conv_transpose3d = lambda x, w, b=None, stride=2, padding=1, output_padding=0, precision=None: F.conv_transpose3d(x, w, b, stride, padding, output_padding)
+        AG.conv_transpose2d = lambda x, w, b=None, stride=2, padding=1, output_padding=0, precision=None: F.conv_transpose2d(x, w, b, stride, padding, output_padding)
+        AG.build_gwc_volume = O.gwc_volume
+        AG.build_concat_volume = O.concat_volume
+        AG.correlation_volume = O.corr_volume
+        AG.disparity_regression = lambda p, maxdisp, keepdim=True: O.disparity_regression(p, maxdisp, keepdim)
+        AG.softmax_disparity_regression = lambda c, keepdim=True: O.disparity_regression(F.softmax(c, 1), c.shape[1], keepdim)
+        AG.upsample_softargmin = lambda c, maxdisp, h, w, align_corners=False: O.upsample_regression(c if c.dim() == 5 else c[:, None], maxdisp, h, w, align_corners)
+
+        class TorchGeo:
+            def __init__(self, f1, f2, gv, num_levels=2, radius=4):
+                self.o, self.meta = O.GeoEncodingVolume(f1.float(), f2.float(), gv.float(), num_levels=num_levels, radius=radius), None
+
+            def __call__(self, disp, coords):
+                with torch.device(disp.device):
+                    return self.o(disp, coords)
+        GEO.CombinedGeoEncodingVolume = TorchGeo
+        return self
+
+    def __exit__(self, *exc):
+        for obj, name, val in self.saved:
+            setattr(obj, name, val)
+        return False
+
+
+def _time_steps(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def eager_training_baseline(name, args, dev, rank, steps=3, warmup=2):
+    """`pytorch_rocm_eager_same_gpu` for a training workload: the same class, optimizer, crop and batch, with every hot-path op executed by
+    stock PyTorch-ROCm (see _eager_torch_mode).  MIOpen's find mode runs during the warm-up steps."""
+    try:
+        with _eager_torch_mode():
+            wl = WORKLOADS[name](args, dev, rank)
+            sec, _ = _time_steps(wl.step, steps, warmup)
+        del wl
+        torch.cuda.empty_cache()
+        return {"value": round((args.batch or 1) / sec, 3), "unit": "stereo-pairs/s", "ms_per_step": round(sec * 1e3, 2),
+                "what": f"same workload class / optimizer / crop with the hot-path ops run by PyTorch-ROCm eager (MIOpen), {steps} steps after {warmup} warm-ups"}
+    except Exception as ex:
+        print(f"[bench] eager training baseline skipped ({type(ex).__name__}: {ex})", file=sys.stderr)
+        return None
+
+
+def secondary_workloads(args, dev, rank, budget_s=75.0):
+    """Compact measurements of the other BASELINE configs after the headline: the driver's default line then carries
+    LightStereo KITTI15 (configs[3]), the IGEV x32 loop (configs[4]), StereoBase whole-model inference and the StereoBase training steps
+    (configs[2]) -- value, ms/step and the dominant launch's roofline fraction each; the time budget bounds the extra run time."""
+    out, t_start = {}, time.perf_counter()
+    plan = [("lightstereo_kitti15", 10, 3), ("igev_refine32", 5, 2), ("stereobase_e2e", 5, 2), ("stereobase_train", 10, 3), ("stereobase_e2e_train", 3, 2)]
+    for name, steps, warmup in plan:
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = {"skipped": "time budget of the default run exhausted"}
+            continue
+        try:
+            a = argparse.Namespace(**{**vars(args), "batch": None, "workload": name})
+            wl = WORKLOADS[name](a, dev, rank)
+            step = wl.step
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            launch = "eager"
+            if wl.graphable and not args.no_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    gout = wl.step()
+                step = lambda g=g, gout=gout: (g.replay(), gout)[1]
+                launch = "hipGraph replay"
+            sec, res = _time_steps(step, steps, 1)
+            assert torch.isfinite(res).all()
+            roofs, _ = generic_rooflines(wl, a, wl.step, 2)
+            r0 = roofs[0] if roofs else None
+            out[name] = {"metric": wl.metric, "value": round(wl.B / sec, 3), "unit": "stereo-pairs/s", "ms_per_step": round(sec * 1e3, 3),
+                         "pairs_per_step": wl.B, "launch": launch,
+                         "dominant_launch": None if r0 is None else {k: r0[k] for k in ("what", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
+            del wl
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"}
+    return out
 
 
 # ============================================================================================ CPU baseline (GwcNet)
@@ -690,6 +805,10 @@ def main():
         line["rooflines"] = roofs[1:]
         line["cpu_baseline"] = cpu
         line["other_precision"] = alt
+        if not args.timed_only and world == 1 and not args.no_workloads:
+            del wl
+            torch.cuda.empty_cache()
+            line["workloads"] = secondary_workloads(args, dev, rank)
     elif rank == 0:
         line["roofline"], line["cpu_baseline"] = None, None
         if not args.stub and not args.timed_only and dev.type == "cuda":
@@ -698,6 +817,10 @@ def main():
             line["roofline"] = roofs[0] if roofs else None
             line["rooflines"] = roofs[1:]
             line["cpu_baseline_note"] = "the CPU leg runs with the default workload only (bench.py without --workload)"
+            if wl.training and world == 1 and not args.no_cpu_baseline:
+                del wl
+                torch.cuda.empty_cache()
+                line["pytorch_rocm_eager_same_gpu"] = eager_training_baseline(args.workload, args, dev, rank)
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

@@ -97,6 +97,11 @@ int osa_build_volume_nhwc_f32(const float* left_gwc, const float* right_gwc, int
  *   mode 1  compute_volume(side='left')  (:44-56): out[B,C,planes,H,W] = reference[w] - target[w-d]   (w >= d, else 0)
  *   mode 2  compute_volume(side='right'):          out[B,C,planes,H,W] = target[w+d] - reference[w]   (w < W-d; plane 0: reference - target)
  *   mode 3  build_sub_volume (:108-117):           out[B,planes,H,W]   = sum_c |l[w] - r[w-d]| (w >= d), sum_c |l[w]| (w < d) */
+/* PSMNet cat_fms with a general disparity sampling (psmnet_cost_processor.py:9-50: start_disp, dilation; cfgs/psmnet uses 0 / 1, which
+ * osa_build_volume_f32 covers): out [B, 2C, n_samples, H, W]; disp_index: DEVICE array of the n_samples integer disparities
+ * (int(torch.linspace(start, start + max_disp - 1, n)) as the reference computes them; negative values sample to the left). */
+int osa_cat_fms_f32(const float* reference_fm, const float* target_fm, float* out, const int* disp_index,
+                    int B, int C, int H, int W, int n_samples, void* stream);
 int osa_pair_volume_f32(const float* left, const float* right, float* out,
                         int B, int C, int groups, int H, int W, int planes, int mode, void* stream);
 

@@ -126,6 +126,7 @@ SIGNATURES = {
                                     c_i, c_fp, c_st]),
     "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
     "osa_disp_update_f32": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_ll, c_fp, c_fp, c_st]),
+    "osa_cat_fms_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_pool2x_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_resize_bilinear_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_context_upsample_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),

@@ -76,8 +76,11 @@ def build_corr_volume(img_left, img_right, max_disp):
 def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
     """psmnet_cost_processor.py:9-50 (always fp32, like the reference's buffer)"""
     if _needs_grad(reference_fm, target_fm):
-        if start_disp != 0 or dilation != 1:
-            raise NotImplementedError("cat_fms: only start_disp=0, dilation=1 (what cfgs/psmnet uses)")
+        if start_disp != 0 or dilation != 1:             # no backward kernel for the general sampling: the reference's own (differentiable) code
+            for mod, attr, old in _saved:
+                if attr == "cat_fms" and callable(old):
+                    return old(reference_fm, target_fm, max_disp, start_disp, dilation)
+            raise NotImplementedError("cat_fms with start_disp / dilation has no autograd path on the engine")
         from . import autograd as AG
         return AG.build_concat_volume(reference_fm.float(), target_fm.float(), max_disp)
     return ops.cat_fms(reference_fm, target_fm, max_disp, start_disp, dilation)

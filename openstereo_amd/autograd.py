@@ -19,7 +19,7 @@ import threading
 
 import torch
 
-from . import _lib, amp, engine, ops
+from . import _lib, amp, engine, ops, timing
 from .ops import _f32c, _p, _stream, empty_cl, is_cl, to_cl
 from .ranges import input_meta, attach_meta
 
@@ -249,9 +249,12 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
     sfx, tail = ("f16x3", (oscale, _ranges(x, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
-    _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
-              B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
-              None, 0, 0, 0.0, *tail)
+    macs = B * out_shape[0] * out_shape[1] * out_shape[2] * Ci * Co * k[0] * k[1] * k[2]
+    with timing.span("conv3d", Ci, Co, k[1], stride, D, H, W, flops=2 * macs,
+                     nbytes=4 * B * (D * H * W * Ci + out_shape[0] * out_shape[1] * out_shape[2] * Co)):
+        _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+                  B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
+                  None, 0, 0, 0.0, *tail)
     return y
 
 
@@ -264,8 +267,10 @@ def _run_deconv(x, packed, oscale, Ci, Co, k, pad, opad, precision):
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
     sfx, tail = ("f16x3", (oscale, _ranges(x, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
-    _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
-              B, D, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
+    with timing.span("deconv3d", Ci, Co, k, 2, D, H, W, flops=2 * B * D * H * W * Ci * Co * k ** 3,
+                     nbytes=4 * B * (D * H * W * Ci + od(D) * od(H) * od(W) * Co)):
+        _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+                  B, D, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
     return y
 
 
@@ -281,9 +286,12 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     if need == 0:
         raise _lib.EngineError("osa_conv3d_wgrad_workspace_bytes: unsupported layer " + str(dims))
     ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
-    _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
-              Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
-              ws.data_ptr(), need, _stream())
+    vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
+    with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2],
+                     nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co)):
+        _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
+                  Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                  ws.data_ptr(), need, _stream())
 
 
 class _Conv3d(torch.autograd.Function):

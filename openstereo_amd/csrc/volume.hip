@@ -451,9 +451,37 @@ __global__ __launch_bounds__(256) void pair_volume_kernel(const PairArgs p) {
     p.out[(((size_t)b * OC + oc) * p.D + d) * plane + hw] = v;
 }
 
+// cat_fms with arbitrary (also negative / dilated) disparity samples, psmnet_cost_processor.py:30-47: plane idx holds disparity
+// i = disp_index[idx];  i >= 0: columns w >= i get (reference[w], target[w - i]);  i < 0: columns w < W + i get (reference[w], target[w - i]);
+// everything else stays zero.
+__global__ __launch_bounds__(256) void cat_fms_kernel(const float* __restrict__ ref, const float* __restrict__ tgt, float* __restrict__ out,
+                                                      const int* __restrict__ disp_index, int C, int H, int W, int n) {
+    const int c2 = blockIdx.y;
+    const int b = blockIdx.z / n, idx = blockIdx.z - b * n;
+    const int hw = blockIdx.x * 256 + threadIdx.x;
+    if (hw >= H * W) return;
+    const int w = hw % W, i = disp_index[idx];
+    const size_t plane = (size_t)H * W;
+    const bool ok = (i >= 0) ? (w >= i) : (w < W + i);
+    float v = 0.f;
+    if (ok) v = (c2 < C) ? ref[((size_t)b * C + c2) * plane + hw] : tgt[((size_t)b * C + (c2 - C)) * plane + hw - i];
+    out[(((size_t)b * 2 * C + c2) * n + idx) * plane + hw] = v;
+}
+
 }  // namespace osa
 
 using namespace osa;
+
+extern "C" int osa_cat_fms_f32(const float* reference_fm, const float* target_fm, float* out, const int* disp_index,
+                               int B, int C, int H, int W, int n_samples, void* stream) {
+    OSA_REQUIRE(reference_fm && target_fm && out && disp_index, "cat_fms: NULL pointer");
+    OSA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && n_samples > 0, "cat_fms: bad dims");
+    OSA_REQUIRE((long long)B * n_samples <= 65535 && 2 * C <= 65535, "cat_fms: grid too large");
+    hipLaunchKernelGGL(cat_fms_kernel, dim3(cdiv((long long)H * W, 256), 2 * C, B * n_samples), dim3(256), 0, (hipStream_t)stream,
+                       reference_fm, target_fm, out, disp_index, C, H, W, n_samples);
+    OSA_LAUNCH_CHECK("cat_fms");
+    return 0;
+}
 
 extern "C" int osa_pair_volume_f32(const float* left, const float* right, float* out,
                                    int B, int C, int groups, int H, int W, int planes, int mode, void* stream) {

@@ -166,12 +166,18 @@ def build_corr_volume(img_left, img_right, max_disp):
 
 
 def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
-    """psmnet_cost_processor.py:9-50 with the configuration PSMNet uses (start_disp=0, dilation=1);
-    always returns fp32 like the reference (its buffer is torch.zeros(...).to(device))."""
-    if start_disp != 0 or dilation != 1:
-        raise NotImplementedError("cat_fms: only start_disp=0, dilation=1 (what cfgs/psmnet uses)")
-    return _build(None, None, 0, _f32c(_chk(reference_fm, "reference_fm", 4)),
-                  _f32c(_chk(target_fm, "target_fm", 4)), max_disp, NCDHW)
+    """psmnet_cost_processor.py:9-50; always returns fp32 like the reference (its buffer is torch.zeros(...).to(device)).  The
+    configuration PSMNet uses (start_disp=0, dilation=1) is the fused concat-volume kernel; any other sampling (negative start, dilation)
+    runs osa_cat_fms_f32 on the reference's own index list int(torch.linspace(start, end, n))."""
+    ref, tgt = _f32c(_chk(reference_fm, "reference_fm", 4)), _f32c(_chk(target_fm, "target_fm", 4))
+    if start_disp == 0 and dilation == 1:
+        return _build(None, None, 0, ref, tgt, max_disp, NCDHW)
+    B, C, H, W = ref.shape
+    n = (max_disp + dilation - 1) // dilation                                          # psmnet_cost_processor.py:31-33
+    idx = torch.tensor([int(i) for i in torch.linspace(start_disp, start_disp + max_disp - 1, n)], dtype=torch.int32, device=ref.device)
+    out = torch.empty((B, 2 * C, n, H, W), device=ref.device, dtype=torch.float32)
+    _lib.call("osa_cat_fms_f32", ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), idx.data_ptr(), B, C, H, W, n, _stream())
+    return out
 
 
 def _pair_volume(left, right, planes, mode, groups=1):

@@ -1,14 +1,14 @@
 #!/bin/bash
-# build_variant.sh NAME [extra hipcc flags]: conv3d.hip / conv_pipe.hip / volume.hip / wgrad.hip compiled with extra flags (e.g.
-# -DOSA_EXPERIMENTS: the measurement switches of osa_common.h), linked with the
-# regular objects into openstereo_amd/lib/variants/NAME.so (A/B experiments via OSA_LIB_PATH)
+# build_variant.sh NAME [extra hipcc flags]: conv3d.hip / volume.hip / wgrad.hip (+ tools/experiments/conv_pipe.hip, the persistent LDS-DMA
+# form that only the -DOSA_EXPERIMENTS build links) compiled with extra flags (e.g. -DOSA_EXPERIMENTS: the measurement switches of
+# osa_common.h), linked with the regular objects into openstereo_amd/lib/variants/NAME.so (A/B experiments via OSA_LIB_PATH)
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p openstereo_amd/lib/variants
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off"
-for f in conv3d conv_pipe volume wgrad; do
-  /opt/rocm/bin/hipcc $FLAGS "$@" -c openstereo_amd/csrc/$f.hip -o openstereo_amd/lib/variants/$NAME.$f.o &
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Iopenstereo_amd/csrc"
+for f in openstereo_amd/csrc/conv3d openstereo_amd/csrc/volume openstereo_amd/csrc/wgrad tools/experiments/conv_pipe; do
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o openstereo_amd/lib/variants/$NAME.$(basename $f).o &
 done
 wait
 OBJS=$(ls openstereo_amd/lib/obj/*.o | grep -v "/conv3d.o\|/conv_pipe.o\|/volume.o\|/wgrad.o")
