@@ -369,8 +369,26 @@ def coex_cost_volume(x, y, maxdisp, group=1):
     return out
 
 
+def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
+    """psmnet_cost_processor.py:9-50: concat volume over the disparities int(linspace(start, start + max_disp - 1, n)), negative ones
+    sampling to the left."""
+    N, C, H, W = reference_fm.shape
+    n = (max_disp + dilation - 1) // dilation
+    out = reference_fm.new_zeros(N, 2 * C, n, H, W, dtype=torch.float32)
+    for idx, i in enumerate(int(v) for v in torch.linspace(start_disp, start_disp + max_disp - 1, n)):
+        if abs(i) >= W:
+            continue
+        if i > 0:
+            out[:, :C, idx, :, i:], out[:, C:, idx, :, i:] = reference_fm[..., i:], target_fm[..., :-i]
+        elif i == 0:
+            out[:, :C, idx], out[:, C:, idx] = reference_fm, target_fm
+        else:
+            out[:, :C, idx, :, :i], out[:, C:, idx, :, :i] = reference_fm[..., :i], target_fm[..., -i:]
+    return out
+
+
 def compute_volume(reference, target, maxdisp, side="left"):
-    """cost_volume.py:44-56 (the reference hard-codes device='cuda': restated, parity unpinned)."""
+    """cost_volume.py:44-56 (pinned by dormant_volumes.npz: the reference run with its device='cuda' zeros redirected to the CPU)."""
     b, c, h, w = reference.shape
     cost = reference.new_zeros(b, c, maxdisp, h, w)
     cost[:, :, 0] = reference - target
@@ -383,7 +401,7 @@ def compute_volume(reference, target, maxdisp, side="left"):
 
 
 def build_sub_volume(feat_l, feat_r, maxdisp):
-    """cost_volume.py:108-117 (device='cuda' hard-coded in the reference: restated, parity unpinned)."""
+    """cost_volume.py:108-117 (pinned by dormant_volumes.npz, see compute_volume)."""
     b, c, h, w = feat_l.shape
     cost = feat_l.new_zeros(b, maxdisp, h, w)
     for i in range(maxdisp):

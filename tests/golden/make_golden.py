@@ -217,14 +217,78 @@ def gen_preprocess():
 
 
 def gen_dormant():
-    """Dormant volume variants: CoExCostVolume (cost_volume.py:9-29) is CPU-runnable -> pinned here.  compute_volume / build_sub_volume
-    (:44-56, :108-117) hard-code device='cuda' and cannot run in this container: their oracle restatements stay unpinned."""
+    """Dormant volume variants.  CoExCostVolume (cost_volume.py:9-29) is CPU-runnable.  compute_volume / build_sub_volume (:44-56, :108-117)
+    hard-code device='cuda' in their torch.zeros calls: the module's `torch` global is replaced by a proxy whose zeros() drops that
+    keyword, everything else is the reference's code (VERDICT r2 #9).  cat_fms (psmnet_cost_processor.py:9-50) with negative start
+    disparities and dilation."""
     from stereo.modeling.cost_volume import cost_volume as cv
+    from stereo.modeling.models.psmnet.psmnet_cost_processor import cat_fms
+
+    class _CpuTorch:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def zeros(*a, **k):
+            k.pop("device", None)
+            return torch.zeros(*a, **k)
     x, y = rnd((2, 8, 5, 20), 301), rnd((2, 8, 5, 20), 302)
     out = {"x": x.numpy(), "y": y.numpy()}
     for grp in (1, 4):
         out[f"coex_g{grp}"] = cv.CoExCostVolume(6, grp)(x, y).numpy()
+    real = cv.torch
+    cv.torch = _CpuTorch()
+    try:
+        out["compute_left"] = cv.compute_volume(x, y, 7, "left").numpy()
+        out["compute_right"] = cv.compute_volume(x, y, 7, "right").numpy()
+        out["sub_volume"] = cv.build_sub_volume(x, y, 7).numpy()
+    finally:
+        cv.torch = real
+    for tag, (md, st, dil) in {"neg": (9, -4, 1), "dil": (12, 2, 3), "negdil": (10, -6, 2)}.items():
+        out[f"catfms_{tag}"] = cat_fms(x, y, max_disp=md, start_disp=st, dilation=dil).numpy()
+        out[f"catfms_{tag}_args"] = np.array([md, st, dil])
     save("dormant_volumes.npz", **out)
+
+
+def gen_unit_gain():
+    """IGEV refinement x32 at 136x240 with UNIT-gain update-block weights (gen_at_size uses gain 0.8 because the recurrence amplifies a
+    1e-6 perturbation ~800x at unit gain).  Stored next to the result: how far the reference's OWN output moves when the initial hidden
+    state is perturbed by 1e-6 (relative) -- the yardstick an fp32-class implementation is held to (VERDICT r2 weak #5)."""
+    import importlib.util
+    from openstereo_amd.utils.weights import synth_state_dict
+    sys.modules.setdefault("timm", types.ModuleType("timm"))
+    from stereo.modeling.models.igev.geometry import Combined_Geo_Encoding_Volume
+    spec = importlib.util.spec_from_file_location("ref_igev_update", os.path.join(REF, "stereo/modeling/models/igev/update.py"))
+    upd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(upd)
+    H, W = 136, 240
+    ml, mr = rnd((1, 96, H, W), 192), rnd((1, 96, H, W), 193)
+    gvol = rnd((1, 8, 48, H, W), 194)
+    coords = torch.arange(W).float().reshape(1, 1, W, 1).repeat(1, H, 1, 1)
+    d0 = rnd((1, 1, H, W), 195).abs() * 3
+    geo_fn = Combined_Geo_Encoding_Volume(ml, mr, gvol, radius=4, num_levels=2)
+    args = Cfg(CORR_LEVELS=2, CORR_RADIUS=4, N_GRU_LAYERS=3, N_DOWNSAMPLE=2)
+    blk = upd.BasicMultiUpdateBlock(args, hidden_dims=[128, 128, 128]).eval()
+    blk.load_state_dict(synth_state_dict(blk, seed=11))                      # default gain: the unit-gain recurrence
+    net = [torch.tanh(rnd((1, 128, H >> i, W >> i), 170 + i)) for i in range(3)]
+    inp = [[rnd((1, 128, H >> i, W >> i), 180 + 3 * i + j) * 0.5 for j in range(3)] for i in range(3)]
+
+    def run(nl):
+        d, nl = d0, [x.clone() for x in nl]
+        for _ in range(32):
+            gf = geo_fn(d, coords)
+            nl = blk(nl, inp, iter16=True, iter08=False, iter04=False, update=False)
+            nl = blk(nl, inp, iter16=True, iter08=True, iter04=False, update=False)
+            nl, mk, dd = blk(nl, inp, gf, d, iter16=True, iter08=True)
+            d = d + dd
+        return d
+    t = time.time()
+    d_ref = run(net)
+    d_pert = run([net[0] * (1.0 + 1e-6)] + net[1:])
+    dev = (d_pert - d_ref).abs()
+    print(f"IGEV refine x32 unit gain: {time.time() - t:.1f} s, disp range {d_ref.min().item():.2f}..{d_ref.max().item():.2f}; a 1e-6 relative "
+          f"perturbation of net[0] moves the result by mean {dev.mean().item():.2e} / max {dev.max().item():.2e} px")
+    save("igev_unit_gain.npz", disp=d_ref, pert_mean=dev.mean(), pert_max=dev.max(), pert_p999=torch.quantile(dev.flatten(), 0.999))
 
 
 def _reference_model(modname, clsname, cfg, stand_ins):
@@ -377,7 +441,7 @@ def gen_e2e_train(feat, cnet):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | unit_gain")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -399,6 +463,9 @@ def main():
         return
     if args.only == "e2e":
         gen_e2e()
+        return
+    if args.only == "unit_gain":
+        gen_unit_gain()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -526,6 +593,7 @@ def main():
     gen_preprocess()
     gen_dormant()
     gen_e2e()
+    gen_unit_gain()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

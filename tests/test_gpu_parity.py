@@ -875,6 +875,16 @@ def test_dormant_volume_variants():
     for grp in (1, 4):
         got = ops.CoExCostVolume(6, grp)(x.to(DEV), y.to(DEV)).cpu()
         torch.testing.assert_close(got, T(g[f"coex_g{grp}"]), rtol=1e-5, atol=1e-6)
+    # the reference's own outputs (its device='cuda' zeros redirected to the CPU when the fixture was generated)
+    assert torch.equal(ops.compute_volume(x.to(DEV), y.to(DEV), 7, "left").cpu(), T(g["compute_left"]))
+    assert torch.equal(ops.compute_volume(x.to(DEV), y.to(DEV), 7, "right").cpu(), T(g["compute_right"]))
+    torch.testing.assert_close(ops.build_sub_volume(x.to(DEV), y.to(DEV), 7).cpu(), T(g["sub_volume"]), rtol=1e-6, atol=1e-6)
+    for tag in ("neg", "dil", "negdil"):            # cat_fms with negative start disparities / dilation (psmnet_cost_processor.py:30-47)
+        md, st, dil = (int(v) for v in g[f"catfms_{tag}_args"])
+        got = ops.cat_fms(x.to(DEV), y.to(DEV), max_disp=md, start_disp=st, dilation=dil)
+        assert got.dtype == torch.float32 and torch.equal(got.cpu(), T(g[f"catfms_{tag}"])), tag
+    wide = ops.cat_fms(x.to(DEV), y.to(DEV), max_disp=30, start_disp=-25, dilation=1)           # |disparity| >= W: all-zero planes
+    assert torch.equal(wide.cpu(), R.cat_fms(x, y, 30, -25, 1))
     for (B, C, H, W, D) in ((2, 12, 5, 37, 9), (1, 8, 3, 6, 10)):
         l, r = rnd((B, C, H, W), 311), rnd((B, C, H, W), 312)
         for side in ("left", "right"):

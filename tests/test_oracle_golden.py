@@ -205,14 +205,21 @@ def test_preprocess_against_reference_transforms():
 
 
 def test_dormant_volume_variants_oracle():
-    """CoExCostVolume restatement vs the reference's class (golden); compute_volume / build_sub_volume are CUDA-only in the reference
-    (device='cuda' hard-coded): checked here against their definitions on a tiny case written out by hand."""
+    """CoExCostVolume, compute_volume, build_sub_volume and cat_fms (negative start, dilation) restatements vs the reference's own outputs
+    (dormant_volumes.npz; compute_volume / build_sub_volume were run with their hard-coded device='cuda' zeros redirected to the CPU,
+    make_golden.gen_dormant), plus a tiny case written out by hand."""
     import torch
     from oracle import torch_ref as R
     g = golden("dormant_volumes.npz")
     x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
     for grp in (1, 4):
         torch.testing.assert_close(R.coex_cost_volume(x, y, 6, grp), torch.from_numpy(g[f"coex_g{grp}"]), rtol=1e-5, atol=1e-6)
+    assert torch.equal(R.compute_volume(x, y, 7, "left"), torch.from_numpy(g["compute_left"]))
+    assert torch.equal(R.compute_volume(x, y, 7, "right"), torch.from_numpy(g["compute_right"]))
+    torch.testing.assert_close(R.build_sub_volume(x, y, 7), torch.from_numpy(g["sub_volume"]), rtol=1e-6, atol=1e-6)
+    for tag in ("neg", "dil", "negdil"):
+        md, st, dil = (int(v) for v in g[f"catfms_{tag}_args"])
+        assert torch.equal(R.cat_fms(x, y, md, st, dil), torch.from_numpy(g[f"catfms_{tag}"])), tag
     l = torch.tensor([[[[1.0, 2.0, 4.0]]], ]).repeat(1, 2, 1, 1); l[:, 1] *= -1          # [1,2,1,3]
     r = torch.tensor([[[[0.5, 1.0, 3.0]]], ]).repeat(1, 2, 1, 1)
     cv = R.compute_volume(l, r, 2, "left")
