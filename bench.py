@@ -210,6 +210,8 @@ class StereoBaseTrain:
         self.feats = [None, r(B, 64, H // 2, W // 2), r(B, 192, H // 4, W // 4), r(B, 120, H // 8, W // 8)]
         self.gt = torch.rand(B, 1, H, W, generator=g).to(dev) * 40
 
+    static = False            # (the loss of this workload has static shapes already)
+
     def step(self):
         self.opt.zero_grad(set_to_none=True)
         out = self.model(*self.x, self.feats)
@@ -318,15 +320,18 @@ class StereoBaseE2ETrain:
         self.model = net
         if int(os.environ.get("WORLD_SIZE", 1)) > 1:
             self.model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
-        self.opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5, eps=1e-8)
+        # capturable: the step counter lives on the device, so the optimizer step can be part of a hipGraph (no effect on the arithmetic)
+        self.opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5, eps=1e-8, capturable=True)
         L, R = synth_images(B, 320, 736, seed=20 + rank)
         self.L, self.R = L.to(dev), R.to(dev)
         self.gt = torch.from_numpy(np.random.default_rng(rank).uniform(1, 100, (B, 320, 736)).astype("float32")).to(dev)
 
+    static = False            # True: static-shape loss without .item() (hipGraph replay of the whole step)
+
     def step(self):
         self.opt.zero_grad(set_to_none=True)
         out = self.model({"left": self.L, "right": self.R})
-        loss, _ = self.raw.get_loss(out, {"disp": self.gt})
+        loss, _ = self.raw.get_loss(out, {"disp": self.gt}, static=self.static)
         loss.backward()
         torch.nn.utils.clip_grad_value_(self.raw.parameters(), 1.0)          # CLIP_GRAD: value 1.0
         self.opt.step()
@@ -352,15 +357,17 @@ class GwcNetTrain:
         self.model = self.raw
         if int(os.environ.get("WORLD_SIZE", 1)) > 1:
             self.model = torch.nn.parallel.DistributedDataParallel(self.raw, device_ids=[dev.index])
-        self.opt = torch.optim.RMSprop(self.model.parameters(), lr=1e-3)      # cfgs/gwcnet/gwcnet_sceneflow.yaml
+        self.opt = torch.optim.RMSprop(self.model.parameters(), lr=1e-3, capturable=True)      # cfgs/gwcnet/gwcnet_sceneflow.yaml (capturable: hipGraph-friendly, same arithmetic)
         L, R = synth_images(B, 256, 512, seed=10 + rank)
         self.L, self.R = L.to(dev), R.to(dev)
         self.gt = torch.from_numpy(np.random.default_rng(rank).uniform(1, 100, (B, 256, 512)).astype("float32")).to(dev)
 
+    static = False
+
     def step(self):
         self.opt.zero_grad(set_to_none=True)
         out = self.model({"left": self.L, "right": self.R})
-        loss, _ = self.raw.get_loss(out, {"disp": self.gt})
+        loss, _ = self.raw.get_loss(out, {"disp": self.gt}, static=self.static)
         loss.backward()
         self.opt.step()
         return loss.detach()
@@ -532,6 +539,42 @@ class _eager_torch_mode:
         return False
 
 
+def capture_training_step(wl):
+    """Whole training step as ONE hipGraph (forward, loss, backward, optimizer step, the per-step weight re-packs with their device-side
+    scales): the eager step is launch-bound (1.7 K - 11 K launches of a few microseconds each).  Nothing is skipped -- every replay runs
+    the same kernels on the updated weights; the loss is the static-shape form (`get_loss(..., static=True)`, same value).  PyTorch's
+    whole-network capture recipe: warm-up on a side stream, grads released before capture so that backward allocates them from the
+    graph's pool.  Returns (graph, step) or None when capture is not possible (the caller then times eager steps)."""
+    try:
+        wl.static = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                wl.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for prm in wl.raw.parameters():                      # stale packs must be re-recorded inside the capture
+            getattr(prm, "_osa_packs", {}).clear()
+        wl.opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = wl.step()
+
+        def step():
+            graph.replay()
+            return graph_out
+        step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(graph_out).all()
+        return graph, step
+    except Exception as ex:
+        print(f"[bench] hipGraph capture of the training step failed ({type(ex).__name__}: {str(ex)[:300]}); running eagerly", file=sys.stderr)
+        wl.static = False
+        torch.cuda.synchronize()
+        return None
+
+
 def _time_steps(step, steps, warmup):
     for _ in range(warmup):
         step()
@@ -577,6 +620,10 @@ def secondary_workloads(args, dev, rank, budget_s=75.0):
                 step()
             torch.cuda.synchronize()
             launch = "eager"
+            if wl.training and not args.no_graph:
+                cap = capture_training_step(wl)
+                if cap is not None:
+                    step, launch = cap[1], "hipGraph replay of the whole training step"
             if wl.graphable and not args.no_graph:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -726,6 +773,12 @@ def main():
     # inner loop -> one graph launch per step).  Warm-up has packed every weight, so only kernels (and the caching allocator's
     # graph pool) are recorded.
     graph = None
+    if wl.training and world == 1 and not args.no_graph and dev.type == "cuda":
+        cap = capture_training_step(wl)
+        if cap is not None:
+            graph, step = cap
+            step()
+            sync()
     if wl.graphable and not args.no_graph and dev.type == "cuda":
         try:
             graph = torch.cuda.CUDAGraph()
@@ -755,7 +808,8 @@ def main():
             "vs_baseline": None, "dtype": "n/a (stub)" if args.stub else DTYPES[args.precision], "data": "synthetic"}
     cfg = wl.config(args)
     cfg.update({"pairs_per_gpu_per_step": B, "parallelism": (f"DDP x{world} (RCCL all-reduce of gradients)" if wl.training else f"independent pairs x{world}"),
-                "precision": args.precision, "launch": "hipGraph replay" if graph is not None else "eager"})
+                "precision": args.precision, "launch": ("hipGraph replay" + (" of the whole training step (forward + loss + backward + optimizer)" if wl.training else ""))
+                if graph is not None else "eager"})
     line["config"] = cfg
 
     if args.workload == "gwcnet" and not args.stub and rank == 0:

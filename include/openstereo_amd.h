@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OSA_ABI_VERSION 2
+#define OSA_ABI_VERSION 3
 #define OSA_META_FLOATS 128   /* floats per range block (osa_f16x3_ranges) */
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
@@ -204,7 +204,20 @@ typedef struct osa_f16x3_ranges {
     float*       y_meta;            /* range block of y (updated) */
     const float* bound_coef;        /* 2 floats, see above */
     const float* redir_bound_coef;  /* 2 floats of the fused redir layer */
+    const float* weight_scale;      /* {wscale, 1 / wscale} written by an osa_*_pack_*_auto call (device memory): when non-NULL,
+                                       weight_scale[1] replaces the `out_scale` argument of the conv call (ABI v3) */
 } osa_f16x3_ranges;
+
+/* Packing with the power-of-two weight pre-scale derived ON THE DEVICE (training: the weights change every optimizer step, and a
+ * host-side scale would cost a synchronisation per layer, role and step and rule out hipGraph capture of the step):
+ * w_amax = max |w| (1 float, device), scale_out = {wscale, 1 / wscale} (2 floats, device, written by the call) -> pass it to the
+ * conv / deconv call through osa_f16x3_ranges.weight_scale.  Same packed image as the *_f16x3 calls given that scale. */
+int osa_conv3d_pack_ex_auto(const float* w_ref, float* w_packed, int Ci, int Co, int kd, int kh, int kw,
+                            int src_transposed, int flip, const float* w_amax, float* scale_out, void* stream);
+int osa_deconv3d_pack_f16x3_auto(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad,
+                                 const float* w_amax, float* scale_out, void* stream);
+int osa_deconv2d_pack_f16x3_auto(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad,
+                                 const float* w_amax, float* scale_out, void* stream);
 
 int osa_conv3d_pack_f16x3(const float* w_ref, float* w_packed,
                           int Ci, int Co, int kd, int kh, int kw, float wscale, void* stream);

@@ -25,7 +25,7 @@ c_ll = C.c_longlong
 class F16x3Ranges(C.Structure):
     """osa_f16x3_ranges (include/openstereo_amd.h): device pointers of the operands' range blocks."""
     _fields_ = [("x_meta", C.c_void_p), ("residual_meta", C.c_void_p), ("redir_meta", C.c_void_p),
-                ("y_meta", C.c_void_p), ("bound_coef", C.c_void_p), ("redir_bound_coef", C.c_void_p)]
+                ("y_meta", C.c_void_p), ("bound_coef", C.c_void_p), ("redir_bound_coef", C.c_void_p), ("weight_scale", C.c_void_p)]
 
 
 c_rng = C.POINTER(F16x3Ranges)
@@ -126,6 +126,9 @@ SIGNATURES = {
                                     c_i, c_fp, c_st]),
     "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
     "osa_disp_update_f32": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_ll, c_fp, c_fp, c_st]),
+    "osa_conv3d_pack_ex_auto": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
+    "osa_deconv3d_pack_f16x3_auto": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
+    "osa_deconv2d_pack_f16x3_auto": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_cat_fms_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_pool2x_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_resize_bilinear_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
@@ -167,7 +170,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        if lib.osa_abi_version() != 2:
+        if lib.osa_abi_version() != 3:
             raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}")
         _lib = lib
     return _lib

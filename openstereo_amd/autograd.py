@@ -164,12 +164,6 @@ def upsample_softargmin(cost_lowres, maxdisp, h, w, align_corners=False):
 
 
 # ----------------------------------------------------------------------------- convolutions
-def _pow2_scale(w):
-    amax = float(w.abs().max())
-    k = 0 if amax == 0.0 or not math.isfinite(amax) else int(math.floor(math.log2(16384.0 / amax)))
-    return 2.0 ** max(-14, min(k, 40))
-
-
 def _wcache(w):
     """Per-weight pack cache handle `(dict, stamp)`.  The dict lives ON the weight tensor object (the nn.Parameter the caller holds), so
     it dies with the model -- a process-wide table keyed on data_ptr would serve a freed model's packs to the next one the allocator
@@ -185,7 +179,16 @@ def _wcache(w):
             w._osa_packs = c = {}
         except Exception:                               # tensor subclasses without a __dict__
             return None
-    return c, (w._version, w.data_ptr(), str(w.device), w.dtype)
+    return _Memo(c, (w._version, w.data_ptr(), str(w.device), w.dtype))
+
+
+class _Memo:
+    """(dict, stamp) handle.  A plain object on purpose: torch.amp.custom_fwd walks tuples / dicts among a Function's arguments and
+    rebuilds them (casting tensors inside), which would hand the Function a COPY of the memo dict."""
+    __slots__ = ("memo", "stamp")
+
+    def __init__(self, memo, stamp):
+        self.memo, self.stamp = memo, stamp
 
 
 def _pack(w, Ci, Co, k, mode, precision, cache=None):
@@ -195,7 +198,7 @@ def _pack(w, Ci, Co, k, mode, precision, cache=None):
     `_wcache` handle of the tensor it came from."""
     if cache is None:
         return _pack_now(w, Ci, Co, k, mode, precision)
-    memo, stamp = cache
+    memo, stamp = cache.memo, cache.stamp
     if memo.get("stamp") != stamp:
         memo.clear()
         memo["stamp"] = stamp
@@ -207,37 +210,46 @@ def _pack(w, Ci, Co, k, mode, precision, cache=None):
 
 
 def _pack_now(w, Ci, Co, k, mode, precision):
-    """mode: 'fwd' | 'dgrad_s1' (role swap + flip) | 'dgrad_of_deconv' (role swap) | 'deconv' / 'deconv2d' (parity-class packing)."""
+    """mode: 'fwd' | 'dgrad_s1' (role swap + flip) | 'dgrad_of_deconv' (role swap) | 'deconv' / 'deconv2d' (parity-class packing).
+    Returns (packed buffer, scale): f32 -> scale 1.0; f16x3 -> a 2-float DEVICE tensor {wscale, 1 / wscale} that the pack kernel derived
+    from max |w| on the device (osa_*_pack_*_auto) -- no host synchronisation per layer / role / optimizer step, and the whole training
+    step can be captured in a hipGraph (the packs are part of the captured work)."""
     f16 = precision == "f16x3"
-    ws = _pow2_scale(w) if f16 else 1.0
     lib = _lib.load()
+    if f16:
+        amax = torch.linalg.vector_norm(w.detach(), float("inf"))          # one reduction kernel, stays on the device
+        sc = torch.empty(2, device=w.device, dtype=torch.float32)
     if mode == "deconv2d":
         n = lib.osa_deconv2d_packed_floats(Ci, Co, k[0])
         buf = torch.zeros(n, device=w.device, dtype=torch.float32)
         if f16:
-            _lib.call("osa_deconv2d_pack_f16x3", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, ws, _stream())
+            _lib.call("osa_deconv2d_pack_f16x3_auto", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, amax.data_ptr(), sc.data_ptr(), _stream())
         else:
             _lib.call("osa_deconv2d_pack_f32", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
     elif mode == "deconv":
         n = lib.osa_deconv3d_packed_floats(Ci, Co, k[0])
         buf = torch.zeros(n, device=w.device, dtype=torch.float32)
         if f16:
-            _lib.call("osa_deconv3d_pack_f16x3", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, ws, _stream())
+            _lib.call("osa_deconv3d_pack_f16x3_auto", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, amax.data_ptr(), sc.data_ptr(), _stream())
         else:
             _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
     else:
         n = lib.osa_conv3d_packed_floats(Ci, Co, *k)
         buf = torch.zeros(n, device=w.device, dtype=torch.float32)
         tr, fl = {"fwd": (0, 0), "dgrad_s1": (1, 1), "dgrad_of_deconv": (0, 0)}[mode]
-        _lib.call("osa_conv3d_pack_ex", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, 1 if f16 else 0, ws, _stream())
-    return buf, 1.0 / ws
+        if f16:
+            _lib.call("osa_conv3d_pack_ex_auto", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, amax.data_ptr(), sc.data_ptr(), _stream())
+        else:
+            _lib.call("osa_conv3d_pack_ex", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, 0, 1.0, _stream())
+    return buf, (sc if f16 else 1.0)
 
 
-def _ranges(x, y):
+def _ranges(x, y, wscale):
     """f16x3 operand ranges of a plain conv call: x (activations or incoming gradients -- whose magnitudes are
     routinely 1e-5 .. 1e-8) is scaled by a power of two derived from its measured max |.| on the device, so the
-    hi/lo fp16 halves keep 22 significant bits whatever the magnitude; exact to undo."""
-    return _lib.F16x3Ranges(input_meta(x).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None)
+    hi/lo fp16 halves keep 22 significant bits whatever the magnitude; exact to undo.  wscale: the packed weights' device-side
+    {scale, 1 / scale} pair (_pack_now)."""
+    return _lib.F16x3Ranges(input_meta(x).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None, wscale.data_ptr())
 
 
 def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape):
@@ -248,7 +260,7 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (oscale, _ranges(x, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = ("f16x3", (1.0, _ranges(x, y, oscale), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
     macs = B * out_shape[0] * out_shape[1] * out_shape[2] * Ci * Co * k[0] * k[1] * k[2]
     with timing.span("conv3d", Ci, Co, k[1], stride, D, H, W, flops=2 * macs,
                      nbytes=4 * B * (D * H * W * Ci + out_shape[0] * out_shape[1] * out_shape[2] * Co)):
@@ -266,7 +278,7 @@ def _run_deconv(x, packed, oscale, Ci, Co, k, pad, opad, precision):
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (oscale, _ranges(x, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = ("f16x3", (1.0, _ranges(x, y, oscale), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
     with timing.span("deconv3d", Ci, Co, k, 2, D, H, W, flops=2 * B * D * H * W * Ci * Co * k ** 3,
                      nbytes=4 * B * (D * H * W * Ci + od(D) * od(H) * od(W) * Co)):
         _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
@@ -399,7 +411,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if CoS != Co:
             y.zero_()
         Ci4 = (Ci + 3) // 4 * 4
-        sfx, tail = ("f16x3", (osc, _ranges(xc, y), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+        sfx, tail = ("f16x3", (1.0, _ranges(xc, y, osc), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
         _lib.call("osa_deconv2d_nhwc_" + sfx, xc.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
                   B, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
         ctx.save_for_backward(xc, wf)

@@ -413,6 +413,40 @@ __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const PackArgs 
     reinterpret_cast<_Float16*>(p.dst)[i] = hl ? (_Float16)(v - (float)hi) : hi;
 }
 
+// Power-of-two weight pre-scale derived ON THE DEVICE from max |w| (training: weights change every optimizer step; a host-side scale
+// would cost one synchronisation per layer, role and step and would rule out hipGraph capture of the step): largest |w| * wscale in
+// [2^13, 2^14) -- floor(log2(16384 / amax)) clamped to [-14, 40], from the exponent bits (no transcendental).  amax 0 / inf / NaN: 1.
+__device__ __forceinline__ float auto_wscale(float amax) {
+    const unsigned b = __builtin_bit_cast(unsigned, amax);
+    const int eb = (int)((b >> 23) & 0xffu);
+    if (eb == 0 || eb == 255) return 1.f;
+    int k = 14 - (eb - 127) - ((b & 0x7fffffu) ? 1 : 0);
+    k = k < -14 ? -14 : (k > 40 ? 40 : k);
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+__global__ __launch_bounds__(256) void pack_weights_f16x3_auto_kernel(const PackArgs p, const float* __restrict__ amax, float* __restrict__ scale_out) {
+    const float wscale = auto_wscale(*amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = wscale; scale_out[1] = 1.0f / wscale; }
+    const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = i & 7; size_t r = i >> 3;
+    const int co = r % p.CoP; r /= p.CoP;
+    const int kg = r & 1; r >>= 1;
+    const int hl = r & 1; r >>= 1;
+    const int t = r % p.T; const int ch = r / p.T;
+    const int ci = ch * CC + 8 * kg + e;
+    float v = 0.f;
+    if (ci < p.Ci && co < p.Co) {
+        const size_t kvol = (size_t)p.kd * p.kh * p.kw;
+        const size_t kidx = ((size_t)p.kz[t] * p.kh + p.ky[t]) * p.kw + p.kx[t];
+        v = wscale * (p.transposed ? p.src[((size_t)ci * p.Co + co) * kvol + kidx]
+                                   : p.src[((size_t)co * p.Ci + ci) * kvol + kidx]);
+    }
+    const _Float16 hi = (_Float16)v;
+    reinterpret_cast<_Float16*>(p.dst)[i] = hl ? (_Float16)(v - (float)hi) : hi;
+}
+
 static inline int pad32(int c) { return (c + 31) / 32 * 32; }
 static inline int nchunks_of(int ci) { return (ci + CC - 1) / CC; }
 static inline size_t packed_floats(int Ci, int Co, int T) {
@@ -511,7 +545,12 @@ extern "C" size_t osa_conv3d_packed_floats(int Ci, int Co, int kd, int kh, int k
     return packed_floats(Ci, Co, kd * kh * kw) + slack_floats(Co);
 }
 
-static void launch_pack(const PackArgs& p, int prec, float wscale, hipStream_t st) {
+static void launch_pack(const PackArgs& p, int prec, float wscale, hipStream_t st, const float* amax_dev = nullptr, float* scale_out = nullptr) {
+    if (amax_dev) {                                    // f16x3 with the device-side scale
+        const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;
+        hipLaunchKernelGGL(pack_weights_f16x3_auto_kernel, dim3(total ? cdiv((long long)total, 256) : 1), dim3(256), 0, st, p, amax_dev, scale_out);
+        return;
+    }
     if (prec == PREC_F32) {
         const size_t total = (size_t)p.nchunks * p.T * JO * 2 * p.CoP * 4;
         if (total) hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, p);
@@ -523,7 +562,7 @@ static void launch_pack(const PackArgs& p, int prec, float wscale, hipStream_t s
 
 static int conv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
                             int kd, int kh, int kw, int prec, float wscale, void* stream,
-                            int src_transposed = 0, int flip = 0) {
+                            int src_transposed = 0, int flip = 0, const float* amax_dev = nullptr, float* scale_out = nullptr) {
     OSA_REQUIRE(w_ref && w_packed, "conv3d_pack: NULL pointer");
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= MAX_TAPS, "conv3d_pack: %dx%dx%d kernel has %d taps (max %d)", kd, kh, kw, T, MAX_TAPS);
@@ -536,9 +575,15 @@ static int conv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
         p.kz[t] = (signed char)(flip ? kd - 1 - z : z); p.ky[t] = (signed char)(flip ? kh - 1 - y : y);
         p.kx[t] = (signed char)(flip ? kw - 1 - x : x);
     }
-    launch_pack(p, prec, wscale, (hipStream_t)stream);
+    launch_pack(p, prec, wscale, (hipStream_t)stream, amax_dev, scale_out);
     OSA_LAUNCH_CHECK("conv3d_pack");
     return 0;
+}
+
+extern "C" int osa_conv3d_pack_ex_auto(const float* w_ref, float* w_packed, int Ci, int Co, int kd, int kh, int kw,
+                                       int src_transposed, int flip, const float* w_amax, float* scale_out, void* stream) {
+    OSA_REQUIRE(w_amax && scale_out, "conv3d_pack_ex_auto: NULL scale pointers");
+    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, PREC_F16X3, 1.f, stream, src_transposed, flip, w_amax, scale_out);
 }
 
 extern "C" int osa_conv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
@@ -596,7 +641,8 @@ static void deconv_taps(int k, int pad, DeconvTaps& d, bool flat = false) {
 }
 
 static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
-                              int k, int pad, int prec, float wscale, void* stream, bool flat = false) {
+                              int k, int pad, int prec, float wscale, void* stream, bool flat = false,
+                              const float* amax_dev = nullptr, float* scale_out = nullptr) {
     OSA_REQUIRE(w_ref && w_packed, "deconv3d_pack: NULL pointer");
     OSA_REQUIRE(k == 3 || k == 4, "deconv3d_pack: kernel %d unsupported (3 or 4)", k);
     DeconvTaps d;
@@ -605,9 +651,21 @@ static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int C
     p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
     p.kd = flat ? 1 : k; p.kh = k; p.kw = k; p.T = d.T; p.nchunks = nchunks_of(Ci); p.transposed = 1;
     for (int t = 0; t < d.T; ++t) { p.kz[t] = d.kz[t]; p.ky[t] = d.ky[t]; p.kx[t] = d.kx[t]; }
-    launch_pack(p, prec, wscale, (hipStream_t)stream);
+    launch_pack(p, prec, wscale, (hipStream_t)stream, amax_dev, scale_out);
     OSA_LAUNCH_CHECK("deconv3d_pack");
     return 0;
+}
+
+extern "C" int osa_deconv3d_pack_f16x3_auto(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad,
+                                            const float* w_amax, float* scale_out, void* stream) {
+    OSA_REQUIRE(w_amax && scale_out, "deconv3d_pack_f16x3_auto: NULL scale pointers");
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, 1.f, stream, false, w_amax, scale_out);
+}
+
+extern "C" int osa_deconv2d_pack_f16x3_auto(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad,
+                                            const float* w_amax, float* scale_out, void* stream) {
+    OSA_REQUIRE(w_amax && scale_out, "deconv2d_pack_f16x3_auto: NULL scale pointers");
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, 1.f, stream, true, w_amax, scale_out);
 }
 
 extern "C" int osa_deconv3d_pack_f32(const float* w_ref, float* w_packed, int Ci, int Co,
@@ -641,6 +699,7 @@ static void set_ranges(ConvArgs& a, const osa_f16x3_ranges* r) {
     if (!r) return;
     a.in_meta = r->x_meta; a.res_meta = r->residual_meta; a.rx_meta = r->redir_meta; a.out_meta = r->y_meta;
     a.coef = r->bound_coef; a.rcoef = r->redir_bound_coef;
+    a.wscale_dev = r->weight_scale;
 }
 
 static int check_common(const char* what, const float* x, const float* w, float* y,

@@ -68,6 +68,7 @@ struct ConvArgs {
     int cps;                      // channel chunks staged per pass (LDS holds cps bricks back to back)
     int act; float slope;
     float oscale;                 // f16x3: 1 / (weight pre-scale), exact power of two; 1 for f32
+    const float* wscale_dev;      // f16x3, optional: {wscale, 1 / wscale} in device memory (osa_*_pack_*_auto); [1] then replaces oscale
     int VQ;                       // LDS voxel stride in 16-byte slots: 4 (compact) or 5 (padded), see finish_geometry
     // fused 1x1x1 "redir" branch of a transposed conv (GwcNet hourglass: relu(conv6(c5) + redir1(x))):
     // rx = NDHWC tensor at OUTPUT resolution (<= 32 channels), rw = its packed 1x1x1 weights (same packing,
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         }
         if (OUTS && p.out_meta && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.out_meta[1] = s_out;
     }
-    const float osc = p.oscale * (1.0f / s_in);      // undoes the weight pre-scale and the input scale (exact)
+    const float osc = (p.wscale_dev ? p.wscale_dev[1] : p.oscale) * (1.0f / s_in);      // undoes the weight pre-scale and the input scale (exact)
     const float rosc = p.roscale * (1.0f / s_rx);
     float am = 0.f;                                  // running max |output| of this lane (unscaled values)
 

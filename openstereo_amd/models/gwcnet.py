@@ -404,11 +404,17 @@ class GwcNet(nn.Module):
             return {"disp_preds": ests, "disp_pred": ests[-1]}
         return {"disp_pred": disp_out["inference_disp"]["disp_est"]}
 
-    def get_loss(self, model_preds, input_data):
-        """models/gwcnet/gwcnet.py:42-53."""
+    def get_loss(self, model_preds, input_data, static=False):
+        """models/gwcnet/gwcnet.py:42-53.  static=True: the same loss with static shapes and no `.item()` (masked mean written as
+        sum(x * mask) / count instead of the boolean-mask gather, whose output size is a host synchronisation), so that a whole
+        training step can be replayed as a hipGraph; the info dict then holds the loss tensor."""
         disp_gt = input_data["disp"]
         mask = (disp_gt < self.maxdisp) & (disp_gt > 0)
         loss = 0.0
         for disp_est, weight in zip(model_preds["disp_preds"], [0.5, 0.5, 0.7, 1.0]):
-            loss = loss + weight * F.smooth_l1_loss(disp_est[mask], disp_gt[mask], reduction="mean")
-        return loss, {"scalar/train/loss_disp": loss.item()}
+            if static:
+                m = mask.to(disp_est.dtype)
+                loss = loss + weight * (F.smooth_l1_loss(disp_est, disp_gt, reduction="none") * m).sum() / m.sum()
+            else:
+                loss = loss + weight * F.smooth_l1_loss(disp_est[mask], disp_gt[mask], reduction="mean")
+        return loss, {"scalar/train/loss_disp": loss.detach() if static else loss.item()}

@@ -196,17 +196,28 @@ def _gru_train_loop(model, a, s, init_disp, geo, iters, n_layers, slow_fast):
     return disp_preds
 
 
-def _sequence_loss(model_pred, disp_gt, max_disp):
-    """stereobase_gru.py:215-243 == igev_stereo.py:209-240: smooth-L1 on the initial disparity + gamma-weighted L1 over the GRU predictions."""
+def _masked_mean(x, valid):
+    """mean of x over `valid` with static shapes: sum(x * valid) / count -- the value of `x[valid].mean()` (up to summation order) without
+    the boolean-mask gather, whose output size is a host synchronisation (it cannot be captured in a hipGraph)."""
+    v = valid.to(x.dtype)
+    return (x * v).sum() / v.sum()
+
+
+def _sequence_loss(model_pred, disp_gt, max_disp, static=False):
+    """stereobase_gru.py:215-243 == igev_stereo.py:209-240: smooth-L1 on the initial disparity + gamma-weighted L1 over the GRU predictions.
+    static=True: the same loss written with static shapes and no `.item()` (see _masked_mean) so that a whole training step can be replayed
+    as a hipGraph; the info dict then holds the loss tensor."""
     valid = ((disp_gt < max_disp) & (disp_gt > 0)).unsqueeze(1)
     disp_gt = disp_gt.unsqueeze(1)
-    loss = F.smooth_l1_loss(model_pred["init_disp"][valid], disp_gt[valid], reduction="mean")
+    mean = (lambda x: _masked_mean(x, valid)) if static else (lambda x: x[valid].mean())
+    loss = mean(F.smooth_l1_loss(model_pred["init_disp"], disp_gt, reduction="none")) if static else \
+        F.smooth_l1_loss(model_pred["init_disp"][valid], disp_gt[valid], reduction="mean")
     preds = model_pred["disp_preds"]
     n = len(preds)
     for i, pr in enumerate(preds):
         gamma = 0.9 ** (15 / (n - 1)) if n > 1 else 1.0
-        loss = loss + gamma ** (n - i - 1) * (pr - disp_gt).abs()[valid].mean()
-    return loss, {"scalar/train/loss_disp": float(loss.detach())}
+        loss = loss + gamma ** (n - i - 1) * mean((pr - disp_gt).abs())
+    return loss, {"scalar/train/loss_disp": loss.detach() if static else float(loss.detach())}
 
 
 def _require_engine(x, who):
@@ -300,8 +311,8 @@ class StereoBase(StereoBaseCostStage):
         init_up = ctx_up(st["init_disp"] * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
         return {"init_disp": init_up, "disp_preds": disp_preds, "disp_pred": disp_preds[-1]}
 
-    def get_loss(self, model_pred, input_data):
-        return _sequence_loss(model_pred, input_data["disp"], self.max_disp)
+    def get_loss(self, model_pred, input_data, static=False):
+        return _sequence_loss(model_pred, input_data["disp"], self.max_disp, static)
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)
@@ -422,8 +433,8 @@ class IGEVStereo(IGEVCostStage):
         init_up = ctx_up(st["init_disp"] * 4.0, spx_pred.float()).unsqueeze(1)
         return {"init_disp": init_up, "disp_preds": disp_preds, "disp_pred": disp_preds[-1]}
 
-    def get_loss(self, model_pred, input_data):
-        return _sequence_loss(model_pred, input_data["disp"], self.max_disp)
+    def get_loss(self, model_pred, input_data, static=False):
+        return _sequence_loss(model_pred, input_data["disp"], self.max_disp, static)
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)
@@ -479,10 +490,14 @@ class LightStereo(LightStereoCostStage):
         disp_4 = F.interpolate(init_disp, image1.shape[2:], mode="bilinear", align_corners=False) * 4
         return {"disp_pred": disp_pred, "disp_4": disp_4}
 
-    def get_loss(self, model_pred, input_data):
-        """lightstereo.py:72-85"""
+    def get_loss(self, model_pred, input_data, static=False):
+        """lightstereo.py:72-85 (static: static-shape form for hipGraph capture, see _sequence_loss)"""
         disp_gt = input_data["disp"].unsqueeze(1)
         mask = (disp_gt < self.max_disp) & (disp_gt > 0)
+        if static:
+            sl1 = lambda p: _masked_mean(F.smooth_l1_loss(p, disp_gt, reduction="none"), mask)
+            loss = sl1(model_pred["disp_pred"]) + 0.3 * sl1(model_pred["disp_4"])
+            return loss, {"scalar/train/loss_disp": loss.detach()}
         loss = F.smooth_l1_loss(model_pred["disp_pred"][mask], disp_gt[mask], reduction="mean") \
             + 0.3 * F.smooth_l1_loss(model_pred["disp_4"][mask], disp_gt[mask], reduction="mean")
         return loss, {"scalar/train/loss_disp": float(loss.detach())}
