@@ -1,5 +1,5 @@
-"""Multi-GPU plumbing for the hot path.  Inference shards by independent stereo pairs -- one
-process per GPU, no data-path collective; the only collective is the timing MAX."""
+"""Parallel plumbing for the hot path.  Across GPUs: inference shards by independent stereo pairs -- one process per GPU, no data-path
+collective; the only collective is the timing MAX.  Inside a GPU: independent sub-batches on concurrent HIP streams."""
 from __future__ import annotations
 
 import torch
@@ -23,3 +23,31 @@ def reduce_step_time(local_seconds: float, device: torch.device) -> float:
 
 def whole_job_rate(pairs_per_rank_per_step: int, steps: int, world: int, seconds: float) -> float:
     return world * pairs_per_rank_per_step * steps / seconds
+
+
+class SubBatchStreams:
+    """Run a batch as `n` independent sub-batches on concurrent HIP streams (fork from / join into the current stream, so the whole thing
+    is capturable in one hipGraph).  Every launch of the hot path ends in a tail where the last workgroups leave most CUs idle (a 64-channel
+    backbone layer at 4 pairs is only ~5 rounds of resident workgroups); with two sub-batches in flight the tail of one launch overlaps
+    the head of the other stream's.  Measured on GwcNet 544x960, 8 pairs per step: 1 stream 176.2-177.3, 2 streams 180.2-180.6, 4
+    streams ~177 pairs/s (profiles/round3/ab_substreams_*.txt); starting sub-batch i + 1 when sub-batch i leaves its 2-D backbone, so that
+    an HBM-leaning stage always runs beside an MFMA-bound one, gains nothing (the step is energy-bound)."""
+
+    def __init__(self, n: int):
+        self.n = max(1, int(n))
+        self.streams = [torch.cuda.Stream() for _ in range(self.n)] if self.n > 1 else []
+
+    def __call__(self, fn, *batched):
+        """fn(*sub_batch_tensors) -> tensor; `batched`: tensors with the pairs on dim 0 (size divisible by n).  Returns the concatenation."""
+        if self.n == 1:
+            return fn(*batched)
+        B = batched[0].shape[0]
+        assert B % self.n == 0, f"batch of {B} pairs does not split into {self.n} sub-batches"
+        per, cur, outs = B // self.n, torch.cuda.current_stream(), []
+        for i, st in enumerate(self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(fn(*[t[i * per:(i + 1) * per] for t in batched]))
+        for st in self.streams:
+            cur.wait_stream(st)
+        return torch.cat(outs, 0)

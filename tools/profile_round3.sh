@@ -9,7 +9,7 @@ TAG=${1:-r3}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --timed-only --no-graph --steps 5 --warmup 2 --batch ${BATCH:-8}"
+CMD="python $R/bench.py --timed-only --no-graph --streams 1 --steps 5 --warmup 2 --batch ${BATCH:-8}"   # one stream: per-kernel durations undisturbed (the default run issues every launch as 2 concurrent half-batches)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace_stdout.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o p -- $CMD > $OUT/pmc_${C}_stdout.log 2>&1
