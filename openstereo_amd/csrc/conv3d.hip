@@ -289,7 +289,10 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         // ... and only while the grid is still small: with >= 192 workgroups (gru16 at 4 pairs per launch: 255) the plain 32-pixel tile is
         // faster than any split (0.035 vs 0.037 / 0.045 ms for 2 / 4 groups), below ~96 workgroups four groups pay (one pair per launch)
         const int want = exp_int("OSA_KS", -1);
-        const long long nwg = (((long long)a.B * a.Ad * a.Ah * a.Aw + g_cfgs[ci].M - 1) / g_cfgs[ci].M) * (a.CoP / g_cfgs[ci].N);
+        // (exact-f32 mode: decided from ONE batch item's pixels, so that the summation order -- and with it every output bit -- does not depend
+        // on how many pairs share the launch; tests/test_gpu_parity.py::test_gwcnet_batch_invariance_and_odd_size)
+        const long long items = (prec == PREC_F32) ? 1 : a.B;
+        const long long nwg = ((items * a.Ad * a.Ah * a.Aw + g_cfgs[ci].M - 1) / g_cfgs[ci].M) * (a.CoP / g_cfgs[ci].N);
         int ks = (a.nchunks % 4 == 0 && a.nchunks >= 16) ? 4 : ((a.nchunks % 2 == 0 && a.nchunks >= 8) ? 2 : 1);
         if (nwg >= 192) ks = 1;
         else if (nwg >= 96 && ks == 4) ks = 2;

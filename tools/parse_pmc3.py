@@ -79,8 +79,10 @@ sq = rows_of("pmc_SQ")
 names = sorted({k[0] for k in sq})
 with open(os.path.join(out_dir, "sq_summary.txt"), "w") as fh:
     fh.write(f"# rocprofv3 --pmc SQ_* pass over bench.py --timed-only --no-graph, f16x3, {BATCH} pairs per step: per kernel instance (largest grid), average per launch.\n"
-             "# SQ_* wave-time counters are in 4-cycle units on gfx950; MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES-normalised launch cycles):\n"
-             "# reported here as SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs) = fraction of SIMD-cycles with the matrix pipe busy.\n")
+             "# SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs (= #MFMA x 32 cycles for v_mfma_f32_32x32x16_f16: checked against the launch's MFMA count);\n"
+             "# GRBM_GUI_ACTIVE is summed over the 8 XCDs, so launch cycles = GRBM_GUI_ACTIVE / 8 and\n"
+             "# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs) = fraction of SIMD-cycles with the matrix pipe busy.\n"
+             "# (the conv3d_32_32 instance averages its 4 launches per step: dres0.0 with 64 input channels and three 32 -> 32 launches)\n")
     for key, sub in KERNELS.items():
         ks = [k for k in sq if sub in k[0]]
         if not ks:
@@ -89,7 +91,7 @@ with open(os.path.join(out_dir, "sq_summary.txt"), "w") as fh:
         vals = {k[2]: sum(sq[k]) / len(sq[k]) for k in ks if k[1] == g}
         gui = vals.get("GRBM_GUI_ACTIVE", 0.0)
         busy = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-        share = busy / (gui * 256 * 4) if gui else float("nan")
+        share = busy / (gui / 8.0 * 256 * 4) if gui else float("nan")
         wave = vals.get("SQ_WAVE_CYCLES", 0.0)
         fh.write(f"{key:26s} grid {g:9d}  GRBM_GUI_ACTIVE {gui:12.0f}  MFMA_BUSY {busy:14.0f} ({share * 100:5.1f} % of SIMD-cycles)  "
                  f"WAIT_ANY/WAVE {vals.get('SQ_WAIT_ANY', 0) / wave if wave else float('nan'):.2f}  WAIT_INST_ANY/WAVE {vals.get('SQ_WAIT_INST_ANY', 0) / wave if wave else float('nan'):.2f}  "
