@@ -59,6 +59,10 @@ enum { OSA_GATE_RAW = 16 };
  * image the kernels stage into LDS), so a consumer copies instead of splitting and a producer splits each
  * value once.  Channel counts must be multiples of 16.  Internal to chains of engine layers. */
 enum { OSA_IN_SPLIT = 32, OSA_OUT_SPLIT = 64, OSA_RES_SPLIT = 128, OSA_REDIR_SPLIT = 256 };
+/* OR'ed into `act` (with OSA_ACT_RELU): y = relu(residual + relu(bn(conv(x)))) instead of relu(bn(conv(x)) + residual) -- the
+ * ResidualBlock of MultiBasicEncoder (models/igev/extractor.py:48-60, models/stereobase/gru_blocks.py:48-60) applies the ReLU to the
+ * branch before the sum.  Plain fp32 outputs only (no split output, no gate). */
+enum { OSA_RES_AFTER_ACT = 512 };
 
 /* ---- misc ------------------------------------------------------------- */
 int         osa_abi_version(void);

@@ -677,7 +677,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
     // code everywhere: its 4-waves-per-SIMD tiles would spill.
     constexpr bool FASTC = (PREC == PREC_F16X3) && (REDIR != 2) && !(NCLS == 1 && MT == 2 && NT == 1);
     const bool fast = FASTC && (a0d + TD <= p.Ad) && (a0h + TH <= p.Ah) && (a0w + TW <= p.Aw) && (n0 + WN * NT * 32 <= p.Co) &&
-                      vec4 && !p.gate && actk <= OSA_ACT_RELU6 && !(p.dbg & (32 | 64));
+                      vec4 && !p.gate && actk <= OSA_ACT_RELU6 && !(p.act & OSA_RES_AFTER_ACT) && !(p.dbg & (32 | 64));
     // A wave finalises NI = MT*NCLS*NT tiles of 32 voxels x 32 channels one after the other.  The
     // residual rows of tile i+PD are requested before tile i is processed (rolling window of PD
     // tiles, static register sets), so the HBM round trip of a residual overlaps the LDS transposes,
@@ -785,8 +785,13 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             const float r4[4] = {rk.x, rk.y, rk.z, rk.w}, g4[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = fmaf(a4[e], s4[e], h4[e]) + r4[e];
+                const float t_ = fmaf(a4[e], s4[e], h4[e]);
+                float v = t_ + r4[e];
                 if constexpr (FULL) { o[e] = act_cheap(v); continue; }
+                if (p.act & OSA_RES_AFTER_ACT) {                    // relu(residual + relu(bn(conv))): RAFT-style ResidualBlock (extractor.py:48-60)
+                    o[e] = fmaxf(fmaxf(t_, 0.f) + r4[e], 0.f);
+                    continue;
+                }
                 if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
                 else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);

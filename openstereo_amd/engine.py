@@ -21,6 +21,7 @@ GATE_RAW = 16          # OR'ed into act: the gate is a plain multiplier, not sig
 # "split" activation tensors (f16x3 mode): every 16-channel chunk stored as [16 x fp16 hi | 16 x fp16 lo]
 # (same bytes as fp32), see include/openstereo_amd.h.  A tensor written that way carries `_osa_split = True`.
 IN_SPLIT, OUT_SPLIT, RES_SPLIT, REDIR_SPLIT = 32, 64, 128, 256
+RES_AFTER_ACT = 512    # OR'ed into act (ReLU layers): relu(residual + relu(bn(conv))) -- MultiBasicEncoder's ResidualBlock
 
 
 def is_split(t) -> bool:
@@ -197,7 +198,7 @@ class PackedConv3d:
                 f(W, self.k[2], self.pad[2], self.dil[2], s))
 
     def __call__(self, x, residual=None, out=None, gate=None, x_off=0, out_off=0, res_off=0, gate_raw=False, redir=None,
-                 out_split=False, gate_channels=0):
+                 out_split=False, gate_channels=0, res_after_act=False):
         """x: logical [B,Cs>=Ci,D,H,W] NDHWC; channels [x_off, x_off+Ci) are read (x_off % 4 == 0).
         Returns logical [B,Co(pad 4),Do,Ho,Wo] NDHWC, or writes channels [out_off, out_off+Co) of `out`
         (channel-slice output replaces torch.cat).  gate: NHWC logits [B,Ho,Wo,>=Co]; the result is
@@ -235,6 +236,9 @@ class PackedConv3d:
         if gate_channels:
             assert gate is not None and gate_channels % 4 == 0 and 0 < gate_channels <= self.Co
             act |= gate_channels << 16
+        if res_after_act:
+            assert residual is not None and self.act == ACT_RELU and gate is None and not out_split and not self.transposed
+            act |= RES_AFTER_ACT
         fmt = (IN_SPLIT if is_split(x) else 0) | (OUT_SPLIT if out_split else 0) | (RES_SPLIT if is_split(residual) else 0) \
             | (REDIR_SPLIT if (redir is not None and is_split(redir[1])) else 0)
         if fmt:

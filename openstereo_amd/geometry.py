@@ -67,7 +67,8 @@ class CombinedGeoEncodingVolume:
             # (`match_left.float()`, igev_stereo.py:184) but its einsum / pooling still run in the autocast dtype; the engine keeps the
             # pyramid in fp32 -- no fp16 overflow of the 96-term correlation sums, and the levels are what _Lookup's kernels read.
             # The pooling is written as a strided add (exactly F.avg_pool2d(x, [1, 2], stride=[1, 2]): (a + b) / 2, a trailing odd
-            # element dropped) instead of F.avg_pool1d: PyTorch 2.10 + ROCm 7.0 faults in that op for fp16 rows (tools/diag_lookup_ac.py).
+            # element dropped) on fp32 tensors; a memory-access fault first blamed on F.avg_pool1d with fp16 rows turned out to be _Lookup's kernels
+            # being handed fp16 levels (no custom_fwd cast at the time; tools/diag_lookup_ac.py) -- the fp32 pyramid is what fixed it.
             with torch.autocast("cuda", enabled=False):
                 f1, f2, gv = init_fmap1.float(), init_fmap2.float(), geo_volume.float()
                 B, C, D, H, W1 = gv.shape

@@ -8,9 +8,9 @@ through the stage modules of igev_style.py / lightstereo.py / igev_update.py, un
 The 2-D feature side is out of the path (SURVEY 8 "out of scope": timm MobileNetV2 / EfficientNet pyramids with
 pretrained weights, MultiBasicEncoder).  The small 2-D heads around it (stem_2, stem_4, conv, desc, concat_conv, spx*,
 context_zqr_convs, refine_*) are ordinary PyTorch-ROCm modules with the reference's names and shapes; the two large
-pieces -- `feature` / `backbone` (timm) and `cnet` -- are *injectable*: pass the reference's own module, or leave the
-default shape-compatible stand-ins (StubFeature, StubContext: strided conv pyramids with the documented channel counts and
-strides).  With the stand-ins the classes run offline end to end, which is what the tests and `bench.py` use; the
+pieces are *injectable*: `feature` / `backbone` (timm: pass the reference's own module, or leave the shape-compatible stand-in
+StubFeature, a strided conv pyramid with the documented channel counts and strides) and `cnet` (default since r3: the engine mirror of the
+reference's MultiBasicEncoder, models/context_encoder.py; StubContext is a light stand-in).  With the stand-ins the classes run offline end to end, which is what the tests and `bench.py` use; the
 numbers they produce are hot-path numbers, never accuracy claims.
 
 To accelerate the reference's *own* model objects (timm present), use `openstereo_amd.attach.patch_reference_modules()`
@@ -32,6 +32,7 @@ from .. import ops
 from ..ops import on_engine
 from .igev_style import BasicConv2d, BasicConv, IGEVFeatureAtt, StereoBaseCostStage, hourglass, _pack_igev
 from .igev_update import BasicMultiUpdateBlock, run_refinement
+from .context_encoder import MultiBasicEncoder
 from .lightstereo import LightStereoCostStage
 from ..engine import cached_pack, SmallCoConv3d
 
@@ -248,7 +249,9 @@ class StereoBase(StereoBaseCostStage):
         volume_channel = self.num_groups + 2 * self_concat
         IN, BN, LR = nn.InstanceNorm2d, nn.BatchNorm2d, nn.LeakyReLU
         self.feature = feature
-        self.cnet = cnet if cnet is not None else StubContext(hd, hd)
+        # r3: the reference's context network itself (plain PyTorch there, engine mirror here, `cnet.*` checkpoint keys); StubContext stays
+        # available as a light stand-in (pass cnet=StubContext(hd, hd))
+        self.cnet = cnet if cnet is not None else MultiBasicEncoder(output_dim=[hd, hd], norm_fn="batch", downsample=g("N_DOWNSAMPLE", 2))
         args = SimpleNamespace(N_GRU_LAYERS=cfgs.N_GRU_LAYERS, CORR_LEVELS=cfgs.CORR_LEVELS, CORR_RADIUS=cfgs.CORR_RADIUS,
                                SLOW_FAST_GRU=cfgs.SLOW_FAST_GRU)
         self._loop_args = args
@@ -383,7 +386,7 @@ class IGEVStereo(IGEVCostStage):
         hd = list(args.HIDDEN_DIMS)
         IN, LR = nn.InstanceNorm2d, nn.LeakyReLU
         self.feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
-        self.cnet = cnet if cnet is not None else StubContext(hd, hd)
+        self.cnet = cnet if cnet is not None else MultiBasicEncoder(output_dim=[hd, hd], norm_fn="batch", downsample=getattr(args, "N_DOWNSAMPLE", 2))
         self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hd)
         self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hd[i], hd[i] * 3, 3, padding=1) for i in range(args.N_GRU_LAYERS)])
         self.stem_2 = nn.Sequential(BasicConvIN(3, 32, kernel_size=3, stride=2, padding=1),

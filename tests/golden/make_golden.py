@@ -291,11 +291,40 @@ def gen_unit_gain():
     save("igev_unit_gain.npz", disp=d_ref, pert_mean=dev.mean(), pert_max=dev.max(), pert_p999=torch.quantile(dev.flatten(), 0.999))
 
 
+def gen_context_encoder():
+    """MultiBasicEncoder (models/igev/extractor.py:194-297; the StereoBase copy models/stereobase/gru_blocks.py:62-148 must agree): the
+    context network in front of the GRU loop, plain PyTorch in the reference (its file only imports timm) -> pinned against the reference's
+    own class, norm_fn='batch', downsample=2 (cfgs/igev, cfgs/stereobase), eval mode, 64x128 image."""
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    sys.modules.setdefault("timm", types.ModuleType("timm"))
+    from stereo.modeling.models.igev.extractor import MultiBasicEncoder as IGEVEnc
+    from stereo.modeling.models.stereobase.gru_blocks import MultiBasicEncoder as SBEnc
+    hd = [128, 128, 128]
+    enc = IGEVEnc(output_dim=[hd, hd], norm_fn="batch", downsample=2).eval()
+    sd = synth_state_dict(enc, seed=19, gain=0.9)
+    enc.load_state_dict(sd)
+    sb = SBEnc(output_dim=[hd, hd], norm_fn="batch", downsample=2).eval()
+    assert set(sb.state_dict()) == set(sd)
+    sb.load_state_dict(sd)
+    img, _ = synth_images(2, 64, 128, seed=33, max_shift=8.0)
+    o = enc(img, num_layers=3)
+    o2 = sb(img, num_layers=3)
+    for a, b in zip(o, o2):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    od = enc(img, dual_inp=True, num_layers=3)
+    out = {f"o{lvl}_{i}": o[j][i] for j, lvl in enumerate(("04", "08", "16")) for i in range(2)}
+    out["dual_v"] = od[3]
+    out["dual_o04_0"] = od[0][0]
+    print("MultiBasicEncoder: |out04| max", o[0][0].abs().max().item(), "std", o[0][0].std().item())
+    save("context_encoder.npz", **out)
+
+
 def _reference_model(modname, clsname, cfg, stand_ins):
-    """Construct the reference's OWN model class with its timm-backed pieces (`Feature` / `Backbone`, `MultiBasicEncoder`: SURVEY 8 "out
-    of scope", timm + pretrained weights are not available offline) replaced by the stand-in modules the engine classes inject by default
-    (openstereo_amd.models.stereo_models.StubFeature / StubContext: plain torch conv pyramids).  Everything else -- __init__, forward,
-    the 2-D heads, the iteration schedule, the final upsampling -- is the reference's code."""
+    """Construct the reference's OWN model class with its timm-backed feature pyramid (`Feature` / `Backbone`: SURVEY 8 "out of scope",
+    timm + pretrained weights are not available offline) replaced by the stand-in module the engine classes inject by default
+    (openstereo_amd.models.stereo_models.StubFeature: a plain torch conv pyramid).  Everything else -- __init__, forward, the context
+    network (MultiBasicEncoder), the 2-D heads, the iteration schedule, the final upsampling -- is the reference's code."""
     import importlib
     sys.modules.setdefault("timm", types.ModuleType("timm"))
     mod = importlib.import_module(modname)
@@ -316,10 +345,10 @@ def gen_e2e(full=True):
     at 544x960, MAX_DISP 192, 32 iterations (contractive update-block weights as in gen_at_size), sub-sampled.
     Inputs / parameters: synth_images(seed=31) and synth_state_dict(seed, head_gain=20, gain=0.9), regenerated by the tests."""
     from openstereo_amd.utils.weights import synth_state_dict, synth_images
-    from openstereo_amd.models.stereo_models import StubFeature, StubContext
+    from openstereo_amd.models.stereo_models import StubFeature
     H, W, MAXD = 128, 256, 64
     feat = lambda *a, **k: StubFeature((48, 64, 192, 160))
-    cnet = lambda output_dim, norm_fn="batch", downsample=2: StubContext(list(output_dim[0]), list(output_dim[1]))
+    cnet = None            # r3: MultiBasicEncoder is the reference's own class on both sides (only the timm pyramid is a stand-in)
     L, R = synth_images(1, H, W, seed=31, max_shift=12.0)
     out = {}
 
@@ -332,7 +361,7 @@ def gen_e2e(full=True):
     cfg = Cfg(MAX_DISP=MAXD, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
               CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
               SLOW_FAST_GRU=False, TRAIN_ITERS=4, EVAL_ITERS=4)
-    sb = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, {"Feature": feat, "MultiBasicEncoder": cnet})
+    sb = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, {"Feature": feat})
     load(sb, 41)
     r = sb({"left": L, "right": R})
     assert len(r["disp_preds"]) == 4
@@ -340,13 +369,13 @@ def gen_e2e(full=True):
     print("StereoBase e2e: disp range", r["disp_pred"].min().item(), r["disp_pred"].max().item(), "std", r["disp_pred"].std().item())
     # slow-fast schedule too (cfgs/stereobase: SLOW_FAST_GRU false; the code path exists, stereobase_gru.py:184-196)
     cfg2 = Cfg(cfg, SLOW_FAST_GRU=True)
-    sb2 = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg2, {"Feature": feat, "MultiBasicEncoder": cnet})
+    sb2 = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg2, {"Feature": feat})
     load(sb2, 41)
     out["stereobase_slowfast_disp"] = sb2({"left": L, "right": R})["disp_pred"]
 
     args = Cfg(MAX_DISP=MAXD, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
                SLOW_FAST_GRU=True, VALID_ITERS=4, TRAIN_ITERS=4)
-    ig = _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat, "MultiBasicEncoder": cnet})
+    ig = _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat})
     load(ig, 43)
     L255, R255 = (L * 40 + 128).clamp(0, 255), (R * 40 + 128).clamp(0, 255)
     r = ig({"left": L255, "right": R255})
@@ -365,7 +394,7 @@ def gen_e2e(full=True):
     if full:
         # BASELINE configs[4] at size: cfgs/igev/igev_sceneflow_amp.yaml (MAX_DISP 192, VALID_ITERS 32), 544x960 (540 padded to /32)
         args = Cfg(args, MAX_DISP=192, VALID_ITERS=32)
-        ig = _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat, "MultiBasicEncoder": cnet})
+        ig = _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat})
         load(ig, 43, gru_gain=0.8)
         Lf, Rf = synth_images(1, 544, 960, seed=31)
         t = time.time()
@@ -381,11 +410,12 @@ E2E_TRAIN_KEYS = {
     "stereobase": ("classifier.weight", "cost_agg.conv1.0.block.0.weight", "cost_agg.conv3_up.block.0.weight", "cost_agg.agg_0.1.block.0.weight",
                    "update_block.gru04.convz.weight", "update_block.gru16.convq.weight", "update_block.disp_head.conv2.weight",
                    "update_block.encoder.convc1.weight", "desc.weight", "concat_conv.1.weight", "spx_gru.0.weight", "spx.0.weight",
-                   "context_zqr_convs.0.weight", "feature.stem.0.0.weight", "cnet.heads.0.0.weight"),
+                   "context_zqr_convs.0.weight", "feature.stem.0.0.weight", "cnet.layer3.1.conv2.weight", "cnet.outputs08.1.0.conv1.weight"),
     "igev": ("classifier.weight", "corr_stem.conv.weight", "cost_agg.conv1.0.conv.weight", "cost_agg.conv2_up.conv.weight",
              "corr_feature_att.feat_att.1.weight", "update_block.gru08.convr.weight", "update_block.gru16.convq.weight",
              "update_block.disp_head.conv2.weight", "update_block.mask_feat_4.0.weight", "desc.weight", "conv.conv.weight",
-             "spx_2_gru.conv1.conv.weight", "spx_gru.0.weight", "spx.0.weight", "stem_2.0.conv.weight", "feature.stem.0.0.weight"),
+             "spx_2_gru.conv1.conv.weight", "spx_gru.0.weight", "spx.0.weight", "stem_2.0.conv.weight", "feature.stem.0.0.weight",
+             "cnet.conv1.weight", "cnet.layer2.1.conv1.weight", "cnet.outputs16.0.weight"),
     "lightstereo": ("cost_agg.conv0.0.pwconv.0.weight", "cost_agg.conv6.0.weight", "cost_agg.conv1.dwconv.0.weight", "cost_agg.att0.conv1_2.weight",
                     "refine_3.block.0.weight", "refine_1.0.block.0.weight", "stem_2.0.block.0.weight", "backbone.stem.0.0.weight"),
 }
@@ -404,33 +434,42 @@ def gen_e2e_train(feat, cnet):
     gt = torch.from_numpy(np.random.default_rng(3).uniform(1.0, 30.0, (1, H, W)).astype(np.float32))
     out = {}
 
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from _smooth import smooth_activations
+    import contextlib
+
     def run(tag, net, seed, left, right):
+        """Two fixtures per class: the reference as written (`<tag>_*`), and the reference with the ReLU-family kinks smoothed
+        (`<tag>_smooth_*`, tests/_smooth.py: the whole-model gradient is discontinuous at every ~0 pre-activation, so only the smoothed
+        network can be pinned tightly across implementations)."""
         net.load_state_dict(synth_state_dict(net, seed=seed, head_gain=20.0, gain=0.9))
         net.train()
         for m in net.modules():
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
                 m.eval()
-        with torch.enable_grad():
-            pred = net({"left": left, "right": right})
-            loss, _ = net.get_loss(pred, {"disp": gt})
-            loss.backward()
-        params = dict(net.named_parameters())
-        out[f"{tag}_loss"] = loss.detach()
-        out[f"{tag}_disp"] = pred["disp_pred"].detach()
-        for k in E2E_TRAIN_KEYS[tag]:
-            g = params[k].grad
-            assert g is not None and float(g.abs().max()) > 0, (tag, k)
-            out[f"{tag}_grad::{k}"] = g.reshape(-1)[:20000].clone()
-        print(f"{tag} training step (reference autograd): loss {loss.item():.4f}")
+        for sfx, ctx in (("", contextlib.nullcontext), ("_smooth", smooth_activations)):
+            net.zero_grad(set_to_none=True)
+            with torch.enable_grad(), ctx():
+                pred = net({"left": left, "right": right})
+                loss, _ = net.get_loss(pred, {"disp": gt})
+                loss.backward()
+            params = dict(net.named_parameters())
+            out[f"{tag}{sfx}_loss"] = loss.detach()
+            out[f"{tag}{sfx}_disp"] = pred["disp_pred"].detach()
+            for k in E2E_TRAIN_KEYS[tag]:
+                g = params[k].grad
+                assert g is not None and float(g.abs().max()) > 0, (tag, k)
+                out[f"{tag}{sfx}_grad::{k}"] = g.reshape(-1)[:20000].clone()
+            print(f"{tag}{sfx} training step (reference autograd): loss {loss.item():.4f}")
 
     cfg = Cfg(MAX_DISP=64, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
               CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
               SLOW_FAST_GRU=False, TRAIN_ITERS=3, EVAL_ITERS=4)
     run("stereobase", _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg,
-                                       {"Feature": feat, "MultiBasicEncoder": cnet}), 41, L, R)
+                                       {"Feature": feat}), 41, L, R)
     args = Cfg(MAX_DISP=64, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
                SLOW_FAST_GRU=True, VALID_ITERS=4, TRAIN_ITERS=3)
-    run("igev", _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat, "MultiBasicEncoder": cnet}),
+    run("igev", _reference_model("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, {"Feature": feat}),
         43, (L * 40 + 128).clamp(0, 255), (R * 40 + 128).clamp(0, 255))
     lcfg = Cfg(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)
     run("lightstereo", _reference_model("stereo.modeling.models.lightstereo.lightstereo", "LightStereo", lcfg,
@@ -441,7 +480,7 @@ def gen_e2e_train(feat, cnet):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | unit_gain")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | unit_gain | context_encoder")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -466,6 +505,9 @@ def main():
         return
     if args.only == "unit_gain":
         gen_unit_gain()
+        return
+    if args.only == "context_encoder":
+        gen_context_encoder()
         return
 
     # ------------------------------------------------------------------ volumes (a1-a4)
@@ -594,6 +636,7 @@ def main():
     gen_dormant()
     gen_e2e()
     gen_unit_gain()
+    gen_context_encoder()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

@@ -229,9 +229,9 @@ def test_stereobase_class_has_the_reference_checkpoint_keys():
     cfg = C(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
             CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
             SLOW_FAST_GRU=False, TRAIN_ITERS=22, EVAL_ITERS=32)
-    ref = _ref_model_keys("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, ("Feature", "MultiBasicEncoder"))
-    own = _own_keys(StereoBase(cfg), ("feature.", "cnet."))
-    assert own == ref                                           # every key outside the injectable feature / cnet, same shapes
+    ref = _ref_model_keys("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, ("Feature",))
+    own = _own_keys(StereoBase(cfg), ("feature.",))
+    assert own == ref and any(k.startswith("cnet.layer1.0.conv1") for k in ref)    # every key outside the injectable timm pyramid (cnet = MultiBasicEncoder included), same shapes
 
 
 def test_lightstereo_class_has_the_reference_checkpoint_keys():
@@ -249,6 +249,6 @@ def test_igev_class_has_the_reference_checkpoint_keys():
     from openstereo_amd.models.stereo_models import IGEVStereo
     args = C(MAX_DISP=192, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
              SLOW_FAST_GRU=True, VALID_ITERS=32, TRAIN_ITERS=22)
-    ref = _ref_model_keys("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, ("Feature", "MultiBasicEncoder"))
-    own = _own_keys(IGEVStereo(args), ("feature.", "cnet."))
-    assert own == ref and len(ref) > 150
+    ref = _ref_model_keys("stereo.modeling.models.igev.igev_stereo", "IGEVStereo", args, ("Feature",))
+    own = _own_keys(IGEVStereo(args), ("feature.",))
+    assert own == ref and len(ref) > 400 and any(k.startswith("cnet.layer2.0.norm3") for k in ref)

@@ -220,14 +220,25 @@ def test_lightstereo_matches_reference_forward(prec):
     torch.testing.assert_close(out["disp_pred"].cpu(), torch.from_numpy(g["lightstereo_disp"]), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("activations", ["smooth", "reference"])
 @pytest.mark.parametrize("which", ["stereobase", "igev", "lightstereo"])
-def test_training_step_matches_reference_autograd(which):
+def test_training_step_matches_reference_autograd(which, activations):
     """Training-mode forward, the reference's loss and the gradients of parameters in every stage (2-D heads, volume / aggregation,
-    classifier, update block, upsampling heads, stand-in backbone) vs CPU autograd of the REFERENCE's own model class
-    (tests/golden/e2e_reference_train.npz, make_golden.gen_e2e_train; frozen BatchNorm).  64x128, 3 GRU iterations."""
+    classifier, update block, context encoder, upsampling heads, stand-in backbone) vs CPU autograd of the REFERENCE's own model class
+    (tests/golden/e2e_reference_train.npz, make_golden.gen_e2e_train; frozen BatchNorm).  64x128, 3 GRU iterations.
+
+    Two fixtures per class.  "smooth": ReLU / LeakyReLU / ReLU6 replaced by smooth surrogates in BOTH the reference run and this one
+    (tests/_smooth.py) -- the whole-model gradient is then a smooth function of the forward values and is pinned to 5e-4 of max |grad|
+    per tensor (measured ~1e-6 .. 1e-5).  "reference": the reference's real activations; every ReLU whose pre-activation is ~0 is a
+    discontinuity of the gradient, and two correct fp32 implementations do not agree on the sign of a 1e-7 pre-activation (measured: one
+    flipped mask element in the first iteration's disparity head moves IGEVStereo's conv.conv.weight gradient by 6e-3 of its max,
+    tools/diag_e2e_grad7.py; the stock PyTorch-ROCm convolutions show the same effect against the CPU), so the bound there is the
+    kink-tolerant 3e-2 -- still far below what a wiring error produces (the avg_pool2d backward bug this test found was 2-5e-2 ... 1)."""
+    import contextlib
     import numpy as np
     import torch.nn as nn
     from conftest import golden
+    from _smooth import smooth_activations
     from openstereo_amd.models.stereo_models import StereoBase, IGEVStereo, LightStereo
     g = golden("e2e_reference_train.npz")
     if which == "stereobase":
@@ -247,23 +258,25 @@ def test_training_step_matches_reference_autograd(which):
     if which == "igev":
         L, Rr = (L * 40 + 128).clamp(0, 255), (Rr * 40 + 128).clamp(0, 255)
     gt = torch.from_numpy(np.random.default_rng(3).uniform(1.0, 30.0, (1, 64, 128)).astype(np.float32)).cuda()
-    out = m({"left": L.cuda(), "right": Rr.cuda()})
-    loss, _ = m.get_loss(out, {"disp": gt})
-    loss.backward()
-    want_loss = float(g[f"{which}_loss"])
+    tag, ctx, bound = (which + "_smooth", smooth_activations, 5e-4) if activations == "smooth" else (which, contextlib.nullcontext, 3e-2)
+    with ctx():
+        out = m({"left": L.cuda(), "right": Rr.cuda()})
+        loss, _ = m.get_loss(out, {"disp": gt})
+        loss.backward()
+    want_loss = float(g[f"{tag}_loss"])
     assert abs(float(loss.detach()) - want_loss) < 2e-4 * abs(want_loss), (float(loss.detach()), want_loss)
-    assert _epe(out["disp_pred"].detach(), g[f"{which}_disp"]) < 1e-3
+    assert _epe(out["disp_pred"].detach(), g[f"{tag}_disp"]) < 1e-3
     params = dict(m.named_parameters())
-    keys = [k.split("::", 1)[1] for k in g.files if k.startswith(f"{which}_grad::")]
+    keys = [k.split("::", 1)[1] for k in g.files if k.startswith(f"{tag}_grad::")]
     assert len(keys) >= 7
     worst = {}
     for k in keys:
-        want = torch.from_numpy(g[f"{which}_grad::{k}"])
+        want = torch.from_numpy(g[f"{tag}_grad::{k}"])
         got = params[k].grad.detach().reshape(-1)[:want.numel()].cpu()
         worst[k] = float((got - want).abs().max() / (want.abs().max() + 1e-20))
     print({k: f"{v:.1e}" for k, v in worst.items()})
-    bad = {k: v for k, v in worst.items() if not v < 5e-4}
-    assert not bad, bad                    # whole-model gradient error <= 5e-4 of max |grad| per tensor
+    bad = {k: v for k, v in worst.items() if not v < bound}
+    assert not bad, bad                    # whole-model gradient error relative to max |grad| per tensor
 
 
 def test_end_to_end_classes_refuse_cpu():
