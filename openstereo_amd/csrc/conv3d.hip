@@ -72,6 +72,12 @@ static const KernelCfg g_cfgs[] = {
 #ifdef OSA_EXPERIMENTS
     OSA_CFG_PINGPONG(2, 1, 8, 1, 8, 8),   // 16: 512 vox x 32 ch  brick 8x8x8, 8 waves (halo amplification 1.95x instead of 2.34x)
     OSA_CFG(2, 2, 8, 1, 8, 8),            // 17: 512 vox x 64 ch  brick 8x8x8, 8 waves
+    // register-tile experiments for the 2-D backbone (B fragments come through the vector-memory path: a 32 px x 64 ch wave issues one
+    // 1 KB weight load per 1.5 MFMAs, a 64 x 64 wave one per 3).  profiles/round3/tiles_2d_B8.txt: 64 x 64 waves on the 64-channel layers
+    // +4 % (inside the run-to-run spread), 8-wave 256 x 128 tiles -14 %; 128 x 64 / 128 x 32 waves (MT = 4, NT = 2 / 1) spill (4-5x slower)
+    // and are not kept.  The weight-load rate is not what holds these layers at 0.26-0.40.
+    OSA_CFG(2, 2, 2, 1, 8, 16),           // 18: 128 px x  64 ch, 2 waves of 64 x 64
+    OSA_CFG(2, 2, 4, 2, 16, 16),          // 19: 256 px x 128 ch, 8 waves of 64 x 64
 #endif
 };
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
