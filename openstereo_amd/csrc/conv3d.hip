@@ -545,6 +545,87 @@ __global__ __launch_bounds__(256) void conv_small_co_tiled_kernel(const ConvArgs
     }
 }
 
+
+// ------------------------------------------------------------------ classifier 32 -> 1, d-marching form --
+// The 3x3x3 "same" convolution 32 -> 1 at the end of every aggregation head (gwcnet_disp_processor.py:76-80, psmnet_cost_processor.py:
+// classif1-3).  The brick form above re-reads its 6x10x10 halo brick per 4x8x8 tile (2.34x the input; 2.7x measured) and is HBM-bound on
+// those re-reads.  Here a workgroup owns a 16 x 16 pixel column and WALKS along d: every input plane (18 x 18 pixels x all 32 channels,
+// 128-byte rows of full cache lines) is staged ONCE, read from LDS once per (tap, channel quad) and feeds three running sums -- the
+// outputs at d-1, d, d+1, whose kd = 2, 1, 0 taps it is.  HBM traffic = (18 x 18) / (16 x 16) x (dseg + 2) / dseg = 1.27-1.37x of one
+// pass; 12 FMAs per ds_read_b128 instead of 4; the next plane's loads are in flight (registers) while the current one is consumed.
+// LDS image: pixel stride 9 slots of 16 B (odd: the 16 lanes of a ds_read_b128 group fall on 16 distinct slots mod 16), row stride 176
+// slots (a multiple of 16, so the two pixel rows a group straddles keep that property): 18 x 176 x 16 B = 50.7 KB, 3 workgroups per CU.
+// Weights: the packed [chunk][tap][co = 1][16] array, wave-uniform addresses -> scalar loads, SGPR operands.
+constexpr int CM_TH = 16, CM_TW = 16, CM_LH = 18, CM_LW = 18, CM_PXQ = 9, CM_ROWQ = 176, CM_ITEMS = CM_LH * CM_LW * 8, CM_PER = (CM_ITEMS + 255) / 256;
+__global__ __launch_bounds__(256) void classifier_march_kernel(const ConvArgs p, const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                               int dseg, int nseg) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int twi = bid % p.tilesW; bid /= p.tilesW;
+    const int thi = bid % p.tilesH; bid /= p.tilesH;
+    const int seg = bid % nseg;
+    const int b = bid / nseg;
+    const int d0 = seg * dseg, d1 = (d0 + dseg < p.Di) ? d0 + dseg : p.Di;
+    const int h0 = thi * CM_TH, w0 = twi * CM_TW;
+    const size_t plane = (size_t)p.Hi * p.Wi * p.xCs;
+    const float* xb = p.x + (size_t)b * p.Di * plane;
+
+    // staging items of this thread: (pixel of the 18 x 18 halo tile, channel quad) -> offset inside a plane (or -1: outside the image)
+    int goff[CM_PER], loff[CM_PER];
+#pragma unroll
+    for (int j = 0; j < CM_PER; ++j) {
+        const int i = tid + 256 * j;
+        const int px = i >> 3, q = i & 7;
+        const int lh = px / CM_LW, lw = px - lh * CM_LW;
+        const int gh = h0 - 1 + lh, gw = w0 - 1 + lw;
+        const bool in = i < CM_ITEMS && gh >= 0 && gh < p.Hi && gw >= 0 && gw < p.Wi;
+        goff[j] = in ? (gh * p.Wi + gw) * p.xCs + q * 4 : -1;
+        loff[j] = (i < CM_ITEMS) ? lh * CM_ROWQ + lw * CM_PXQ + q : -1;
+    }
+    float4 pre[CM_PER];
+    auto issue = [&](int pd) {
+        const float* xp = xb + (size_t)pd * plane;
+#pragma unroll
+        for (int j = 0; j < CM_PER; ++j)
+            pre[j] = (goff[j] >= 0) ? *reinterpret_cast<const float4*>(xp + goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const int tw_ = tid % CM_TW, th_ = tid / CM_TW;
+    const float4* xt = smem + th_ * CM_ROWQ + tw_ * CM_PXQ;
+    const float4* w4 = reinterpret_cast<const float4*>(wpk);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;          // running sums of the outputs at pd - 1, pd, pd + 1
+    issue(d0 > 0 ? d0 - 1 : 0);
+    for (int pd = d0 - 1; pd <= d1; ++pd) {
+        if (pd >= 0 && pd < p.Di) {               // uniform over the workgroup
+            __syncthreads();                      // the previous plane's readers are done
+#pragma unroll
+            for (int j = 0; j < CM_PER; ++j)
+                if (loff[j] >= 0) smem[loff[j]] = pre[j];
+            __syncthreads();
+            if (pd + 1 <= d1 && pd + 1 < p.Di) issue(pd + 1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 xv = xt[kh * CM_ROWQ + kw * CM_PXQ + q];
+                        const int wi = ((q >> 2) * 27 + kh * 3 + kw) * 4 + (q & 3);        // float4 index of (chunk, tap kd = 0, quad)
+                        const float4 wk0 = w4[wi], wk1 = w4[wi + 9 * 4], wk2 = w4[wi + 18 * 4];
+                        a0 = fmaf(xv.x, wk2.x, a0); a0 = fmaf(xv.y, wk2.y, a0); a0 = fmaf(xv.z, wk2.z, a0); a0 = fmaf(xv.w, wk2.w, a0);
+                        a1 = fmaf(xv.x, wk1.x, a1); a1 = fmaf(xv.y, wk1.y, a1); a1 = fmaf(xv.z, wk1.z, a1); a1 = fmaf(xv.w, wk1.w, a1);
+                        a2 = fmaf(xv.x, wk0.x, a2); a2 = fmaf(xv.y, wk0.y, a2); a2 = fmaf(xv.z, wk0.z, a2); a2 = fmaf(xv.w, wk0.w, a2);
+                    }
+        }
+        const int od = pd - 1, oh = h0 + th_, ow = w0 + tw_;
+        if (od >= d0 && od < d1 && oh < p.Hi && ow < p.Wi) {
+            const size_t vox = (((size_t)b * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+            p.y[vox * p.yCs] = a0 + (bias ? bias[0] : 0.f) + (p.res ? p.res[vox * p.yCs] : 0.f);
+        }
+        a0 = a1; a1 = a2; a2 = 0.f;
+    }
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -957,12 +1038,30 @@ static int small_co_impl(const float* x, const float* w_ref, bool packed, const 
     a.LD = 4 + 2 * pad_d; a.LH = 8 + 2 * pad_h; a.LW = 8 + 2 * pad_w;
     a.tilesD = cdiv(D, 4); a.tilesH = cdiv(H, 8); a.tilesW = cdiv(W, 8);
     finish_geometry(a, 8, true);       // thread q reads voxel q of the 4x8x8 tile: the MFMA A-operand pattern, compact image
+    hipStream_t st = (hipStream_t)stream;
+    if (packed && Co == 1 && Ci == 32 && xCs == 32 && kd == 3 && kh == 3 && kw == 3 && !exp_set("OSA_NO_MARCH")) {
+        // the classifier shape: d-marching form (one pass over the input + an 18x18 / 16x16 halo).  D is cut into segments only as far as
+        // needed to give every CU several workgroups (each segment re-reads 2 halo planes)
+        a.tilesH = cdiv(H, CM_TH); a.tilesW = cdiv(W, CM_TW);
+        const long long cols = (long long)B * a.tilesH * a.tilesW;
+        int nseg = (int)((2048 + cols - 1) / cols);
+        { const int o = exp_int("OSA_MARCH_NSEG", 0); if (o) nseg = o; }
+        if (nseg > D / 8) nseg = D / 8;
+        if (nseg < 1) nseg = 1;
+        const int dseg = cdiv(D, nseg);
+        nseg = cdiv(D, dseg);
+        OSA_REQUIRE(cols * nseg < (1ll << 31), "conv3d_small_co: grid too large");
+        OSA_REQUIRE((long long)H * W * xCs < (1ll << 31), "conv3d_small_co: plane too large");
+        const size_t mlds = (size_t)CM_LH * CM_ROWQ * sizeof(float4);
+        hipLaunchKernelGGL(classifier_march_kernel, dim3((unsigned)(cols * nseg)), dim3(256), mlds, st, a, w_ref, bias, dseg, nseg);
+        OSA_LAUNCH_CHECK("conv3d_small_co (march)");
+        return 0;
+    }
     const size_t lds = ((size_t)a.LD * a.PlaneQ * 4 + (packed ? 0 : (size_t)a.nchunks * a.T * Co * 16)) * sizeof(float);
     OSA_REQUIRE(lds <= 160 * 1024, "conv3d_small_co: %zu B of LDS needed", lds);
     const long long nblk = (long long)B * a.tilesD * a.tilesH * a.tilesW;
     OSA_REQUIRE(nblk < (1ll << 31), "conv3d_small_co: grid too large");
     dim3 grid((unsigned)nblk), block(256);
-    hipStream_t st = (hipStream_t)stream;
 #define OSA_SC_LAUNCH1(CO, WG)                                                                              \
     do {                                                                                                    \
         if (lds > 64 * 1024)                                                                                \

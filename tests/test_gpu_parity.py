@@ -196,6 +196,25 @@ def test_small_co_classifier_vs_oracle():
     close(y, ref, atol=2e-4, rtol=2e-5, what="classifier head")
 
 
+@pytest.mark.parametrize("shape", [(2, 19, 37, 45), (1, 3, 16, 16), (1, 1, 5, 70), (3, 24, 33, 17)])
+def test_classifier_marching_form_vs_oracle(shape):
+    """The 32 -> 1 classifier shape takes the d-marching kernel (conv3d.hip, classifier_march_kernel): ragged 16x16 tiles, several D
+    segments (19 planes -> 2 segments of 10), D smaller than the halo, bias and residual."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import SmallCoConv3d
+    B, D, H, W = shape
+    conv = nn.Conv3d(32, 1, 3, 1, 1, bias=True)
+    conv.weight.data = synth_tensor("clsm.w", conv.weight.shape, 1)
+    conv.bias.data = synth_tensor("clsm.b", conv.bias.shape, 1)
+    rng = np.random.default_rng(11)
+    x = T(rng.normal(0, 1, (B, 32, D, H, W)).astype(np.float32))
+    r = T(rng.normal(0, 1, (B, 1, D, H, W)).astype(np.float32))
+    with torch.no_grad():
+        ref = conv(x) + r
+    y = SmallCoConv3d(conv.to(DEV))(ops.to_cl(x.to(DEV)), residual=ops.to_cl(r.to(DEV), pad_to=1))
+    close(y, ref, atol=2e-4, rtol=2e-5, what=f"classifier head (marching form) {shape}")
+
+
 # ----------------------------------------------------------------------------- GwcNet stages / model
 def test_gwc_hourglass_vs_reference_golden():
     from openstereo_amd.models.gwcnet import Hourglass
