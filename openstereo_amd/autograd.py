@@ -141,8 +141,10 @@ class _UpsampleSoftArgmin(torch.autograd.Function):
         B, Dl, Hl, Wl = c.shape
         g = _f32c(dout)
         dc = torch.empty_like(c)
-        _lib.call("osa_upsample_softargmin_bwd_f32", c.data_ptr(), g.data_ptr(), dc.data_ptr(), B, Dl, Hl, Wl,
-                  int(maxdisp), int(h), int(w), 1 if align else 0, _stream())
+        need = _lib.load().osa_upsample_softargmin_bwd_workspace_bytes(B, Dl, int(h), int(w))     # [B,Dl,H,W] scratch: atomic-free, deterministic
+        ws = torch.empty((need + 3) // 4, device=c.device, dtype=torch.float32)
+        _lib.call("osa_upsample_softargmin_bwd_ws_f32", c.data_ptr(), g.data_ptr(), dc.data_ptr(), B, Dl, Hl, Wl,
+                  int(maxdisp), int(h), int(w), 1 if align else 0, ws.data_ptr(), need, _stream())
         return dc, None, None, None, None
 
 

@@ -148,6 +148,100 @@ __global__ __launch_bounds__(256) void upsample_softargmin_bwd_kernel(const UpBw
     }
 }
 
+
+// ---- two-pass, atomic-free form (osa_upsample_softargmin_bwd_ws_f32) ---------------------------------------------------------------
+// The one-kernel form above scatters 4 * Dl float atomics per output pixel (25 M of them for one 256x512 pair, ~25 pixels contending for
+// every low-res cell): 0.75 ms per head, 6.7 % of a GwcNet training step, and a run-dependent summation order.
+// pass 1 (fold): one thread per output pixel, as above, but the Dl folded gradients go to a scratch tensor G[b][dl][y][x] (coalesced).
+// pass 2 (gather): one thread per low-res cell sums w_y * w_x * G over the output pixels whose bilinear footprint contains the cell, in
+// a fixed order -- deterministic, no zero-fill, no atomics.
+template <int NT>
+__global__ __launch_bounds__(NT) void upsample_softargmin_bwd_fold_kernel(const UpBwdArgs p, float* __restrict__ G) {
+    extern __shared__ float sh[];            // cl[Dl][NT] then gl[Dl][NT]
+    float* cl = sh; float* gl = sh + (size_t)p.Dl * NT;
+    const int tid = threadIdx.x;
+    const long long HW = (long long)p.H * p.W;
+    const long long i = (long long)blockIdx.x * NT + tid;
+    const bool live = i < (long long)p.B * HW;
+    const long long ii = live ? i : 0;
+    const int b = (int)(ii / HW);
+    const int hw = (int)(ii - (long long)b * HW);
+    const int y = hw / p.W, x = hw - y * p.W;
+    int y0, y1, x0, x1; float ly, lx;
+    src_index_b(y, p.sh, p.align, p.Hl, y0, y1, ly);
+    src_index_b(x, p.sw, p.align, p.Wl, x0, x1, lx);
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    const size_t plane = (size_t)p.Hl * p.Wl;
+    const float* c = p.cost + (size_t)b * p.Dl * plane;
+    const size_t o00 = (size_t)y0 * p.Wl + x0, o01 = (size_t)y0 * p.Wl + x1, o10 = (size_t)y1 * p.Wl + x0, o11 = (size_t)y1 * p.Wl + x1;
+    float m = -INFINITY;
+    for (int dl = 0; dl < p.Dl; ++dl) {
+        const float* cp = c + (size_t)dl * plane;
+        const float v = w00 * cp[o00] + w01 * cp[o01] + w10 * cp[o10] + w11 * cp[o11];
+        cl[dl * NT + tid] = v; gl[dl * NT + tid] = 0.f;
+        m = fmaxf(m, v);
+    }
+    float se = 0.f, sdisp = 0.f;
+    for (int d = 0; d < p.D; ++d) {
+        int d0, d1; float ld;
+        src_index_b(d, p.sd, p.align, p.Dl, d0, d1, ld);
+        const float e = expf((1.f - ld) * cl[d0 * NT + tid] + ld * cl[d1 * NT + tid] - m);
+        se += e; sdisp = fmaf(e, (float)d, sdisp);
+    }
+    const float inv = 1.f / se, disp = sdisp * inv;
+    const float g = live ? p.dout[i] : 0.f;
+    for (int d = 0; d < p.D; ++d) {
+        int d0, d1; float ld;
+        src_index_b(d, p.sd, p.align, p.Dl, d0, d1, ld);
+        const float e = expf((1.f - ld) * cl[d0 * NT + tid] + ld * cl[d1 * NT + tid] - m);
+        const float gd = e * inv * ((float)d - disp) * g;
+        gl[d0 * NT + tid] += (1.f - ld) * gd;
+        gl[d1 * NT + tid] += ld * gd;
+    }
+    if (!live) return;
+    float* gp = G + (size_t)b * p.Dl * HW + hw;
+    for (int dl = 0; dl < p.Dl; ++dl) gp[(size_t)dl * HW] = gl[dl * NT + tid];
+}
+
+// output positions whose source interval can contain low-res index `il` (a conservative range; the exact test is src_index_b)
+__device__ __forceinline__ void footprint(int il, float scale, int align, int out_size, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+    const float off = align ? 0.f : 0.5f;
+    const float a = ((float)il - 1.f + off) / scale - off, b = ((float)il + 1.f + off) / scale - off;
+    lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+
+__global__ __launch_bounds__(256) void upsample_softargmin_bwd_gather_kernel(const UpBwdArgs p, const float* __restrict__ G) {
+    const long long total = (long long)p.B * p.Dl * p.Hl * p.Wl;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int xl = (int)(i % p.Wl); long long r = i / p.Wl;
+    const int yl = (int)(r % p.Hl); r /= p.Hl;               // r = b * Dl + dl
+    int ylo, yhi, xlo, xhi;
+    footprint(yl, p.sh, p.align, p.H, ylo, yhi);
+    footprint(xl, p.sw, p.align, p.W, xlo, xhi);
+    const float* g = G + (size_t)r * p.H * p.W;
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+        int y0, y1; float ly;
+        src_index_b(y, p.sh, p.align, p.Hl, y0, y1, ly);
+        const float wy = ((y0 == yl) ? (1.f - ly) : 0.f) + ((y1 == yl) ? ly : 0.f);
+        if (wy == 0.f) continue;
+        const float* gr = g + (size_t)y * p.W;
+        float row = 0.f;
+        for (int x = xlo; x <= xhi; ++x) {
+            int x0, x1; float lx;
+            src_index_b(x, p.sw, p.align, p.Wl, x0, x1, lx);
+            const float wx = ((x0 == xl) ? (1.f - lx) : 0.f) + ((x1 == xl) ? lx : 0.f);
+            row = fmaf(wx, gr[x], row);
+        }
+        acc = fmaf(wy, row, acc);
+    }
+    p.dcost[i] = acc;
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -215,5 +309,35 @@ extern "C" int osa_upsample_softargmin_bwd_f32(const float* cost_lowres, const f
     const long long total = (long long)B * H * W;
     hipLaunchKernelGGL(upsample_softargmin_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), lds, st, a);
     OSA_LAUNCH_CHECK("upsample_softargmin_bwd");
+    return 0;
+}
+
+extern "C" size_t osa_upsample_softargmin_bwd_workspace_bytes(int B, int Dl, int H, int W) {
+    if (B <= 0 || Dl <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * Dl * H * W * sizeof(float);
+}
+
+extern "C" int osa_upsample_softargmin_bwd_ws_f32(const float* cost_lowres, const float* dout, float* dcost_lowres,
+                                                  int B, int Dl, int Hl, int Wl, int D, int H, int W,
+                                                  int align_corners, void* workspace, size_t workspace_bytes, void* stream) {
+    OSA_REQUIRE(cost_lowres && dout && dcost_lowres && workspace, "upsample_softargmin_bwd_ws: NULL pointer");
+    OSA_REQUIRE(workspace_bytes >= osa_upsample_softargmin_bwd_workspace_bytes(B, Dl, H, W) && ((size_t)workspace & 15) == 0,
+                "upsample_softargmin_bwd_ws: workspace too small or misaligned (osa_upsample_softargmin_bwd_workspace_bytes)");
+    constexpr int NT = 128;
+    const size_t lds = (size_t)Dl * NT * sizeof(float) * 2;
+    OSA_REQUIRE(lds <= 160 * 1024, "upsample_softargmin_bwd_ws: Dl=%d too large for LDS", Dl);
+    UpBwdArgs a;
+    a.cost = cost_lowres; a.dout = dout; a.dcost = dcost_lowres;
+    a.B = B; a.Dl = Dl; a.Hl = Hl; a.Wl = Wl; a.D = D; a.H = H; a.W = W; a.align = align_corners ? 1 : 0;
+    auto sc = [&](int in, int out) { return a.align ? ((out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f) : (float)in / (float)out; };
+    a.sd = sc(Dl, D); a.sh = sc(Hl, H); a.sw = sc(Wl, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)upsample_softargmin_bwd_fold_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float* G = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(upsample_softargmin_bwd_fold_kernel<NT>, dim3(cdiv((long long)B * H * W, NT)), dim3(NT), lds, st, a, G);
+    OSA_LAUNCH_CHECK("upsample_softargmin_bwd_ws (fold)");
+    hipLaunchKernelGGL(upsample_softargmin_bwd_gather_kernel, dim3(cdiv((long long)B * Dl * Hl * Wl, 256)), dim3(256), 0, st, a, (const float*)G);
+    OSA_LAUNCH_CHECK("upsample_softargmin_bwd_ws (gather)");
     return 0;
 }

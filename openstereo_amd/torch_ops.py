@@ -184,8 +184,10 @@ def _usa_bwd(ctx, g):
     B, Dl, Hl, Wl = c.shape
     gg = _f32c(g)
     dc = torch.empty_like(c)
-    _lib.call("osa_upsample_softargmin_bwd_f32", c.data_ptr(), gg.data_ptr(), dc.data_ptr(), B, Dl, Hl, Wl,
-              int(maxdisp), int(h), int(w), 1 if align else 0, _stream())
+    need = _lib.load().osa_upsample_softargmin_bwd_workspace_bytes(B, Dl, int(h), int(w))
+    ws = torch.empty((need + 3) // 4, device=c.device, dtype=torch.float32)
+    _lib.call("osa_upsample_softargmin_bwd_ws_f32", c.data_ptr(), gg.data_ptr(), dc.data_ptr(), B, Dl, Hl, Wl,
+              int(maxdisp), int(h), int(w), 1 if align else 0, ws.data_ptr(), need, _stream())
     dc = dc.to(ctx.dtype)
     return (dc.unsqueeze(1) if ctx.five else dc), None, None, None, None
 

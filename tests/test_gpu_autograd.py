@@ -59,11 +59,16 @@ def test_regression_backward_vs_oracle_autograd():
     p2 = prob.to(DEV).requires_grad_(); AG.disparity_regression(p2, 12, False).backward(g.to(DEV))
     close(p2.grad, p1.grad, 1e-6, 1e-6, "regression dprob")
     low = rn((2, 1, 6, 5, 7), 6, 2.0)
-    for align, (D, H, W) in ((False, (24, 20, 28)), (True, (24, 20, 28)), (False, (17, 13, 21))):
+    # x4 (the heads' case), align_corners, fractional scales, identity, a scale > 8 and one below 2 -- the atomic-free two-pass form
+    # (osa_upsample_softargmin_bwd_ws_f32: fold per output pixel, then a fixed-order gather over every low-res cell's bilinear footprint)
+    for align, (D, H, W) in ((False, (24, 20, 28)), (True, (24, 20, 28)), (False, (17, 13, 21)), (True, (17, 13, 21)), (True, (6, 5, 7)),
+                             (False, (6, 5, 7)), (False, (60, 47, 9)), (False, (9, 8, 12))):
         gg = rn((2, H, W), 7)
         l1 = low.clone().requires_grad_(); O.upsample_regression(l1, D, H, W, align).backward(gg)
         l2 = low.to(DEV).requires_grad_(); AG.upsample_softargmin(l2, D, H, W, align).backward(gg.to(DEV))
         close(l2.grad, l1.grad, 2e-5, 1e-4, f"upsample_softargmin dcost align={align} {D}x{H}x{W}")
+        l3 = low.to(DEV).requires_grad_(); AG.upsample_softargmin(l3, D, H, W, align).backward(gg.to(DEV))
+        assert torch.equal(l2.grad, l3.grad), "the two-pass backward is deterministic"
 
 
 CONV_BWD = [  # name, Ci, Co, k, stride, pad, dil, dims
