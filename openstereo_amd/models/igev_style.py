@@ -197,12 +197,14 @@ class Hourglass(nn.Module):
 class StereoBaseCostStage(nn.Module):
     """The volume -> aggregation -> initial-disparity slice of stereobase_gru.py:139-164 with the
     reference's attribute names (`cost_agg`, `classifier`), so those checkpoint keys load:
-      gwc volume (num_groups) [+ concat volume] -> Hourglass -> Conv3d(c,1,3) -> softmax -> regression."""
+      [gwc volume (num_groups)] [+ concat volume] [+ extra volumes] -> Hourglass -> Conv3d(c,1,3) -> softmax -> regression.
+    `extra_channels` / `extras`: the dormant variants of stereobase_gru.py:152-159 (`build_sub_volume`: 1 channel, `InterlacedVolume`:
+    INTERLACED_CHANNELS) arrive as NCDHW tensors and are appended behind the fused gwc + concat channels, in the reference's order."""
 
-    def __init__(self, max_disp=192, num_groups=8, concat_channels=8, backbone_channels=None):
+    def __init__(self, max_disp=192, num_groups=8, concat_channels=8, backbone_channels=None, extra_channels=0):
         super().__init__()
-        self.max_disp, self.num_groups, self.concat_channels = max_disp, num_groups, concat_channels
-        volume_channel = num_groups + 2 * concat_channels
+        self.max_disp, self.num_groups, self.concat_channels, self.extra_channels = max_disp, num_groups, concat_channels, extra_channels
+        volume_channel = num_groups + 2 * concat_channels + extra_channels
         self.cost_agg = Hourglass(volume_channel, backbone_channels)
         self.classifier = nn.Conv3d(volume_channel, 1, 3, 1, 1, bias=False)
         self._cls = None
@@ -211,23 +213,51 @@ class StereoBaseCostStage(nn.Module):
         self._cls = None
         self.cost_agg.reset_engine()
 
-    def forward_train(self, match_left, match_right, concat_left, concat_right, features_left):
+    def forward_train(self, match_left, match_right, concat_left, concat_right, features_left, extras=None):
         """Training path (BASELINE configs[2]): differentiable engine ops end to end -- volumes, hourglass
         convolutions, classifier, fused softmax + regression -- BatchNorm / activations as torch modules."""
         from .. import autograd as A
         D4 = self.max_disp // 4
-        vol = torch.cat((A.build_gwc_volume(match_left, match_right, D4, self.num_groups),
-                         A.build_concat_volume(concat_left, concat_right, D4)), 1)
+        parts = []
+        if self.num_groups:
+            parts.append(A.build_gwc_volume(match_left, match_right, D4, self.num_groups))
+        if self.concat_channels:
+            parts.append(A.build_concat_volume(concat_left, concat_right, D4))
+        parts += [e.float() for e in (extras or ())]
+        vol = torch.cat(parts, 1)
         geo = self.cost_agg.forward_train(vol, features_left)
         cost = A.conv_module(self.classifier, geo).squeeze(1)
         init_disp = A.softmax_disparity_regression(cost, keepdim=True)
         return {"init_disp": init_disp, "prob": torch.softmax(cost, dim=1), "geo_encoding_volume": geo}
 
-    def forward(self, match_left, match_right, concat_left, concat_right, features_left):
+    def forward(self, match_left, match_right, concat_left, concat_right, features_left, extras=None):
         if self.training or (torch.is_grad_enabled() and (match_left.requires_grad or any(p.requires_grad for p in self.parameters()))):
-            return self.forward_train(match_left, match_right, concat_left, concat_right, features_left)
-        vol = ops.build_cost_volume_cl(match_left, match_right, self.num_groups, concat_left, concat_right,
-                                       maxdisp=self.max_disp // 4)
+            return self.forward_train(match_left, match_right, concat_left, concat_right, features_left, extras)
+        assert sum(e.shape[1] for e in (extras or ())) == self.extra_channels, "extras do not match extra_channels"
+        D4 = self.max_disp // 4
+        if (self.num_groups + 2 * self.concat_channels + self.extra_channels) % 4:
+            # the fused NDHWC chain (concatenations at channel offsets c, 2c, 4c) needs channel counts in multiples of 4; the dormant
+            # configurations that break this (a 1-channel sub volume: 33 channels) take the composition of the training path instead --
+            # the same engine convolutions through their autograd Functions, BatchNorm / activations as torch modules
+            with torch.no_grad():
+                return self.forward_train(match_left, match_right, concat_left, concat_right, features_left, extras)
+        vol = None
+        if self.num_groups or self.concat_channels:
+            vol = ops.build_cost_volume_cl(match_left if self.num_groups else None, match_right if self.num_groups else None, self.num_groups,
+                                           concat_left if self.concat_channels else None, concat_right if self.concat_channels else None, maxdisp=D4)
+        if self.extra_channels:
+            # dormant variants: NCDHW pieces copied behind the fused channels of one NDHWC buffer (strided torch copies: not a tuned path)
+            n0 = self.num_groups + 2 * self.concat_channels
+            B, _, H, W = match_left.shape
+            full = ops.empty_cl(B, (n0 + self.extra_channels + 3) // 4 * 4, D4, H, W, match_left.device)
+            full.zero_()
+            if vol is not None:
+                full[:, :n0] = vol[:, :n0]
+            c = n0
+            for e in extras:
+                full[:, c:c + e.shape[1]] = e.float()
+                c += e.shape[1]
+            vol = full
         geo = self.cost_agg.forward_cl(vol, features_left)
         cost = cached_pack(self, "_cls", lambda: SmallCoConv3d(self.classifier), mods=(self.classifier,))(geo)   # [B,1,D/4,H/4,W/4]
         init_disp, prob = ops.softmax_disparity_regression(cost[:, 0], self.max_disp // 4, keepdim=True, return_prob=True)

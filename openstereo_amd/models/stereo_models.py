@@ -33,6 +33,7 @@ from ..ops import on_engine
 from .igev_style import BasicConv2d, BasicConv, IGEVFeatureAtt, StereoBaseCostStage, hourglass, _pack_igev
 from .igev_update import BasicMultiUpdateBlock, run_refinement
 from .context_encoder import MultiBasicEncoder
+from .interlaced import InterlacedVolume
 from .lightstereo import LightStereoCostStage
 from ..engine import cached_pack, SmallCoConv3d
 
@@ -228,25 +229,33 @@ def _require_engine(x, who):
 
 # ----------------------------------------------------------------------------- StereoBase (BASELINE configs[2])
 class StereoBase(StereoBaseCostStage):
-    """stereobase_gru.py:14-213 (gwc [+ concat] volume configuration; USE_SUB_VOLUME / USE_INTERLACED_VOLUME are not built).
+    """stereobase_gru.py:14-213.  Every volume switch of the reference is honoured: USE_GWC_VOLUME / USE_CONCAT_VOLUME (the fused NDHWC
+    builder), and the two dormant variants no shipped config enables -- USE_SUB_VOLUME (ops.build_sub_volume, 1 channel) and
+    USE_INTERLACED_VOLUME (models/interlaced.py, INTERLACED_CHANNELS) -- appended behind the fused channels in the reference's order.
 
     `cfgs`: attribute namespace with the reference's keys (MAX_DISP, NUM_GROUPS, USE_CONCAT_VOLUME, CONCAT_CHANNELS,
     HIDDEN_DIMS, N_GRU_LAYERS, CORR_RADIUS, CORR_LEVELS, SLOW_FAST_GRU, EVAL_ITERS, TRAIN_ITERS)."""
 
     def __init__(self, cfgs, feature=None, cnet=None):
         g = lambda k, d: getattr(cfgs, k, d)
-        if g("USE_SUB_VOLUME", False) or g("USE_INTERLACED_VOLUME", False) or not g("USE_GWC_VOLUME", True):
-            raise NotImplementedError("openstereo_amd StereoBase: only the gwc (+ concat) volume configuration is built (build_sub_volume exists "
-                                      "as an engine op, ops.build_sub_volume, but is not wired into the fused NDHWC volume; InterlacedVolume is not built)")
         self_concat = g("CONCAT_CHANNELS", 12) if g("USE_CONCAT_VOLUME", False) else 0
+        groups = g("NUM_GROUPS", 8) if g("USE_GWC_VOLUME", True) else 0
+        use_sub, use_inter = bool(g("USE_SUB_VOLUME", False)), bool(g("USE_INTERLACED_VOLUME", False))
+        inter_ch = g("INTERLACED_CHANNELS", 8) if use_inter else 0
+        if groups + self_concat + use_sub + inter_ch == 0:
+            raise ValueError("StereoBase: every volume switch is off (USE_GWC_VOLUME / USE_CONCAT_VOLUME / USE_SUB_VOLUME / USE_INTERLACED_VOLUME)")
         feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
         bc = list(getattr(feature, "output_channels", (48, 64, 192, 160)))
         bc[0] += 48
-        super().__init__(max_disp=cfgs.MAX_DISP, num_groups=g("NUM_GROUPS", 8), concat_channels=self_concat, backbone_channels=bc)
+        super().__init__(max_disp=cfgs.MAX_DISP, num_groups=groups, concat_channels=self_concat, backbone_channels=bc,
+                         extra_channels=int(use_sub) + inter_ch)
+        self.use_sub_volume, self.use_interlaced_volume = use_sub, use_inter
+        if use_inter:
+            self.build_interlaced_volume = InterlacedVolume(inter_ch)
         self.cfgs = cfgs
         self.n_gru_layers, self.slow_fast_gru = cfgs.N_GRU_LAYERS, cfgs.SLOW_FAST_GRU
         hd = list(cfgs.HIDDEN_DIMS)
-        volume_channel = self.num_groups + 2 * self_concat
+        volume_channel = self.num_groups + 2 * self_concat + self.extra_channels
         IN, BN, LR = nn.InstanceNorm2d, nn.BatchNorm2d, nn.LeakyReLU
         self.feature = feature
         # r3: the reference's context network itself (plain PyTorch there, engine mirror here, `cnet.*` checkpoint keys); StubContext stays
@@ -289,6 +298,20 @@ class StereoBase(StereoBaseCostStage):
         return dict(features_left=fl, match_left=ml, match_right=mr, concat_left=cl, concat_right=cr, stem_2x=stem_2x,
                     net_list=net_list, inp_list=inp_list, spx_logits=spx_logits)
 
+    def _extra_volumes(self, ml, mr):
+        """stereobase_gru.py:152-159: the dormant volume variants, NCDHW, in the reference's concatenation order."""
+        D4, out = self.max_disp // 4, []
+        if self.use_sub_volume:
+            if ml.requires_grad or mr.requires_grad:             # differentiable torch form of cost_volume.py:108-117 (the engine op has no backward)
+                W = ml.shape[3]
+                sub = torch.stack([torch.cat((ml[..., :i].abs().sum(1), (ml[..., i:] - mr[..., :W - i]).abs().sum(1)), -1) for i in range(D4)], 1)
+            else:
+                sub = ops.build_sub_volume(ml, mr, D4)
+            out.append(sub.unsqueeze(1))
+        if self.use_interlaced_volume:
+            out.append(self.build_interlaced_volume(ml, mr, D4))
+        return out
+
     def upsample_disp(self, disp, mask_feat_4, stem_2x):
         """stereobase_gru.py:114-119 with softmax, x4 gain and the 3x3 convex combination in one kernel."""
         logits = self.spx_gru(self.spx_2_gru(mask_feat_4, stem_2x))
@@ -308,7 +331,8 @@ class StereoBase(StereoBaseCostStage):
         block convs (BasicMultiUpdateBlock.forward_train); BatchNorm / activations / the small 2-D heads are torch modules."""
         from ..attach import context_upsample as ctx_up
         s = self.side(image1, image2)
-        st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"])
+        st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"],
+                                         self._extra_volumes(s["match_left"], s["match_right"]))
         disp_preds = _gru_train_loop(self, self.cfgs, s, st["init_disp"], st["geo_encoding_volume"], self.cfgs.TRAIN_ITERS,
                                      self.n_gru_layers, self.slow_fast_gru)
         init_up = ctx_up(st["init_disp"] * 4.0, F.softmax(s["spx_logits"], 1).float()).unsqueeze(1)
@@ -319,7 +343,8 @@ class StereoBase(StereoBaseCostStage):
 
     def _infer(self, image1, image2):
         s = self.side(image1, image2)
-        st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"])
+        st = StereoBaseCostStage.forward(self, s["match_left"], s["match_right"], s["concat_left"], s["concat_right"], s["features_left"],
+                                         self._extra_volumes(s["match_left"], s["match_right"]))
         r = run_refinement(self.update_block, self._loop_args, s["match_left"], s["match_right"], st["geo_encoding_volume"],
                            s["net_list"], s["inp_list"], st["init_disp"], self.cfgs.EVAL_ITERS)
         disp_up = self.upsample_disp(r["disp"], r["mask_feat_4"], s["stem_2x"])

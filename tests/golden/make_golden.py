@@ -477,10 +477,52 @@ def gen_e2e_train(feat, cnet):
     save("e2e_reference_train.npz", **out)
 
 
+def gen_e2e_dormant():
+    """StereoBase with the dormant volume switches (stereobase_gru.py:22-23,152-159; no shipped config sets them): the reference's own class,
+    (a) USE_SUB_VOLUME + USE_INTERLACED_VOLUME on top of gwc + concat (8 + 16 + 1 + 8 = 33 volume channels), (b) gwc + interlaced only
+    (16 channels: the fused NDHWC route).  build_sub_volume's device='cuda' zeros are redirected as in gen_dormant.  Also the
+    InterlacedVolume module alone (cost_volume.py:120-169).  96x192, MAX_DISP 32, 3 iterations."""
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    from openstereo_amd.models.stereo_models import StubFeature
+    from stereo.modeling.cost_volume import cost_volume as cv
+
+    class _CpuTorch:
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def zeros(*a, **k):
+            k.pop("device", None)
+            return torch.zeros(*a, **k)
+    feat = lambda *a, **k: StubFeature((48, 64, 192, 160))
+    L, R = synth_images(1, 96, 192, seed=35, max_shift=6.0)
+    out = {}
+    iv = cv.InterlacedVolume(8).eval()
+    iv.load_state_dict(synth_state_dict(iv, seed=23, gain=0.9))
+    fl, fr = rnd((2, 96, 7, 19), 311), rnd((2, 96, 7, 19), 312)
+    out["interlaced_alone"] = iv(fl, fr, 6)
+    print("InterlacedVolume alone: max", out["interlaced_alone"].abs().max().item())
+    base = Cfg(MAX_DISP=32, NUM_GROUPS=8, USE_GWC_VOLUME=True, CONCAT_CHANNELS=8, INTERLACED_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+               N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, TRAIN_ITERS=3, EVAL_ITERS=3)
+    real = cv.torch
+    cv.torch = _CpuTorch()
+    try:
+        for tag, flags in (("all", dict(USE_CONCAT_VOLUME=True, USE_SUB_VOLUME=True, USE_INTERLACED_VOLUME=True)),
+                           ("inter", dict(USE_CONCAT_VOLUME=False, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=True))):
+            net = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", Cfg(base, **flags), {"Feature": feat})
+            net.load_state_dict(synth_state_dict(net, seed=53, head_gain=20.0, gain=0.9))
+            r = net({"left": L, "right": R})
+            out[f"sb_{tag}_disp"], out[f"sb_{tag}_init"] = r["disp_pred"], r["init_disp"]
+            print(f"StereoBase dormant [{tag}]: disp range", r["disp_pred"].min().item(), r["disp_pred"].max().item(), "std", r["disp_pred"].std().item())
+    finally:
+        cv.torch = real
+    save("e2e_dormant.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | unit_gain | context_encoder")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | e2e_dormant | unit_gain | context_encoder")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -502,6 +544,9 @@ def main():
         return
     if args.only == "e2e":
         gen_e2e()
+        return
+    if args.only == "e2e_dormant":
+        gen_e2e_dormant()
         return
     if args.only == "unit_gain":
         gen_unit_gain()
@@ -637,6 +682,7 @@ def main():
     gen_e2e()
     gen_unit_gain()
     gen_context_encoder()
+    gen_e2e_dormant()
 
     # ------------------------------------------------------------------ PSMNet, BASELINE configs[0]: 256x512, D=64
     from stereo.modeling.models.psmnet.psmnet import PSMNet

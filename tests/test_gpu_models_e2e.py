@@ -279,6 +279,47 @@ def test_training_step_matches_reference_autograd(which, activations):
     assert not bad, bad                    # whole-model gradient error relative to max |grad| per tensor
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("which", ["all", "inter"])
+def test_stereobase_dormant_volume_switches_vs_reference(which, prec):
+    """USE_SUB_VOLUME + USE_INTERLACED_VOLUME on top of gwc + concat (33 volume channels: the composition route) and gwc + interlaced
+    only (16 channels: the fused NDHWC route) vs the reference's own StereoBase class with those switches
+    (tests/golden/e2e_dormant.npz, make_golden.gen_e2e_dormant).  96x192, MAX_DISP 32, 3 iterations."""
+    from conftest import golden
+    from openstereo_amd.models.stereo_models import StereoBase
+    g = golden("e2e_dormant.npz")
+    flags = dict(USE_CONCAT_VOLUME=True, USE_SUB_VOLUME=True, USE_INTERLACED_VOLUME=True) if which == "all" else \
+        dict(USE_CONCAT_VOLUME=False, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=True)
+    m = StereoBase(SimpleNamespace(MAX_DISP=32, NUM_GROUPS=8, USE_GWC_VOLUME=True, CONCAT_CHANNELS=8, INTERLACED_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                                   N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, TRAIN_ITERS=3, EVAL_ITERS=3,
+                                   **flags)).eval()
+    _load(m, 53)
+    m = m.cuda()
+    L, Rr = synth_images(1, 96, 192, seed=35, max_shift=6.0)
+    out = _with_precision(prec, lambda: m({"left": L.cuda(), "right": Rr.cuda()}))
+    assert g[f"sb_{which}_disp"].std() > 0.5
+    assert _epe(out["init_disp"], g[f"sb_{which}_init"]) < 1e-3, _epe(out["init_disp"], g[f"sb_{which}_init"])
+    assert _epe(out["disp_pred"], g[f"sb_{which}_disp"]) < 1e-3, _epe(out["disp_pred"], g[f"sb_{which}_disp"])
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_interlaced_volume_vs_reference(prec):
+    """cost_volume.py:120-169 alone: the three depth-strided Conv3d + the 1x1 head as four fused 2-D engine launches per disparity."""
+    import numpy as np
+    from conftest import golden
+    from openstereo_amd.models.interlaced import InterlacedVolume
+    g = golden("e2e_dormant.npz")
+    iv = InterlacedVolume(8).eval()
+    iv.load_state_dict(synth_state_dict(iv, seed=23, gain=0.9))
+    iv = iv.cuda()
+    rn = lambda shape, seed: torch.from_numpy(np.random.default_rng(seed).normal(0, 1, shape).astype(np.float32))
+    fl, fr = rn((2, 96, 7, 19), 311).cuda(), rn((2, 96, 7, 19), 312).cuda()
+    with torch.no_grad():
+        out = _with_precision(prec, lambda: iv(fl, fr, 6))
+    want = torch.from_numpy(g["interlaced_alone"])
+    torch.testing.assert_close(out.cpu(), want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+
+
 def test_end_to_end_classes_refuse_cpu():
     """No CPU path: CPU tensors are refused loudly (training mode is covered by tests/test_gpu_autograd.py)."""
     from openstereo_amd.models.stereo_models import LightStereo
