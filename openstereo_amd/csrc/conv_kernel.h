@@ -286,6 +286,19 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
+    // XT: "transposed accumulators" -- an r3 experiment, compiled out by default (-DOSA_XT=1 builds it: tools/build_variant.sh).  The plain
+    // f16x3 convolutions that write split tensors issue their MFMAs with the operands swapped (weights as A, activations as B: the same
+    // products summed in the same order -- verified bit-identical on 7 layer shapes, tools/diag_xt.py), so a lane's 16 accumulators of a
+    // 32 x 32 tile are 16 CHANNELS of ONE voxel -- voxel lane & 31, channels (r & 3) + 8 (r >> 2) + 4 hh -- instead of 16 voxels of one
+    // channel.  The epilogue then needs no transpose through LDS (16 ds_write_b32 + 4 ds_read_b128 and two LDS round trips per tile):
+    // one v_permlane32_swap per value pair gives every lane 8 consecutive channels, i.e. the 16-byte hi and lo rows of a split tensor.
+    // MEASURED: the whole model is 14 % SLOWER (155.1 vs 179.9 pairs/s, profiles/round3/ab_xt_epilogue.txt).  A lane then stores 16 B of
+    // a voxel of its own, so a wave's store (and residual load) touches 32 different 128-byte lines instead of 8 whole ones: the
+    // transpose through LDS is what buys coalesced rows, and it is the cheaper of the two.
+#ifndef OSA_XT
+#define OSA_XT 0
+#endif
+    constexpr bool XT = OSA_XT && (PREC == PREC_F16X3) && OUTS && NCLS == 1 && !REDIR && !PIPE && KS == 1;
     static_assert((TW & (TW - 1)) == 0 && (TH & (TH - 1)) == 0, "TH/TW powers of two");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
 
@@ -448,9 +461,15 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                         for (int n = 0; n < NT; ++n) {
                             const f16x8 ah = __builtin_bit_cast(f16x8, Ac[u][0][m]), al = __builtin_bit_cast(f16x8, Ac[u][1][m]);
                             const f16x8 bh = __builtin_bit_cast(f16x8, Bc[u][0][n]), bl = __builtin_bit_cast(f16x8, Bc[u][1][n]);
-                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ac[m][n], 0, 0, 0);
-                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, ac[m][n], 0, 0, 0);
-                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, ac[m][n], 0, 0, 0);
+                            if constexpr (XT) {          // D^T = W . X^T: lane = voxel, accumulators = channels
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, ac[m][n], 0, 0, 0);
+                            } else {
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, ac[m][n], 0, 0, 0);
+                                ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, ac[m][n], 0, 0, 0);
+                            }
                         }
                 }
             }
@@ -1049,7 +1068,124 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             else run(std::false_type{});
         }
     }
-    if constexpr (!REDIR && OUTS) {
+    if constexpr (XT) {
+        // ---- transposed-accumulator epilogue: lane (col, hh) owns voxel `col` of M tile m; per 16-channel block P of the N tile it holds
+        // channels 16P + 4hh + {0..3} (accumulators 8P .. 8P+3) and 16P + 8 + 4hh + {0..3} (8P+4 .. 8P+7).  v_permlane32_swap exchanges the
+        // first quad of the hh = 1 lanes with the second quad of the hh = 0 lanes: afterwards a lane holds the 8 CONSECUTIVE channels
+        // 16P + 8hh .. + 7 -- one 16-byte row of hi halves and one of lo halves in the split layout, like the residual it reads.
+        auto rowT = [&](auto F, int m, int& v0, bool& vok) {
+            constexpr bool FULL = decltype(F)::value;
+            const int q = (wm * MT + m) * 32 + col;
+            const int ad = a0d + q / (TW * TH), ah = a0h + (q / TW) % TH, aw = a0w + q % TW;
+            vok = FULL || (ad < p.Ad && ah < p.Ah && aw < p.Aw);
+            const int os_ = (!FULL && (p.dbg & 64)) ? 1 : p.os;
+            v0 = ((ad * os_) * p.Ho + ah * os_) * p.Wo + aw * os_;
+        };
+        auto load_res8T = [&](auto F, int i, float4 (&rv)[4]) {
+            constexpr bool FULL = decltype(F)::value;
+            const int n = i % NT, m = i / NT;
+            int v0, coff, goff; bool vok;
+            rowT(F, m, v0, vok);
+            class_off(0, coff, goff);
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const int co = n0 + (wn * NT + n) * 32 + 16 * P + 8 * hh;
+                const int off = (v0 + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                if constexpr (FULL) {
+                    const float* rs = rbase + (off & rmask);
+                    rv[2 * P] = *reinterpret_cast<const float4*>(rs);
+                    rv[2 * P + 1] = *reinterpret_cast<const float4*>(rs + 8);
+                    continue;
+                }
+                rv[2 * P] = make_float4(0.f, 0.f, 0.f, 0.f); rv[2 * P + 1] = rv[2 * P];
+                if (p.res && vok && co < p.Co) {
+                    rv[2 * P] = *reinterpret_cast<const float4*>(resb + off);            // 8 hi halves
+                    rv[2 * P + 1] = *reinterpret_cast<const float4*>(resb + off + 8);    // 8 lo halves
+                }
+            }
+        };
+        auto finish8T = [&](auto F, int i, const float4 (&rv)[4], const float4 (&sc8)[2][2], const float4 (&sh8)[2][2]) {
+            constexpr bool FULL = decltype(F)::value;
+            const int n = i % NT, m = i / NT;
+            int v0, coff, goff; bool vok;
+            rowT(F, m, v0, vok);
+            class_off(0, coff, goff);
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const int co = n0 + (wn * NT + n) * 32 + 16 * P + 8 * hh;
+                const bool cok = FULL || co < p.Co;
+                float a8[2][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {         // executed by all 64 lanes (no lane-dependent branch around it)
+                    // (__float_as_uint of a scalar copy: __builtin_bit_cast applied to the vector element itself makes this clang fold every
+                    // swap of the tile onto accumulator 0 -- tools/experiments note in DESIGN.md 3.2 r3)
+                    const float xf = acc[0][m][n][8 * P + e], yf = acc[0][m][n][8 * P + 4 + e];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
+                    a8[0][e] = __uint_as_float(sw[0]); a8[1][e] = __uint_as_float(sw[1]);
+                }
+                uint2 hq[2], lq[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (FULL || p.res) {
+                        const uint4 hb = __builtin_bit_cast(uint4, rv[2 * P]), lb = __builtin_bit_cast(uint4, rv[2 * P + 1]);
+                        r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
+                        r = mul4(r, s_res_inv);
+                        if constexpr (FULL) r = make_float4(has_res ? r.x : 0.f, has_res ? r.y : 0.f, has_res ? r.z : 0.f, has_res ? r.w : 0.f);
+                    }
+                    const float s4[4] = {sc8[P][h2].x, sc8[P][h2].y, sc8[P][h2].z, sc8[P][h2].w}, t4[4] = {sh8[P][h2].x, sh8[P][h2].y, sh8[P][h2].z, sh8[P][h2].w};
+                    const float r4[4] = {r.x, r.y, r.z, r.w};
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaf(a8[h2][e], s4[e], t4[e]) + r4[e];
+                        if constexpr (FULL) { o[e] = act_cheap(v); continue; }
+                        if (actk == OSA_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (actk == OSA_ACT_LEAKY) v = (v > 0.f) ? v : v * p.slope;
+                        else if (actk == OSA_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                        else if (actk == OSA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                        else if (actk == OSA_ACT_TANH) v = tanhf(v);
+                        o[e] = v;
+                    }
+                    if (vok && cok) am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+                    split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
+                }
+                if (FULL || (vok && cok && !(p.dbg & 32))) {
+                    float* ys = yb + (v0 + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                    *reinterpret_cast<uint4*>(ys) = make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y);
+                    *reinterpret_cast<uint4*>(ys + 8) = make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y);
+                }
+            }
+        };
+        float4 sc8[NT][2][2], sh8[NT][2][2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int P = 0; P < 2; ++P)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int co = n0 + (wn * NT + n) * 32 + 16 * P + 8 * hh + 4 * h2;
+                    sc8[n][P][h2] = make_float4(osc, osc, osc, osc); sh8[n][P][h2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (co + 3 < p.Co && p.scale) {
+                        sc8[n][P][h2] = *reinterpret_cast<const float4*>(p.scale + co); sh8[n][P][h2] = *reinterpret_cast<const float4*>(p.shift + co);
+                        sc8[n][P][h2].x *= osc; sc8[n][P][h2].y *= osc; sc8[n][P][h2].z *= osc; sc8[n][P][h2].w *= osc;
+                    }
+                }
+        auto run = [&](auto F) {
+#pragma unroll
+            for (int i = 0; i < PD; ++i) load_res8T(F, i, rvb[i]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                finish8T(F, i, rvb[i % PD], sc8[i % NT], sh8[i % NT]);
+                if (i + PD < NI) load_res8T(F, i + PD, rvb[i % PD]);
+                OSA_TRACE(21 + i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if constexpr (FASTC) { if (fast) run(std::true_type{}); else run(std::false_type{}); }
+        else run(std::false_type{});
+    }
+    if constexpr (!REDIR && OUTS && !XT) {
         float4 sc8[NT][2], sh8[NT][2];
 #pragma unroll
         for (int n = 0; n < NT; ++n) bn8(n, sc8[n], sh8[n]);
