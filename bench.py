@@ -53,7 +53,7 @@ KERNEL_NAMES = {
     ("conv", "f32"): "void osa::conv_mfma_kernel<0, 1, 1, 2, 1, 4, 1, 8, 8, 0, 0, 0, 1>(osa::ConvArgs)",
     "volume": "void osa::build_volume_quads_kernel<2, 8>(osa::VolQArgs)",
     "head": "osa::upsample4_softargmin_kernel(osa::UpArgs)",
-    "classifier": "void osa::conv_small_co_tiled_kernel<1, true>(osa::ConvArgs, float const*, float const*)",
+    "classifier": "osa::classifier_march_kernel(osa::ConvArgs, float const*, float const*, int, int)",
 }
 
 

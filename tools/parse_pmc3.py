@@ -12,7 +12,7 @@ KERNELS = {
     "conv3d_32_32_V0_f16x3": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
     "volume": "build_volume_quads_kernel<2, 8>",
     "head": "upsample4_softargmin_kernel",
-    "classifier": "conv_small_co_tiled_kernel<1, true>",
+    "classifier": "classifier_march_kernel",
     "deconv_64_32_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1, 0, 1>",
     "deconv_128_64_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 2, 1, 0, 1>",
     "conv_s2_32_64": "conv_mfma_kernel<1, 1, 3, 1, 1, 2, 2, 4, 8, 0, 1, 0, 1>",
