@@ -10,7 +10,7 @@ out_dir = sys.argv[1]
 BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 KERNELS = {
     "conv3d_32_32_V0_f16x3": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
-    "volume": "build_volume_quads_kernel<2, 8>",
+    "volume": "build_volume_quads_kernel<2, 8",
     "head": "upsample4_softargmin_kernel",
     "classifier": "classifier_march_kernel",
     "deconv_64_32_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1, 0, 1>",
