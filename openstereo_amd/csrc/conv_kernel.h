@@ -821,13 +821,13 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             }
             if constexpr (FULL) {
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-                *reinterpret_cast<float4*>(yb + (v0[k] + coff) * p.yCs + co) = make_float4(o[0], o[1], o[2], o[3]);
+                store16(yb + (v0[k] + coff) * p.yCs + co, make_float4(o[0], o[1], o[2], o[3]));
                 continue;
             }
             if (vok[k] && cok && !(p.dbg & 32)) {             // dbg 32: no stores (timing only)
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                 float* yp = yb + (v0[k] + coff) * p.yCs + co;
-                if (vec4) *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                if (vec4) store16(yp, make_float4(o[0], o[1], o[2], o[3]));
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -924,8 +924,8 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             }
             if (FULL || (vok[k] && cok && !(p.dbg & 32))) {
                 float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
-                *reinterpret_cast<uint4*>(ys) = make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y);
-                *reinterpret_cast<uint4*>(ys + 8) = make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y);
+                store16(ys, make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y));
+                store16(ys + 8, make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y));
             }
         }
     };
@@ -1152,8 +1152,8 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 }
                 if (FULL || (vok && cok && !(p.dbg & 32))) {
                     float* ys = yb + (v0 + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
-                    *reinterpret_cast<uint4*>(ys) = make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y);
-                    *reinterpret_cast<uint4*>(ys + 8) = make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y);
+                    store16(ys, make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y));
+                    store16(ys + 8, make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y));
                 }
             }
         };

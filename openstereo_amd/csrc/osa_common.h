@@ -78,6 +78,31 @@ __device__ __forceinline__ void publish_amax(float* meta, float am, unsigned see
 // MI355X: 8 XCDs, each with a private L2; workgroup b is observed on XCD b % 8.
 // Remap so that every XCD walks a contiguous run of tile ids (neighbouring tiles
 // share halos -> L2 hits).  Bijective for any grid size.
+// 16-byte activation stores of the big producers (conv epilogues, volume builder).  -DOSA_NT_STORE=1 issues them with the non-temporal
+// hint (streaming outputs of 0.2-3.2 GB per launch that the next launch reads long after L2 / Infinity Cache have turned over): an r3
+// A/B experiment (tools/build_variant.sh ntstore -DOSA_NT_STORE=1), see DESIGN.md 3.2.
+#ifndef OSA_NT_STORE
+#define OSA_NT_STORE 0
+#endif
+typedef float osa_f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned osa_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(float* dst, const float4& v) {
+#if OSA_NT_STORE
+    osa_f32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<osa_f32x4_t*>(dst));
+#else
+    *reinterpret_cast<float4*>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void store16(float* dst, const uint4& v) {
+#if OSA_NT_STORE
+    osa_u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<osa_u32x4_t*>(dst));
+#else
+    *reinterpret_cast<uint4*>(dst) = v;
+#endif
+}
+
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     const unsigned q = nblk >> 3, r = nblk & 7u;
     const unsigned xcd = bid & 7u, idx = bid >> 3;

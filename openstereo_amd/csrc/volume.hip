@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
         }
         if (wp < p.W && (!(q.dbg & 1) || o.x == 12345.678f)) {
             const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + wp;
-            *reinterpret_cast<float4*>(vout + vox * p.VC) = o;
+            store16(vout + vox * p.VC, o);
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
     };
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
         }
         if (wlive && (!(q.dbg & 1) || o.x == 12345.678f)) {
             const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
-            *reinterpret_cast<float4*>(vout + vox * p.VC) = o;
+            store16(vout + vox * p.VC, o);
             am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
         }
     }
