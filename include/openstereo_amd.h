@@ -433,6 +433,11 @@ int osa_upsample_softargmin_bwd_ws_f32(const float* cost_lowres, const float* do
                                        int B, int Dl, int Hl, int Wl, int D, int H, int W,
                                        int align_corners, void* workspace, size_t workspace_bytes, void* stream);
 
+/* max |x| over n contiguous floats (16-byte aligned) folded into the range block `meta` (osa_f16x3_ranges layout: 8 slots, atomic max) --
+ * the device-side operand range of a tensor that reaches an f16x3 layer from outside the engine (what torch.linalg.vector_norm(x, inf)
+ * computed before r3; no reference counterpart: the reference has no split-precision arithmetic). */
+int osa_amax_f32(const float* x, long long n, float* meta, void* stream);
+
 /* ---- disparity refinement ----------------------------- */
 /* convex 3x3 up-sampling: out[b,y,x] = sum_k W[b,k,y,x] * (gain*disp_low)[b, y/scale + k/3-1, x/scale + k%3-1]
  * disp_low [B,1,h,w], weights [B,9,h*scale,w*scale], out [B,h*scale,w*scale].

@@ -96,6 +96,7 @@ SIGNATURES = {
     "osa_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_bwd_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_amax_f32": (c_i, [c_fp, C.c_longlong, c_fp, c_st]),
     "osa_upsample_softargmin_bwd_workspace_bytes": (C.c_size_t, [c_i] * 4),
     "osa_upsample_softargmin_bwd_ws_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, C.c_size_t, c_st]),
     "osa_deconv3d_redir_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,

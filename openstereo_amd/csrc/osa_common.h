@@ -75,9 +75,6 @@ __device__ __forceinline__ void publish_amax(float* meta, float am, unsigned see
     }
 }
 
-// MI355X: 8 XCDs, each with a private L2; workgroup b is observed on XCD b % 8.
-// Remap so that every XCD walks a contiguous run of tile ids (neighbouring tiles
-// share halos -> L2 hits).  Bijective for any grid size.
 // 16-byte activation stores of the big producers (conv epilogues, volume builder).  -DOSA_NT_STORE=1 issues them with the non-temporal
 // hint (streaming outputs of 0.2-3.2 GB per launch that the next launch reads long after L2 / Infinity Cache have turned over): an r3
 // A/B experiment (tools/build_variant.sh ntstore -DOSA_NT_STORE=1), see DESIGN.md 3.2.
@@ -103,6 +100,9 @@ __device__ __forceinline__ void store16(float* dst, const uint4& v) {
 #endif
 }
 
+// MI355X: 8 XCDs, each with a private L2; workgroup b is observed on XCD b % 8.
+// Remap so that every XCD walks a contiguous run of tile ids (neighbouring tiles
+// share halos -> L2 hits).  Bijective for any grid size.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     const unsigned q = nblk >> 3, r = nblk & 7u;
     const unsigned xcd = bid & 7u, idx = bid >> 3;

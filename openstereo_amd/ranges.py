@@ -3,6 +3,8 @@
 Layout and arithmetic are documented with `osa_f16x3_ranges` in include/openstereo_amd.h."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 # ----------------------------------------------------------------------------- f16x3 operand ranges
@@ -37,9 +39,40 @@ def new_meta(device, stream=None) -> torch.Tensor:
     return a[0][i * META_FLOATS:(i + 1) * META_FLOATS]
 
 
-def _amax_into(slot0, t):
-    """max |t| -> the 0-dim view `slot0` with ONE reduction kernel (no abs() temporary, no copy): the infinity norm."""
-    torch.linalg.vector_norm(t.detach(), float("inf"), dtype=torch.float32 if t.dtype != torch.float32 else None, out=slot0)   # all dims, no reshape (no copy of strided tensors)
+# osa_amax_f32 (csrc/layout.hip) is exact and ~1.7x faster than torch's infinity norm, also inside replayed hipGraphs in isolation
+# (tools/diag_amax_graph.py) -- but with it on FORWARD tensors the captured GwcNet training step replays NaN from its second replay on
+# (eager steps, StereoBase's captured step and backward-only use are fine; running torch's reduction next to it cures it; cause not found:
+# tools/diag_train_nan.py, profiles/round3/diag/amax_kernel_training_graph.txt).  So the default stays torch's reduction;
+# OSA_ENGINE_AMAX=1 (or ranges.ENGINE_AMAX = True) selects the kernel.
+ENGINE_AMAX = bool(os.environ.get("OSA_ENGINE_AMAX"))
+
+
+def _dense(t) -> bool:
+    """storage of `t` is exactly numel() elements from data_ptr() (any permutation of a contiguous layout)"""
+    if t.is_contiguous():
+        return True
+    try:
+        from torch._prims_common import is_non_overlapping_and_dense
+        return bool(is_non_overlapping_and_dense(t))
+    except Exception:
+        return False
+
+
+def _amax_into(m, t):
+    """max |t| into the (fresh) range block `m` by ONE reduction, no temporaries: torch's infinity norm, or -- ENGINE_AMAX -- the engine's
+    own kernel for dense fp32 CUDA tensors (float4 grid-stride loads, one atomic per workgroup, the block's 8 slots)."""
+    t = t.detach()
+    if ENGINE_AMAX:
+        mode = os.environ.get("OSA_AMAX_MODE", "")          # diagnostics: "fwd" / "bwd" = kernel only outside / inside autograd's backward
+        in_bwd = torch._C._current_graph_task_id() != -1
+        use = not ((mode == "fwd" and in_bwd) or (mode == "bwd" and not in_bwd))
+        if use and t.is_cuda and t.dtype == torch.float32 and t.numel() > 0 and (t.data_ptr() & 15) == 0 and _dense(t):
+            from . import _lib
+            if mode == "both":                                    # diagnostics: torch's reduction into a scratch block as well
+                torch.linalg.vector_norm(t, float("inf"), out=new_meta(t.device)[0])
+            _lib.call("osa_amax_f32", t.data_ptr(), t.numel(), m.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            return
+    torch.linalg.vector_norm(t, float("inf"), dtype=torch.float32 if t.dtype != torch.float32 else None, out=m[0])   # all dims, no reshape (no copy of strided tensors)
 
 
 def meta_of(t):
@@ -54,7 +87,7 @@ def input_meta(t) -> torch.Tensor:
     m = getattr(t, "_osa_meta", None)
     if m is None:
         m = new_meta(t.device)
-        _amax_into(m[0], t)
+        _amax_into(m, t)
     return m
 
 
@@ -64,7 +97,7 @@ def ensure_meta(t) -> torch.Tensor:
     m = getattr(t, "_osa_meta", None)
     if m is None:
         m = new_meta(t.device)
-        _amax_into(m[0], t)
+        _amax_into(m, t)
         t._osa_meta = m
     return m
 

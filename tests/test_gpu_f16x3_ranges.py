@@ -146,6 +146,30 @@ def test_gwcnet_f16x3_image_scale_sweep(scale):
     assert epe < 1e-3, f"EPE {epe} at image scale {scale:g}"
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 4, 9, 11), (2, 3, 5, 7), (1, 7), (3, 64, 33, 65)])
+def test_input_meta_of_outside_tensors_is_the_exact_maximum(shape):
+    """Operands that reach an f16x3 layer from torch ops get their range from torch's infinity norm or -- ranges.ENGINE_AMAX -- from
+    osa_amax_f32 (dense fp32, 16-byte aligned: contiguous, channels-last, permuted; anything else falls back): the exact max |x| either way."""
+    from openstereo_amd import ranges
+    from openstereo_amd.ranges import amax_of, input_meta
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(*shape, generator=g) * 3).to(DEV)
+    variants = [x, x.to(torch.float16), x[..., 1:], x.flatten()[1:]]
+    if x.dim() == 4:
+        variants += [x.contiguous(memory_format=torch.channels_last), x.permute(0, 2, 3, 1)]
+    if x.dim() == 5:
+        variants += [x.contiguous(memory_format=torch.channels_last_3d)]
+    old = ranges.ENGINE_AMAX
+    try:
+        for use_kernel in (False, True):
+            ranges.ENGINE_AMAX = use_kernel
+            for v in variants:
+                got = float(amax_of(input_meta(v)))
+                assert got == float(v.float().abs().max()), (use_kernel, tuple(v.shape), v.stride(), v.dtype)
+    finally:
+        ranges.ENGINE_AMAX = old
+
+
 def test_range_block_tracks_max_and_graph_replay_is_reproducible():
     """The producing kernel folds max |y| into the output's range block; a captured graph re-zeroes its own blocks,
     so replays are bit-identical to the eager result even when an earlier replay saw larger values."""
