@@ -45,6 +45,7 @@ def new_meta(device, stream=None) -> torch.Tensor:
 # tools/diag_train_nan.py, profiles/round3/diag/amax_kernel_training_graph.txt).  So the default stays torch's reduction;
 # OSA_ENGINE_AMAX=1 (or ranges.ENGINE_AMAX = True) selects the kernel.
 ENGINE_AMAX = bool(os.environ.get("OSA_ENGINE_AMAX"))
+DIAG = {"count": 0, "lo": 0, "hi": 1 << 30, "log": None}
 
 
 def _dense(t) -> bool:
@@ -66,6 +67,13 @@ def _amax_into(m, t):
         mode = os.environ.get("OSA_AMAX_MODE", "")          # diagnostics: "fwd" / "bwd" = kernel only outside / inside autograd's backward
         in_bwd = torch._C._current_graph_task_id() != -1
         use = not ((mode == "fwd" and in_bwd) or (mode == "bwd" and not in_bwd))
+        if mode == "idx":                                     # diagnostics (tools/diag_train_nan2.py): kernel for forward calls [lo, hi) of a step only
+            use = False
+            if not in_bwd:
+                i = DIAG["count"]; DIAG["count"] = i + 1
+                use = DIAG["lo"] <= i < DIAG["hi"]
+                if DIAG["log"] is not None:
+                    DIAG["log"].append((i, tuple(t.shape), t.stride(), t.data_ptr() % 4096))
         if use and t.is_cuda and t.dtype == torch.float32 and t.numel() > 0 and (t.data_ptr() & 15) == 0 and _dense(t):
             from . import _lib
             if mode == "both":                                    # diagnostics: torch's reduction into a scratch block as well
