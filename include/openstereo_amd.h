@@ -373,6 +373,21 @@ int osa_conv3d_wgrad_ws_f32(const float* x, const float* dy, float* dw,
                             int kd, int kh, int kw, int stride,
                             int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
                             int transposed, float* workspace, size_t workspace_bytes, void* stream);
+/* Split-precision (f16x3) weight gradient (r3): the same gradient on v_mfma_f32_32x32x16_f16 -- 16 positions per instruction, operands
+ * split into fp16 hi + lo and pre-scaled by powers of two from the tensors' range blocks (x_meta, dy_meta: osa_f16x3_ranges layout,
+ * max |.| in the 8 slots), fp32 accumulation, same two-stage deterministic reduction.  Covers unit-stride, unit-dilation Conv3d / Conv2d
+ * layers with kh, kw <= 3 (3x3 planes, or kd == 1); the workspace query returns 0 for anything else (use osa_conv3d_wgrad_ws_f32). */
+size_t osa_conv3d_wgrad_f16x3_workspace_bytes(int B, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co,
+                                              int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w,
+                                              int dil_d, int dil_h, int dil_w, int transposed);
+int osa_conv3d_wgrad_ws_f16x3(const float* x, const float* dy, float* dw,
+                              int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                              int Do, int Ho, int Wo, int Co, int dyCs,
+                              int kd, int kh, int kw, int stride,
+                              int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                              int transposed, const float* x_meta, const float* dy_meta,
+                              float* workspace, size_t workspace_bytes, void* stream);
+
 
 /* small-Cout 'same' convolution (Co <= 4, e.g. the 32->1 classifier heads). Reference weight
  * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer).

@@ -246,15 +246,15 @@ def _pack_now(w, Ci, Co, k, mode, precision):
     return buf, (sc if f16 else 1.0)
 
 
-def _ranges(x, y, wscale):
+def _ranges(x, y, wscale, xmeta=None):
     """f16x3 operand ranges of a plain conv call: x (activations or incoming gradients -- whose magnitudes are
     routinely 1e-5 .. 1e-8) is scaled by a power of two derived from its measured max |.| on the device, so the
     hi/lo fp16 halves keep 22 significant bits whatever the magnitude; exact to undo.  wscale: the packed weights' device-side
     {scale, 1 / scale} pair (_pack_now)."""
-    return _lib.F16x3Ranges(input_meta(x).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None, wscale.data_ptr())
+    return _lib.F16x3Ranges((xmeta if xmeta is not None else input_meta(x)).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None, wscale.data_ptr())
 
 
-def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape):
+def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape, xmeta=None):
     """x NDHWC (channels padded to 4). plain conv, no epilogue extras."""
     B, Cs, D, H, W = x.shape
     CoS = (Co + 3) // 4 * 4
@@ -262,7 +262,7 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (1.0, _ranges(x, y, oscale), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = ("f16x3", (1.0, _ranges(x, y, oscale, xmeta), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
     macs = B * out_shape[0] * out_shape[1] * out_shape[2] * Ci * Co * k[0] * k[1] * k[2]
     with timing.span("conv3d", Ci, Co, k[1], stride, D, H, W, flops=2 * macs,
                      nbytes=4 * B * (D * H * W * Ci + out_shape[0] * out_shape[1] * out_shape[2] * Co)):
@@ -292,17 +292,33 @@ def _out(n, k, p, d, s):
     return (n + 2 * p - d * (k - 1) - 1) // s + 1
 
 
-def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed):
-    """Weight gradient, two-stage form (osa_conv3d_wgrad_ws_f32): partial tiles in a scratch tensor from the caching allocator, summed
-    in a fixed order -- deterministic, and free of the contended float atomics of the one-stage form."""
+WGRAD_F16X3 = True      # f16x3 mode: weight gradients of the layers osa_conv3d_wgrad_ws_f16x3 covers on the split-precision kernel (False: always exact fp32)
+
+
+def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed, precision="f32", xmeta=None, dymeta=None):
+    """Weight gradient, two-stage form: partial tiles in a scratch tensor from the caching allocator, summed in a fixed order --
+    deterministic, and free of the contended float atomics of the one-stage form.  precision "f16x3": the split-precision kernel where it
+    applies (unit stride / dilation, 3x3 planes: osa_conv3d_wgrad_ws_f16x3, operand ranges from the tensors' range blocks), the exact
+    fp32 kernel (osa_conv3d_wgrad_ws_f32) everywhere else."""
     dims = (B, D, H, W, Ci, Do, Ho, Wo, Co, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed)
-    need = _lib.load().osa_conv3d_wgrad_workspace_bytes(*dims)
+    lib = _lib.load()
+    vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
+    span = dict(flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2], nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co))
+    if precision == "f16x3" and WGRAD_F16X3:
+        need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
+        if need:
+            ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
+            mx = xmeta if xmeta is not None else input_meta(xc)
+            with timing.span("wgrad_f16x3", Ci, Co, k[1], stride, D, H, W, transposed, **span):
+                _lib.call("osa_conv3d_wgrad_ws_f16x3", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
+                          Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                          mx.data_ptr(), (dymeta if dymeta is not None else input_meta(dyc)).data_ptr(), ws.data_ptr(), need, _stream())
+            return
+    need = lib.osa_conv3d_wgrad_workspace_bytes(*dims)
     if need == 0:
         raise _lib.EngineError("osa_conv3d_wgrad_workspace_bytes: unsupported layer " + str(dims))
     ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
-    vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
-    with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2],
-                     nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co)):
+    with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
         _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
                   Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
                   ws.data_ptr(), need, _stream())
@@ -322,8 +338,11 @@ class _Conv3d(torch.autograd.Function):
         B, _, D, H, W = xc.shape
         sd = 1 if (D == 1 and k[0] == 1) else stride
         oshape = (_out(D, k[0], pad[0], dil[0], sd), _out(H, k[1], pad[1], dil[1], stride), _out(W, k[2], pad[2], dil[2], stride))
-        y = _run_conv(xc, packed, osc, Ci, Co, k, stride, pad, dil, precision, oshape)
+        # one max |x| reduction serves the forward conv and (ctx.xmeta) the f16x3 weight gradient; kept on ctx, not on the tensor object
+        xmeta = input_meta(xc) if precision == "f16x3" else None
+        y = _run_conv(xc, packed, osc, Ci, Co, k, stride, pad, dil, precision, oshape, xmeta)
         ctx.save_for_backward(xc, wf)
+        ctx.xmeta = xmeta
         ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
         ctx.cache = cache
         return y[:, :Co]
@@ -336,13 +355,14 @@ class _Conv3d(torch.autograd.Function):
         Co, Ci = wf.shape[:2]
         k = tuple(wf.shape[2:])
         dyc = to_cl(dy)
+        dymeta = input_meta(dyc) if precision == "f16x3" else None       # shared by the data gradient and the weight gradient
         B, _, D, H, W = xc.shape
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if stride == 1:
                 packed, osc = _pack(wf, Co, Ci, k, "dgrad_s1", precision, ctx.cache)
                 p2 = tuple(dil[i] * (k[i] - 1) - pad[i] for i in range(3))
-                dxc = _run_conv(dyc, packed, osc, Co, Ci, k, 1, p2, dil, precision, (D, H, W))
+                dxc = _run_conv(dyc, packed, osc, Co, Ci, k, 1, p2, dil, precision, (D, H, W), dymeta)
             else:
                 assert k == (3, 3, 3) and pad == (1, 1, 1) and dil == (1, 1, 1) and D % 2 == 0 and H % 2 == 0 and W % 2 == 0, \
                     "stride-2 data gradient: 3x3x3, pad 1, even input dims (what the aggregation networks use)"
@@ -352,7 +372,7 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
-            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0)
+            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, ctx.xmeta, dymeta)
         return dx, dw, None, None, None, None, None
 
 

@@ -47,6 +47,7 @@ struct WgradArgs {
     int cls;
     signed char tapid[64];
     signed char g_t0[8], g_nt[8], g_par[8];   // first tap / tap count / parity bits (pd<<2 | ph<<1 | pw) of every class
+    const float* Pmeta; const float* Qmeta;   // f16x3 form: range blocks (max |.|) of the P and Q tensors
 };
 
 template <int TD, int TH, int TW>     // position brick, TD*TH*TW = 256 (64 per wave) or 64 (16 per wave)
@@ -179,6 +180,206 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+
+// ---- split-precision (f16x3) form --------------------------------------------------------------------------------------------------
+// dW = sum_pos P[pos][a] Q[pos + off][b] on v_mfma_f32_32x32x16_f16: K = 16 POSITIONS per instruction (8x the fp32 instruction's 2, at
+// half its cycles), three instructions per product (P_hi Q_lo + P_lo Q_hi + P_hi Q_hi, fp32 accumulate), operands pre-scaled by
+// powers of two from their tensors' range blocks.  An MFMA operand lane holds 8 consecutive K values of ONE channel, so the LDS images are
+// channel-major with the position axis contiguous -- [channel][row][w] in fp16 hi and lo planes -- and a K half-block is one w-row of 8
+// positions.  Staging transposes: a thread takes (two w-neighbours, four channels), converts, and writes 32-bit hi / lo pairs.
+// A tap's Q operand is the same row shifted by dh rows and dw = 0..2 halves; rows are padded to 16-byte multiples, one ds_read_b128 +
+// one ds_read_b32 per row and plane serve all three dw (dw = 0: as read, dw = 1: v_alignbit by 16, dw = 2: the next dwords).
+// Unit stride, unit dilation, tap groups = one kd plane (<= 9 taps); 128-position bricks (2x8x8, flat 1x8x16): 59 / 49 KB of LDS, 2 / 3
+// workgroups per CU.  Same accumulator layout, workspace records and reduce kernel as the fp32 form.
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float wg_pow2_scale(float amax) {              // = pow2_scale of conv_kernel.h: amax * s in [2^14, 2^15)
+    const unsigned b = __builtin_bit_cast(unsigned, amax);
+    const int eb = (int)((b >> 23) & 0xffu);
+    if (eb == 0 || eb == 255) return 1.f;
+    int k = 15 - (eb - 126);
+    k = k < -60 ? -60 : (k > 60 ? 60 : k);
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+// two scaled values -> packed fp16 hi pair (round toward zero) and lo pair (x - hi, rounded to nearest); low half = first value
+__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const wf16x2 h = __builtin_bit_cast(wf16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const wf16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int TD, int TH, int TW>     // 128 positions: 2x8x8 or (flat) 1x8x16
+__global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
+    static_assert(TD * TH * TW == 128 && (TW == 8 || TW == 16), "128-position bricks");
+    constexpr int ROWH = (TW == 8) ? 16 : 24;        // halves per Q row in LDS (LW <= TW + 2, padded to a 16-byte multiple)
+    constexpr int LHM = TH + 2;                      // Q rows per plane in LDS (host: at most 2 halo rows)
+    constexpr int CHS_P = 136;                       // halves per channel (128 positions + 8: 16-byte rows of consecutive channels on distinct slots)
+    constexpr int CHS_Q = TD * LHM * ROWH + 8;       // 328 / 248
+    static_assert((CHS_P / 8) % 2 == 1 && (CHS_Q / 8) % 2 == 1, "odd number of 16-byte slots per channel");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* const Ph = smem_h;               // [32][CHS_P] hi halves of the P tile
+    unsigned short* const Pl = Ph + 32 * CHS_P;
+    unsigned short* const Qh = Pl + 32 * CHS_P;      // [32][CHS_Q] hi halves of the Q brick
+    unsigned short* const Ql = Qh + 32 * CHS_Q;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, hh = lane >> 5;
+    const int tg = blockIdx.x % p.tgroups;
+    int sidx = blockIdx.x / p.tgroups;
+    const int atiles = (p.A + 31) / 32;
+    const int a0 = (blockIdx.y % atiles) * 32, b0 = (blockIdx.y / atiles) * 32;
+    const int khw = p.kh * p.kw;
+    const int t0 = tg * khw;                         // tap group = the taps of one kd plane (host: kh * kw == 9, or a single group)
+    const int od = p.od[t0];
+    const int nstripsW = (p.tilesW + p.strip - 1) / p.strip;
+    const int sw = sidx % nstripsW; sidx /= nstripsW;
+    const int thi = sidx % p.tilesH; sidx /= p.tilesH;
+    const int tdi = sidx % p.tilesD; const int b = sidx / p.tilesD;
+    const float sP = wg_pow2_scale(amax_read(p.Pmeta)), sQ = wg_pow2_scale(amax_read(p.Qmeta));
+    const float inv = (1.0f / sP) * (1.0f / sQ);
+
+    f32x16 acc[WG_TAPS];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int npq = (p.LW + 1) >> 1;                 // voxel pairs per Q row
+    const int nQ = TD * p.LH * npq * 8;              // staging items of the Q brick: (row, pair, channel quad)
+    for (int twi = sw * p.strip; twi < (sw + 1) * p.strip && twi < p.tilesW; ++twi) {
+        const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
+        __syncthreads();
+        // ---- stage the P tile: 64 position pairs x 8 channel quads
+        for (int it = tid; it < 64 * 8; it += 256) {
+            const int c4 = it & 7, q0 = (it >> 3) * 2;
+            const int pw = q0 % TW, ph = (q0 / TW) % TH, pd = q0 / (TW * TH);
+            const int gd = p0d + pd, gh = p0h + ph, gw = p0w + pw;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (gd < p.Pd && gh < p.Ph) {
+                const float* src = p.P + ((((size_t)b * p.Pd + gd) * p.Ph + gh) * p.Pw + gw) * p.PCs + a0 + c4 * 4;
+                const int nc = p.PC - (a0 + c4 * 4);                 // channels left from this quad's first
+                if (gw < p.Pw) {
+                    if (nc >= 4) v0 = *reinterpret_cast<const float4*>(src);
+                    else { if (nc > 0) v0.x = src[0]; if (nc > 1) v0.y = src[1]; if (nc > 2) v0.z = src[2]; }
+                }
+                if (gw + 1 < p.Pw) {
+                    const float* s1 = src + p.PCs;
+                    if (nc >= 4) v1 = *reinterpret_cast<const float4*>(s1);
+                    else { if (nc > 0) v1.x = s1[0]; if (nc > 1) v1.y = s1[1]; if (nc > 2) v1.z = s1[2]; }
+                }
+            }
+            const float x0[4] = {v0.x, v0.y, v0.z, v0.w}, x1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned h, l;
+                wg_split2(x0[j] * sP, x1[j] * sP, h, l);
+                *reinterpret_cast<unsigned*>(Ph + (c4 * 4 + j) * CHS_P + q0) = h;
+                *reinterpret_cast<unsigned*>(Pl + (c4 * 4 + j) * CHS_P + q0) = l;
+            }
+        }
+        // ---- stage the Q brick of this tap group's d offset: TD planes x LH rows x LW voxels (pairs)
+        const int q0d = p0d + od, q0h = p0h + p.hmin, q0w = p0w + p.wmin;
+        for (int it = tid; it < nQ; it += 256) {
+            const int c4 = it & 7; int r = it >> 3;
+            const int pr = r % npq; r /= npq;
+            const int lh = r % p.LH, ld = r / p.LH;
+            const int lw = pr * 2;
+            const int gd = q0d + ld, gh = q0h + lh, gw = q0w + lw;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if ((unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh) {
+                const float* src = p.Q + ((((size_t)b * p.Qd + gd) * p.Qh + gh) * p.Qw + gw) * p.QCs + b0 + c4 * 4;
+                const int nc = p.QC - (b0 + c4 * 4);
+                if ((unsigned)gw < (unsigned)p.Qw) {
+                    if (nc >= 4) v0 = *reinterpret_cast<const float4*>(src);
+                    else { if (nc > 0) v0.x = src[0]; if (nc > 1) v0.y = src[1]; if (nc > 2) v0.z = src[2]; }
+                }
+                if ((unsigned)(gw + 1) < (unsigned)p.Qw) {
+                    const float* s1 = src + p.QCs;
+                    if (nc >= 4) v1 = *reinterpret_cast<const float4*>(s1);
+                    else { if (nc > 0) v1.x = s1[0]; if (nc > 1) v1.y = s1[1]; if (nc > 2) v1.z = s1[2]; }
+                }
+            }
+            const float x0[4] = {v0.x, v0.y, v0.z, v0.w}, x1[4] = {v1.x, v1.y, v1.z, v1.w};
+            const int off = (ld * LHM + lh) * ROWH + lw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned h, l;
+                wg_split2(x0[j] * sQ, x1[j] * sQ, h, l);
+                *reinterpret_cast<unsigned*>(Qh + (c4 * 4 + j) * CHS_Q + off) = h;
+                *reinterpret_cast<unsigned*>(Ql + (c4 * 4 + j) * CHS_Q + off) = l;
+            }
+        }
+        __syncthreads();
+        // ---- this wave's two K blocks of 16 positions: half-block hb = 8 consecutive w positions of one row
+        uint4 ah[2], al[2];
+        int qoff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hb = (wave * 2 + i) * 2 + hh;
+            ah[i] = *reinterpret_cast<const uint4*>(Ph + col * CHS_P + hb * 8);
+            al[i] = *reinterpret_cast<const uint4*>(Pl + col * CHS_P + hb * 8);
+            // Q row of the same positions at dh = 0: TW = 8: hb = pd * TH + ph; TW = 16: hb = 2 * ph + (w half)
+            const int prow = (TW == 8) ? hb : (hb >> 1);
+            const int pd = prow / TH, ph = prow % TH;
+            qoff[i] = col * CHS_Q + (pd * LHM + ph) * ROWH + ((TW == 16) ? (hb & 1) * 8 : 0);
+        }
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            if (dh < p.kh) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned short* qh = Qh + qoff[i] + dh * ROWH;
+                    const unsigned short* ql = Ql + qoff[i] + dh * ROWH;
+                    const uint4 vh = *reinterpret_cast<const uint4*>(qh), vl = *reinterpret_cast<const uint4*>(ql);
+                    const unsigned eh = *reinterpret_cast<const unsigned*>(qh + 8), el = *reinterpret_cast<const unsigned*>(ql + 8);
+                    const wf16x8 pa_h = __builtin_bit_cast(wf16x8, ah[i]), pa_l = __builtin_bit_cast(wf16x8, al[i]);
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        if (dw < p.kw) {
+                            uint4 bh, bl;
+                            if (dw == 0) { bh = vh; bl = vl; }
+                            else if (dw == 1) {
+                                bh = make_uint4(__builtin_amdgcn_alignbit(vh.y, vh.x, 16), __builtin_amdgcn_alignbit(vh.z, vh.y, 16),
+                                                __builtin_amdgcn_alignbit(vh.w, vh.z, 16), __builtin_amdgcn_alignbit(eh, vh.w, 16));
+                                bl = make_uint4(__builtin_amdgcn_alignbit(vl.y, vl.x, 16), __builtin_amdgcn_alignbit(vl.z, vl.y, 16),
+                                                __builtin_amdgcn_alignbit(vl.w, vl.z, 16), __builtin_amdgcn_alignbit(el, vl.w, 16));
+                            } else { bh = make_uint4(vh.y, vh.z, vh.w, eh); bl = make_uint4(vl.y, vl.z, vl.w, el); }
+                            const wf16x8 qb_h = __builtin_bit_cast(wf16x8, bh), qb_l = __builtin_bit_cast(wf16x8, bl);
+                            f32x16& c = acc[dh * 3 + dw];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_l, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_l, qb_h, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_h, c, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- partial tiles to the workspace, tap j = dh * kw + dw of the group (records and reduce kernel of the fp32 form)
+    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WG_TAPS * 1024) + lane;
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_h);
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            if (dh < p.kh && dw < p.kw) {               // uniform over the workgroup
+                const int t = dh * 3 + dw, j = dh * p.kw + dw;
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[t][r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dst[(j * 16 + r) * 64] = (acc[t][r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane]) * inv;
+                }
+                __syncthreads();
+            }
+        }
+}
+
 // Second stage: dW[a][b][tap] = sum over the workgroups (position strips) of one (tile, tap group).  One thread per (tap, tile element).
 struct WgradReduceArgs {
     const float* ws; float* dW;
@@ -219,7 +420,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
                       int Do, int Ho, int Wo, int Co, int dyCs,
                       int kd, int kh, int kw, int stride,
                       int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
-                      int transposed, float* ws, size_t ws_bytes, size_t* query, void* stream) {
+                      int transposed, float* ws, size_t ws_bytes, size_t* query, void* stream,
+                      int f16x3 = 0, const float* x_meta = nullptr, const float* dy_meta = nullptr) {
     if (!query) OSA_REQUIRE(x && dy && dw, "conv3d_wgrad: NULL pointer");
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= 64, "conv3d_wgrad: %d taps unsupported", T);
@@ -286,6 +488,49 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         a.tgroups = 8;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (f16x3) {
+        // split-precision form (wgrad_f16x3_kernel): unit stride, unit dilation, one kd plane of <= 9 taps per workgroup.  Not eligible
+        // -> *query = 0 / error: the caller keeps the fp32 form.
+        const bool ok = !transposed && a.s == 1 && dil_d == 1 && dil_h == 1 && dil_w == 1 && kh <= 3 && kw <= 3 && (kh * kw == 9 || kd == 1);
+        if (query && !ok) { *query = 0; return 0; }
+        OSA_REQUIRE(ok, "conv3d_wgrad_f16x3: layer not eligible (unit stride / dilation, kh, kw <= 3, 3x3 planes or kd == 1)");
+        const bool flat16 = (a.Pd == 1 && kd == 1);
+        const int TD = flat16 ? 1 : 2, TH = 8, TW = flat16 ? 16 : 8;
+        a.LD = TD; a.LH = TH + (hmax - a.hmin); a.LW = TW + (wmax - a.wmin);
+        a.tgroups = (kh * kw == 9) ? kd : 1;
+        a.tilesD = cdiv(a.Pd, TD); a.tilesH = cdiv(a.Ph, TH); a.tilesW = cdiv(a.Pw, TW);
+        const int chs_q = TD * (TH + 2) * (flat16 ? 24 : 16) + 8;
+        const size_t lds = (size_t)(2 * 32 * 136 + 2 * 32 * chs_q) * sizeof(unsigned short);
+        const int gy = cdiv(a.A, 32) * cdiv(a.Bc, 32);
+        const long long rows = (long long)B * a.tilesD * a.tilesH * a.tgroups * gy;
+        const long long slots = 256ll * 2;
+        long long best = -1; int best_strip = a.tilesW;
+        for (int strip = a.tilesW; strip >= 1; --strip) {
+            const long long wgs = rows * cdiv(a.tilesW, strip);
+            const long long cost = (long long)cdiv(wgs, slots) * (strip + 1);
+            if (best < 0 || cost < best) { best = cost; best_strip = strip; }
+        }
+        a.strip = exp_int("OSA_WGRAD_STRIP", best_strip);
+        if (a.strip < 1 || a.strip > a.tilesW) a.strip = best_strip;
+        const long long gx = (long long)B * a.tilesD * a.tilesH * cdiv(a.tilesW, a.strip) * a.tgroups;
+        OSA_REQUIRE(gx < (1ll << 31) && gy <= 65535, "conv3d_wgrad_f16x3: grid too large");
+        const size_t need = (size_t)gx * gy * WG_TAPS * 1024 * sizeof(float);
+        if (query) { *query = need; return 0; }
+        OSA_REQUIRE(ws && ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad_f16x3: workspace of %zu B needed (got %zu)", need, ws_bytes);
+        OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
+        a.ws = ws; a.Pmeta = dy_meta; a.Qmeta = x_meta;          // conv: P = dy, Q = x
+        dim3 grid((unsigned)gx, gy), block(256);
+        if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8>), grid, block, lds, st, a);
+        OSA_LAUNCH_CHECK("conv3d_wgrad_f16x3");
+        WgradReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        r.ws = ws; r.dW = dw; r.gx = (int)gx; r.tgroups = a.tgroups; r.nstrips = (int)(gx / a.tgroups);
+        r.A = a.A; r.Bc = a.Bc; r.kvol = T; r.atiles = cdiv(a.A, 32); r.T = T; r.cls = 0;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_TAPS * 1024 / 256, a.tgroups, gy), dim3(256), 0, st, r);
+        OSA_LAUNCH_CHECK("conv3d_wgrad_f16x3_reduce");
+        return 0;
+    }
     const bool two_stage = query || ws;
     if (!two_stage) {
         hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.A * a.Bc * T * sizeof(float), st);
@@ -382,4 +627,27 @@ extern "C" int osa_conv3d_wgrad_ws_f32(const float* x, const float* dy, float* d
     OSA_REQUIRE(workspace, "conv3d_wgrad_ws: NULL workspace (osa_conv3d_wgrad_workspace_bytes gives its size)");
     return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
                       dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream);
+}
+
+/* split-precision (f16x3) weight gradient, two-stage form only.  workspace_bytes query returns 0 for layers the form does not cover
+ * (strided / dilated / transposed layers, kernels wider than 3): the caller then uses osa_conv3d_wgrad_ws_f32. */
+extern "C" size_t osa_conv3d_wgrad_f16x3_workspace_bytes(int B, int Di, int Hi, int Wi, int Ci, int Do, int Ho, int Wo, int Co,
+                                                         int kd, int kh, int kw, int stride, int pad_d, int pad_h, int pad_w,
+                                                         int dil_d, int dil_h, int dil_w, int transposed) {
+    size_t need = 0;
+    if (wgrad_impl(nullptr, nullptr, nullptr, B, Di, Hi, Wi, Ci, 4, Do, Ho, Wo, Co, 4, kd, kh, kw, stride, pad_d, pad_h, pad_w,
+                   dil_d, dil_h, dil_w, transposed, nullptr, 0, &need, nullptr, 1)) return 0;
+    return need;
+}
+
+extern "C" int osa_conv3d_wgrad_ws_f16x3(const float* x, const float* dy, float* dw,
+                                         int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                         int Do, int Ho, int Wo, int Co, int dyCs,
+                                         int kd, int kh, int kw, int stride,
+                                         int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                                         int transposed, const float* x_meta, const float* dy_meta,
+                                         float* workspace, size_t workspace_bytes, void* stream) {
+    OSA_REQUIRE(workspace, "conv3d_wgrad_ws_f16x3: NULL workspace (osa_conv3d_wgrad_f16x3_workspace_bytes gives its size)");
+    return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
+                      dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, 1, x_meta, dy_meta);
 }

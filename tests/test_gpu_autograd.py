@@ -100,6 +100,46 @@ def test_conv3d_backward_vs_torch_autograd(case, prec):
     close(we.grad, wr.grad, 2e-4, 1e-4, f"{name} dw [{prec}]")
 
 
+WGRAD_X3 = [  # name, Ci, Co, k (kd, kh, kw), pad, dims (D, H, W), batch
+    ("3d 32-32", 32, 32, (3, 3, 3), (1, 1, 1), (6, 9, 12), 2),
+    ("3d 64-40 ragged", 64, 40, (3, 3, 3), (1, 1, 1), (5, 17, 11), 1),
+    ("3d 1x1x1 48-32", 48, 32, (1, 1, 1), (0, 0, 0), (3, 9, 10), 2),
+    ("2d 3x3 384-128 (gru)", 384, 128, (1, 3, 3), (0, 1, 1), (1, 20, 46), 1),
+    ("2d 3x3 36-7 ragged", 36, 7, (1, 3, 3), (0, 1, 1), (1, 9, 33), 2),
+    ("2d 1x1 164-64", 164, 64, (1, 1, 1), (0, 0, 0), (1, 17, 31), 1),
+    ("2d 3x1 16-16", 16, 16, (1, 3, 1), (0, 1, 0), (1, 12, 20), 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_X3, ids=[c[0] for c in WGRAD_X3])
+def test_wgrad_f16x3_kernel_vs_fp32_kernel_and_torch(case):
+    """osa_conv3d_wgrad_ws_f16x3 (16 positions per MFMA, fp16 hi / lo operands from channel-major LDS images, tap shifts by funnel shift)
+    against the exact-fp32 weight-gradient kernel (<= 4e-6 of max |dW|: the f16x3 product error) and torch autograd; deterministic."""
+    from openstereo_amd import autograd as AG, _lib
+    name, Ci, Co, k, pad, (D, H, W), B = case
+    x = rn((B, Ci, D, H, W), 13).to(DEV) * 3.0
+    w = (synth_tensor(name + ".w", (Co, Ci) + k, 1) * 3.0).to(DEV)
+    gy = (rn((B, Co, D, H, W), 14) * 1e-3).to(DEV)            # gradient-sized magnitudes
+    need = _lib.load().osa_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, Ci, D, H, W, Co, *k, 1, *pad, 1, 1, 1, 0)
+    assert need > 0, "these layers are covered by the split-precision form"
+    res = {}
+    for tag, on in (("x3", True), ("x3 again", True), ("f32", False)):
+        old = AG.WGRAD_F16X3
+        AG.WGRAD_F16X3 = on
+        try:
+            we = w.clone().requires_grad_()
+            AG.conv3d(x, we, None, 1, pad, 1, precision="f16x3").backward(gy)
+            res[tag] = we.grad.clone()
+        finally:
+            AG.WGRAD_F16X3 = old
+    assert torch.equal(res["x3"], res["x3 again"])
+    scale = float(res["f32"].abs().max())
+    assert float((res["x3"] - res["f32"]).abs().max()) <= 4e-6 * scale, float((res["x3"] - res["f32"]).abs().max()) / scale
+    wr = w.clone().requires_grad_()
+    F.conv3d(x, wr, None, 1, pad, 1).backward(gy)
+    assert float((res["x3"] - wr.grad).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", [("k3 64-32", 64, 32, 3, 1, 1, (3, 5, 7)), ("k4 16-8", 16, 8, 4, 1, 0, (4, 5, 6))], ids=["k3", "k4"])
 def test_conv_transpose3d_backward_vs_torch_autograd(case, prec):
