@@ -485,20 +485,23 @@ def generic_rooflines(wl, args, eager_step, nrep):
     stats = engine.collect_timing(rec)
     per_step = {"/".join(map(str, k)): round(sum(v) / nrep, 4) for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1]))}
     peak, why = PEAKS[args.precision]
-    convs = {k: v for k, v in stats.items() if k in timing.work and k[0] in ("conv3d", "deconv3d", "wgrad")}
+    convs = {k: v for k, v in stats.items() if k in timing.work and k[0] in ("conv3d", "deconv3d", "wgrad", "wgrad_f16x3")}
     out = []
     for k, v in sorted(convs.items(), key=lambda kv: -sum(kv[1]))[:3]:
         ms = sum(v) / len(v)
         flops, nbytes = timing.work[k]
         tf, gbs = flops / ms / 1e9, nbytes / ms / 1e6
         kind, ci, co, kk, st, d, h, w = k[:8]
-        if kind == "wgrad":                                  # weight gradients are exact-fp32 MFMA in both modes (csrc/wgrad.hip)
+        if kind == "wgrad":                                  # exact-fp32 MFMA weight gradients (strided / transposed layers; every layer in f32 mode)
             peak, why = PEAKS["f32"]
+        elif kind == "wgrad_f16x3":                          # split-precision weight gradients (csrc/wgrad.hip, wgrad_f16x3_kernel)
+            peak, why = PEAKS["f16x3"]
         else:
             peak, why = PEAKS[args.precision]
         mfma_bound = flops / (peak * 1e12) >= nbytes / (HBM_PEAK * 1e9)              # which roofline the launch sits under
         rec_ = {"kernel": "osa::wgrad_kernel<...> + osa::wgrad_reduce_kernel (csrc/wgrad.hip)" if kind == "wgrad" else
-                          "osa::conv_mfma_kernel<...> (tile picked per layer, csrc/conv3d.hip pick_cfg)",
+                          ("osa::wgrad_f16x3_kernel<...> + osa::wgrad_reduce_kernel (csrc/wgrad.hip)" if kind == "wgrad_f16x3" else
+                           "osa::conv_mfma_kernel<...> (tile picked per layer, csrc/conv3d.hip pick_cfg)"),
                 "what": f"{kind} {ci}->{co} k{kk} stride {st} @ {d}x{h}x{w}, {len(v) // nrep} launches per step",
                 "bound": "mfma" if mfma_bound else "hbm", "avg_launch_ms": round(ms, 4), "traffic": None,
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 3), "algorithmic_mb_per_launch": round(nbytes / 1e6, 2)}

@@ -246,70 +246,94 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
 
     const int npq = (p.LW + 1) >> 1;                 // voxel pairs per Q row
     const int nQ = TD * p.LH * npq * 8;              // staging items of the Q brick: (row, pair, channel quad)
-    for (int twi = sw * p.strip; twi < (sw + 1) * p.strip && twi < p.tilesW; ++twi) {
+    // Staging items of this thread (the same for every brick): P: 64 position pairs x 8 channel quads = 2 per thread; Q: (row, voxel
+    // pair, channel quad), up to QIT per thread.  All global loads of a brick are issued back to back into registers (a loop of
+    // load -> convert -> ds_write per item costs one HBM / L2 round trip PER ITEM: measured 11.5 us per brick), and the NEXT brick's loads
+    // are issued before the MFMA phase of the current one, so their latency hides behind it.
+    constexpr int PIT = 2, QIT = (TD * LHM * ((TW + 3) / 2) * 8 + 255) / 256;
+    int p_src[PIT], p_dst[PIT], q_src[QIT], q_dst[QIT];          // element offsets inside the batch item (relative to the brick origin) / LDS halves
+    unsigned p_ok[PIT], q_ok[QIT];                                // bit 0: item exists; the coordinates are re-checked per brick
+    int p_d[PIT], p_h[PIT], p_w[PIT], q_d[QIT], q_h[QIT], q_w[QIT];
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) {
+        const int it = tid + 256 * k;
+        const int c4 = it & 7, q0 = (it >> 3) * 2;
+        p_w[k] = q0 % TW; p_h[k] = (q0 / TW) % TH; p_d[k] = q0 / (TW * TH);
+        p_src[k] = c4 * 4; p_dst[k] = (c4 * 4) * CHS_P + q0; p_ok[k] = 1u;
+    }
+#pragma unroll
+    for (int k = 0; k < QIT; ++k) {
+        const int it = tid + 256 * k;
+        const int c4 = it & 7; int r = it >> 3;
+        const int pr = r % npq; r /= npq;
+        q_h[k] = r % p.LH; q_d[k] = r / p.LH; q_w[k] = pr * 2;
+        q_src[k] = c4 * 4; q_dst[k] = (c4 * 4) * CHS_Q + (q_d[k] * LHM + q_h[k]) * ROWH + q_w[k];
+        q_ok[k] = (it < nQ) ? 1u : 0u;
+    }
+    float4 pv[PIT][2], qv[QIT][2];
+    auto load4 = [&](const float* src, int nc, bool ok) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
+            else { if (nc > 0) v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
+        }
+        return v;
+    };
+    auto issue_loads = [&](int twi) {
         const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
-        __syncthreads();
-        // ---- stage the P tile: 64 position pairs x 8 channel quads
-        for (int it = tid; it < 64 * 8; it += 256) {
-            const int c4 = it & 7, q0 = (it >> 3) * 2;
-            const int pw = q0 % TW, ph = (q0 / TW) % TH, pd = q0 / (TW * TH);
-            const int gd = p0d + pd, gh = p0h + ph, gw = p0w + pw;
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (gd < p.Pd && gh < p.Ph) {
-                const float* src = p.P + ((((size_t)b * p.Pd + gd) * p.Ph + gh) * p.Pw + gw) * p.PCs + a0 + c4 * 4;
-                const int nc = p.PC - (a0 + c4 * 4);                 // channels left from this quad's first
-                if (gw < p.Pw) {
-                    if (nc >= 4) v0 = *reinterpret_cast<const float4*>(src);
-                    else { if (nc > 0) v0.x = src[0]; if (nc > 1) v0.y = src[1]; if (nc > 2) v0.z = src[2]; }
-                }
-                if (gw + 1 < p.Pw) {
-                    const float* s1 = src + p.PCs;
-                    if (nc >= 4) v1 = *reinterpret_cast<const float4*>(s1);
-                    else { if (nc > 0) v1.x = s1[0]; if (nc > 1) v1.y = s1[1]; if (nc > 2) v1.z = s1[2]; }
-                }
-            }
-            const float x0[4] = {v0.x, v0.y, v0.z, v0.w}, x1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int gd = p0d + p_d[k], gh = p0h + p_h[k], gw = p0w + p_w[k];
+            const bool row = gd < p.Pd && gh < p.Ph;
+            const float* src = p.P + ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
+            const int nc = p.PC - (a0 + p_src[k]);
+            pv[k][0] = load4(src, nc, row && gw < p.Pw);
+            pv[k][1] = load4(src + p.PCs, nc, row && gw + 1 < p.Pw);
+        }
+        const int q0d = p0d + od, q0h = p0h + p.hmin, q0w = p0w + p.wmin;
+#pragma unroll
+        for (int k = 0; k < QIT; ++k) {
+            const int gd = q0d + q_d[k], gh = q0h + q_h[k], gw = q0w + q_w[k];
+            const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
+            const float* src = p.Q + ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
+            const int nc = p.QC - (b0 + q_src[k]);
+            qv[k][0] = load4(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
+            qv[k][1] = load4(src + p.QCs, nc, row && (unsigned)(gw + 1) < (unsigned)p.Qw);
+        }
+    };
+    auto commit = [&]() {                           // registers -> scaled fp16 hi / lo pairs in LDS
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const float x0[4] = {pv[k][0].x, pv[k][0].y, pv[k][0].z, pv[k][0].w}, x1[4] = {pv[k][1].x, pv[k][1].y, pv[k][1].z, pv[k][1].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 unsigned h, l;
                 wg_split2(x0[j] * sP, x1[j] * sP, h, l);
-                *reinterpret_cast<unsigned*>(Ph + (c4 * 4 + j) * CHS_P + q0) = h;
-                *reinterpret_cast<unsigned*>(Pl + (c4 * 4 + j) * CHS_P + q0) = l;
+                *reinterpret_cast<unsigned*>(Ph + p_dst[k] + j * CHS_P) = h;
+                *reinterpret_cast<unsigned*>(Pl + p_dst[k] + j * CHS_P) = l;
             }
         }
-        // ---- stage the Q brick of this tap group's d offset: TD planes x LH rows x LW voxels (pairs)
-        const int q0d = p0d + od, q0h = p0h + p.hmin, q0w = p0w + p.wmin;
-        for (int it = tid; it < nQ; it += 256) {
-            const int c4 = it & 7; int r = it >> 3;
-            const int pr = r % npq; r /= npq;
-            const int lh = r % p.LH, ld = r / p.LH;
-            const int lw = pr * 2;
-            const int gd = q0d + ld, gh = q0h + lh, gw = q0w + lw;
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if ((unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh) {
-                const float* src = p.Q + ((((size_t)b * p.Qd + gd) * p.Qh + gh) * p.Qw + gw) * p.QCs + b0 + c4 * 4;
-                const int nc = p.QC - (b0 + c4 * 4);
-                if ((unsigned)gw < (unsigned)p.Qw) {
-                    if (nc >= 4) v0 = *reinterpret_cast<const float4*>(src);
-                    else { if (nc > 0) v0.x = src[0]; if (nc > 1) v0.y = src[1]; if (nc > 2) v0.z = src[2]; }
-                }
-                if ((unsigned)(gw + 1) < (unsigned)p.Qw) {
-                    const float* s1 = src + p.QCs;
-                    if (nc >= 4) v1 = *reinterpret_cast<const float4*>(s1);
-                    else { if (nc > 0) v1.x = s1[0]; if (nc > 1) v1.y = s1[1]; if (nc > 2) v1.z = s1[2]; }
-                }
-            }
-            const float x0[4] = {v0.x, v0.y, v0.z, v0.w}, x1[4] = {v1.x, v1.y, v1.z, v1.w};
-            const int off = (ld * LHM + lh) * ROWH + lw;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned h, l;
-                wg_split2(x0[j] * sQ, x1[j] * sQ, h, l);
-                *reinterpret_cast<unsigned*>(Qh + (c4 * 4 + j) * CHS_Q + off) = h;
-                *reinterpret_cast<unsigned*>(Ql + (c4 * 4 + j) * CHS_Q + off) = l;
+        for (int k = 0; k < QIT; ++k) {
+            if (q_ok[k]) {
+                const float x0[4] = {qv[k][0].x, qv[k][0].y, qv[k][0].z, qv[k][0].w}, x1[4] = {qv[k][1].x, qv[k][1].y, qv[k][1].z, qv[k][1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned h, l;
+                    wg_split2(x0[j] * sQ, x1[j] * sQ, h, l);
+                    *reinterpret_cast<unsigned*>(Qh + q_dst[k] + j * CHS_Q) = h;
+                    *reinterpret_cast<unsigned*>(Ql + q_dst[k] + j * CHS_Q) = l;
+                }
             }
         }
+    };
+    const int tw_first = sw * p.strip, tw_end = ((sw + 1) * p.strip < p.tilesW) ? (sw + 1) * p.strip : p.tilesW;
+    issue_loads(tw_first);
+    for (int twi = tw_first; twi < tw_end; ++twi) {
+        __syncthreads();                             // the previous brick's fragment reads are done
+        commit();
         __syncthreads();
+        if (twi + 1 < tw_end) issue_loads(twi + 1);  // in flight during the MFMA phase below
         // ---- this wave's two K blocks of 16 positions: half-block hb = 8 consecutive w positions of one row
         uint4 ah[2], al[2];
         int qoff[2];
