@@ -48,6 +48,7 @@ struct WgradArgs {
     signed char tapid[64];
     signed char g_t0[8], g_nt[8], g_par[8];   // first tap / tap count / parity bits (pd<<2 | ph<<1 | pw) of every class
     const float* Pmeta; const float* Qmeta;   // f16x3 form: range blocks (max |.|) of the P and Q tensors
+    int dbg;                                  // experiments build (OSA_WG_DBG): timing-only ablations of wgrad_f16x3_kernel -- 1 no global loads, 2 no LDS commit, 4 no MFMA phase, 8 no hand-over
 };
 
 template <int TD, int TH, int TW>     // position brick, TD*TH*TW = 256 (64 per wave) or 64 (16 per wave)
@@ -62,9 +63,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, hh = lane >> 5;
 
-    // blockIdx.x -> (strip index over bricks, tap group); blockIdx.y -> (a tile, b tile)
-    const int tg = blockIdx.x % p.tgroups;
-    int sidx = blockIdx.x / p.tgroups;
+    // blockIdx.x -> (strip index over bricks, tap group); blockIdx.y -> (a tile, b tile).  (Walking the ids XCD-contiguously -- xcd_remap,
+    // so that the tap groups of one strip share an L2 -- was measured: the fp32 form unchanged, the f16x3 form 12-27 % SLOWER.)
+    const unsigned bx = blockIdx.x;
+    const int tg = bx % p.tgroups;
+    int sidx = bx / p.tgroups;
     const int atiles = (p.A + 31) / 32;
     const int a0 = (blockIdx.y % atiles) * 32, b0 = (blockIdx.y / atiles) * 32;
     const int t0 = p.cls ? p.g_t0[tg] : tg * WG_TAPS;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         // ---- partial tiles to the workspace (lane-contiguous, plain stores); wgrad_reduce_kernel adds them up.  Float atomics on the
         // 27-64 K words of dW from every workgroup serialise in L2 (measured 4.5 G atomics/s: 0.5 ms per workgroup once a few thousand
         // of them contend) and make the gradient depend on the arrival order; this path is deterministic.
-        float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WG_TAPS * 1024) + lane;
+        float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + bx) * (WG_TAPS * 1024) + lane;
         // every wave holds a partial sum over its quarter of the positions: add the 4 waves up through LDS first, tap by tap
         // (3 x 16 x 64 floats = 12 KB at a time)
         __syncthreads();
@@ -224,8 +227,9 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, hh = lane >> 5;
-    const int tg = blockIdx.x % p.tgroups;
-    int sidx = blockIdx.x / p.tgroups;
+    const unsigned bx = blockIdx.x;
+    const int tg = bx % p.tgroups;
+    int sidx = bx / p.tgroups;
     const int atiles = (p.A + 31) / 32;
     const int a0 = (blockIdx.y % atiles) * 32, b0 = (blockIdx.y / atiles) * 32;
     const int khw = p.kh * p.kw;
@@ -271,6 +275,10 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         q_ok[k] = (it < nQ) ? 1u : 0u;
     }
     float4 pv[PIT][2], qv[QIT][2];
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) pv[k][0] = pv[k][1] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int k = 0; k < QIT; ++k) qv[k][0] = qv[k][1] = make_float4(1.f, 1.f, 1.f, 1.f);
     auto load4 = [&](const float* src, int nc, bool ok) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         return v;
     };
     auto issue_loads = [&](int twi) {
+        if (p.dbg & 1) return;
         const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         }
     };
     auto commit = [&]() {                           // registers -> scaled fp16 hi / lo pairs in LDS
+        if (p.dbg & 2) return;
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
             const float x0[4] = {pv[k][0].x, pv[k][0].y, pv[k][0].z, pv[k][0].w}, x1[4] = {pv[k][1].x, pv[k][1].y, pv[k][1].z, pv[k][1].w};
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         commit();
         __syncthreads();
         if (twi + 1 < tw_end) issue_loads(twi + 1);  // in flight during the MFMA phase below
+        if (p.dbg & 4) continue;
         // ---- this wave's two K blocks of 16 positions: half-block hb = 8 consecutive w positions of one row
         uint4 ah[2], al[2];
         int qoff[2];
@@ -380,7 +391,8 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         }
     }
     // ---- partial tiles to the workspace, tap j = dh * kw + dw of the group (records and reduce kernel of the fp32 form)
-    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WG_TAPS * 1024) + lane;
+    if ((p.dbg & 8) && acc[0][0] != 12345.678f) return;
+    float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + bx) * (WG_TAPS * 1024) + lane;
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem_h);
 #pragma unroll
@@ -543,6 +555,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         OSA_REQUIRE(ws && ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad_f16x3: workspace of %zu B needed (got %zu)", need, ws_bytes);
         OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
         a.ws = ws; a.Pmeta = dy_meta; a.Qmeta = x_meta;          // conv: P = dy, Q = x
+        a.dbg = exp_int("OSA_WG_DBG", 0);
         dim3 grid((unsigned)gx, gy), block(256);
         if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8>), grid, block, lds, st, a);
