@@ -293,6 +293,10 @@ def _out(n, k, p, d, s):
 
 
 WGRAD_F16X3 = True      # f16x3 mode: weight gradients of the layers osa_conv3d_wgrad_ws_f16x3 covers on the split-precision kernel (False: always exact fp32)
+# The same kernel also covers stride-2 / transposed layers (class mode: parity sub-lattices, one tap group per d delta).  Correct (tests) but not
+# faster than the fp32 class-mode kernel, which takes a whole class of up to 8 taps per staged brick where this form needs two groups of
+# <= 4 (measured: GwcNet step 33.9 -> 34.4 ms, StereoBase whole model 176 -> 184 ms): off by default.
+WGRAD_F16X3_CLASS = False
 
 
 def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed, precision="f32", xmeta=None, dymeta=None):
@@ -304,7 +308,7 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     lib = _lib.load()
     vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
     span = dict(flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2], nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co))
-    if precision == "f16x3" and WGRAD_F16X3:
+    if precision == "f16x3" and WGRAD_F16X3 and ((stride == 1 and not transposed) or WGRAD_F16X3_CLASS):
         need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
         if need:
             ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
@@ -409,7 +413,7 @@ class _ConvTranspose3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
-            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, (k, k, k), 2, (pad, pad, pad), (1, 1, 1), 1)
+            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, (k, k, k), 2, (pad, pad, pad), (1, 1, 1), 1, precision)
         return dx, dw, None, None, None, None
 
 
@@ -457,7 +461,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w5)
             Ho, Wo = dyc.shape[3:]
-            _wgrad(xc, dyc, dw, B, 1, H, W, Ci, 1, Ho, Wo, Co, (1, k, k), 2, (0, pad, pad), (1, 1, 1), 1)
+            _wgrad(xc, dyc, dw, B, 1, H, W, Ci, 1, Ho, Wo, Co, (1, k, k), 2, (0, pad, pad), (1, 1, 1), 1, precision)
             dw = dw[:, :, 0]
         return dx, dw, None, None, None, None
 

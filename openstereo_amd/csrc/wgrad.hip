@@ -46,7 +46,10 @@ struct WgradArgs {
     // class mode (transposed convs): tap arrays are class-major, tapid maps back to the kernel index
     int cls;
     signed char tapid[64];
-    signed char g_t0[8], g_nt[8], g_par[8];   // first tap / tap count / parity bits (pd<<2 | ph<<1 | pw) of every class
+    signed char g_t0[16], g_nt[16], g_par[16];   // first tap / tap count / parity bits (pd<<2 | ph<<1 | pw) of every tap group (fp32 form: the 8 classes)
+    // f16x3 form: a tap group is the taps of ONE d offset (of one parity class in class mode): up to 16 groups
+    signed char g_od[16];                      // its d offset (class mode: delta on the sub-lattice)
+    signed char g_slot[16][9];                 // accumulator slot dh * 3 + dw -> tap index inside the group, or -1
     const float* Pmeta; const float* Qmeta;   // f16x3 form: range blocks (max |.|) of the P and Q tensors
     int dbg;                                  // experiments build (OSA_WG_DBG): timing-only ablations of wgrad_f16x3_kernel -- 1 no global loads, 2 no LDS commit, 4 no MFMA phase, 8 no hand-over
 };
@@ -232,9 +235,13 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     int sidx = bx / p.tgroups;
     const int atiles = (p.A + 31) / 32;
     const int a0 = (blockIdx.y % atiles) * 32, b0 = (blockIdx.y / atiles) * 32;
-    const int khw = p.kh * p.kw;
-    const int t0 = tg * khw;                         // tap group = the taps of one kd plane (host: kh * kw == 9, or a single group)
-    const int od = p.od[t0];
+    // tap group = the taps of one d offset (host tables); class mode (stride-2 / transposed layers): Q is read on the parity sub-lattice
+    // q = 2 * (pos + delta) + par of the group's class, where it is unit stride
+    const int od = p.g_od[tg];
+    const int par = p.cls ? p.g_par[tg] : 0;
+    const int pard = (par >> 2) & 1, parh = (par >> 1) & 1, parw = par & 1;
+    const int qs = p.cls ? 2 : 1;
+    const int ghmin = p.cls ? -parh : p.hmin, gwmin = p.cls ? -parw : p.wmin;
     const int nstripsW = (p.tilesW + p.strip - 1) / p.strip;
     const int sw = sidx % nstripsW; sidx /= nstripsW;
     const int thi = sidx % p.tilesH; sidx /= p.tilesH;
@@ -299,15 +306,15 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
             pv[k][0] = load4(src, nc, row && gw < p.Pw);
             pv[k][1] = load4(src + p.PCs, nc, row && gw + 1 < p.Pw);
         }
-        const int q0d = p0d + od, q0h = p0h + p.hmin, q0w = p0w + p.wmin;
+        const int q0d = p0d + od, q0h = p0h + ghmin, q0w = p0w + gwmin;
 #pragma unroll
         for (int k = 0; k < QIT; ++k) {
-            const int gd = q0d + q_d[k], gh = q0h + q_h[k], gw = q0w + q_w[k];
+            const int gd = qs * (q0d + q_d[k]) + pard, gh = qs * (q0h + q_h[k]) + parh, gw = qs * (q0w + q_w[k]) + parw;   // tensor coordinates
             const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
             const float* src = p.Q + ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
             const int nc = p.QC - (b0 + q_src[k]);
             qv[k][0] = load4(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
-            qv[k][1] = load4(src + p.QCs, nc, row && (unsigned)(gw + 1) < (unsigned)p.Qw);
+            qv[k][1] = load4(src + qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw);
         }
     };
     auto commit = [&]() {                           // registers -> scaled fp16 hi / lo pairs in LDS
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         }
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
-            if (dh < p.kh) {
+            if (p.g_slot[tg][dh * 3] >= 0 || p.g_slot[tg][dh * 3 + 1] >= 0 || p.g_slot[tg][dh * 3 + 2] >= 0) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const unsigned short* qh = Qh + qoff[i] + dh * ROWH;
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
                     const wf16x8 pa_h = __builtin_bit_cast(wf16x8, ah[i]), pa_l = __builtin_bit_cast(wf16x8, al[i]);
 #pragma unroll
                     for (int dw = 0; dw < 3; ++dw) {
-                        if (dw < p.kw) {
+                        if (p.g_slot[tg][dh * 3 + dw] >= 0) {
                             uint4 bh, bl;
                             if (dw == 0) { bh = vh; bl = vl; }
                             else if (dw == 1) {
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
             }
         }
     }
-    // ---- partial tiles to the workspace, tap j = dh * kw + dw of the group (records and reduce kernel of the fp32 form)
+    // ---- partial tiles to the workspace, slot dh * 3 + dw -> tap j of the group (records and reduce kernel of the fp32 form)
     if ((p.dbg & 8) && acc[0][0] != 12345.678f) return;
     float* dst = p.ws + ((size_t)blockIdx.y * gridDim.x + bx) * (WG_TAPS * 1024) + lane;
     __syncthreads();
@@ -399,8 +406,9 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) {
-            if (dh < p.kh && dw < p.kw) {               // uniform over the workgroup
-                const int t = dh * 3 + dw, j = dh * p.kw + dw;
+            const int j = p.g_slot[tg][dh * 3 + dw];    // uniform over the workgroup
+            if (j >= 0) {
+                const int t = dh * 3 + dw;
                 if (wave > 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[t][r];
@@ -421,7 +429,7 @@ struct WgradReduceArgs {
     const float* ws; float* dW;
     int gx, tgroups, nstrips;     // workspace layout: workgroup = y * gx + strip * tgroups + tg
     int A, Bc, kvol, atiles, T, cls;
-    signed char tapid[64], g_t0[8], g_nt[8];
+    signed char tapid[64], g_t0[16], g_nt[16];
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs p) {
     const int e = blockIdx.x * 256 + threadIdx.x;            // (t, r, lane) inside one workgroup record
@@ -525,15 +533,51 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
     }
     hipStream_t st = (hipStream_t)stream;
     if (f16x3) {
-        // split-precision form (wgrad_f16x3_kernel): unit stride, unit dilation, one kd plane of <= 9 taps per workgroup.  Not eligible
-        // -> *query = 0 / error: the caller keeps the fp32 form.
-        const bool ok = !transposed && a.s == 1 && dil_d == 1 && dil_h == 1 && dil_w == 1 && kh <= 3 && kw <= 3 && (kh * kw == 9 || kd == 1);
+        // split-precision form (wgrad_f16x3_kernel): unit dilation; unit stride with <= 3x3 planes, or the stride-2 / transposed layers in
+        // class mode (the parity classes built above).  A tap group = the taps of one d offset (of one class).  Not eligible -> *query = 0 /
+        // error: the caller keeps the fp32 form.
+        bool ok = dil_d == 1 && dil_h == 1 && dil_w == 1;
+        if (a.s == 1) ok = ok && !transposed && kh <= 3 && kw <= 3;
         if (query && !ok) { *query = 0; return 0; }
-        OSA_REQUIRE(ok, "conv3d_wgrad_f16x3: layer not eligible (unit stride / dilation, kh, kw <= 3, 3x3 planes or kd == 1)");
+        OSA_REQUIRE(ok, "conv3d_wgrad_f16x3: layer not eligible (unit dilation; unit-stride layers: kh, kw <= 3)");
         const bool flat16 = (a.Pd == 1 && kd == 1);
         const int TD = flat16 ? 1 : 2, TH = 8, TW = flat16 ? 16 : 8;
-        a.LD = TD; a.LH = TH + (hmax - a.hmin); a.LW = TW + (wmax - a.wmin);
-        a.tgroups = (kh * kw == 9) ? kd : 1;
+        int ng = 0;
+        memset(a.g_slot, -1, sizeof(a.g_slot));
+        if (a.cls) {
+            // split every class's (d-major) tap run by its d delta
+            signed char c_t0[8], c_nt[8];
+            memcpy(c_t0, a.g_t0, 8); memcpy(c_nt, a.g_nt, 8);
+            for (int c = 0; c < 8; ++c) {
+                const int parh = (c >> 1) & 1, parw = c & 1;
+                int i = c_t0[c];
+                const int e = c_t0[c] + c_nt[c];
+                while (i < e) {
+                    int j = i;
+                    while (j < e && a.od[j] == a.od[i]) ++j;
+                    OSA_REQUIRE(ng < 16, "conv3d_wgrad_f16x3: more than 16 tap groups");
+                    a.g_t0[ng] = (signed char)i; a.g_nt[ng] = (signed char)(j - i); a.g_par[ng] = (signed char)c; a.g_od[ng] = a.od[i];
+                    for (int t2 = i; t2 < j; ++t2) {
+                        const int dh = a.oh[t2] + parh, dw = a.ow[t2] + parw;            // delta - (-par) in {0, 1}
+                        OSA_REQUIRE(dh >= 0 && dh <= 2 && dw >= 0 && dw <= 2 && a.g_slot[ng][dh * 3 + dw] < 0, "conv3d_wgrad_f16x3: tap offsets out of range");
+                        a.g_slot[ng][dh * 3 + dw] = (signed char)(t2 - i);
+                    }
+                    ++ng; i = j;
+                }
+            }
+            a.LH = TH + 1; a.LW = TW + 1;
+        } else {
+            // taps are (z, y, x)-major: group = one z
+            const int khw = kh * kw;
+            for (int z = 0; z < kd; ++z) {
+                a.g_t0[ng] = (signed char)(z * khw); a.g_nt[ng] = (signed char)khw; a.g_par[ng] = 0; a.g_od[ng] = a.od[z * khw];
+                for (int y = 0; y < kh; ++y) for (int xx = 0; xx < kw; ++xx) a.g_slot[ng][y * 3 + xx] = (signed char)(y * kw + xx);
+                ++ng;
+            }
+            a.LH = TH + (hmax - a.hmin); a.LW = TW + (wmax - a.wmin);
+        }
+        a.LD = TD;
+        a.tgroups = ng;
         a.tilesD = cdiv(a.Pd, TD); a.tilesH = cdiv(a.Ph, TH); a.tilesW = cdiv(a.Pw, TW);
         const int chs_q = TD * (TH + 2) * (flat16 ? 24 : 16) + 8;
         const size_t lds = (size_t)(2 * 32 * 136 + 2 * 32 * chs_q) * sizeof(unsigned short);
@@ -554,7 +598,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         if (query) { *query = need; return 0; }
         OSA_REQUIRE(ws && ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad_f16x3: workspace of %zu B needed (got %zu)", need, ws_bytes);
         OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
-        a.ws = ws; a.Pmeta = dy_meta; a.Qmeta = x_meta;          // conv: P = dy, Q = x
+        a.ws = ws;
+        a.Pmeta = transposed ? x_meta : dy_meta; a.Qmeta = transposed ? dy_meta : x_meta;       // conv: P = dy, Q = x; transposed: P = x, Q = dy
         a.dbg = exp_int("OSA_WG_DBG", 0);
         dim3 grid((unsigned)gx, gy), block(256);
         if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16>), grid, block, lds, st, a);
@@ -563,7 +608,13 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         WgradReduceArgs r;
         memset(&r, 0, sizeof(r));
         r.ws = ws; r.dW = dw; r.gx = (int)gx; r.tgroups = a.tgroups; r.nstrips = (int)(gx / a.tgroups);
-        r.A = a.A; r.Bc = a.Bc; r.kvol = T; r.atiles = cdiv(a.A, 32); r.T = T; r.cls = 0;
+        r.A = a.A; r.Bc = a.Bc; r.kvol = T; r.atiles = cdiv(a.A, 32); r.T = T;
+        // the reduce kernel's class mode reads (first tap, count) per group and maps class-major taps back through tapid: used for BOTH modes
+        // here (unit stride: identity tapid), because a group is one z plane of kh * kw taps, not a run of WG_TAPS
+        r.cls = 1;
+        if (a.cls) memcpy(r.tapid, a.tapid, sizeof(r.tapid));
+        else for (int t2 = 0; t2 < T; ++t2) r.tapid[t2] = (signed char)t2;
+        memcpy(r.g_t0, a.g_t0, sizeof(r.g_t0)); memcpy(r.g_nt, a.g_nt, sizeof(r.g_nt));
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_TAPS * 1024 / 256, a.tgroups, gy), dim3(256), 0, st, r);
         OSA_LAUNCH_CHECK("conv3d_wgrad_f16x3_reduce");
         return 0;

@@ -111,6 +111,34 @@ WGRAD_X3 = [  # name, Ci, Co, k (kd, kh, kw), pad, dims (D, H, W), batch
 ]
 
 
+WGRAD_X3_CLS = [  # name, kind, Ci, Co, k, pad, opad, dims (D, H, W), batch   -- class mode: stride-2 convs and stride-2 transposed convs
+    ("conv s2 32-64", "conv", 32, 64, 3, 1, 0, (8, 12, 16), 2),
+    ("conv s2 24-40 ragged", "conv", 24, 40, 3, 1, 0, (6, 10, 18), 1),
+    ("deconv k3 64-32", "deconv3d", 64, 32, 3, 1, 1, (3, 5, 7), 2),
+    ("deconv k4 48-24", "deconv3d", 48, 24, 4, 1, 0, (4, 5, 9), 1),
+    ("deconv2d k4 64-9", "deconv2d", 64, 9, 4, 1, 0, (1, 20, 46), 1),
+    ("deconv2d k4 32-32", "deconv2d", 32, 32, 4, 1, 0, (1, 9, 17), 2),
+]
+
+
+def _wgrad_three_ways(run):
+    """weight gradient of `run(weight)` with the f16x3 kernel (twice: determinism) and with the exact fp32 kernel"""
+    from openstereo_amd import autograd as AG
+    res = {}
+    for tag, on in (("x3", True), ("x3 again", True), ("f32", False)):
+        old = (AG.WGRAD_F16X3, AG.WGRAD_F16X3_CLASS)
+        AG.WGRAD_F16X3 = AG.WGRAD_F16X3_CLASS = on          # class mode (strided / transposed layers) is opt-in
+        try:
+            res[tag] = run()
+        finally:
+            AG.WGRAD_F16X3, AG.WGRAD_F16X3_CLASS = old
+    assert torch.equal(res["x3"], res["x3 again"])
+    scale = float(res["f32"].abs().max())
+    err = float((res["x3"] - res["f32"]).abs().max()) / scale
+    assert err <= 4e-6, err
+    return res["x3"], scale
+
+
 @pytest.mark.parametrize("case", WGRAD_X3, ids=[c[0] for c in WGRAD_X3])
 def test_wgrad_f16x3_kernel_vs_fp32_kernel_and_torch(case):
     """osa_conv3d_wgrad_ws_f16x3 (16 positions per MFMA, fp16 hi / lo operands from channel-major LDS images, tap shifts by funnel shift)
@@ -122,22 +150,48 @@ def test_wgrad_f16x3_kernel_vs_fp32_kernel_and_torch(case):
     gy = (rn((B, Co, D, H, W), 14) * 1e-3).to(DEV)            # gradient-sized magnitudes
     need = _lib.load().osa_conv3d_wgrad_f16x3_workspace_bytes(B, D, H, W, Ci, D, H, W, Co, *k, 1, *pad, 1, 1, 1, 0)
     assert need > 0, "these layers are covered by the split-precision form"
-    res = {}
-    for tag, on in (("x3", True), ("x3 again", True), ("f32", False)):
-        old = AG.WGRAD_F16X3
-        AG.WGRAD_F16X3 = on
-        try:
-            we = w.clone().requires_grad_()
-            AG.conv3d(x, we, None, 1, pad, 1, precision="f16x3").backward(gy)
-            res[tag] = we.grad.clone()
-        finally:
-            AG.WGRAD_F16X3 = old
-    assert torch.equal(res["x3"], res["x3 again"])
-    scale = float(res["f32"].abs().max())
-    assert float((res["x3"] - res["f32"]).abs().max()) <= 4e-6 * scale, float((res["x3"] - res["f32"]).abs().max()) / scale
+
+    def run():
+        we = w.clone().requires_grad_()
+        AG.conv3d(x, we, None, 1, pad, 1, precision="f16x3").backward(gy)
+        return we.grad.clone()
+    got, scale = _wgrad_three_ways(run)
     wr = w.clone().requires_grad_()
     F.conv3d(x, wr, None, 1, pad, 1).backward(gy)
-    assert float((res["x3"] - wr.grad).abs().max()) <= 2e-5 * scale
+    assert float((got - wr.grad).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("case", WGRAD_X3_CLS, ids=[c[0] for c in WGRAD_X3_CLS])
+def test_wgrad_f16x3_class_mode_vs_fp32_kernel_and_torch(case):
+    """The same kernel on the parity sub-lattices of stride-2 convolutions and stride-2 transposed convolutions (3-D k = 3 / 4, 2-D k = 4):
+    tap groups = one d delta of one class, Q staged by a stride-2 gather."""
+    from openstereo_amd import autograd as AG
+    name, kind, Ci, Co, k, pad, opad, (D, H, W), B = case
+    x = rn((B, Ci, D, H, W), 15).to(DEV) * 3.0
+    if kind == "conv":
+        w = (synth_tensor(name + ".w", (Co, Ci, k, k, k), 1) * 3.0).to(DEV)
+        ref = lambda xx, ww: F.conv3d(xx, ww, None, 2, pad)
+        eng = lambda xx, ww: AG.conv3d(xx, ww, None, 2, pad, 1, precision="f16x3")
+    elif kind == "deconv3d":
+        w = (synth_tensor(name + ".w", (Ci, Co, k, k, k), 1) * 3.0).to(DEV)
+        ref = lambda xx, ww: F.conv_transpose3d(xx, ww, None, 2, pad, opad)
+        eng = lambda xx, ww: AG.conv_transpose3d(xx, ww, None, 2, pad, opad, precision="f16x3")
+    else:
+        x = x[:, :, 0]
+        w = (synth_tensor(name + ".w", (Ci, Co, k, k), 1) * 3.0).to(DEV)
+        ref = lambda xx, ww: F.conv_transpose2d(xx, ww, None, 2, pad, opad)
+        eng = lambda xx, ww: AG.conv_transpose2d(xx, ww, None, 2, pad, opad, precision="f16x3")
+    with torch.no_grad():
+        gy = torch.randn_like(ref(x, w)) * 1e-3
+
+    def run():
+        we = w.clone().requires_grad_()
+        eng(x, we).backward(gy)
+        return we.grad.clone()
+    got, scale = _wgrad_three_ways(run)
+    wr = w.clone().requires_grad_()
+    ref(x, wr).backward(gy)
+    assert float((got - wr.grad).abs().max()) <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
