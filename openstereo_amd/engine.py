@@ -54,7 +54,12 @@ def get_precision() -> str:
 
 # ----------------------------------------------------------------------------- packed-weight caches
 class _PackEntry:
-    __slots__ = ("slots", "key", "value")
+    __slots__ = ("slots", "key", "value", "event", "stream", "synced")
+
+
+# Set by parallel.SubBatchStreams(n > 1): several streams of one process use the engine concurrently, so a packed form built on one
+# stream must be ordered before its first use on every other stream (see cached_pack).  Single-stream processes skip the bookkeeping.
+MULTI_STREAM = False
 
 
 def _tensor_slots(mods):
@@ -75,11 +80,18 @@ def cached_pack(owner, attr, build, mods=None):
     train / eval every epoch, optimisers and load_state_dict update parameters in place and .to() moves them, so
     the cache key is (arithmetic mode, (data_ptr, version counter) of every parameter and buffer the packed form was
     built from).  ~0.15 us per tensor per forward; hipGraph replays never get here.  `owner.<attr> = None` (what the
-    reset_engine() methods do) still forces a rebuild, e.g. after replacing a sub-module object."""
+    reset_engine() methods do) still forces a rebuild, e.g. after replacing a sub-module object.
+
+    Streams (MULTI_STREAM): the pack kernels run on the stream that was current at build time.  A hit from ANOTHER stream first makes
+    that stream wait for an event recorded behind the build (once per stream and build) -- without it a sub-batch stream could read
+    packs that the first sub-batch's stream is still writing.  Inside a stream capture the wait is recorded only when the
+    build itself was captured (fork / join edge of the graph); builds from an eager warm-up are complete by the time a capture starts
+    (torch.cuda.graph synchronises first)."""
     ent = owner.__dict__.get(attr)
     if not isinstance(ent, _PackEntry):
         ent = _PackEntry()
         ent.slots, ent.key, ent.value = _tensor_slots(mods if mods is not None else (owner,)), None, None
+        ent.event = ent.stream = ent.synced = None
         object.__setattr__(owner, attr, ent)
     key = [_precision]
     for d, n in ent.slots:
@@ -91,6 +103,19 @@ def cached_pack(owner, attr, build, mods=None):
     if ent.key != key:
         ent.value = build()
         ent.key = key
+        ent.event = None
+        if MULTI_STREAM and torch.cuda.is_available():
+            cur = torch.cuda.current_stream()
+            ent.event = torch.cuda.Event()
+            ent.event.record(cur)
+            ent.stream, ent.synced = cur.cuda_stream, (torch.cuda.is_current_stream_capturing(), set())
+    elif ent.event is not None:
+        cur = torch.cuda.current_stream()
+        h = cur.cuda_stream
+        if h != ent.stream and h not in ent.synced[1]:
+            if ent.synced[0] or not torch.cuda.is_current_stream_capturing():
+                cur.wait_event(ent.event)
+            ent.synced[1].add(h)
     return ent.value
 
 

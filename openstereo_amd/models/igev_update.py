@@ -297,15 +297,25 @@ class BasicMultiUpdateBlock(nn.Module):
             if hasattr(m, "_eng"):
                 m._eng = None
 
+    def end_forward(self):
+        """Drop the per-level state buffers (and the references to the context tensors they were keyed on).  run_refinement calls this
+        when its loop is done; direct forward_cl callers call it between forwards when they rewrite `inp` through raw pointers."""
+        self.__dict__.pop("_lv", None)
+
     def _levels(self, net, inp, n_gru):
         """Per-level state buffers, kept across the calls of one forward: `net[i]` handed back by the previous call IS level i's buffer
         (identity), anything else (first call, a caller that replaced a hidden state) is copied in.  A new set of context tensors
         (`inp`) starts a new forward."""
         ctx = [t for ts in inp[:n_gru] for t in ts]     # the state holds these references, so identity is a safe key (no id() reuse)
         shapes = [tuple(t.shape[2:]) for t in net[:n_gru]]
+        # The levels hold a COPY of the context terms (crz = [cr | cz]), so the key also carries what tells a changed content apart: the
+        # tensors' version counters (in-place torch updates of static graph inputs bump them) and the capture state (levels made in an eager
+        # warm-up must not be reused inside a capture: the crz copy would not be part of the graph).  Writes through raw pointers / `.data`
+        # are invisible to both -- call `end_forward()` (or `reset_engine()`) after such an update.
+        stamp = ([t._version for t in ctx], torch.cuda.is_current_stream_capturing() if ctx and ctx[0].is_cuda else False)
         st = self.__dict__.get("_lv")
-        if st is None or st[0][1] != shapes or len(st[0][0]) != len(ctx) or any(a is not b for a, b in zip(st[0][0], ctx)):
-            key = (ctx, shapes)
+        if st is None or st[0][1] != shapes or st[0][2] != stamp or len(st[0][0]) != len(ctx) or any(a is not b for a, b in zip(st[0][0], ctx)):
+            key = (ctx, shapes, stamp)
             hd = [g.convz.out_channels for g in (self.gru04, self.gru08, self.gru16)]
             cx = [128 + (hd[1] if n_gru > 1 else 0), hd[0] + (hd[2] if n_gru > 2 else 0), hd[1]]
             lv = [g.new_level(net[i], inp[i][0], inp[i][1], inp[i][2], cx[i]) if i < n_gru else None
@@ -320,7 +330,9 @@ class BasicMultiUpdateBlock(nn.Module):
 
     def forward_cl(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True, want_mask=True, disp_in_place=False):
         """Engine tensors everywhere.  Returns `net` as the per-level state buffers (channels [0, hidden) are the hidden state): hand them
-        back unchanged for the next call, or read them with cl_to_nchw(t, hidden).  want_mask=False skips mask_feat_4 (returns None for it):
+        back unchanged for the next call, or read them with cl_to_nchw(t, hidden).  The levels are cached across the calls of one forward,
+        keyed on the identity, version counters and capture state of the `inp` tensors: `inp` must not be rewritten through raw pointers
+        between calls without an `end_forward()` in between.  want_mask=False skips mask_feat_4 (returns None for it):
         in test mode only the last iteration's mask features are used (igev_stereo.py:203-207)."""
         n_gru = self.args.N_GRU_LAYERS if hasattr(self, "args") else self.n_gru_layers    # igev/update.py vs stereobase/gru_blocks.py
         lv = self._levels(net, inp, n_gru)
@@ -466,4 +478,6 @@ def run_refinement(update_block, a, match_left, match_right, geo_encoding_volume
         net, mask, delta = update_block.forward_cl(net, inp, geo_feat, disp4, iter16=n_gru == 3, iter08=n_gru >= 2,
                                                    want_mask=it == iters - 1, disp_in_place=True)
         advance(delta)
-    return {"disp": disp, "mask_feat_4": cl_to_nchw(mask, 32), "net_list": [cl_to_nchw(t, r.shape[1]) for t, r in zip(net, net_list)]}
+    out = {"disp": disp, "mask_feat_4": cl_to_nchw(mask, 32), "net_list": [cl_to_nchw(t, r.shape[1]) for t, r in zip(net, net_list)]}
+    update_block.end_forward()          # the level buffers and the context references die with the forward
+    return out

@@ -36,18 +36,36 @@ class SubBatchStreams:
     def __init__(self, n: int):
         self.n = max(1, int(n))
         self.streams = [torch.cuda.Stream() for _ in range(self.n)] if self.n > 1 else []
+        self._warm = False          # the first call runs its sub-batches chained (see __call__); rearm() asks for another chained call
+        if self.n > 1:
+            from . import engine
+            engine.MULTI_STREAM = True      # packed forms built on one stream are event-ordered before their use on another (engine.cached_pack)
+
+    def rearm(self):
+        """Run the next call chained again (after swapping the model / its weights for objects that build their engine state lazily)."""
+        self._warm = False
 
     def __call__(self, fn, *batched):
-        """fn(*sub_batch_tensors) -> tensor; `batched`: tensors with the pairs on dim 0 (size divisible by n).  Returns the concatenation."""
+        """fn(*sub_batch_tensors) -> tensor; `batched`: tensors with the pairs on dim 0 (size divisible by n).  Returns the concatenation.
+
+        Process-global engine state that is built lazily on first use (packed weights, f16x3 range arenas, workspaces) is created on
+        whatever stream gets there first.  Range arenas are per stream (ranges.new_meta) and packed forms carry an event
+        (engine.cached_pack); on top of that the FIRST call of this object (and the first after rearm()) runs its sub-batches one after the other (stream i + 1 waits
+        for stream i), so anything else a model builds on first use is complete before a second stream touches it.  Later calls --
+        and the hipGraph captured from them -- run the sub-batches concurrently."""
         if self.n == 1:
             return fn(*batched)
         B = batched[0].shape[0]
         assert B % self.n == 0, f"batch of {B} pairs does not split into {self.n} sub-batches"
         per, cur, outs = B // self.n, torch.cuda.current_stream(), []
+        chain = not self._warm
+        prev = cur
         for i, st in enumerate(self.streams):
-            st.wait_stream(cur)
+            st.wait_stream(prev if chain else cur)
             with torch.cuda.stream(st):
                 outs.append(fn(*[t[i * per:(i + 1) * per] for t in batched]))
+            prev = st
         for st in self.streams:
             cur.wait_stream(st)
+        self._warm = True
         return torch.cat(outs, 0)

@@ -17,26 +17,46 @@ import torch
 # zero-fill is replayed with the graph.
 META_FLOATS = 128      # OSA_META_FLOATS: max |value| in 8 slots at [0], [16], ... [112]; [1] = scale of a split tensor
 _ARENA_SLOTS = 256
-_arena = None        # [tensor, next free slot, allocated during stream capture?, stream handle it was made on]
+# Arenas are keyed by (device, raw stream handle): a slot is only ever handed to work on the stream its arena's zero-fill
+# was issued on, so the memset is ordered before every producer / consumer of the block by stream order alone -- also inside a captured
+# graph with forked branches (SubBatchStreams: the memset node of a branch's arena sits in that branch).  r3 shared one arena between
+# streams and only re-examined the capture state on a stream change: an arena zeroed on sub-stream 1 could hand slots to sub-stream 2
+# with no dependency on the memset.
+_arenas = {}         # (device, stream handle) -> [tensor, next free slot, allocated during stream capture?]
+_last = None         # (stream handle, device, arena) of the previous call: the common case is one dict-free comparison
 
 
 def new_meta(device, stream=None) -> torch.Tensor:
-    """A fresh zeroed range block on `device`.  `stream` (raw handle of the current stream, when the caller has it
-    anyway) keys the arena: stream capture runs on a stream of its own, so a change of stream is when the capture
-    state is re-examined -- the per-call cost is then one integer comparison.  (A block from a pre-capture arena
-    baked into a graph would merely never be re-zeroed: its maximum then covers every replay so far -- still a
-    valid bound, the results just stop being independent of history.)"""
-    global _arena
-    a = _arena
-    if a is None or a[1] >= _ARENA_SLOTS or a[0].device != device or stream is None or a[3] != stream:
-        cap = torch.cuda.is_current_stream_capturing()
-        if a is None or a[1] >= _ARENA_SLOTS or a[0].device != device or a[2] != cap:
-            a = _arena = [torch.zeros(_ARENA_SLOTS * META_FLOATS, device=device, dtype=torch.float32), 0, cap, stream]
-        else:
-            a[3] = stream
+    """A fresh zeroed range block on `device` for work on `stream` (raw handle; default: the current stream).  Stream capture runs on
+    streams of its own and gets arenas of its own (allocated from the graph's pool, zero-filled by a captured memset that replays with
+    the graph); an arena made outside capture is never handed out inside one and vice versa.  (A block from a pre-capture arena baked
+    into a graph would never be re-zeroed: its maximum would cover every replay so far.)"""
+    global _last
+    if stream is None:
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    # (the capture state is re-examined on every call: SubBatchStreams uses the SAME side streams in its eager warm-up and inside the
+    # capture, so a stream handle alone does not tell)
+    cap = torch.cuda.is_current_stream_capturing() if device.type == "cuda" else False
+    l = _last
+    if l is not None and l[0] == stream and l[1] == device and l[2][1] < _ARENA_SLOTS and l[2][2] == cap:
+        a = l[2]
+    else:
+        key = (device, stream)
+        a = _arenas.get(key)
+        if a is None or a[1] >= _ARENA_SLOTS or a[2] != cap:
+            a = _arenas[key] = [torch.zeros(_ARENA_SLOTS * META_FLOATS, device=device, dtype=torch.float32), 0, cap]
+        _last = (stream, device, a)
     i = a[1]
     a[1] = i + 1
     return a[0][i * META_FLOATS:(i + 1) * META_FLOATS]
+
+
+def reset_arenas():
+    """Forget every arena (handed-out blocks stay alive through their tensors).  Call between a warm-up and a stream capture, or after a
+    captured graph is destroyed, to drop arenas that belong to dead streams / pools."""
+    global _last
+    _arenas.clear()
+    _last = None
 
 
 # osa_amax_f32 (csrc/layout.hip) is exact and ~1.7x faster than torch's infinity norm, also inside replayed hipGraphs in isolation
@@ -45,7 +65,6 @@ def new_meta(device, stream=None) -> torch.Tensor:
 # tools/diag_train_nan.py, profiles/round3/diag/amax_kernel_training_graph.txt).  So the default stays torch's reduction;
 # OSA_ENGINE_AMAX=1 (or ranges.ENGINE_AMAX = True) selects the kernel.
 ENGINE_AMAX = bool(os.environ.get("OSA_ENGINE_AMAX"))
-DIAG = {"count": 0, "lo": 0, "hi": 1 << 30, "log": None}
 
 
 def _dense(t) -> bool:
@@ -63,23 +82,10 @@ def _amax_into(m, t):
     """max |t| into the (fresh) range block `m` by ONE reduction, no temporaries: torch's infinity norm, or -- ENGINE_AMAX -- the engine's
     own kernel for dense fp32 CUDA tensors (float4 grid-stride loads, one atomic per workgroup, the block's 8 slots)."""
     t = t.detach()
-    if ENGINE_AMAX:
-        mode = os.environ.get("OSA_AMAX_MODE", "")          # diagnostics: "fwd" / "bwd" = kernel only outside / inside autograd's backward
-        in_bwd = torch._C._current_graph_task_id() != -1
-        use = not ((mode == "fwd" and in_bwd) or (mode == "bwd" and not in_bwd))
-        if mode == "idx":                                     # diagnostics (tools/diag_train_nan2.py): kernel for forward calls [lo, hi) of a step only
-            use = False
-            if not in_bwd:
-                i = DIAG["count"]; DIAG["count"] = i + 1
-                use = DIAG["lo"] <= i < DIAG["hi"]
-                if DIAG["log"] is not None:
-                    DIAG["log"].append((i, tuple(t.shape), t.stride(), t.data_ptr() % 4096))
-        if use and t.is_cuda and t.dtype == torch.float32 and t.numel() > 0 and (t.data_ptr() & 15) == 0 and _dense(t):
-            from . import _lib
-            if mode == "both":                                    # diagnostics: torch's reduction into a scratch block as well
-                torch.linalg.vector_norm(t, float("inf"), out=new_meta(t.device)[0])
-            _lib.call("osa_amax_f32", t.data_ptr(), t.numel(), m.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            return
+    if ENGINE_AMAX and t.is_cuda and t.dtype == torch.float32 and t.numel() > 0 and (t.data_ptr() & 15) == 0 and _dense(t):
+        from . import _lib
+        _lib.call("osa_amax_f32", t.data_ptr(), t.numel(), m.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return
     torch.linalg.vector_norm(t, float("inf"), dtype=torch.float32 if t.dtype != torch.float32 else None, out=m[0])   # all dims, no reshape (no copy of strided tensors)
 
 

@@ -9,9 +9,12 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 
 Pinning: tests/golden/*.npz hold outputs of the REAL reference (imported from /root/reference by
 tests/golden/make_golden.py in the build container); tests/test_oracle_golden.py checks this
-restatement against them.  Parity status: pinned for GwcNet (full model + every stage) and for
-the shared/PSMNet/IGEV volume + regression helpers; StereoBase/LightStereo/IGEV full models are
-"parity unpinned" (timm backbone unavailable offline).
+restatement against them.  Parity status: pinned for GwcNet and PSMNet (full models + every stage), the
+shared / IGEV volume + regression helpers, the StereoBase / IGEV / LightStereo cost stages and update
+block, and -- since r3 -- the StereoBase / IGEVStereo / LightStereo whole models, forward and CPU
+autograd, against the reference's OWN classes (tests/golden/e2e_reference*.npz).  "Parity unpinned":
+only the timm feature trunks themselves (package / weights unavailable offline); the fixtures
+replace exactly `model.blocks` by the same stand-in on both sides.
 """
 from __future__ import annotations
 
