@@ -638,6 +638,9 @@ def secondary_workloads(args, dev, rank, budget_s=75.0):
                 step()
             torch.cuda.synchronize()
             launch = "eager"
+            # the same step launched kernel by kernel from Python (what a user of the reference's own eval / train loop gets: tools/measure.py:49-89,
+            # trainer_template.py:283 do not capture graphs) -- printed next to the graph-replay figure
+            e_sec, _ = _time_steps(step, min(steps, 3), 0)
             if wl.training and not args.no_graph:
                 cap = capture_training_step(wl)
                 if cap is not None:
@@ -654,6 +657,7 @@ def secondary_workloads(args, dev, rank, budget_s=75.0):
             r0 = roofs[0] if roofs else None
             out[name] = {"metric": wl.metric, "value": round(wl.B / sec, 3), "unit": "stereo-pairs/s", "ms_per_step": round(sec * 1e3, 3),
                          "pairs_per_step": wl.B, "launch": launch,
+                         "eager_value": round(wl.B / e_sec, 3), "eager_ms_per_step": round(e_sec * 1e3, 3),
                          "dominant_launch": None if r0 is None else {k: r0[k] for k in ("what", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
             del wl
             torch.cuda.empty_cache()
@@ -835,6 +839,10 @@ def main():
         roofs, alt, latency_1, cpu = [], None, None, None
         if not args.timed_only:
             nrep = max(2, min(args.steps, 5))
+            if graph is not None and world == 1:
+                # like for like with the reference's loops, which launch eagerly: the same step, same arithmetic mode, no graph
+                e_sec, _ = _time_steps(eager_step, nrep, 1)
+                line["eager_value"], line["eager_ms_per_step"] = round(B / e_sec, 3), round(e_sec * 1e3, 3)
             roofs, per_step = gwcnet_rooflines(wl, args, wl.step_single, nrep)
             if roofs and wl.nstreams > 1:
                 roofs[0]["note"] = (f"kernel timed in a single-stream replay of the same forward ({B} pairs per launch, nothing else on the GPU); the timed region "

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OSA_ABI_VERSION 3
+#define OSA_ABI_VERSION 4
 #define OSA_META_FLOATS 128   /* floats per range block (osa_f16x3_ranges) */
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
@@ -500,6 +500,37 @@ int osa_preprocess_pair_f32(const void* left_hwc, const void* right_hwc, int is_
                             int H, int W, int Hp, int Wp,
                             const float* mean3, const float* std3,
                             float* out, int layout, void* stream);
+
+/* ---- f16 arithmetic mode (r4): the autocast arithmetic of the reference's AMP configs ----
+ * cfgs/stereobase/stereobase_sceneflow.yaml:50, cfgs/lightstereo/lightstereo_s_sceneflow.yaml:36, cfgs/igev/igev_sceneflow_amp.yaml:40 set
+ * AMP: true and stereo/trainer/trainer_template.py:211,281 wraps every forward in torch.autocast: convolutions then multiply fp16 operands
+ * and accumulate in fp32.  These entry points do the same on the MFMA engine: operands rounded to fp16 (nearest even), ONE
+ * v_mfma_f32_32x32x16_f16 per product (the f16x3 mode spends three), fp32 accumulation, fp32 BN / bias / activation epilogue.
+ * Tensors are fp32 NDHWC, or fp16 NDHWC where the flags below (OR'ed into `act`) say so; channel counts and strides are in ELEMENTS of
+ * each tensor, fp16 tensors need them % 8 == 0.  An fp16 output takes an fp16 residual.  No operand scaling and no range blocks: values
+ * beyond 65504 become inf exactly as under autocast.  Same argument lists as the *_f32 calls otherwise; weights packed with *_pack_f16
+ * (buffer sizes: the *_packed_floats functions, an upper bound here). */
+enum { OSA_IN_F16 = 32, OSA_OUT_F16 = 64, OSA_RES_F16 = 128 };
+int osa_conv3d_pack_f16(const float* w_ref, float* w_packed, int Ci, int Co, int kd, int kh, int kw, void* stream);
+int osa_deconv3d_pack_f16(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad, void* stream);
+int osa_deconv2d_pack_f16(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad, void* stream);
+int osa_conv3d_ndhwc_f16(const void* x, const float* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+                         int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int kd, int kh, int kw, int stride,
+                         int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w, const float* gate_logits, int gCs,
+                         int act, float slope, void* stream);
+int osa_deconv3d_ndhwc_f16(const void* x, const float* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+                           int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int k, int pad, int opad,
+                           const float* gate_logits, int gCs, int act, float slope, void* stream);
+int osa_deconv2d_nhwc_f16(const void* x, const float* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+                          int B, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int k, int pad, int opad,
+                          const float* gate_logits, int gCs, int act, float slope, void* stream);
+
+/* ---- d-marching form of the 3x3x3 stride-1 convolutions with 32 output channels (r4, csrc/conv_march.h) ----
+ * osa_conv3d_ndhwc_f16x3 runs eligible layers (3x3x3, stride 1, padding 1, Ci % 32 == 0, Co == 32, no gate: GwcNet / PSMNet dres0,
+ * dres1, classif*.0 -- gwcnet_disp_processor.py:40-81) as workgroups that own a pixel column and walk along d, each staged input plane
+ * feeding three output planes.  Same arguments, same semantics; results agree with the brick form to fp32 rounding (different summation
+ * order).  This counter tells how many calls of this process took that form (tests assert that the intended layers do). */
+long long osa_conv3d_march_launches(void);
 
 #ifdef __cplusplus
 }

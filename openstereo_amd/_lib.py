@@ -149,6 +149,29 @@ SIGNATURES = {
     "osa_geo_lookup_bwd_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
                                      c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_preprocess_pair_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_fp, c_i, c_st]),
+    "osa_conv3d_pack_f16": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_deconv3d_pack_f16": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
+    "osa_deconv2d_pack_f16": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
+    "osa_conv3d_ndhwc_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                   c_i, c_i, c_i, c_i, c_i, c_i,
+                                   c_i, c_i, c_i,
+                                   c_i, c_i, c_i, c_i,
+                                   c_i, c_i, c_i,
+                                   c_i, c_i, c_i,
+                                   c_fp, c_i,
+                                   c_i, c_f, c_st]),
+    "osa_deconv3d_ndhwc_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                     c_i, c_i, c_i, c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_i, c_i, c_i,
+                                     c_fp, c_i,
+                                     c_i, c_f, c_st]),
+    "osa_deconv2d_nhwc_f16": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                    c_i, c_i, c_i, c_i, c_i,
+                                    c_i, c_i, c_i,
+                                    c_i, c_i, c_i,
+                                    c_fp, c_i, c_i, c_f, c_st]),
+    "osa_conv3d_march_launches": (c_ll, []),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
@@ -173,10 +196,15 @@ def load():
                 "(hipcc, gfx950). There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)   # AttributeError if the .so does not export it
+            try:
+                fn = getattr(lib, name)   # AttributeError if the .so does not export it
+            except AttributeError:
+                if os.environ.get("OSA_LIB_PATH"):      # A/B experiment builds may predate an entry point; the shipped library may not
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
-        if lib.osa_abi_version() != 3:
+        if lib.osa_abi_version() != 4:
             raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}")
         _lib = lib
     return _lib

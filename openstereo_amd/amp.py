@@ -1,10 +1,11 @@
 """torch.autocast contract of the drop-in surface (reference: trainer_template.py:205-230,281 run every forward under
 `torch.cuda.amp.autocast(enabled=cfgs.OPTIMIZATION.AMP)`; cfgs/igev/igev_sceneflow_amp.yaml is the AMP config BASELINE configs[4] names).
 
-The engine computes in fp32-class arithmetic whatever the autocast region says -- lower precision would not make the HIP kernels faster
-(HBM tensors are fp32, the matrix-core work is already fp16 hi/lo splits) and the point of the f16x3 mode is fp32-class results.  What a
-caller of the reference's functions / modules relies on under autocast is the DTYPE of what comes back (the next torch op promotes against
-it) and values within fp16 tolerance of the eager composition.  Rules, derived from PyTorch's CUDA autocast op lists applied to the
+Arithmetic: inside an fp16 autocast region (inference, no_grad) the engine layers run the native f16 mode (r4, engine.effective_precision:
+fp16 operands, one MFMA per product, fp32 accumulate -- what the reference's autocast convolutions compute, a third of the matrix work of
+the f16x3 mode); bf16 regions, training and OSA_AUTOCAST_NATIVE=0 keep the global fp32-class mode.  Either way, what a caller of the
+reference's functions / modules relies on under autocast is the DTYPE of what comes back (the next torch op promotes against it) and
+values within low-precision tolerance of the eager composition.  Rules, derived from PyTorch's CUDA autocast op lists applied to the
 reference's code:
 
   * convolutions (`conv2d/3d`, `conv_transpose2d/3d`) are on the lower-precision list: a module whose forward ends in a convolution

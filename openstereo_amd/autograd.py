@@ -466,10 +466,17 @@ class _ConvTranspose2d(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+def _train_precision(precision):
+    """arithmetic mode of the differentiable convolutions: the requested / global one, except that the inference-only "f16" mode
+    (engine.PRECISIONS) trains on the f16x3 kernels"""
+    p = precision or engine.get_precision()
+    return "f16x3" if p == "f16" else p
+
+
 def conv_transpose2d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (2, 2)
-    y = _ConvTranspose2d.apply(x, weight, p2(padding)[0], p2(output_padding)[0], precision or engine.get_precision(), _wcache(weight))
+    y = _ConvTranspose2d.apply(x, weight, p2(padding)[0], p2(output_padding)[0], _train_precision(precision), _wcache(weight))
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
@@ -481,14 +488,14 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv3d (groups=1, isotropic stride 1|2) on the engine; output is NDHWC-strided."""
     s = _t3(stride)
     assert s[0] == s[1] == s[2]
-    y = _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), precision or engine.get_precision(), _wcache(weight))
+    y = _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), _train_precision(precision), _wcache(weight))
     return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
 
 
 def conv_transpose3d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
     assert _t3(stride) == (2, 2, 2)
     p, op = _t3(padding)[0], _t3(output_padding)[0]
-    y = _ConvTranspose3d.apply(x, weight, p, op, precision or engine.get_precision(), _wcache(weight))
+    y = _ConvTranspose3d.apply(x, weight, p, op, _train_precision(precision), _wcache(weight))
     return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
 
 
@@ -504,7 +511,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv2d (groups=1, stride 1) on the engine: the D = 1 case of conv3d (forward, dgrad and wgrad kernels)."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (1, 1), "engine conv2d autograd: stride 1 (strided 2-D layers stay torch ops in training)"
-    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), precision or engine.get_precision(), _wcache(weight))
+    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight))
     y = y[:, :, 0]
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIBNAME = "libopenstereo_amd.so"
-SOURCES = ["api.hip", "volume.hip", "conv3d.hip", "softargmin.hip", "layout.hip", "refine.hip", "backward.hip", "wgrad.hip", "geometry.hip", "dwconv.hip"]
+SOURCES = ["api.hip", "volume.hip", "conv3d.hip", "conv_inst_f32.hip", "conv_inst_f16x3.hip", "conv_inst_f16.hip", "conv_march.hip", "softargmin.hip", "layout.hip", "refine.hip", "backward.hip", "wgrad.hip", "geometry.hip", "dwconv.hip"]
 ARCH = "gfx950"
 HIPCC_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
@@ -46,7 +46,7 @@ def lib_path() -> str:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "osa_common.h"), os.path.join(CSRC, "conv_kernel.h"),
+    headers = [os.path.join(CSRC, "osa_common.h"), os.path.join(CSRC, "conv_kernel.h"), os.path.join(CSRC, "conv_march.h"), os.path.join(CSRC, "conv_inst.h"), os.path.join(CSRC, "conv_inst_impl.h"), os.path.join(CSRC, "conv_cfgs.def"),
                os.path.join(HERE, "..", "include", "openstereo_amd.h")]
 
     def compile_one(src: str) -> str:

@@ -1,105 +1,54 @@
 // 3-D cost-aggregation convolutions for gfx950: host side (tile selection, LDS geometry, weight packing, C ABI) and the
 // instantiations of the stage -> barrier -> taps kernel.  Kernel template: conv_kernel.h.
 #include "conv_kernel.h"
+#include "conv_inst.h"
 
 namespace osa {
 
 // ------------------------------------------------------------------ dispatch --
+// Geometry of a tile configuration; the kernels themselves live in per-mode tables (conv_inst.h: one translation unit per arithmetic
+// mode, compiled in parallel).
 struct KernelCfg {
     const char* name;
     int M, N;              // voxels / channels per workgroup
     int TD, TH, TW, threads;
-    void (*fn[2])(const ConvArgs);      // [PREC_F32], [PREC_F16X3]
-    void (*fn3[2])(const ConvArgs);     // same, B-ring pipeline (tap count a multiple of 3); may be null
-    void (*fns[2])(const ConvArgs);     // f16x3 with split output (OUTS = 1): [ping-pong], [B ring or null]
-    int ks;                             // split-K groups inside the workgroup (0 / 1: none)
-};
-
-constexpr int TAPS_PER_ITER = 1;   // taps per half-iteration of the ping-pong pipeline
-#define OSA_CFG(MT, NT, WM, WN, TH, TW)                                                      \
-    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
-      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
-      { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
-        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
-      { conv_mfma_kernel<PREC_F32, 1, 3, MT, NT, WM, WN, TH, TW>,                             \
-        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW> },                         \
-      { conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 1>,         \
-        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW, 0, 1> } }
-
-// same tile without the B ring: at 4 waves per SIMD (128 registers) the ring version of the
-// 256-voxel x 32-channel tile spills, the ping-pong version (116 registers) does not
-#define OSA_CFG_PINGPONG(MT, NT, WM, WN, TH, TW)                                             \
-    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32,               \
-      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64,                                        \
-      { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW>,                 \
-        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW> },             \
-      { nullptr, nullptr },                                                                  \
-      { conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 1>, nullptr } }
-
-// split-K tiles for small maps (conv_kernel.h, KS): KS groups of WM x WN waves share a workgroup, each walks 1 / KS of the input chunks
-#define OSA_CFG_KS(MT, NT, WM, WN, TH, TW, KS)                                               \
-    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW "_ks" #KS, WM * MT * 32, WN * NT * 32,       \
-      WM * MT * 32 / (TH * TW), TH, TW, WM * WN * KS * 64,                                   \
-      { conv_mfma_kernel<PREC_F32, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS>,    \
-        conv_mfma_kernel<PREC_F16X3, 1, TAPS_PER_ITER, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS> },\
-      { conv_mfma_kernel<PREC_F32, 1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS>,                \
-        conv_mfma_kernel<PREC_F16X3, 1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 0, KS> },            \
-      { nullptr, nullptr }, KS }
-static const KernelCfg g_ks_cfgs[] = {
-    OSA_CFG_KS(1, 1, 1, 4, 4, 8, 4),     // 0: 32 pixels x 128 channels, 4 K groups (16 waves)
-    OSA_CFG_KS(1, 1, 2, 2, 4, 16, 4),    // 1: 64 pixels x  64 channels, 4 K groups
-    OSA_CFG_KS(1, 1, 1, 4, 4, 8, 2),     // 2: 32 pixels x 128 channels, 2 K groups
-    OSA_CFG_KS(1, 1, 2, 2, 4, 16, 2),    // 3: 64 pixels x  64 channels, 2 K groups
+    int ks;                // split-K groups inside the workgroup (0 / 1: none)
+    int table, idx;        // 0: ConvFnTables::cfgs[idx], 1: ::ks[idx], 2: ::deconv[idx]
 };
 
 static const KernelCfg g_cfgs[] = {
-    OSA_CFG_PINGPONG(2, 1, 4, 1, 8, 8),   // 0: 256 vox x  32 ch   brick 4x8x8
-    OSA_CFG(2, 2, 4, 1, 8, 8),   // 1: 256 vox x  64 ch   brick 4x8x8
-    OSA_CFG(2, 2, 2, 2, 8, 8),   // 2: 128 vox x 128 ch   brick 2x8x8
-    OSA_CFG(1, 1, 4, 1, 4, 8),   // 3: 128 vox x  32 ch   brick 4x4x8
-    OSA_CFG(1, 2, 4, 1, 4, 8),   // 4: 128 vox x  64 ch   brick 4x4x8
-    OSA_CFG(1, 1, 2, 2, 4, 8),   // 5:  64 vox x  64 ch   brick 2x4x8   (stride-2 layers)
-    OSA_CFG(1, 2, 2, 2, 4, 8),   // 6:  64 vox x 128 ch   brick 2x4x8
-    OSA_CFG_PINGPONG(2, 1, 4, 1, 16, 16), // 7: 256 vox x  32 ch   brick 1x16x16 (2-D layers)
-    OSA_CFG(2, 2, 4, 1, 16, 16), // 8: 256 vox x  64 ch   brick 1x16x16
-    OSA_CFG(2, 2, 2, 2, 8, 16),  // 9: 128 vox x 128 ch   brick 1x8x16
-    OSA_CFG(4, 1, 4, 1, 8, 8),   // 10: 512 vox x 32 ch   brick 8x8x8
-    OSA_CFG(1, 1, 1, 4, 4, 8),   // 11: 32 vox x 128 ch   brick 1x4x8   (tiny layers: more workgroups)
-    OSA_CFG(1, 1, 4, 1, 8, 16),  // 12: 128 vox x 32 ch   brick 1x8x16  (2-D layers, more workgroups)
-    OSA_CFG(1, 2, 4, 1, 8, 16),  // 13: 128 vox x 64 ch   brick 1x8x16
-    OSA_CFG(1, 1, 2, 2, 4, 16),  // 14:  64 vox x 64 ch   brick 1x4x16  (2-D stride-2 layers)
-    OSA_CFG(1, 1, 2, 1, 4, 8),   // 15:  64 vox x 32 ch   brick 2x4x8   (stride-2 layers with <= 32 outputs; 2 waves)
-#ifdef OSA_EXPERIMENTS
-    OSA_CFG_PINGPONG(2, 1, 8, 1, 8, 8),   // 16: 512 vox x 32 ch  brick 8x8x8, 8 waves (halo amplification 1.95x instead of 2.34x)
-    OSA_CFG(2, 2, 8, 1, 8, 8),            // 17: 512 vox x 64 ch  brick 8x8x8, 8 waves
-    // register-tile experiments for the 2-D backbone (B fragments come through the vector-memory path: a 32 px x 64 ch wave issues one
-    // 1 KB weight load per 1.5 MFMAs, a 64 x 64 wave one per 3).  profiles/round3/tiles_2d_B8.txt: 64 x 64 waves on the 64-channel layers
-    // +4 % (inside the run-to-run spread), 8-wave 256 x 128 tiles -14 %; 128 x 64 / 128 x 32 waves (MT = 4, NT = 2 / 1) spill (4-5x slower)
-    // and are not kept.  The weight-load rate is not what holds these layers at 0.26-0.40.
-    OSA_CFG(2, 2, 2, 1, 8, 16),           // 18: 128 px x  64 ch, 2 waves of 64 x 64
-    OSA_CFG(2, 2, 4, 2, 16, 16),          // 19: 256 px x 128 ch, 8 waves of 64 x 64
-#endif
+#define OSA_CFG_X(RING, MT, NT, WM, WN, TH, TW)                                                                  \
+    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW, WM * MT * 32, WN * NT * 32, WM * MT * 32 / (TH * TW), TH, TW, WM * WN * 64, 0, 0, -1 },
+#define OSA_KS_X(MT, NT, WM, WN, TH, TW, KS)
+#include "conv_cfgs.def"
+#undef OSA_CFG_X
+#undef OSA_KS_X
 };
 constexpr int N_CFGS = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
+// split-K tiles for small maps (conv_kernel.h, KS): KS groups of WM x WN waves share a workgroup, each walks 1 / KS of the input chunks
+static const KernelCfg g_ks_cfgs[] = {
+#define OSA_CFG_X(RING, MT, NT, WM, WN, TH, TW)
+#define OSA_KS_X(MT, NT, WM, WN, TH, TW, KS)                                                                     \
+    { #MT "x" #NT "_" #WM "x" #WN "_" #TH "x" #TW "_ks" #KS, WM * MT * 32, WN * NT * 32, WM * MT * 32 / (TH * TW), TH, TW, WM * WN * KS * 64, KS, 1, -1 },
+#include "conv_cfgs.def"
+#undef OSA_CFG_X
+#undef OSA_KS_X
+};
+
 // fused transposed conv: 128 input-resolution positions x 32 channels x 8 parity classes per workgroup
-static const KernelCfg g_deconv_redir_cfg = {
-    "deconv8_redir_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
-    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, 1>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 1> },
-    { nullptr, nullptr }, { conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1>, nullptr } };
-static const KernelCfg g_deconv_redir64_cfg = {
-    "deconv8_redir64_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
-    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8, 2>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 2> },
-    { nullptr, nullptr }, { conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 2, 1>, nullptr } };
-static const KernelCfg g_deconv_cfg = {
-    "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256,
-    { conv_mfma_kernel<PREC_F32, 8, 1, 1, 1, 4, 1, 4, 8>, conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8> },
-    { nullptr, nullptr }, { conv_mfma_kernel<PREC_F16X3, 8, 1, 1, 1, 4, 1, 4, 8, 0, 1>, nullptr } };
+static const KernelCfg g_deconv_redir_cfg = { "deconv8_redir_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256, 0, 2, 0 };
+static const KernelCfg g_deconv_redir64_cfg = { "deconv8_redir64_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256, 0, 2, 1 };
+static const KernelCfg g_deconv_cfg = { "deconv8_1x1_4x1_4x8", 128, 32, 4, 4, 8, 256, 0, 2, 2 };
 // fused 2-D transposed conv (D = 1): 128 input-resolution pixels x 32 channels x 4 parity classes
-static const KernelCfg g_deconv_flat_cfg = {
-    "deconv4_1x1_4x1_8x16", 128, 32, 1, 8, 16, 256,
-    { conv_mfma_kernel<PREC_F32, 4, 1, 1, 1, 4, 1, 8, 16>, conv_mfma_kernel<PREC_F16X3, 4, 1, 1, 1, 4, 1, 8, 16> },
-    { nullptr, nullptr }, { nullptr, nullptr } };
+static const KernelCfg g_deconv_flat_cfg = { "deconv4_1x1_4x1_8x16", 128, 32, 1, 8, 16, 256, 0, 2, 3 };
+
+static const KernelFns& fns_of(const KernelCfg& k, int prec) {
+    const ConvFnTables& t = (prec == PREC_F32) ? conv_tables_f32() : ((prec == PREC_F16X3) ? conv_tables_f16x3() : conv_tables_f16());
+    if (k.table == 0) return t.cfgs[&k - g_cfgs];
+    if (k.table == 1) return t.ks[&k - g_ks_cfgs];
+    return t.deconv[k.idx];
+}
 
 static int pick_cfg(const ConvArgs& a, int stride) {
     {
@@ -190,9 +139,9 @@ static int launch_conv_pipe(ConvArgs& a, int stride, int prec, hipStream_t st, c
     if (a.Ad < 2) return 0;                            // flat (2-D) maps: the 3-D bricks below would idle 3 of their 4 planes
     const int tile = (a.CoP == 32) ? 0 : ((a.CoP == 64) ? 1 : ((a.CoP == 128) ? 2 : -1));
     if (tile < 0) return 0;
-    static const KernelCfg shapes[3] = { {"pipe_2x1_4x1_8x8", 256, 32, 4, 8, 8, 256, {}, {}, {}},
-                                         {"pipe_2x2_4x1_8x8", 256, 64, 4, 8, 8, 256, {}, {}, {}},
-                                         {"pipe_2x2_2x2_8x8", 128, 128, 2, 8, 8, 256, {}, {}, {}} };
+    static const KernelCfg shapes[3] = { {"pipe_2x1_4x1_8x8", 256, 32, 4, 8, 8, 256, 0, 3, -1},
+                                         {"pipe_2x2_4x1_8x8", 256, 64, 4, 8, 8, 256, 0, 3, -1},
+                                         {"pipe_2x2_2x2_8x8", 128, 128, 2, 8, 8, 256, 0, 3, -1} };
     const KernelCfg& k = shapes[tile];
     if ((long long)a.Di * a.Hi * a.Wi * a.xCs * 4 >= (1ll << 32)) return 0;          // per-row buffer descriptors: 32-bit byte counts
     a.tilesD = cdiv(a.Ad, k.TD); a.tilesH = cdiv(a.Ah, k.TH); a.tilesW = cdiv(a.Aw, k.TW);
@@ -273,6 +222,9 @@ static void set_stagger(ConvArgs& a, const KernelCfg& k, void (*fn)(const ConvAr
     if (exp_int("OSA_STAG_PRINT", 0)) fprintf(stderr, "[stagger] %s slots %d tap %.2f us mem %.2f us step %.2f us\n", k.name, slots, tap_us, mem_us, step_us);
 }
 
+// d-marching form of the 3x3x3 stride-1 32-output-channel layers (f16x3): conv_march.hip.  1 = launched, 0 = not eligible, -1 = error
+int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
+
 static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what,
                        const KernelCfg* forced = nullptr) {
 #ifdef OSA_EXPERIMENTS
@@ -342,7 +294,17 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         OSA_REQUIRE(ovox * cs < (1ll << 31), "%s: one batch item of the output exceeds 2^31 elements", what);
         OSA_REQUIRE((long long)a.Di * a.Hi * a.Wi * a.xCs < (1ll << 31), "%s: one batch item of the input exceeds 2^31 elements", what);
     }
-    if (a.act & (OSA_IN_SPLIT | OSA_OUT_SPLIT | OSA_RES_SPLIT | OSA_REDIR_SPLIT)) {
+    if (prec == PREC_F16) {
+        // fp16 tensors (OSA_IN_F16 / OSA_OUT_F16 / OSA_RES_F16): channel strides arrive here in FLOAT units (conv3d_impl / deconv3d_impl halved them)
+        OSA_REQUIRE(!a.rx, "%s: the f16 mode has no fused redir branch", what);
+        if (a.act & OSA_IN_SPLIT) OSA_REQUIRE(a.Ci % 4 == 0 && a.xCs % 4 == 0, "%s: fp16 input needs channels %% 8 == 0", what);
+        if (a.act & OSA_OUT_SPLIT) {
+            OSA_REQUIRE(a.Co % 8 == 0 && a.yCs % 4 == 0 && !a.gate && ((size_t)a.y & 15) == 0, "%s: fp16 output needs Co, yCs %% 8 == 0 and no gate", what);
+            if (a.res) OSA_REQUIRE(a.act & OSA_RES_SPLIT, "%s: an fp16 output takes an fp16 residual", what);
+        }
+        if ((a.act & OSA_RES_SPLIT) && a.res) OSA_REQUIRE(a.Co % 4 == 0 && a.rCs % 2 == 0 && ((size_t)a.res & 7) == 0, "%s: fp16 residual needs Co %% 4 == 0, rCs %% 4 == 0", what);
+        if ((a.act & OSA_RES_SPLIT) && (a.act & OSA_OUT_SPLIT) && a.res) OSA_REQUIRE(a.rCs % 4 == 0 && ((size_t)a.res & 15) == 0, "%s: fp16 residual of an fp16 output needs rCs %% 8 == 0", what);
+    } else if (a.act & (OSA_IN_SPLIT | OSA_OUT_SPLIT | OSA_RES_SPLIT | OSA_REDIR_SPLIT)) {
         OSA_REQUIRE(prec == PREC_F16X3, "%s: split activation tensors exist in the f16x3 mode only", what);
         if (a.act & OSA_IN_SPLIT) OSA_REQUIRE(a.Ci % 16 == 0, "%s: split input needs Ci %% 16 == 0 (got %d)", what, a.Ci);
         if (a.act & OSA_OUT_SPLIT) OSA_REQUIRE(a.Co % 16 == 0 && a.yCs % 16 == 0 && !a.gate && ((size_t)a.y & 15) == 0,
@@ -354,14 +316,16 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     }
     // LDS-DMA staging of split inputs (one global_load_lds_dwordx4 per brick row, no VGPR round trip): +1 % on the whole GwcNet step
     // (interleaved A/B, profiles/round3/ab_dma_s2u.txt); OSA_DMA=0 in the experiments build switches it off
-    a.dma = (exp_int("OSA_DMA", 1) && prec == PREC_F16X3 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0;
+    a.dma = (exp_int("OSA_DMA", 1) && prec != PREC_F32 && (a.act & OSA_IN_SPLIT) && a.VQ == 4 && a.LW * 4 <= 64) ? 1 : 0;
     // tap counts that are multiples of 3 (3x3x3, 3x3) run the B-ring pipeline
     const bool no_ring = exp_set("OSA_NORING");
-    void (*fn)(const ConvArgs) = (k.fn3[prec] && a.T % 3 == 0 && !no_ring) ? k.fn3[prec] : k.fn[prec];
+    const KernelFns& kf = fns_of(k, prec);
+    void (*fn)(const ConvArgs) = (kf.fn3 && a.T % 3 == 0 && !no_ring) ? kf.fn3 : kf.fn;
     if (a.act & OSA_OUT_SPLIT) {
-        fn = (k.fns[1] && a.T % 3 == 0 && !no_ring) ? k.fns[1] : k.fns[0];
-        OSA_REQUIRE(fn != nullptr, "%s: this tile configuration has no split-output variant", what);
+        fn = (kf.fns3 && a.T % 3 == 0 && !no_ring) ? kf.fns3 : kf.fns;
+        OSA_REQUIRE(fn != nullptr, "%s: this tile configuration has no split- / fp16-output variant", what);
     }
+    OSA_REQUIRE(fn != nullptr, "%s: tile configuration %s is not built for this arithmetic mode", what, k.name);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
@@ -420,6 +384,27 @@ __global__ __launch_bounds__(256) void pack_weights_f16x3_kernel(const PackArgs 
     }
     const _Float16 hi = (_Float16)v;
     reinterpret_cast<_Float16*>(p.dst)[i] = hl ? (_Float16)(v - (float)hi) : hi;
+}
+
+// f16 image (PREC_F16): chunks of 32 input channels, 16-byte unit index ((((ch*T + t)*2 + hl)*2 + kg)*CoP + co) holds the 8 fp16 values
+// W_t[ci = ch*32 + 16*hl + 8*kg + e][co], e = 0..7, rounded to nearest even (what autocast's cast does to the weights); no scaling.
+__global__ __launch_bounds__(256) void pack_weights_f16_kernel(const PackArgs p) {
+    const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;      // fp16 elements
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = i & 7; size_t r = i >> 3;
+    const int co = r % p.CoP; r /= p.CoP;
+    const int kg = r & 1; r >>= 1;
+    const int hl = r & 1; r >>= 1;
+    const int t = r % p.T; const int ch = r / p.T;
+    const int ci = ch * 32 + 16 * hl + 8 * kg + e;
+    float v = 0.f;
+    if (ci < p.Ci && co < p.Co) {
+        const size_t kvol = (size_t)p.kd * p.kh * p.kw;
+        const size_t kidx = ((size_t)p.kz[t] * p.kh + p.ky[t]) * p.kw + p.kx[t];
+        v = p.transposed ? p.src[((size_t)ci * p.Co + co) * kvol + kidx] : p.src[((size_t)co * p.Ci + ci) * kvol + kidx];
+    }
+    reinterpret_cast<_Float16*>(p.dst)[i] = (_Float16)v;
 }
 
 // Power-of-two weight pre-scale derived ON THE DEVICE from max |w| (training: weights change every optimizer step; a host-side scale
@@ -644,6 +629,9 @@ static void launch_pack(const PackArgs& p, int prec, float wscale, hipStream_t s
     if (prec == PREC_F32) {
         const size_t total = (size_t)p.nchunks * p.T * JO * 2 * p.CoP * 4;
         if (total) hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, p);
+    } else if (prec == PREC_F16) {
+        const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;
+        if (total) hipLaunchKernelGGL(pack_weights_f16_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, p);
     } else {
         const size_t total = (size_t)p.nchunks * p.T * 2 * 2 * p.CoP * 8;
         if (total) hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(cdiv((long long)total, 256)), dim3(256), 0, st, p, wscale);
@@ -659,7 +647,7 @@ static int conv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int Co,
     OSA_REQUIRE(Ci > 0 && Co > 0, "conv3d_pack: bad channels %d->%d", Ci, Co);
     PackArgs p;
     p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
-    p.kd = kd; p.kh = kh; p.kw = kw; p.T = T; p.nchunks = nchunks_of(Ci); p.transposed = src_transposed ? 1 : 0;
+    p.kd = kd; p.kh = kh; p.kw = kw; p.T = T; p.nchunks = (prec == PREC_F16) ? cdiv(Ci, 32) : nchunks_of(Ci); p.transposed = src_transposed ? 1 : 0;
     int t = 0;
     for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int x = 0; x < kw; ++x, ++t) {
         p.kz[t] = (signed char)(flip ? kd - 1 - z : z); p.ky[t] = (signed char)(flip ? kh - 1 - y : y);
@@ -691,7 +679,7 @@ extern "C" int osa_conv3d_pack_ex(const float* w_ref, float* w_packed, int Ci, i
                                   int kd, int kh, int kw, int src_transposed, int flip,
                                   int f16x3, float wscale, void* stream) {
     OSA_REQUIRE(wscale > 0.f, "conv3d_pack_ex: wscale must be a positive power of two");
-    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, f16x3 ? PREC_F16X3 : PREC_F32, wscale, stream,
+    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, (f16x3 == 2) ? PREC_F16 : (f16x3 ? PREC_F16X3 : PREC_F32), wscale, stream,
                             src_transposed, flip);
 }
 
@@ -699,6 +687,10 @@ extern "C" int osa_conv3d_pack_f16x3(const float* w_ref, float* w_packed, int Ci
                                      int kd, int kh, int kw, float wscale, void* stream) {
     OSA_REQUIRE(wscale > 0.f, "conv3d_pack_f16x3: wscale must be a positive power of two");
     return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, PREC_F16X3, wscale, stream);
+}
+
+extern "C" int osa_conv3d_pack_f16(const float* w_ref, float* w_packed, int Ci, int Co, int kd, int kh, int kw, void* stream) {
+    return conv3d_pack_impl(w_ref, w_packed, Ci, Co, kd, kh, kw, PREC_F16, 1.f, stream);
 }
 
 extern "C" size_t osa_deconv3d_packed_floats(int Ci, int Co, int k) {
@@ -739,7 +731,7 @@ static int deconv3d_pack_impl(const float* w_ref, float* w_packed, int Ci, int C
     deconv_taps(k, pad, d, flat);
     PackArgs p;
     p.src = w_ref; p.dst = w_packed; p.Ci = Ci; p.Co = Co; p.CoP = pad32(Co);
-    p.kd = flat ? 1 : k; p.kh = k; p.kw = k; p.T = d.T; p.nchunks = nchunks_of(Ci); p.transposed = 1;
+    p.kd = flat ? 1 : k; p.kh = k; p.kw = k; p.T = d.T; p.nchunks = (prec == PREC_F16) ? cdiv(Ci, 32) : nchunks_of(Ci); p.transposed = 1;
     for (int t = 0; t < d.T; ++t) { p.kz[t] = d.kz[t]; p.ky[t] = d.ky[t]; p.kx[t] = d.kx[t]; }
     launch_pack(p, prec, wscale, (hipStream_t)stream, amax_dev, scale_out);
     OSA_LAUNCH_CHECK("deconv3d_pack");
@@ -767,6 +759,13 @@ extern "C" int osa_deconv3d_pack_f16x3(const float* w_ref, float* w_packed, int 
                                        int k, int pad, float wscale, void* stream) {
     OSA_REQUIRE(wscale > 0.f, "deconv3d_pack_f16x3: wscale must be a positive power of two");
     return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16X3, wscale, stream);
+}
+
+extern "C" int osa_deconv3d_pack_f16(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad, void* stream) {
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16, 1.f, stream);
+}
+extern "C" int osa_deconv2d_pack_f16(const float* w_ref, float* w_packed, int Ci, int Co, int k, int pad, void* stream) {
+    return deconv3d_pack_impl(w_ref, w_packed, Ci, Co, k, pad, PREC_F16, 1.f, stream, true);
 }
 
 // ---- 2-D transposed conv (nn.ConvTranspose2d, stride 2): the D = 1 case, 4 parity classes
@@ -802,6 +801,25 @@ static int check_common(const char* what, const float* x, const float* w, float*
     OSA_REQUIRE(((size_t)x & 15) == 0, "%s: x not 16-byte aligned", what);
     OSA_REQUIRE(yCs >= Co, "%s: yCs=%d < Co=%d", what, yCs, Co);
     if (residual) OSA_REQUIRE(rCs >= Co, "%s: rCs=%d < Co=%d", what, rCs, Co);
+    return 0;
+}
+
+// f16 mode: the C ABI gives channel counts / strides in ELEMENTS of each tensor; the kernel addresses every tensor through float
+// pointers, so an fp16 tensor's stride (and, for the input, its channel count) is halved here.  A chunk is 32 input channels.
+static int f16_units(ConvArgs& a, const char* what) {
+    a.nchunks = cdiv(a.Ci, 32);
+    if (a.act & OSA_IN_SPLIT) {
+        OSA_REQUIRE(a.Ci % 8 == 0 && a.xCs % 8 == 0, "%s: fp16 input needs Ci, xCs %% 8 == 0 (got %d / %d)", what, a.Ci, a.xCs);
+        a.Ci /= 2; a.xCs /= 2;
+    }
+    if (a.act & OSA_OUT_SPLIT) {
+        OSA_REQUIRE(a.yCs % 8 == 0, "%s: fp16 output needs yCs %% 8 == 0 (got %d)", what, a.yCs);
+        a.yCs /= 2;
+    }
+    if ((a.act & OSA_RES_SPLIT) && a.res) {
+        OSA_REQUIRE(a.rCs % 4 == 0, "%s: fp16 residual needs rCs %% 4 == 0 (got %d)", what, a.rCs);
+        a.rCs /= 2;
+    }
     return 0;
 }
 
@@ -844,7 +862,13 @@ static int conv3d_impl(const float* x, const float* w_packed,
     }
     a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
     a.act = act; a.slope = slope; a.oscale = oscale;
+    if (prec == PREC_F16 && f16_units(a, "conv3d")) return -1;
     set_ranges(a, rng);
+    if (prec == PREC_F16X3 && kd == 3 && kh == 3 && kw == 3 && stride == 1 && a.isd == 1 && pad_d == 1 && pad_h == 1 && pad_w == 1 &&
+        dil_d == 1 && dil_h == 1 && dil_w == 1) {
+        const int r = launch_conv_march(a, (hipStream_t)stream, "conv3d (march)");
+        if (r != 0) return r < 0 ? r : 0;
+    }
     return launch_conv(a, stride, prec, (hipStream_t)stream, "conv3d");
 }
 
@@ -863,6 +887,15 @@ extern "C" int osa_conv3d_ndhwc_f32(OSA_CONV_PARAMS, void* stream) {
 
 extern "C" int osa_conv3d_ndhwc_f16x3(OSA_CONV_PARAMS, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
     return conv3d_impl(OSA_CONV_ARGS, PREC_F16X3, out_scale, stream, ranges);
+}
+
+// f16 mode (PREC_F16): x / residual / y are fp32 tensors, or fp16 tensors where OSA_IN_F16 / OSA_RES_F16 / OSA_OUT_F16 say so
+extern "C" int osa_conv3d_ndhwc_f16(const void* x_, const float* w_packed, const float* scale, const float* shift, const void* residual_, void* y_,
+                                    int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int kd, int kh, int kw, int stride,
+                                    int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w, const float* gate_logits, int gCs,
+                                    int act, float slope, void* stream) {
+    const float* x = static_cast<const float*>(x_); const float* residual = static_cast<const float*>(residual_); float* y = static_cast<float*>(y_);
+    return conv3d_impl(OSA_CONV_ARGS, PREC_F16, 1.f, stream);
 }
 
 static int deconv3d_impl(const float* x, const float* w_packed,
@@ -899,6 +932,7 @@ static int deconv3d_impl(const float* x, const float* w_packed,
     for (int c = 0; c < 8; ++c) a.cls_end[c] = d.cls_end[c];
     a.nchunks = nchunks_of(Ci); a.CoP = pad32(Co);
     a.act = act; a.slope = slope; a.oscale = oscale;
+    if (prec == PREC_F16 && f16_units(a, flat ? "deconv2d" : "deconv3d")) return -1;
     if (rx) {
         OSA_REQUIRE(!flat && !residual && !gate_logits, "deconv3d_redir: residual / gate cannot be combined with the fused redir branch");
         OSA_REQUIRE(rw_packed && rCi > 0 && rCi <= 64 && rCi % 4 == 0 && rxCs >= rCi && rxCs % 4 == 0 && ((size_t)rx & 15) == 0,
@@ -926,6 +960,13 @@ extern "C" int osa_deconv3d_ndhwc_f32(OSA_DECONV_PARAMS, void* stream) {
 
 extern "C" int osa_deconv3d_ndhwc_f16x3(OSA_DECONV_PARAMS, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
     return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16X3, out_scale, stream, false, nullptr, 0, 0, nullptr, nullptr, nullptr, 1.f, ranges);
+}
+
+extern "C" int osa_deconv3d_ndhwc_f16(const void* x_, const float* w_packed, const float* scale, const float* shift, const void* residual_, void* y_,
+                                      int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int k, int pad, int opad,
+                                      const float* gate_logits, int gCs, int act, float slope, void* stream) {
+    const float* x = static_cast<const float*>(x_); const float* residual = static_cast<const float*>(residual_); float* y = static_cast<float*>(y_);
+    return deconv3d_impl(OSA_DECONV_ARGS, PREC_F16, 1.f, stream);
 }
 
 // transposed conv with the 1x1x1 redir branch computed in its epilogue (see ConvArgs::rx)
@@ -959,6 +1000,13 @@ extern "C" int osa_deconv2d_nhwc_f32(OSA_DECONV2D_PARAMS, void* stream) {
 
 extern "C" int osa_deconv2d_nhwc_f16x3(OSA_DECONV2D_PARAMS, float out_scale, const osa_f16x3_ranges* ranges, void* stream) {
     return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F16X3, out_scale, stream, true, nullptr, 0, 0, nullptr, nullptr, nullptr, 1.f, ranges);
+}
+
+extern "C" int osa_deconv2d_nhwc_f16(const void* x_, const float* w_packed, const float* scale, const float* shift, const void* residual_, void* y_,
+                                     int B, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int k, int pad, int opad,
+                                     const float* gate_logits, int gCs, int act, float slope, void* stream) {
+    const float* x = static_cast<const float*>(x_); const float* residual = static_cast<const float*>(residual_); float* y = static_cast<float*>(y_);
+    return deconv3d_impl(OSA_DECONV2D_ARGS, PREC_F16, 1.f, stream, true);
 }
 
 __global__ __launch_bounds__(256) void small_co_pack_kernel(const float* __restrict__ src, float* __restrict__ dst,

@@ -42,7 +42,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //              fp32-class accuracy (dropped term Alo.Blo ~ 2^-22 relative).  Weights are pre-scaled
 //              by a power of two into the fp16 normal range (undone exactly in the epilogue);
 //              activations are saturated to +-65504 when split.
-enum { PREC_F32 = 0, PREC_F16X3 = 1 };
+//   PREC_F16   the autocast arithmetic of the reference's AMP configs (cfgs/stereobase, cfgs/lightstereo, cfgs/igev *_amp:
+//              trainer_template.py:211,281 wrap every forward in torch.autocast): operands rounded to fp16 (nearest even), ONE
+//              v_mfma_f32_32x32x16_f16 per product, fp32 accumulation, fp32 epilogue.  A staged chunk is 32 input channels
+//              ([ch 0-15 | ch 16-31], the same 64-byte LDS image as an f16x3 chunk of 16), activations may live in HBM as fp16
+//              NDHWC tensors (OSA_IN_F16 / OSA_OUT_F16 / OSA_RES_F16 = the *_SPLIT flag bits), no operand scaling: values beyond
+//              65504 become inf exactly as they do under autocast.
+enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 constexpr int CC = 16;        // input channels staged per pass (packed-weight format constant)
 constexpr int VS = CC + 4;    // LDS voxel stride in floats
@@ -183,8 +189,8 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
 #pragma unroll
                 for (int cl = 0; cl < NCL; ++cl) {
                     float4* dst = smem + cl * brickQ;
-                    if constexpr (PREC == PREC_F32) {
-                        dst[lo[u]] = v[u][cl];
+                    if constexpr (PREC == PREC_F32 || PREC == PREC_F16) {
+                        dst[lo[u]] = v[u][cl];          // (f16 mode: this function stages fp16 tensors -- a 16-byte quad = 8 channels; fp32 inputs: stage_brick_cvt16)
                     } else {
                         if (p.act & OSA_IN_SPLIT) { dst[lo[u]] = v[u][cl]; continue; }   // already [hi | lo] in HBM
                         // voxel image: [16 x fp16 hi | 16 x fp16 lo]; this quad's 4 channels -> 8 B each
@@ -198,6 +204,57 @@ __device__ __forceinline__ void stage_brick(const ConvArgs& p, float4* smem, int
                         s2[vbase + 4 + c4] = l2;
                     }
                 }
+            }
+    }
+}
+
+// f16 mode, fp32 input tensor: chunk `c0 / CC` covers the 32 channels [2 c0, 2 c0 + 32); an item is (voxel, 8-channel group): two
+// float4 loads, rounded to nearest-even fp16 (what `.half()` / autocast's cast does), one 16-byte LDS store.
+__device__ __forceinline__ float4 cvt8_f16(const float4 a, const float4 b) {
+    const f16x8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+    return __builtin_bit_cast(float4, h);
+}
+template <int NTHR, int NCL, int SU = OSA_STAGE_U>
+__device__ __forceinline__ void stage_brick_cvt16(const ConvArgs& p, float4* smem, int brickQ, int b, int c0,
+                                                  int g0d, int g0h, int g0w, int tid) {
+    constexpr int U = (NCL == 1) ? SU / 2 : SU / 4;
+    static_assert(U >= 1, "staging depth");
+    const int total = p.LD * p.LH * p.LW * (CC / 4);
+    const int LHW = p.LH * p.LW;
+    const float* xb = p.x + (size_t)b * p.Di * p.Hi * p.Wi * p.xCs + 2 * c0;
+    for (int base = tid; base < total; base += NTHR * U) {
+        float4 v[U][NCL][2];
+        int lo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = base + u * NTHR;
+            lo[u] = -1;
+#pragma unroll
+            for (int cl = 0; cl < NCL; ++cl) v[u][cl][0] = v[u][cl][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < total) {
+                const int c4 = it & 3, vx = it >> 2;
+                const int ld = __umulhi((unsigned)vx, p.magicHW);
+                const int r = vx - ld * LHW;
+                const int lh = __umulhi((unsigned)r, p.magicW);
+                const int lw = r - lh * p.LW;
+                const int gd = g0d + ld, gh = g0h + lh, gw = g0w + lw;
+                lo[u] = ld * p.PlaneQ + lh * p.RowQ + lw * p.VQ + c4;
+                if (((unsigned)gd < (unsigned)p.Di) && ((unsigned)gh < (unsigned)p.Hi) && ((unsigned)gw < (unsigned)p.Wi)) {
+                    const float* src = xb + ((gd * p.Hi + gh) * p.Wi + gw) * p.xCs + c4 * 8;
+#pragma unroll
+                    for (int cl = 0; cl < NCL; ++cl) {
+                        const int c = 2 * c0 + cl * 2 * CC + c4 * 8;
+                        if (c < p.Ci) v[u][cl][0] = *reinterpret_cast<const float4*>(src + cl * 2 * CC);
+                        if (c + 4 < p.Ci) v[u][cl][1] = *reinterpret_cast<const float4*>(src + cl * 2 * CC + 4);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lo[u] >= 0) {
+#pragma unroll
+                for (int cl = 0; cl < NCL; ++cl) (smem + cl * brickQ)[lo[u]] = cvt8_f16(v[u][cl][0], v[u][cl][1]);
             }
     }
 }
@@ -452,6 +509,15 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                                 ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].z, Bc[u][j][n].z, ac[m][n], 0, 0, 0);
                                 ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[u][j][m].w, Bc[u][j][n].w, ac[m][n], 0, 0, 0);
                             }
+                } else if constexpr (PREC == PREC_F16) {
+                    // [0] = channels 0-15, [1] = channels 16-31 of this 32-channel chunk: one MFMA each
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ac[u][0][m]), __builtin_bit_cast(f16x8, Bc[u][0][n]), ac[m][n], 0, 0, 0);
+                            ac[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ac[u][1][m]), __builtin_bit_cast(f16x8, Bc[u][1][n]), ac[m][n], 0, 0, 0);
+                        }
                 } else {
                     // [0] = hi halves, [1] = lo halves of the 16 channels of this chunk (K = 16 per MFMA);
                     // small cross terms first, then hi.hi
@@ -560,7 +626,10 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         const int tid_g = tid - kg * (NW * 64);
         for (int i = 0; i < cpg; ++i) {
             if (i) __syncthreads();
-            if (!(p.dbg & 1)) stage_brick<NW * 64, PREC, 1>(p, smem + kg * brickQ, brickQ, b, (kg * cpg + i) * CC, g0d, g0h, g0w, tid_g, s_in);
+            if (!(p.dbg & 1)) {
+                if (PREC == PREC_F16 && !(p.act & OSA_IN_SPLIT)) stage_brick_cvt16<NW * 64, 1>(p, smem + kg * brickQ, brickQ, b, (kg * cpg + i) * CC, g0d, g0h, g0w, tid_g);
+                else stage_brick<NW * 64, PREC, 1>(p, smem + kg * brickQ, brickQ, b, (kg * cpg + i) * CC, g0d, g0h, g0w, tid_g, s_in);
+            }
             __syncthreads();
             sm = smem + kg * brickQ;
             chunk_taps([]() {});
@@ -594,9 +663,16 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         if (ch0) __syncthreads();
         OSA_TRACE(trace_ev); ++trace_ev;                 // pass start (after the previous pass's readers are done)
         const int ncl = (p.nchunks - ch0 < p.cps) ? (p.nchunks - ch0) : p.cps;
-        if (!(p.dbg & 1) && PREC == PREC_F16X3 && p.dma) {
+        if (!(p.dbg & 1) && PREC != PREC_F32 && p.dma) {
             for (int cl = 0; cl < ncl; ++cl)
                 stage_brick_dma<NW * 64>(p, smem + cl * brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+        } else if (!(p.dbg & 1) && PREC == PREC_F16 && !(p.act & OSA_IN_SPLIT)) {
+            constexpr int SU = OSA_S2TILE ? OSA_S2_U : OSA_STAGE_U;
+            int cl = 0;
+            for (; cl + 2 <= ncl; cl += 2)
+                stage_brick_cvt16<NW * 64, 2, SU>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
+            if (cl < ncl)
+                stage_brick_cvt16<NW * 64, 1, SU>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid);
         } else if (!(p.dbg & 1)) {
             constexpr int SU = OSA_S2TILE ? OSA_S2_U : OSA_STAGE_U;
             int cl = 0;
@@ -694,7 +770,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
     // 256-voxel x 32-channel tile of the dominant 32 -> 32 layers: two tiles per wave and 4 waves per SIMD hide the waits anyway, and
     // the second code path costs it 6 registers at its 128 cap (measured -1.5 % on that launch).  The f32 mode keeps the predicated
     // code everywhere: its 4-waves-per-SIMD tiles would spill.
-    constexpr bool FASTC = (PREC == PREC_F16X3) && (REDIR != 2) && !(NCLS == 1 && MT == 2 && NT == 1);
+    constexpr bool FASTC = (PREC != PREC_F32) && (REDIR != 2) && !(NCLS == 1 && MT == 2 && NT == 1);
     const bool fast = FASTC && (a0d + TD <= p.Ad) && (a0h + TH <= p.Ah) && (a0w + TW <= p.Aw) && (n0 + WN * NT * 32 <= p.Co) &&
                       vec4 && !p.gate && actk <= OSA_ACT_RELU6 && !(p.act & OSA_RES_AFTER_ACT) && !(p.dbg & (32 | 64));
     // A wave finalises NI = MT*NCLS*NT tiles of 32 voxels x 32 channels one after the other.  The
@@ -706,7 +782,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
 #ifndef OSA_PD_REDIR
 #define OSA_PD_REDIR 2
 #endif
-    constexpr int PD = REDIR ? ((REDIR == 1) ? OSA_PD_REDIR : 2) : ((NCLS >= 4) ? ((PREC == PREC_F16X3 && NCLS == 8) ? 2 : 3) : ((NI < 2) ? NI : 2));
+    constexpr int PD = REDIR ? ((REDIR == 1) ? OSA_PD_REDIR : 2) : ((NCLS >= 4) ? ((PREC != PREC_F32 && NCLS == 8) ? 2 : 3) : ((NI < 2) ? NI : 2));
     // voxel bookkeeping of the 4 rows (vsub + 8k) this lane finalises in M tile m
     auto rows_of = [&](auto F, int m, int (&v0)[4], int (&g0)[4], bool (&vok)[4]) {
         constexpr bool FULL = decltype(F)::value;
@@ -749,6 +825,9 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                     const uint2 h = *reinterpret_cast<const uint2*>(rs + split_off_hi(co));
                     const uint2 l = *reinterpret_cast<const uint2*>(rs + split_off_lo(co));
                     rv[k] = __builtin_bit_cast(float4, make_uint4(h.x, h.y, l.x, l.y));     // decoded in finish()
+                } else if (PREC == PREC_F16 && (p.act & OSA_RES_SPLIT)) {                 // fp16 residual (rCs in float units): decoded here
+                    const f16x4 h = __builtin_bit_cast(f16x4, *reinterpret_cast<const uint2*>(resb + (v0[k] + coff) * p.rCs + (co >> 1)));
+                    rv[k] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
                 } else if (vec4) rv[k] = *reinterpret_cast<const float4*>(rp);
                 else {
                     float* rr = &rv[k].x;
@@ -860,17 +939,19 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         const int co = n0 + (wn * NT + n) * 32 + c8;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            // f16x3: 8 hi + 8 lo halves of the split residual; f16: the 8 fp16 values themselves (one 16-byte row, rCs in float units)
+            const int roff = (PREC == PREC_F16) ? (co >> 1) : ((co >> 4) * 16 + ((co & 15) >> 3) * 4);
             if constexpr (FULL) {
-                const float* rs = rbase + (((v0[k] + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4) & rmask);
+                const float* rs = rbase + (((v0[k] + coff) * p.rCs + roff) & rmask);
                 rv[2 * k] = *reinterpret_cast<const float4*>(rs);
-                rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);
+                if constexpr (PREC != PREC_F16) rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);
                 continue;
             }
             rv[2 * k] = make_float4(0.f, 0.f, 0.f, 0.f); rv[2 * k + 1] = rv[2 * k];
             if (p.res && vok[k] && co < p.Co) {
-                const float* rs = resb + (v0[k] + coff) * p.rCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                const float* rs = resb + (v0[k] + coff) * p.rCs + roff;
                 rv[2 * k] = *reinterpret_cast<const float4*>(rs);            // 8 hi halves
-                rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);    // 8 lo halves
+                if constexpr (PREC != PREC_F16) rv[2 * k + 1] = *reinterpret_cast<const float4*>(rs + 8);    // 8 lo halves
             }
         }
     };
@@ -900,8 +981,13 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((FULL && !REDIR) || p.res) {
                     const uint4 hb = __builtin_bit_cast(uint4, rv[2 * k]), lb = __builtin_bit_cast(uint4, rv[2 * k + 1]);
-                    r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
-                    r = mul4(r, s_res_inv);
+                    if constexpr (PREC == PREC_F16) {
+                        const f16x4 q = __builtin_bit_cast(f16x4, h2 ? make_uint2(hb.z, hb.w) : make_uint2(hb.x, hb.y));
+                        r = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+                    } else {
+                        r = h2 ? join_f16(make_uint2(hb.z, hb.w), make_uint2(lb.z, lb.w)) : join_f16(make_uint2(hb.x, hb.y), make_uint2(lb.x, lb.y));
+                        r = mul4(r, s_res_inv);
+                    }
                     if constexpr (FULL) r = make_float4(has_res ? r.x : 0.f, has_res ? r.y : 0.f, has_res ? r.z : 0.f, has_res ? r.w : 0.f);
                 }
                 const float a4[4] = {av[k][h2].x, av[k][h2].y, av[k][h2].z, av[k][h2].w};
@@ -920,12 +1006,19 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                     o[e] = v;
                 }
                 if (vok[k] && cok) am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
-                split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
+                if constexpr (PREC == PREC_F16) {          // fp16 output tensor: round to nearest even, the lane's 8 channels are one 16-byte row
+                    const f16x4 q = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                    hq[h2] = __builtin_bit_cast(uint2, q); lq[h2] = hq[h2];
+                } else split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
             }
             if (FULL || (vok[k] && cok && !(p.dbg & 32))) {
-                float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
-                store16(ys, make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y));
-                store16(ys + 8, make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y));
+                if constexpr (PREC == PREC_F16) {
+                    store16(yb + (v0[k] + coff) * p.yCs + (co >> 1), make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y));     // yCs in float units
+                } else {
+                    float* ys = yb + (v0[k] + coff) * p.yCs + (co >> 4) * 16 + ((co & 15) >> 3) * 4;
+                    store16(ys, make_uint4(hq[0].x, hq[0].y, hq[1].x, hq[1].y));
+                    store16(ys + 8, make_uint4(lq[0].x, lq[0].y, lq[1].x, lq[1].y));
+                }
             }
         }
     };

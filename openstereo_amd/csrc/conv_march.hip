@@ -1,0 +1,89 @@
+// d-marching 3x3x3 convolutions (conv_march.h): instantiations and host-side launch.  A translation unit of its own so that the
+// brick kernel's ~200 instantiations (conv3d.hip) are not recompiled with it.
+#include "conv_march.h"
+
+namespace osa {
+
+// ------------------------------------------------------------------ d-marching form (conv_march.h) --
+// 3x3x3 stride-1 "same" convolutions with 32 output channels in the f16x3 mode.  Returns 1 when launched, 0 when the layer is not
+// eligible (the brick kernel then runs it), -1 on error.
+static long long g_march_launches = 0;
+long long march_launches() { return g_march_launches; }
+
+struct MarchCfg { int nwv, tw, th; size_t lds; void (*fn[2])(const ConvArgs, int, int); };
+#define OSA_MARCH_CFG(NWV, TW) { NWV, TW, MarchGeo<NWV, TW>::TH, MarchGeo<NWV, TW>::lds_bytes(),                      \
+                                 { conv_march_kernel<NWV, TW, 0>, conv_march_kernel<NWV, TW, 1> } }
+static const MarchCfg g_march_cfgs[] = {
+    OSA_MARCH_CFG(2, 16),     // 0:  8 x 16 pixel column, 2 waves, 4 workgroups per CU
+    OSA_MARCH_CFG(4, 32),     // 1:  8 x 32, 4 waves, 2 per CU
+    OSA_MARCH_CFG(4, 16),     // 2: 16 x 16, 4 waves, 2 per CU
+};
+
+int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
+    if (!exp_int("OSA_MARCH", 1)) return 0;
+    if (a.T != 27 || a.Co != 32 || a.CoP != 32 || a.nchunks % 2 != 0 || a.Di < 3 || a.gate || a.rx) return 0;
+    const int actk = a.act & 15;
+    if (actk > OSA_ACT_LEAKY || (a.act & (OSA_GATE_RAW | OSA_RES_AFTER_ACT)) || ((unsigned)a.act >> 16)) return 0;
+    if ((a.yCs & 3) || ((size_t)a.y & 15) || (a.res && ((a.rCs & 3) || ((size_t)a.res & 15)))) return 0;
+    if ((long long)a.Do * a.Ho * a.Wo * (a.yCs > a.rCs ? a.yCs : a.rCs) >= (1ll << 31)) return 0;
+    if ((long long)a.Di * a.Hi * a.Wi * a.xCs >= (1ll << 31)) return 0;
+    if (a.act & OSA_IN_SPLIT) OSA_REQUIRE(a.Ci % 16 == 0, "%s: split input needs Ci %% 16 == 0 (got %d)", what, a.Ci);
+    if (a.act & OSA_OUT_SPLIT) {
+        OSA_REQUIRE(a.yCs % 16 == 0, "%s: split output needs yCs %% 16 == 0", what);
+        if (a.res) OSA_REQUIRE(a.act & OSA_RES_SPLIT, "%s: a split output takes a split residual", what);
+    }
+    if ((a.act & OSA_RES_SPLIT) && a.res) OSA_REQUIRE(a.rCs % 16 == 0, "%s: split residual needs rCs %% 16 == 0", what);
+    // pixel-column shape: least padded area; ties -> the 2-wave 8 x 16 column (4 workgroups per CU, finest grain)
+    int gi = exp_int("OSA_MARCH_GEO", -1);
+    if (gi < 0 || gi > 2) {
+        long long best = -1;
+        for (int i = 0; i < 3; ++i) {
+            const MarchCfg& g = g_march_cfgs[i];
+            const long long area = (long long)cdiv(a.Ho, g.th) * g.th * cdiv(a.Wo, g.tw) * g.tw;
+            if (best < 0 || area < best) { best = area; gi = i; }
+        }
+    }
+    const MarchCfg& g = g_march_cfgs[gi];
+    a.tilesD = 1; a.tilesH = cdiv(a.Ho, g.th); a.tilesW = cdiv(a.Wo, g.tw);
+    a.dmin = a.hmin = a.wmin = -1;
+    a.LD = 1; a.LH = g.th + 2; a.LW = g.tw + 2;
+    a.VQ = 5;
+    a.RowQ = (g.tw == 16) ? ((a.LW * 5 + 15) / 16 * 16) : a.LW * 5;
+    a.PlaneQ = a.LH * a.RowQ;
+    a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    a.magicH = (unsigned)((0x100000000ull + a.LH - 1) / a.LH);
+    a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
+    a.cps = 2; a.dma = 0; a.dbg = exp_int("OSA_DBG", 0);
+    // D segments: a workgroup walks dseg output planes (+ 2 boundary planes that are staged for one third of their taps).  Cost model in
+    // plane-steps: rounds of resident workgroups x (dseg + 2 boundary planes of a cut column, staged and multiplied in full); the fewest segments win a tie.
+    const long long cols = (long long)a.B * a.tilesH * a.tilesW;
+    const long long slots = (long long)((g.nwv == 2) ? 4 : 2) * 256;
+    int nseg = 1;
+    {
+        double best = 1e30;
+        for (int n = 1; n <= 16 && n * 2 <= a.Di; ++n) {
+            const int ds = cdiv(a.Di, n), ns = cdiv(a.Di, ds);
+            if (ns != n) continue;
+            const double cost = (double)((cols * ns + slots - 1) / slots) * (ds + (ns > 1 ? 2.0 : 0.0));
+            if (cost < best - 1e-9) { best = cost; nseg = ns; }
+        }
+        const int o = exp_int("OSA_MARCH_NSEG", 0);
+        if (o > 0 && o * 2 <= a.Di) nseg = o;
+    }
+    const int dseg = cdiv(a.Di, nseg);
+    nseg = cdiv(a.Di, dseg);
+    OSA_REQUIRE(cols * nseg < (1ll << 31), "%s: grid too large", what);
+    void (*fn)(const ConvArgs, int, int) = g.fn[(a.act & OSA_OUT_SPLIT) ? 1 : 0];
+    static bool attr_set[3][2];
+    bool& done = attr_set[gi][(a.act & OSA_OUT_SPLIT) ? 1 : 0];
+    if (!done && g.lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); }
+    done = true;
+    hipLaunchKernelGGL(fn, dim3((unsigned)(cols * nseg)), dim3(g.nwv * 64), g.lds, st, a, dseg, nseg);
+    OSA_LAUNCH_CHECK(what);
+    ++g_march_launches;
+    return 1;
+}
+
+}  // namespace osa
+
+extern "C" long long osa_conv3d_march_launches(void) { return osa::march_launches(); }

@@ -25,7 +25,18 @@ RES_AFTER_ACT = 512    # OR'ed into act (ReLU layers): relu(residual + relu(bn(c
 
 
 def is_split(t) -> bool:
-    return t is not None and getattr(t, "_osa_split", False)
+    """tensor is in an engine-chain storage format: f16x3 split hi/lo (tagged `_osa_split`) or an fp16 tensor of the f16 mode"""
+    return t is not None and (getattr(t, "_osa_split", False) or t.dtype == torch.float16)
+
+
+def chains(precision: str) -> bool:
+    """layers of this arithmetic mode hand each other chain-format tensors (`out_split=True`): split hi/lo in f16x3, fp16 in f16"""
+    return precision in ("f16x3", "f16")
+
+
+def chain_ok(layer) -> bool:
+    """`layer`'s output can be written in its mode's chain format: every 16-channel chunk complete (f16x3) / 8-channel row complete (f16)"""
+    return (layer.precision == "f16x3" and layer.Co % 16 == 0) or (layer.precision == "f16" and layer.Co % 8 == 0)
 
 
 from .ranges import META_FLOATS, new_meta, meta_of, input_meta, ensure_meta, fold_amax, attach_meta   # noqa: E402,F401  (f16x3 operand ranges)
@@ -36,7 +47,10 @@ enable_timing, collect_timing = timing.enable, timing.collect
 # Arithmetic mode of the MFMA convolutions:
 #   "f32"   exact fp32 products on v_mfma_f32_32x32x2_f32
 #   "f16x3" split precision: x = hi + lo (two fp16), Ahi.Bhi + Ahi.Blo + Alo.Bhi, fp32 accumulate
-PRECISIONS = ("f32", "f16x3")
+#   "f16"   the reference's autocast arithmetic (its AMP configs: trainer_template.py:211,281): operands rounded to fp16, one MFMA per
+#           product, fp32 accumulate and epilogue; chained layers hand fp16 NDHWC tensors to each other (`out_split=True` then means
+#           "fp16 output").  Inference only -- training-mode modules run the f16x3 kernels under this setting.
+PRECISIONS = ("f32", "f16x3", "f16")
 _precision = os.environ.get("OSA_PRECISION", "f32")
 assert _precision in PRECISIONS, f"OSA_PRECISION must be one of {PRECISIONS}"
 
@@ -49,6 +63,21 @@ def set_precision(p: str):
 
 
 def get_precision() -> str:
+    return _precision
+
+
+# Inside a `torch.autocast("cuda", dtype=torch.float16)` region the reference's convolutions multiply fp16 operands (its AMP configs:
+# trainer_template.py:211,281).  With AUTOCAST_NATIVE the engine layers built / fetched in such a region use the "f16" mode -- the same
+# arithmetic, one MFMA per product -- instead of the global mode (f16x3 would be correct too: 3x the matrix work for accuracy autocast
+# has already given up).  bf16 autocast regions keep the global mode (no native bf16 kernels).  OSA_AUTOCAST_NATIVE=0 switches it off.
+AUTOCAST_NATIVE = os.environ.get("OSA_AUTOCAST_NATIVE", "1") != "0"
+
+
+def effective_precision() -> str:
+    """arithmetic mode of engine layers packed NOW: the global mode, or "f16" inside an fp16 autocast region (AUTOCAST_NATIVE)"""
+    if AUTOCAST_NATIVE and _precision != "f16" and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16 \
+            and not torch.is_grad_enabled():
+        return "f16"
     return _precision
 
 
@@ -93,7 +122,7 @@ def cached_pack(owner, attr, build, mods=None):
         ent.slots, ent.key, ent.value = _tensor_slots(mods if mods is not None else (owner,)), None, None
         ent.event = ent.stream = ent.synced = None
         object.__setattr__(owner, attr, ent)
-    key = [_precision]
+    key = [effective_precision()]
     for d, n in ent.slots:
         t = d.get(n)
         if t is None:
@@ -138,7 +167,7 @@ class PackedConv3d:
     """conv (or stride-2 transposed conv) + folded BN + activation, weights in MFMA operand order."""
 
     def __init__(self, conv, bn=None, act=ACT_NONE, slope=0.01, precision=None):
-        self.precision = precision or _precision
+        self.precision = precision or effective_precision()
         assert self.precision in PRECISIONS
         w = conv.weight.detach()
         if not w.is_cuda:
@@ -172,6 +201,7 @@ class PackedConv3d:
         self.coef = torch.stack([gain.float(), smax.float()]).contiguous()
         st = _stream()
         f16 = self.precision == "f16x3"
+        h16 = self.precision == "f16"
         self.out_scale = 1.0
         wscale = 1.0
         if f16:
@@ -196,6 +226,8 @@ class PackedConv3d:
             if f16:
                 _lib.call(fam + "_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
                           self.k[1], self.pad[1], wscale, st)
+            elif h16:
+                _lib.call(fam + "_pack_f16", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, self.k[1], self.pad[1], st)
             else:
                 _lib.call(fam + "_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
                           self.k[1], self.pad[1], st)
@@ -208,6 +240,8 @@ class PackedConv3d:
             self.packed = torch.zeros(n, device=w.device, dtype=torch.float32)
             if f16:
                 _lib.call("osa_conv3d_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, wscale, st)
+            elif h16:
+                _lib.call("osa_conv3d_pack_f16", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, st)
             else:
                 _lib.call("osa_conv3d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, st)
 
@@ -234,16 +268,22 @@ class PackedConv3d:
         its epilogue (GwcNet hourglass conv6 + redir1); replaces `residual`.  out_split=True (f16x3 only)
         writes the output as a split tensor (see IN_SPLIT ...); split inputs / residuals are recognised by
         their `_osa_split` tag, so chains of engine layers pass them along without further arguments."""
-        assert is_cl(x) and x.dtype == torch.float32, "engine tensors are fp32 NDHWC"
+        h16 = self.precision == "f16"
+        assert is_cl(x) and (x.dtype == torch.float32 or (h16 and x.dtype == torch.float16)), "engine tensors are fp32 NDHWC (f16 mode: fp32 or fp16)"
         B, Cs, D, H, W = x.shape
-        assert Cs >= x_off + self.Ci and Cs % 4 == 0 and x_off % 4 == 0, f"input has {Cs} channels, layer expects {self.Ci}"
-        Ci = (self.Ci + 3) // 4 * 4     # padded channels of x are zero by construction
+        cpad = 8 if x.dtype == torch.float16 else 4         # 16-byte channel rows
+        assert Cs >= x_off + self.Ci and Cs % cpad == 0 and x_off % cpad == 0, f"input has {Cs} channels, layer expects {self.Ci}"
+        Ci = min((self.Ci + cpad - 1) // cpad * cpad, Cs - x_off)     # padded channels of x are zero by construction
         Do, Ho, Wo = self.out_shape(D, H, W)
         if out is None:
-            CoS = (self.Co + 3) // 4 * 4
-            out = empty_cl(B, CoS, Do, Ho, Wo, x.device)
+            # f16 mode: fp16 output where the chain asks for it and the kernel can write it (complete 8-channel rows, fp16 residual, no gate)
+            o16 = h16 and out_split and self.Co % 8 == 0 and gate is None and (residual is None or residual.dtype == torch.float16)
+            CoS = (self.Co + 7) // 8 * 8 if o16 else (self.Co + 3) // 4 * 4
+            out = empty_cl(B, CoS, Do, Ho, Wo, x.device, torch.float16 if o16 else torch.float32)
             if CoS != self.Co:
                 out.zero_()
+        if h16:
+            out_split = out.dtype == torch.float16          # f16 mode: the chain format is the dtype of the output buffer
         assert is_cl(out) and tuple(out.shape[2:]) == (Do, Ho, Wo) and out.shape[1] >= out_off + self.Co
         yCs = out.shape[1]
         rCs = 0
@@ -255,8 +295,8 @@ class PackedConv3d:
         if gate is not None:
             assert gate.is_contiguous() and tuple(gate.shape[:3]) == (B, Ho, Wo) and gate.shape[3] >= self.Co
             gCs = gate.shape[3]
-        xp, yp = x.data_ptr() + 4 * x_off, out.data_ptr() + 4 * out_off
-        rp = None if residual is None else residual.data_ptr() + 4 * res_off
+        xp, yp = x.data_ptr() + x.element_size() * x_off, out.data_ptr() + out.element_size() * out_off
+        rp = None if residual is None else residual.data_ptr() + residual.element_size() * res_off
         act = self.act | (GATE_RAW if (gate is not None and gate_raw) else 0)
         if gate_channels:
             assert gate is not None and gate_channels % 4 == 0 and 0 < gate_channels <= self.Co
@@ -266,7 +306,12 @@ class PackedConv3d:
             act |= RES_AFTER_ACT
         fmt = (IN_SPLIT if is_split(x) else 0) | (OUT_SPLIT if out_split else 0) | (RES_SPLIT if is_split(residual) else 0) \
             | (REDIR_SPLIT if (redir is not None and is_split(redir[1])) else 0)
-        if fmt:
+        if fmt and h16:
+            assert redir is None and (gate is None or not out_split)
+            assert not (fmt & RES_SPLIT) or res_off % 4 == 0
+            assert not out_split or (self.Co % 8 == 0 and yCs % 8 == 0 and out_off % 8 == 0 and (residual is None or residual.dtype == torch.float16))
+            act |= fmt
+        elif fmt:
             assert self.precision == "f16x3", "split activation tensors exist in the f16x3 mode only"
             assert gate is None
             assert not (fmt & IN_SPLIT) or x_off % 16 == 0          # split layout is per 16-channel chunk
@@ -287,8 +332,9 @@ class PackedConv3d:
         with timing.span("deconv3d" if self.transposed else "conv3d", self.Ci, self.Co, self.k[0], self.stride[1], D, H, W,
                          flops=2 * macs, nbytes=nbytes):
             tail = (self.out_scale, rng, st) if self.precision == "f16x3" else (st,)
-            sfx = "f16x3" if self.precision == "f16x3" else "f32"
+            sfx = self.precision
             if redir is not None:
+                assert not h16, "the f16 mode has no fused redir branch (run the 1x1x1 layer and pass it as residual)"
                 rl, rt = redir
                 assert self.transposed and not self.flat_deconv and residual is None and gate is None
                 assert rl.precision == self.precision and rl.k == (1, 1, 1) and rl.Co == self.Co and rl.act == ACT_NONE
@@ -313,7 +359,7 @@ class PackedConv3d:
                           self.k[0], self.k[1], self.k[2], self.stride[1],
                           self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2],
                           _p(gate), gCs, act, self.slope, *tail)
-        if out_split:
+        if out_split and not h16:
             out._osa_split = True
         return out
 

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import autograd as AG
 from .. import amp, ops, timing
-from ..engine import is_split, cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
+from ..engine import is_split, chains, cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_RELU
 
 
 def run_train(mod, x):
@@ -111,7 +111,7 @@ class _Features(nn.Module):
         pk = self._pack()
         # f16x3: maps that only engine layers read travel in the split hi/lo format (engine.OUT_SPLIT); the
         # l2|l3|l4 buffer the volume builder reads, and anything added to a slice of it, stay plain fp32
-        sp = _SPLIT_ACT and pk["first"][0].precision == "f16x3"
+        sp = _SPLIT_ACT and chains(pk["first"][0].precision)
         x = ops.to_cl(img.unsqueeze(2))                 # [N,4,1,H,W], 4th channel zero
         for conv in pk["first"]:
             x = conv(x, out_split=sp)
@@ -262,11 +262,12 @@ class Hourglass(nn.Module):
         c1 = p["c1"](x, **s)
         c2 = p["c2"](c1, **s)
         c4 = p["c4"](p["c3"](c2, **s), **s)
-        if _FUSE_REDIR and p["r2"].Ci <= 64:
+        fuse = _FUSE_REDIR and p["c5"].precision != "f16"       # (the f16 mode has no fused redir branch: separate 1x1x1 launch)
+        if fuse and p["r2"].Ci <= 64:
             c5 = p["c5"](c4, redir=(p["r2"], c2), **s)  # relu(conv5(c4) + redir2(c2)), redir2 inside conv5's epilogue
         else:
             c5 = p["c5"](c4, residual=p["r2"](c2, **s), **s)
-        if _FUSE_REDIR and p["r1"].Ci <= 32:
+        if fuse and p["r1"].Ci <= 32:
             return p["c6"](c5, redir=(p["r1"], x), **s)  # relu(conv6(c5) + redir1(x)), redir1 inside conv6's epilogue
         return p["c6"](c5, residual=p["r1"](x, **s), **s)    # relu(conv6(c5) + redir1(x))
 
@@ -322,7 +323,7 @@ class GwcDispProcessor(nn.Module):
     def aggregate_cl(self, volume):
         """NDHWC volume -> low-res cost [B,1,D/4,H/4,W/4] (classif3 output)."""
         p = self._pack()
-        split = _SPLIT_ACT and p["d00"].precision == "f16x3"
+        split = _SPLIT_ACT and chains(p["d00"].precision)
         s = dict(out_split=True) if split else {}
         cost0 = p["d02"](p["d00"](volume, **s), **s)
         cost0 = p["d12"](p["d10"](cost0, **s), residual=cost0, **s)      # dres1(cost0) + cost0

@@ -51,8 +51,12 @@ def same(got, want, dt, what, scale=None, exact=None):
     if exact is not None:
         drift = float((want.float() - exact.float()).abs().max()) / s
         bound = max(bound, 2.0 * drift)
-        own = float((got.float() - exact.float()).abs().max()) / s            # the engine's own error: one rounding to dt at the end
-        assert own < tol(dt), f"{what}: engine result is {own:.2e} of max |.| away from the fp32 composition"
+        own = float((got.float() - exact.float()).abs().max()) / s            # the engine's own error
+        from openstereo_amd import engine
+        # fp32-class arithmetic (bf16 regions, OSA_AUTOCAST_NATIVE=0): one rounding to dt at the end.  fp16 regions run the native f16
+        # mode (r4: the reference's own autocast arithmetic, engine.effective_precision): as far from the truth as the eager composition is
+        own_bound = max(tol(dt), 2.0 * drift) if (engine.AUTOCAST_NATIVE and dt == torch.float16) else tol(dt)
+        assert own < own_bound, f"{what}: engine result is {own:.2e} of max |.| away from the fp32 composition (bound {own_bound:.1e})"
     assert err < bound, f"{what}: max err {err:.2e} of max |.| (bound {bound:.1e})"
 
 

@@ -884,6 +884,66 @@ def test_pipelined_conv_on_split_inputs_vs_torch(case):
     close(y[:, :Co], ref, atol=3e-5, rtol=3e-5, what=f"pipelined conv {name}")
 
 
+MARCH_CASES = [
+    # name, Ci, (B, D, H, W), input kind, residual kind, split output, activation
+    ("32 fp32 in, ragged", 32, (2, 7, 11, 21), "plain", None, False, "relu"),
+    ("64 fp32 in (dres0.0)", 64, (1, 9, 17, 33), "plain", None, True, "relu"),
+    ("32 split chain + split res (dres1.2)", 32, (2, 12, 16, 32), "split", "split", True, "none"),
+    ("32 split in, plain res, fp32 out (classif.0-like)", 32, (1, 5, 9, 40), "split", "plain", False, "leaky"),
+    ("32 many columns, uncut D", 32, (3, 16, 40, 48), "split", None, True, "relu"),
+    ("32 D = 3", 32, (1, 3, 8, 16), "plain", None, False, "relu"),
+    ("96 channels (3 passes)", 96, (1, 6, 10, 18), "plain", None, False, "relu"),
+]
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=[c[0] for c in MARCH_CASES])
+def test_conv3d_marching_form_vs_torch(case, lib):
+    """f16x3 3x3x3 stride-1 convolutions with 32 output channels run in the d-marching form (csrc/conv_march.h): pixel columns walked
+    along d with three running output planes.  Ragged H / W, cut and uncut D, 2 / 4 / 6 input chunks, fp32 and split inputs, residuals
+    and outputs, all three activations -- against torch, against the brick form (exact-f32 mode) and bit-identical when repeated; the
+    launch counter proves the form under test is the one that ran."""
+    from openstereo_amd import ops
+    from openstereo_amd.engine import PackedConv3d, is_split
+    name, Ci, (B, D, H, W), in_kind, res_kind, out_split, act = case
+    Co = 32
+    eye = lambda c: (lambda m: (setattr(m.weight, "data", torch.eye(c).reshape(c, c, 1, 1, 1).clone()), m)[1])(nn.Conv3d(c, c, 1, bias=False))
+    conv = nn.Conv3d(Ci, Co, 3, 1, 1, bias=False)
+    conv.weight.data = synth_tensor(name + ".w", conv.weight.shape, 1)
+    bn = _bn_for(Co, 2, name)
+    x = T(np.random.default_rng(3).normal(0, 1, (B, Ci, D, H, W)).astype(np.float32))
+    res = torch.randn(B, Co, D, H, W, generator=torch.Generator().manual_seed(4)) if res_kind else None
+    actf = {"relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.01), "none": lambda t: t}[act]
+    with torch.no_grad():
+        ref = bn(conv(x))
+        if res is not None:
+            ref = ref + res
+        ref = actf(ref)
+    xc = ops.to_cl(x.to(DEV))
+    xs = PackedConv3d(eye(Ci).to(DEV), None, 0, precision="f16x3")(xc, out_split=True) if in_kind == "split" else xc
+    rs = None
+    if res_kind == "plain":
+        rs = ops.to_cl(res.to(DEV))
+    elif res_kind == "split":
+        rs = PackedConv3d(eye(Co).to(DEV), None, 0, precision="f16x3")(ops.to_cl(res.to(DEV)), out_split=True)
+    acode = {"none": 0, "relu": 1, "leaky": 2}[act]
+    pc = PackedConv3d(conv.to(DEV), bn.to(DEV), acode, 0.01, precision="f16x3")
+    n0 = lib.osa_conv3d_march_launches()
+    y = pc(xs, residual=rs, out_split=out_split)
+    assert lib.osa_conv3d_march_launches() == n0 + 1, "the layer did not take the marching form"
+    y2 = pc(xs, residual=rs, out_split=out_split)
+    assert torch.equal(y, y2)
+    assert is_split(y) == out_split
+    if out_split:
+        y = PackedConv3d(eye(Co).to(DEV), None, 0, precision="f16x3")(y)
+    close(y[:, :Co], ref, atol=3e-5, rtol=3e-5, what=f"marching conv {name} vs torch")
+    # the brick form (exact-f32 mode never marches) on fp32 tensors
+    pb = PackedConv3d(conv.to(DEV), bn.to(DEV), acode, 0.01, precision="f32")
+    n1 = lib.osa_conv3d_march_launches()
+    yb = pb(xc, residual=None if res is None else ops.to_cl(res.to(DEV)))
+    assert lib.osa_conv3d_march_launches() == n1
+    close(y[:, :Co], yb[:, :Co], atol=3e-5, rtol=3e-5, what=f"marching conv {name} vs brick form")
+
+
 def test_dormant_volume_variants():
     """CoExCostVolume / compute_volume / build_sub_volume (cost_volume.py:9-29, 44-56, 108-117) on the engine vs the oracle restatements
     (CoEx also vs the reference's own output), incl. maxdisp > W and a ragged width."""

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--set", default="3d", choices=["3d", "2d", "gru"], help="2d: the feature extractor's layers (batch = 2 x --batch images); gru: update-block layers")
     ap.add_argument("--env", default="", help="extra experiment switches for every run, e.g. OSA_CPS=16,OSA_CPS_LDS=150000")
+    ap.add_argument("--split", action="store_true", help="f16x3: split input and split output, as inside the GwcNet aggregation chain (3-D conv layers)")
+    ap.add_argument("--envs", default="", help="semicolon list of experiment-switch sets to sweep per layer, e.g. 'OSA_MARCH=0;OSA_MARCH_GEO=0;OSA_MARCH_GEO=1,OSA_MARCH_NSEG=2' (experiments build)")
     ap.add_argument("--dbgs", default="", help="comma list of OSA_DBG masks to sweep (timing-only kernel ablations)")
     args = ap.parse_args()
     dev = "cuda:0"
@@ -84,6 +86,8 @@ def main():
     cfgs = [None] + [int(c) for c in args.cfgs.split(",") if c != ""]
     if args.dbgs:       # ablation sweep: reuse the cfg loop, value = -(mask) - 1
         cfgs = [None] + [-int(c) - 1 for c in args.dbgs.split(",")]
+    if args.envs:       # switch-set sweep: reuse the cfg loop, value = the "K=V,K=V" string
+        cfgs = [e for e in args.envs.split(";")]
     total = {}
     layers = [l + (1,) for l in LAYERS] if args.set == "3d" else (LAYERS_2D if args.set == "2d" else LAYERS_GRU)
     nb = args.batch * (2 if args.set == "2d" else 1)
@@ -100,6 +104,11 @@ def main():
         x = ops.empty_cl(nb, Ci, *dims, dev)
         x.normal_()
         ranges.ensure_meta(x)          # one range reduction, not one per call
+        split = args.split and kind == "conv" and Ci % 16 == 0 and Co % 16 == 0
+        if split:                      # split image of x through an identity 1x1x1 layer
+            idm = nn.Conv3d(Ci, Ci, 1, bias=False).to(dev)
+            idm.weight.data = torch.eye(Ci, device=dev).reshape(Ci, Ci, 1, 1, 1).clone()
+            x = PackedConv3d(idm, None, 0)(x, out_split=True)
         layer = SmallCoConv3d(m) if kind == "small" else PackedConv3d(m, (nn.BatchNorm2d(Co) if kind == "conv2d" else nn.BatchNorm3d(Co)).to(dev).eval(), 1)
         od = layer.out_shape(*dims) if kind != "small" else dims
         macs = nb * Ci * Co * (k ** (2 if kind == "conv2d" else 3)) * (od[0] * od[1] * od[2]) / (8 if kind == "deconv" else 1)
@@ -107,18 +116,24 @@ def main():
         for cfg in cfgs:
             os.environ.pop("OSA_CONV_CFG", None)
             os.environ.pop("OSA_DBG", None)
-            if cfg is not None and cfg < 0:
+            swept = []
+            if isinstance(cfg, str):
+                for kv in cfg.split(","):
+                    if "=" in kv:
+                        os.environ[kv.split("=")[0]] = kv.split("=")[1]; swept.append(kv.split("=")[0])
+            elif cfg is not None and cfg < 0:
                 os.environ["OSA_DBG"] = str(-cfg - 1)
             elif cfg is not None:
                 os.environ["OSA_CONV_CFG"] = str(cfg)
             try:
+                call = (lambda: layer(x, out_split=True)) if split else (lambda: layer(x))
                 for _ in range(3):
-                    layer(x)
+                    call()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
-                    layer(x)
+                    call()
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / args.iters
@@ -127,6 +142,8 @@ def main():
                     total["auto"] = total.get("auto", 0) + ms * count
             except Exception as ex:  # config not applicable to this layer
                 line += f" | cfg {cfg}: n/a ({str(ex)[:40]})"
+            for k_ in swept:
+                os.environ.pop(k_, None)
         print(line, flush=True)
     os.environ.pop("OSA_CONV_CFG", None)
     os.environ.pop("OSA_DBG", None)
