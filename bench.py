@@ -40,9 +40,11 @@ H_IMG, W_IMG, H_PAD, W_PAD, MAXDISP = 540, 960, 544, 960, 192
 # MI355X_MICROARCH.md dense peaks.  f16x3 executes 3 fp16 MFMAs per fp32-equivalent product, so the roofline for
 # ALGORITHMIC flops in that mode is 2500 / 3.
 PEAKS = {"f32": (157.3, "v_mfma_f32_32x32x2_f32 dense peak"),
-         "f16x3": (2500.0 / 3.0, "fp16 MFMA dense peak 2500 TF / 3 MFMAs per fp32-equivalent product")}
+         "f16x3": (2500.0 / 3.0, "fp16 MFMA dense peak 2500 TF / 3 MFMAs per fp32-equivalent product"),
+         "f16": (2500.0, "fp16 MFMA dense peak (one MFMA per product, fp32 accumulate)")}
 HBM_PEAK = 8000.0          # GB/s (spec; ~6.3 TB/s achievable)
-DTYPES = {"f32": "f32", "f16x3": "f32 via f16x3 split-MFMA (hi/lo fp16 operands, f32 accumulate; HBM tensors f32)"}
+DTYPES = {"f32": "f32", "f16x3": "f32 via f16x3 split-MFMA (hi/lo fp16 operands, f32 accumulate; HBM tensors f32)",
+          "f16": "f16 (the reference's autocast arithmetic: fp16 operands, one MFMA per product, f32 accumulate and epilogue)"}
 # algorithmic work per pair
 DOM_GFLOP = 2 * 27 * 32 * 32 * 48 * 136 * 240 / 1e9       # one 3x3x3 32->32 layer at 48x136x240 (43.32 GMAC)
 BACKBONE_GFLOP = 461.6
@@ -75,9 +77,10 @@ def parse():
     ap.add_argument("--workload", default="gwcnet",
                     choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "stereobase_e2e_train", "gwcnet_train",
                              "stereobase_e2e", "igev_e2e", "lightstereo_e2e"))
-    ap.add_argument("--precision", choices=("f16x3", "f32"), default=os.environ.get("OSA_PRECISION", "f16x3"),
+    ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=os.environ.get("OSA_PRECISION", "f16x3"),
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
+    ap.add_argument("--amp", action="store_true", help="inference workloads: run the step inside torch.autocast(fp16) -- engine layers in the native f16 mode")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (default workload) / the same-GPU PyTorch-ROCm eager leg (training workloads)")
     ap.add_argument("--no-workloads", action="store_true", help="default workload: skip the compact measurements of the other BASELINE configs (`workloads`)")
@@ -620,19 +623,34 @@ def eager_training_baseline(name, args, dev, rank, steps=3, warmup=2):
         return None
 
 
-def secondary_workloads(args, dev, rank, budget_s=75.0):
+def _amp_step(step):
+    """the step inside an fp16 autocast region"""
+    def f():
+        with torch.autocast("cuda", dtype=torch.float16):
+            return step()
+    return f
+
+
+def secondary_workloads(args, dev, rank, budget_s=110.0):
     """Compact measurements of the other BASELINE configs after the headline: the driver's default line then carries
     LightStereo KITTI15 (configs[3]), the IGEV x32 loop (configs[4]), StereoBase whole-model inference and the StereoBase training steps
     (configs[2]) -- value, ms/step and the dominant launch's roofline fraction each; the time budget bounds the extra run time."""
     out, t_start = {}, time.perf_counter()
-    plan = [("lightstereo_kitti15", 10, 3), ("igev_refine32", 5, 2), ("stereobase_e2e", 5, 2), ("stereobase_train", 10, 3), ("stereobase_e2e_train", 3, 2)]
-    for name, steps, warmup in plan:
+    # (name, steps, warm-ups, amp): amp = the same workload inside torch.autocast(fp16), the way the reference runs its AMP configs
+    # (cfgs/lightstereo/*: AMP true, cfgs/igev/igev_sceneflow_amp.yaml, cfgs/stereobase/stereobase_sceneflow.yaml:50;
+    # trainer_template.py:281) -- the engine layers then use the native f16 mode (engine.effective_precision)
+    plan = [("lightstereo_kitti15", 10, 3, False), ("lightstereo_kitti15", 10, 3, True), ("igev_refine32", 5, 2, False), ("igev_refine32", 5, 2, True),
+            ("stereobase_e2e", 5, 2, False), ("stereobase_e2e", 5, 2, True), ("stereobase_train", 10, 3, False), ("stereobase_e2e_train", 3, 2, False)]
+    for wname, steps, warmup, amp in plan:
+        name = wname + ("_amp" if amp else "")
         if time.perf_counter() - t_start > budget_s:
             out[name] = {"skipped": "time budget of the default run exhausted"}
             continue
         try:
-            a = argparse.Namespace(**{**vars(args), "batch": None, "workload": name})
-            wl = WORKLOADS[name](a, dev, rank)
+            a = argparse.Namespace(**{**vars(args), "batch": None, "workload": wname})
+            wl = WORKLOADS[wname](a, dev, rank)
+            if amp:
+                wl.step = _amp_step(wl.step)
             step = wl.step
             for _ in range(warmup):
                 step()
@@ -653,9 +671,10 @@ def secondary_workloads(args, dev, rank, budget_s=75.0):
                 launch = "hipGraph replay"
             sec, res = _time_steps(step, steps, 1)
             assert torch.isfinite(res).all()
-            roofs, _ = generic_rooflines(wl, a, wl.step, 2)
+            roofs, _ = generic_rooflines(wl, argparse.Namespace(**{**vars(a), "precision": "f16"}) if amp else a, wl.step, 2)
             r0 = roofs[0] if roofs else None
-            out[name] = {"metric": wl.metric, "value": round(wl.B / sec, 3), "unit": "stereo-pairs/s", "ms_per_step": round(sec * 1e3, 3),
+            out[name] = {"metric": wl.metric, "dtype": DTYPES["f16"] if amp else DTYPES[args.precision],
+                         "value": round(wl.B / sec, 3), "unit": "stereo-pairs/s", "ms_per_step": round(sec * 1e3, 3),
                          "pairs_per_step": wl.B, "launch": launch,
                          "eager_value": round(wl.B / e_sec, 3), "eager_ms_per_step": round(e_sec * 1e3, 3),
                          "dominant_launch": None if r0 is None else {k: r0[k] for k in ("what", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
@@ -778,6 +797,8 @@ def main():
 
     wl = (_Stub if args.stub else WORKLOADS[args.workload])(args, dev, rank)
     B = wl.B
+    if args.amp and not wl.training and not args.stub:
+        wl.step = _amp_step(wl.step)
 
     def sync():
         if dev.type == "cuda":

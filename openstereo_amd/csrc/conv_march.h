@@ -33,7 +33,13 @@ struct MarchGeo {
     static constexpr int PLANEQ = LH * ROWQ;            // float4 slots per staged chunk-plane
     static constexpr int NTHR = NWV * 64;
     static constexpr int CPP = 2;                       // 16-channel chunks staged per pass
-    static constexpr size_t lds_bytes() { return (size_t)CPP * PLANEQ * 16 + (size_t)NWV * 32 * 36 * 4; }
+    static constexpr int BRING = 4;                     // LDS ring of B (weight) steps: 6 fragments of 1 KB per (chunk, kh, kw) step
+    static constexpr int BSTEPQ = 6 * 64;               // float4 slots per step
+    // planes of the pass + B ring; the epilogue's wave-private transpose tiles alias the planes (all waves are past the taps by then)
+    static constexpr size_t lds_bytes() {
+        return (size_t)CPP * PLANEQ * 16 + (size_t)BRING * BSTEPQ * 16;
+    }
+    static_assert((size_t)NWV * 32 * 36 * 4 <= (size_t)CPP * PLANEQ * 16, "epilogue tiles must fit into the plane buffer");
 };
 
 template <int NWV, int TW, int OUTS>
@@ -41,7 +47,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
     using G = MarchGeo<NWV, TW>;
     constexpr int MT = G::MT, TH = G::TH, ROWQ = G::ROWQ, VQ = G::VQ, PLANEQ = G::PLANEQ, NTHR = G::NTHR;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float* const tbase = reinterpret_cast<float*>(smem + G::CPP * PLANEQ);     // wave-private transpose tiles of the epilogue
+    float* const tbase = reinterpret_cast<float*>(smem);                       // wave-private transpose tiles of the epilogue: alias the planes
+    float4* const bring = smem + G::CPP * PLANEQ;                              // B ring: [BRING steps][kd * 2 + hl][64 lanes] float4
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +94,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
             for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
     // B operands: float4 index ((ch*27 + kd*9 + khw) * 2 + hl) * 2*CoP + hh*CoP + col   (CoP == 32)
-    const float4* const wl = p.w + (size_t)hh * p.CoP + col;
     const int bstep = 2 * p.CoP;            // float4s between the hi and the lo image of a tap
     const int tstep = 2 * bstep;            // float4s per tap
     const int npass = p.nchunks / G::CPP;
@@ -95,16 +101,6 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
     // folded-BN scale / shift of the channels this lane finalises
     const int cq = (lane & 7) * 4, vsub = lane >> 3;        // fp32 output: 4 channels of 4 voxels
     const int c8 = (lane & 3) * 8, vs2 = lane >> 2;         // split output: 8 channels of 2 voxels
-    float4 sc[2], sh[2];
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        const int co = OUTS ? c8 + 4 * h2 : cq;
-        sc[h2] = make_float4(osc, osc, osc, osc); sh[h2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) {
-            sc[h2] = *reinterpret_cast<const float4*>(p.scale + co); sh[h2] = *reinterpret_cast<const float4*>(p.shift + co);
-            sc[h2].x *= osc; sc[h2].y *= osc; sc[h2].z *= osc; sc[h2].w *= osc;
-        }
-    }
     const int actk = p.act & 15;
     const float act_ns = (actk == OSA_ACT_NONE) ? 1.f : ((actk == OSA_ACT_LEAKY) ? p.slope : 0.f);    // slope for v < 0 (none / relu / leaky)
     const size_t ovox_b = (size_t)b * p.Do * p.Ho * p.Wo;
@@ -112,67 +108,114 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
     const float* const resb = p.res ? p.res + ovox_b * p.rCs : nullptr;
     float* const tb = tbase + wm * (32 * 36);
 
+    // ---- B operands.  A (chunk, kh, kw) step needs the 6 fragments (kd = 0..2) x (hi, lo) of 1 KB each -- the SAME for every wave of every
+    // workgroup.  Loaded per wave from L2 (v1 of this kernel) they bound the tap loop: timing-only ablations at 8 pairs (profiles/round4/
+    // march_v1_ablation*.txt): taps 2.02 ms, without the B loads 1.36 ms, B loads + LDS reads without MFMAs 1.15 ms -- the vector-memory
+    // path delivers ~37 B/clk/CU of 16-byte-per-lane loads and every wave pulls 6 KB per 18 MFMAs through it, L1 hit or not.  Now ONE
+    // wave fetches a fragment for the whole workgroup with one LDS-DMA instruction (global_load_lds_dwordx4: lane i -> 16 bytes at row + 16 i,
+    // exactly the fragment's order in the packed stream), two steps ahead into a 3-deep LDS ring; every wave reads its operands from
+    // there with conflict-free ds_read_b128 (LDS: 256 B/clk/CU).  One s_barrier per step publishes the landed step.
+    // A step's 6 KB = 384 float4 slots [fragment f = kd * 2 + hl][64 lanes], split evenly over the waves: wave w fetches slots
+    // [w * PERW, (w + 1) * PERW) with NI instructions (the last one lane-predicated when PERW is not a multiple of 64).  The LDS
+    // destination of an instruction is linear (M0 base + 16 * lane), the global source per lane is the slot's place in the packed stream.
+    // Inline asm on purpose: through the builtin the compiler orders EVERY later ds_read behind the transfer (s_waitcnt vmcnt(0) right
+    // after the issue), which is exactly the wait this ring exists to avoid; the hardware orders nothing, the barrier protocol below does.
+    constexpr int PERW = 384 / NWV, NI = (PERW + 63) / 64;
+    const unsigned bring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)bring;
+    unsigned boff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = wm * PERW + i * 64 + lane, f = j >> 6;
+        boff[i] = (unsigned)(((f >> 1) * 9 * tstep + (f & 1) * bstep + (j & 63)) * 16);
+    }
+    auto dma_b = [&](const int buf, const int ch, const int khw) {
+        const char* base = reinterpret_cast<const char*>(p.w) + (size_t)(ch * 27 + khw) * tstep * 16;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if ((i + 1) * 64 <= PERW || i * 64 + lane < PERW) {
+                const char* src = base + boff[i];
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(bring_lds + (unsigned)((buf * 384 + wm * PERW + i * 64) * 16));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+            }
+        }
+    };
     // ---- one pass: taps of the two staged chunks [ch0, ch0 + 2) of plane pd, all three kd.  At the two ends of a D segment one or two
     // of the three output planes lie outside [d0, d1): their sums are computed and dropped (2 plane-steps of MFMAs per cut segment, 2/3
     // of one for an uncut column) -- a second code path over the accumulators (compile-time kd masks were tried) makes this compiler
     // spill 170-240 registers, which costs far more.
+    // Ring protocol (BRING = 4 slots, step t lives in slot t % 4).  Step s, after barrier s: issue the transfer of step s + 3 into the slot
+    // step s - 1 was read from (every wave is past barrier s, i.e. done with step s - 1); read the operands of the next micro-steps from
+    // slots s and s + 1; at the end of the step wait until all but the newest transfer have landed (vmcnt(NI): step s + 2 is home, step
+    // s + 3 keeps flying -- two steps of latency tolerance); barrier s + 1 then publishes step s + 2 to every wave.
+    // Caller: dma_b(t, ch0, t) for t = 0, 1, 2 issued before the plane was staged (they land behind the staging barrier).
+    // (OSA_M2_*: timing-only ablations, tools/r4/build_march_variant.sh -- results wrong by construction)
     auto run_pass = [&](const int ch0) {
-        constexpr int MASK = 7;
-        float4 A[2][MT][2], B[2][3][2];
+        float4 A[2][MT][2], B[3][2];           // A: ping-pong per step; B: 3-deep rotation over (step, kd) micro-steps -- [hi, lo] of one kd, read 2 micro-steps ahead
         auto load_a = [&](float4 (&An)[MT][2], const int cl, const int khw) {
             const int off = cl * PLANEQ + (khw / 3) * ROWQ + (khw % 3) * VQ;
 #pragma unroll
             for (int m = 0; m < MT; ++m) { An[m][0] = smem[abase[m] + off]; An[m][1] = smem[abase[m] + off + 2]; }
         };
-        auto load_b = [&](float4 (&Bn)[3][2], const int ch, const int khw) {
-            const float4* wq = wl + (size_t)(ch * 27 + khw) * tstep;
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd)
-                if ((MASK >> kd) & 1) { Bn[kd][0] = wq[kd * 9 * tstep]; Bn[kd][1] = wq[kd * 9 * tstep + bstep]; }
+        auto load_b = [&](float4 (&Bn)[2], const int u) {       // micro-step u = step * 3 + kd
+#if !defined(OSA_M2_NOBREAD)
+            const int buf = (u / 3) % G::BRING, kd = u % 3;
+            Bn[0] = bring[(buf * 6 + kd * 2) * 64 + lane]; Bn[1] = bring[(buf * 6 + kd * 2 + 1) * 64 + lane];
+#endif
         };
-        // (OSA_M_*: timing-only ablations of this loop, tools/r4/build_march_variant.sh -- results wrong by construction)
-        load_b(B[0], ch0, 0);
+        load_b(B[0], 0);
+        load_b(B[1], 1);
         load_a(A[0], 0, 0);
-#if defined(OSA_M_NOB) || defined(OSA_M_NOA)
-        load_b(B[1], ch0, 1);
-        load_a(A[1], 0, 1);
+#if defined(OSA_M2_NOBREAD)
+        B[0][0] = B[0][1] = B[1][0] = B[1][1] = B[2][0] = B[2][1] = smem[abase[0]];
 #endif
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
-            if (s + 1 < 18) {
-#if defined(OSA_M_STATB)
-                load_b(B[(s + 1) & 1], ch0, (s + 1) & 1);
-#elif !defined(OSA_M_NOB)
-                load_b(B[(s + 1) & 1], ch0 + (s + 1) / 9, (s + 1) % 9);
+#if !defined(OSA_M2_NOBAR)
+            if (s > 0) __builtin_amdgcn_s_barrier();          // every wave's share of step s + 1 has landed
 #endif
-#if !defined(OSA_M_NOA)
-                load_a(A[(s + 1) & 1], (s + 1) / 9, (s + 1) % 9);
+#if !defined(OSA_M2_NODMA)
+            if (s + 3 < 18) dma_b((s + 3) % G::BRING, ch0 + (s + 3) / 9, (s + 3) % 9);
 #endif
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // kd = 0 -> output plane pd + 1 (acc[2]), kd = 1 -> pd (acc[1]), kd = 2 -> pd - 1 (acc[0]); small cross terms first
+            if (s + 1 < 18) load_a(A[(s + 1) & 1], (s + 1) / 9, (s + 1) % 9);
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int kd = 0; kd < 3; ++kd) {
+                const int u = s * 3 + kd;
+                if (u + 2 < 54) load_b(B[(u + 2) % 3], u + 2);      // (kd = 1, 2 reach into step s + 1: landed and published by barrier s)
+                __builtin_amdgcn_sched_barrier(0);
+                // kd = 0 -> output plane pd + 1 (acc[2]), kd = 1 -> pd (acc[1]), kd = 2 -> pd - 1 (acc[0]); small cross terms first
 #pragma unroll
-                for (int kd = 0; kd < 3; ++kd)
-                    if ((MASK >> kd) & 1) {
+                for (int term = 0; term < 3; ++term)
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const f16x8 a = __builtin_bit_cast(f16x8, A[s & 1][m][term == 1 ? 1 : 0]);
-                            const f16x8 w = __builtin_bit_cast(f16x8, B[s & 1][kd][term == 0 ? 1 : 0]);
-#if defined(OSA_M_NOMFMA)
-                            acc[2 - kd][m][term] += (float)a[0] * (float)w[0];
-#else
-                            acc[2 - kd][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc[2 - kd][m], 0, 0, 0);
-#endif
-                        }
+                    for (int m = 0; m < MT; ++m) {
+                        const f16x8 a = __builtin_bit_cast(f16x8, A[s & 1][m][term == 1 ? 1 : 0]);
+                        const f16x8 w = __builtin_bit_cast(f16x8, B[u % 3][term == 0 ? 1 : 0]);
+                        acc[2 - kd][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc[2 - kd][m], 0, 0, 0);
                     }
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if !defined(OSA_M2_NOWAIT)
+            // the transfer of step s + 2 (issued a step ago) has landed; the one just issued keeps flying
+            if (s + 3 < 18) { if constexpr (NI == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
     };
 
     // ---- epilogue of the finished output plane `od` (accumulator set 0): BN affine + residual + activation, NDHWC store
     auto epilogue = [&](const int od) {
+        // folded-BN scale / shift of the channels this lane finalises (re-read per plane from L2: 4 registers x 4 not held across the tap loop)
+        float4 sc[2], sh[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int co = OUTS ? c8 + 4 * h2 : cq;
+            sc[h2] = make_float4(osc, osc, osc, osc); sh[h2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) {
+                sc[h2] = *reinterpret_cast<const float4*>(p.scale + co); sh[h2] = *reinterpret_cast<const float4*>(p.shift + co);
+                sc[h2].x *= osc; sc[h2].y *= osc; sc[h2].z *= osc; sc[h2].w *= osc;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int tq = (wm * MT + m) * 32;                      // first voxel of this M-tile inside the TH x TW pixel tile
@@ -249,15 +292,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
         const bool v2 = (pd - 1 >= d0) && (pd - 1 < d1);      // output plane pd - 1 completes with this input plane
         if (pd >= 0 && pd < p.Di) {                       // (planes outside the tensor are zero: nothing to add)
             for (int pass = 0; pass < npass; ++pass) {
-                __syncthreads();                          // the previous pass's readers are done
-#if !defined(OSA_M_NOSTAGE)
+                __syncthreads();                          // the previous pass's readers (planes and B ring) / the epilogue's tiles are done
+                dma_b(0, pass * G::CPP, 0);
+                dma_b(1, pass * G::CPP, 1);
+                dma_b(2, pass * G::CPP, 2);
+#if !defined(OSA_M2_NOSTAGE)
                 stage_brick<NTHR, PREC_F16X3, 2, 8>(p, smem, PLANEQ, b, pass * (G::CPP * CC), pd, g0h, g0w, tid, s_in);
 #endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 run_pass(pass * G::CPP);
             }
         }
-#if defined(OSA_M_NOEPI)
+#if defined(OSA_M2_NOEPI)
         if (v2) {
             float t_ = 0.f;
 #pragma unroll
@@ -267,7 +314,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
             if (t_ == 12345.678f) yb[0] = t_;
         }
 #else
-        if (v2) epilogue(pd - 1);
+        if (v2) {
+            __syncthreads();                              // every wave is past its taps: the plane buffer becomes the transpose tiles
+            epilogue(pd - 1);
+        }
 #endif
         // rotate: the plane that was pd becomes pd - 1 of the next step
 #pragma unroll

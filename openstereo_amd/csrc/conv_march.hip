@@ -33,11 +33,13 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
         if (a.res) OSA_REQUIRE(a.act & OSA_RES_SPLIT, "%s: a split output takes a split residual", what);
     }
     if ((a.act & OSA_RES_SPLIT) && a.res) OSA_REQUIRE(a.rCs % 16 == 0, "%s: split residual needs rCs %% 16 == 0", what);
-    // pixel-column shape: least padded area; ties -> the 2-wave 8 x 16 column (4 workgroups per CU, finest grain)
+    // pixel-column shape: least padded area among the 4-wave columns (16 x 16 first: measured 2-4 % ahead of 8 x 32 at 544x960,
+    // profiles/round4/march_v3_ring4_ablation_ab.txt; the 2-wave 8 x 16 column loses 20 % since the B ring costs it a workgroup per CU)
     int gi = exp_int("OSA_MARCH_GEO", -1);
     if (gi < 0 || gi > 2) {
         long long best = -1;
-        for (int i = 0; i < 3; ++i) {
+        static const int order[2] = {2, 1};
+        for (int i : order) {
             const MarchCfg& g = g_march_cfgs[i];
             const long long area = (long long)cdiv(a.Ho, g.th) * g.th * cdiv(a.Wo, g.tw) * g.tw;
             if (best < 0 || area < best) { best = area; gi = i; }
@@ -57,7 +59,9 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     // D segments: a workgroup walks dseg output planes (+ 2 boundary planes that are staged for one third of their taps).  Cost model in
     // plane-steps: rounds of resident workgroups x (dseg + 2 boundary planes of a cut column, staged and multiplied in full); the fewest segments win a tie.
     const long long cols = (long long)a.B * a.tilesH * a.tilesW;
-    const long long slots = (long long)((g.nwv == 2) ? 4 : 2) * 256;
+    int per_cu = (int)((160 * 1024) / g.lds);                       // resident workgroups per CU: LDS, and 2 waves per SIMD by registers
+    if (per_cu > 8 / g.nwv) per_cu = 8 / g.nwv;
+    const long long slots = (long long)per_cu * 256;
     int nseg = 1;
     {
         double best = 1e30;
