@@ -240,8 +240,9 @@ class StereoBaseTrain:
 
 
 class _E2EInference:
-    """Whole-model inference of the end-to-end classes of openstereo_amd/models/stereo_models.py (stand-in 2-D backbone: torch modules;
-    everything from the volume to the full-resolution disparity on the engine)."""
+    """Whole-model inference of the end-to-end classes of openstereo_amd/models/stereo_models.py with the reference's feature pyramid
+    (feature_pyramid.py: MobileNetV2-100 trunk mirror -- unpinned, timm absent -- + the reference-written FPN decoder, pinned), all of it
+    on the engine in eval mode."""
     scaling, graphable, training = "weak", True, False
     H, W = 544, 960
 
@@ -260,7 +261,7 @@ class _E2EInference:
 
 
 class StereoBaseE2E(_E2EInference):
-    metric = "stereo-pairs/s, StereoBase (stand-in backbone) at 544x960 D=192, 32 GRU iterations"
+    metric = "stereo-pairs/s, StereoBase (MobileNetV2-100 trunk mirror, unpinned + reference FPN, pinned) at 544x960 D=192, 32 GRU iterations"
 
     def __init__(self, args, dev, rank):
         from types import SimpleNamespace
@@ -268,15 +269,15 @@ class StereoBaseE2E(_E2EInference):
         self.B = args.batch or 2
         cfg = SimpleNamespace(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
                               N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=32, TRAIN_ITERS=22)
-        self._finish(StereoBase(cfg), args, dev, rank, 41)
+        self._finish(StereoBase(cfg, feature="mobilenetv2"), args, dev, rank, 41)
 
     def config(self, args):
-        return {"workload": "StereoBase inference, whole model with stand-in 2-D backbone (gwc + concat volume -> hourglass -> classifier -> regression -> "
+        return {"workload": "StereoBase inference, whole model incl. the MobileNetV2-100 feature pyramid on the engine (gwc + concat volume -> hourglass -> classifier -> regression -> "
                             "geometry lookup + 32 GRU iterations -> convex upsampling), 544x960 D=192 (cfgs/stereobase/stereobase_sceneflow.yaml, EVAL_ITERS 32)"}
 
 
 class IGEVE2E(_E2EInference):
-    metric = "stereo-pairs/s, IGEV-Stereo (stand-in backbone) at 544x960 D=192, 32 GRU iterations"
+    metric = "stereo-pairs/s, IGEV-Stereo (MobileNetV2-100 trunk mirror, unpinned + reference FPN, pinned) at 544x960 D=192, 32 GRU iterations"
 
     def __init__(self, args, dev, rank):
         from types import SimpleNamespace
@@ -284,15 +285,15 @@ class IGEVE2E(_E2EInference):
         self.B = args.batch or 2
         a = SimpleNamespace(MAX_DISP=192, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=True,
                             VALID_ITERS=32, N_DOWNSAMPLE=2)
-        self._finish(IGEVStereo(a), args, dev, rank, 43, scale255=True)
+        self._finish(IGEVStereo(a, feature="mobilenetv2"), args, dev, rank, 43, scale255=True)
 
     def config(self, args):
-        return {"workload": "IGEV-Stereo inference, whole model with stand-in 2-D backbone (gwc volume -> corr_stem + FeatureAtt -> hourglass -> classifier -> "
+        return {"workload": "IGEV-Stereo inference, whole model incl. the MobileNetV2-100 feature pyramid on the engine (gwc volume -> corr_stem + FeatureAtt -> hourglass -> classifier -> "
                             "regression -> geometry lookup + 32 slow-fast GRU iterations -> convex upsampling), 544x960 D=192 (BASELINE configs[4])"}
 
 
 class LightStereoE2E(_E2EInference):
-    metric = "stereo-pairs/s, LightStereo-S (stand-in backbone) at 384x1248 D=192"
+    metric = "stereo-pairs/s, LightStereo-S (MobileNetV2-100 trunk mirror, unpinned + reference FPN, pinned) at 384x1248 D=192"
     H, W = 384, 1248
 
     def __init__(self, args, dev, rank):
@@ -300,10 +301,10 @@ class LightStereoE2E(_E2EInference):
         from openstereo_amd.models.stereo_models import LightStereo
         self.B = args.batch or 8
         cfg = SimpleNamespace(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)
-        self._finish(LightStereo(cfg), args, dev, rank, 47)
+        self._finish(LightStereo(cfg, backbone="mobilenetv2"), args, dev, rank, 47)
 
     def config(self, args):
-        return {"workload": "LightStereo-S inference, whole model with stand-in 2-D backbone (correlation volume -> 2-D aggregation -> regression -> convex "
+        return {"workload": "LightStereo-S inference, whole model incl. the MobileNetV2-100 feature pyramid on the engine (correlation volume -> 2-D aggregation -> regression -> convex "
                             "upsampling), KITTI15 375x1242 padded to 384x1248 (BASELINE configs[3])"}
 
 
@@ -312,7 +313,7 @@ class StereoBaseE2ETrain:
     (cfgs/stereobase/stereobase_sceneflow.yaml) -- volumes, hourglass, classifier, regression, geometry-encoding lookup and 22 GRU iterations
     (TRAIN_ITERS) with convex upsampling after each, the loss of stereobase_gru.py:215-243, backward, AdamW step; frozen BN.  The timm
     pyramid / context encoder are the shape-compatible stand-ins (torch modules, trained along)."""
-    metric = "training stereo-pairs/s, StereoBase (stand-in backbone) at 320x736 crop, 22 GRU iterations"
+    metric = "training stereo-pairs/s, StereoBase (MobileNetV2-100 trunk mirror + reference FPN) at 320x736 crop, 22 GRU iterations"
     scaling, graphable, training = "weak", False, True
 
     def __init__(self, args, dev, rank):
@@ -323,7 +324,7 @@ class StereoBaseE2ETrain:
         self.B = B = args.batch or 1
         cfg = SimpleNamespace(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
                               N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=32, TRAIN_ITERS=22)
-        net = StereoBase(cfg)
+        net = StereoBase(cfg, feature="mobilenetv2")
         net.load_state_dict(synth_state_dict(net, seed=41, head_gain=20.0, gain=0.9))
         net = net.to(dev).train()
         for m in net.modules():                                   # FREEZE_BN: true

@@ -525,6 +525,17 @@ int osa_deconv2d_nhwc_f16(const void* x, const float* w_packed, const float* sca
                           int B, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int k, int pad, int opad,
                           const float* gate_logits, int gCs, int act, float slope, void* stream);
 
+/* ---- InstanceNorm2d (+ activation) on NHWC maps (r4, csrc/norm.hip) ----
+ * The normalisation of the reference-written FPN decoders of the feature pyramids: Conv2xUp / BasicConv2d(norm_layer=nn.InstanceNorm2d)
+ * (models/stereobase/backbone.py:46-53), Conv2x_IN / BasicConv_IN (models/igev/extractor.py:338-341, models/igev/submodule.py:78-108) and
+ * LightStereo's out_conv (models/lightstereo/backbone.py:57-59): affine = False, per (image, channel) mean / biased variance over H x W,
+ * y = act((x - mean) / sqrt(var + eps)).  x: [B][HW][xCs], y: [B][HW][yCs] (a channel slice of a concat buffer when the caller offsets the
+ * pointer), C channels; act: OSA_ACT_NONE | OSA_ACT_RELU | OSA_ACT_LEAKY.  workspace: osa_instnorm_workspace_floats(B, HW, C) floats;
+ * deterministic (no float atomics).  y_meta: NULL or y's range block. */
+size_t osa_instnorm_workspace_floats(int B, long long HW, int C);
+int osa_instnorm_nhwc_f32(const float* x, float* y, int B, long long HW, int C, int xCs, int yCs, float eps, int act, float slope,
+                          float* workspace, float* y_meta, void* stream);
+
 /* ---- d-marching form of the 3x3x3 stride-1 convolutions with 32 output channels (r4, csrc/conv_march.h) ----
  * osa_conv3d_ndhwc_f16x3 runs eligible layers (3x3x3, stride 1, padding 1, Ci % 32 == 0, Co == 32, no gate: GwcNet / PSMNet dres0,
  * dres1, classif*.0 -- gwcnet_disp_processor.py:40-81) as workgroups that own a pixel column and walk along d, each staged input plane

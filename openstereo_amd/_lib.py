@@ -171,6 +171,8 @@ SIGNATURES = {
                                     c_i, c_i, c_i,
                                     c_i, c_i, c_i,
                                     c_fp, c_i, c_i, c_f, c_st]),
+    "osa_instnorm_workspace_floats": (C.c_size_t, [c_i, c_ll, c_i]),
+    "osa_instnorm_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_f, c_i, c_f, c_fp, c_fp, c_st]),
     "osa_conv3d_march_launches": (c_ll, []),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),

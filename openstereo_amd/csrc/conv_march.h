@@ -2,14 +2,20 @@
 // aggregation networks -- GwcNet dres0 / dres1 / classif*.0 (gwcnet_disp_processor.py:40-81), PSMNet dres0 / dres1 -- which carry 56 % of
 // GwcNet's 3-D MACs.
 //
-// The brick kernel (conv_kernel.h) stages a 6x10x10 halo brick per 4x8x8 output brick: 2.34x the input in staged bytes (2.0x measured at
-// the HBM side, the d-halo is re-fetched by bricks that run 510 workgroups apart), and every A fragment it reads from LDS feeds one tap
-// of one output voxel row.  Here a workgroup owns a TH x TW pixel column and WALKS along d (the classifier's trick, conv3d.hip
-// classifier_march_kernel):
-//   * every input plane (TH+2) x (TW+2) x 32 channels is staged ONCE per pass and serves the three output planes d-1, d, d+1 whose
-//     kd = 2, 1, 0 taps it is -- three accumulator sets per wave (96 accumulator registers, 2 waves per SIMD);
-//   * an A fragment (one ds_read_b128 pair) of in-plane tap (kh, kw) feeds 3 x 3 MFMAs instead of 3: LDS reads per MFMA fall 3x;
-//   * staged bytes: (TH+2)(TW+2) / (TH TW) x (dseg + 2) / dseg = 1.4-1.6x of one pass instead of 2.34x.
+// The brick kernel (conv_kernel.h) stages a 6x10x10 halo brick per 4x8x8 output brick -- 2.34x the input in staged bytes, 2.0x measured at
+// the HBM side -- and every wave pulls its B (weight) fragments through the vector-memory path.  Here a workgroup owns a TH x TW pixel
+// column and WALKS along d (the classifier's trick, conv3d.hip classifier_march_kernel):
+//   * every input plane (TH+2) x (TW+2) x 16 channels is staged ONCE per pass and serves the three output planes d-1, d, d+1 whose
+//     kd = 2, 1, 0 taps it is -- three accumulator sets per wave (96 accumulator registers, 2 waves per SIMD); staged bytes fall to
+//     (TH+2)(TW+2) / (TH TW) x (dseg + 2) / dseg = 1.3-1.5x of one pass, LDS reads of A fragments per MFMA fall 3x;
+//   * B operands come through an LDS ring filled by LDS-DMA, ONE fetch per workgroup and step instead of one per wave: timing-only
+//     ablations of v1 (operands per wave from L2; profiles/round4/march_v1_ablation_and_f16_tests.txt) showed the tap loop bound by them
+//     -- taps 2.02 ms, without the B loads 1.36 ms, loads alone 1.15 ms: the vector-memory path delivers ~37 B/clk/CU of 16-byte-per-lane
+//     loads, L1 hit or not; v3 (ring) brought the taps to 1.66 ms (march_v3_ring4_ablation_ab.txt);
+//   * (v4) split inputs are staged ASYNCHRONOUSLY: while the taps of pass q = (plane, 16-channel chunk) run from one plane buffer, the
+//     plane-chunk of pass q + 1 lands in the other by LDS-DMA, one 1 KB piece per wave and step.  v3's ablations had staging (0.48 ms)
+//     and epilogue (0.28 ms) exactly additive to the taps (1.66 ms): with two workgroups per CU nothing hides a workgroup's 6-8 us of
+//     staging latency per 7 us of MFMA work.
 // The packed weight stream is the brick kernel's ([chunk][tap][hi|lo][k-group][Cout][8 x fp16], tap = kd*9 + kh*3 + kw): a (chunk, kh, kw)
 // step reads its three kd taps 9 tap-steps apart.  Same split arithmetic (Ahi.Blo + Alo.Bhi + Ahi.Bhi, fp32 accumulate), same operand
 // ranges and the same epilogue semantics as conv_mfma_kernel; the summation ORDER differs (kd outermost), so results agree to fp32
@@ -19,9 +25,9 @@
 
 namespace osa {
 
-// NWV waves per workgroup, every wave owns MT = 2 M-tiles of 32 voxels.  TW = 32: an M-tile is one row of 32 pixels; TW = 16: two rows of
-// 16.  LDS image of a chunk-plane: voxels 5 slots (80 B) apart -- the 16 lanes of a ds_read_b128 group fall on 16 distinct 16-byte slots
-// (mod 256 B) -- and, for TW = 16, rows a multiple of 16 slots apart (the group straddles two rows).
+// NWV = 4 waves per workgroup, every wave owns MT = 2 M-tiles of 32 voxels.  TW = 32: an M-tile is one row of 32 pixels; TW = 16: two rows
+// of 16.  LDS image of a chunk-plane: voxels 5 slots (80 B) apart -- the 16 lanes of a ds_read_b128 group fall on 16 distinct 16-byte
+// slots (mod 256 B) -- and, for TW = 16, rows a multiple of 16 slots apart (the group straddles two rows).
 template <int NWV, int TW>
 struct MarchGeo {
     static constexpr int MT = 2;
@@ -30,25 +36,41 @@ struct MarchGeo {
     static constexpr int LH = TH + 2, LW = TW + 2;
     static constexpr int VQ = 5;
     static constexpr int ROWQ = (TW == 16) ? ((LW * VQ + 15) / 16 * 16) : LW * VQ;
-    static constexpr int PLANEQ = LH * ROWQ;            // float4 slots per staged chunk-plane
+    static constexpr int NPI = (LH * ROWQ + 63) / 64;   // LDS-DMA instructions (64 slots of 16 B each) per chunk-plane
+    static constexpr int PLANEQ = NPI * 64;             // float4 slots per chunk-plane buffer
+    static constexpr int NP = (NPI + NWV - 1) / NWV;    // pieces per wave and pass
     static constexpr int NTHR = NWV * 64;
-    static constexpr int CPP = 2;                       // 16-channel chunks staged per pass
     static constexpr int BRING = 4;                     // LDS ring of B (weight) steps: 6 fragments of 1 KB per (chunk, kh, kw) step
     static constexpr int BSTEPQ = 6 * 64;               // float4 slots per step
-    // planes of the pass + B ring; the epilogue's wave-private transpose tiles alias the planes (all waves are past the taps by then)
-    static constexpr size_t lds_bytes() {
-        return (size_t)CPP * PLANEQ * 16 + (size_t)BRING * BSTEPQ * 16;
-    }
-    static_assert((size_t)NWV * 32 * 36 * 4 <= (size_t)CPP * PLANEQ * 16, "epilogue tiles must fit into the plane buffer");
+    // two plane buffers (pass q reads buffer q & 1, the epilogue's wave-private transpose tiles alias it once its taps are done) + B ring
+    static constexpr size_t lds_bytes() { return (size_t)2 * PLANEQ * 16 + (size_t)BRING * BSTEPQ * 16; }
+    static_assert((size_t)NWV * 32 * 36 * 4 <= (size_t)PLANEQ * 16, "epilogue tiles must fit into one plane buffer");
+    static_assert(NP <= 7, "one piece per wave and step, all of them forced home by the waits of steps 2..8");
 };
 
-template <int NWV, int TW, int OUTS>
+// s_waitcnt vmcnt(n): the immediates of the LDS-DMA protocol are instruction counts; n is a constant after unrolling, the switch folds
+__device__ __forceinline__ void wait_vmcnt(const int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+}
+
+__device__ const float4 g_march_zeros[4] = {};       // source of the LDS-DMA lanes that fill padding / out-of-image slots
+
+// INS = 1: the input is a split tensor (16-byte quads are the LDS image: asynchronous LDS-DMA staging); INS = 0: fp32 input, split while
+// it is staged through registers at the start of every pass (GwcNet: dres0.0 only, which reads the volume builder's fp32 output).
+template <int NWV, int TW, int OUTS, int INS>
 __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs p, const int dseg, const int nseg) {
     using G = MarchGeo<NWV, TW>;
-    constexpr int MT = G::MT, TH = G::TH, ROWQ = G::ROWQ, VQ = G::VQ, PLANEQ = G::PLANEQ, NTHR = G::NTHR;
+    constexpr int MT = G::MT, TH = G::TH, ROWQ = G::ROWQ, VQ = G::VQ, PLANEQ = G::PLANEQ, NTHR = G::NTHR, NP = G::NP, NPI = G::NPI;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float* const tbase = reinterpret_cast<float*>(smem);                       // wave-private transpose tiles of the epilogue: alias the planes
-    float4* const bring = smem + G::CPP * PLANEQ;                              // B ring: [BRING steps][kd * 2 + hl][64 lanes] float4
+    float4* const bring = smem + 2 * PLANEQ;                                   // B ring: [BRING steps][kd * 2 + hl][64 lanes] float4
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,7 +87,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
 
     // ---- f16x3 operand ranges (as conv_mfma_kernel)
     float s_in = 1.f, s_res_inv = 1.f, s_out = 1.f;
-    if (p.in_meta) s_in = (p.act & OSA_IN_SPLIT) ? p.in_meta[1] : pow2_scale(amax_read(p.in_meta));
+    if (p.in_meta) s_in = INS ? p.in_meta[1] : pow2_scale(amax_read(p.in_meta));
     if (p.res && p.res_meta && (p.act & OSA_RES_SPLIT)) s_res_inv = 1.0f / p.res_meta[1];
     if (OUTS && p.coef && p.in_meta) {
         float bound = p.coef[0] * amax_read(p.in_meta) + p.coef[1];
@@ -96,9 +118,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
     // B operands: float4 index ((ch*27 + kd*9 + khw) * 2 + hl) * 2*CoP + hh*CoP + col   (CoP == 32)
     const int bstep = 2 * p.CoP;            // float4s between the hi and the lo image of a tap
     const int tstep = 2 * bstep;            // float4s per tap
-    const int npass = p.nchunks / G::CPP;
+    const int nch = p.nchunks;
 
-    // folded-BN scale / shift of the channels this lane finalises
     const int cq = (lane & 7) * 4, vsub = lane >> 3;        // fp32 output: 4 channels of 4 voxels
     const int c8 = (lane & 3) * 8, vs2 = lane >> 2;         // split output: 8 channels of 2 voxels
     const int actk = p.act & 15;
@@ -106,105 +127,73 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
     const size_t ovox_b = (size_t)b * p.Do * p.Ho * p.Wo;
     float* const yb = p.y + ovox_b * p.yCs;
     const float* const resb = p.res ? p.res + ovox_b * p.rCs : nullptr;
-    float* const tb = tbase + wm * (32 * 36);
 
-    // ---- B operands.  A (chunk, kh, kw) step needs the 6 fragments (kd = 0..2) x (hi, lo) of 1 KB each -- the SAME for every wave of every
-    // workgroup.  Loaded per wave from L2 (v1 of this kernel) they bound the tap loop: timing-only ablations at 8 pairs (profiles/round4/
-    // march_v1_ablation*.txt): taps 2.02 ms, without the B loads 1.36 ms, B loads + LDS reads without MFMAs 1.15 ms -- the vector-memory
-    // path delivers ~37 B/clk/CU of 16-byte-per-lane loads and every wave pulls 6 KB per 18 MFMAs through it, L1 hit or not.  Now ONE
-    // wave fetches a fragment for the whole workgroup with one LDS-DMA instruction (global_load_lds_dwordx4: lane i -> 16 bytes at row + 16 i,
-    // exactly the fragment's order in the packed stream), two steps ahead into a 3-deep LDS ring; every wave reads its operands from
-    // there with conflict-free ds_read_b128 (LDS: 256 B/clk/CU).  One s_barrier per step publishes the landed step.
-    // A step's 6 KB = 384 float4 slots [fragment f = kd * 2 + hl][64 lanes], split evenly over the waves: wave w fetches slots
-    // [w * PERW, (w + 1) * PERW) with NI instructions (the last one lane-predicated when PERW is not a multiple of 64).  The LDS
-    // destination of an instruction is linear (M0 base + 16 * lane), the global source per lane is the slot's place in the packed stream.
-    // Inline asm on purpose: through the builtin the compiler orders EVERY later ds_read behind the transfer (s_waitcnt vmcnt(0) right
-    // after the issue), which is exactly the wait this ring exists to avoid; the hardware orders nothing, the barrier protocol below does.
+    // ---- LDS-DMA.  An instruction moves 64 x 16 bytes: lane i -> LDS [M0 base + 16 i], from a per-lane global address.  Inline asm on
+    // purpose: through the builtin the compiler orders EVERY later ds_read behind the transfer (s_waitcnt vmcnt(0) right after the issue),
+    // which is exactly the wait the rings exist to avoid; the hardware orders nothing (MI355X_MICROARCH.md), the vmcnt / barrier protocol
+    // below does.  Every instruction is issued by every wave with all lanes on (lanes without data fetch zeros): the vmcnt immediates
+    // of the protocol count instructions.
+    auto dma = [&](const char* src, const unsigned lds_byte) {
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+    };
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned bring_lds = smem_lds + 2u * PLANEQ * 16u;
+    const char* const zsrc = reinterpret_cast<const char*>(g_march_zeros);
+
+    // B: a step's 6 KB = 384 float4 slots [fragment f = kd * 2 + hl][64 lanes], split evenly over the waves: wave w fetches slots
+    // [w * 96, (w + 1) * 96) with NI = 2 instructions (the second covers 32 slots: its upper lanes are switched off by the exec mask,
+    // the instruction itself is always issued).
     constexpr int PERW = 384 / NWV, NI = (PERW + 63) / 64;
-    const unsigned bring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)bring;
     unsigned boff[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int j = wm * PERW + i * 64 + lane, f = j >> 6;
+        const int j = wm * PERW + i * 64 + lane, f = (j >> 6) < 6 ? (j >> 6) : 5;
         boff[i] = (unsigned)(((f >> 1) * 9 * tstep + (f & 1) * bstep + (j & 63)) * 16);
     }
-    auto dma_b = [&](const int buf, const int ch, const int khw) {
+    auto dma_b = [&](const int slot, const int ch, const int khw) {
         const char* base = reinterpret_cast<const char*>(p.w) + (size_t)(ch * 27 + khw) * tstep * 16;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if ((i + 1) * 64 <= PERW || i * 64 + lane < PERW) {
-                const char* src = base + boff[i];
-                const unsigned m0v = __builtin_amdgcn_readfirstlane(bring_lds + (unsigned)((buf * 384 + wm * PERW + i * 64) * 16));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
-            }
-        }
+        for (int i = 0; i < NI; ++i)
+            if ((i + 1) * 64 <= PERW || i * 64 + lane < PERW)
+                dma(base + boff[i], bring_lds + (unsigned)((slot * 384 + wm * PERW + i * 64) * 16));
     };
-    // ---- one pass: taps of the two staged chunks [ch0, ch0 + 2) of plane pd, all three kd.  At the two ends of a D segment one or two
-    // of the three output planes lie outside [d0, d1): their sums are computed and dropped (2 plane-steps of MFMAs per cut segment, 2/3
-    // of one for an uncut column) -- a second code path over the accumulators (compile-time kd masks were tried) makes this compiler
-    // spill 170-240 registers, which costs far more.
-    // Ring protocol (BRING = 4 slots, step t lives in slot t % 4).  Step s, after barrier s: issue the transfer of step s + 3 into the slot
-    // step s - 1 was read from (every wave is past barrier s, i.e. done with step s - 1); read the operands of the next micro-steps from
-    // slots s and s + 1; at the end of the step wait until all but the newest transfer have landed (vmcnt(NI): step s + 2 is home, step
-    // s + 3 keeps flying -- two steps of latency tolerance); barrier s + 1 then publishes step s + 2 to every wave.
-    // Caller: dma_b(t, ch0, t) for t = 0, 1, 2 issued before the plane was staged (they land behind the staging barrier).
-    // (OSA_M2_*: timing-only ablations, tools/r4/build_march_variant.sh -- results wrong by construction)
-    auto run_pass = [&](const int ch0) {
-        float4 A[2][MT][2], B[3][2];           // A: ping-pong per step; B: 3-deep rotation over (step, kd) micro-steps -- [hi, lo] of one kd, read 2 micro-steps ahead
-        auto load_a = [&](float4 (&An)[MT][2], const int cl, const int khw) {
-            const int off = cl * PLANEQ + (khw / 3) * ROWQ + (khw % 3) * VQ;
+
+    // planes (INS): piece i of this wave is DMA instruction n = i * NWV + wave of the NPI that fill a chunk-plane buffer (a wave whose
+    // n would exceed NPI - 1 repeats instruction NPI - 1: same bytes to the same slots).  Slot j = 64 n + lane -> (row, voxel, quad) of the
+    // padded image; its source inside the (plane, chunk) slab, or the zero block for padding and pixels outside the image.
+    unsigned poff[INS ? NP : 1];
+    unsigned pvalid = 0u;
+    if constexpr (INS) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { An[m][0] = smem[abase[m] + off]; An[m][1] = smem[abase[m] + off + 2]; }
-        };
-        auto load_b = [&](float4 (&Bn)[2], const int u) {       // micro-step u = step * 3 + kd
-#if !defined(OSA_M2_NOBREAD)
-            const int buf = (u / 3) % G::BRING, kd = u % 3;
-            Bn[0] = bring[(buf * 6 + kd * 2) * 64 + lane]; Bn[1] = bring[(buf * 6 + kd * 2 + 1) * 64 + lane];
-#endif
-        };
-        load_b(B[0], 0);
-        load_b(B[1], 1);
-        load_a(A[0], 0, 0);
-#if defined(OSA_M2_NOBREAD)
-        B[0][0] = B[0][1] = B[1][0] = B[1][1] = B[2][0] = B[2][1] = smem[abase[0]];
-#endif
-#pragma unroll
-        for (int s = 0; s < 18; ++s) {
-#if !defined(OSA_M2_NOBAR)
-            if (s > 0) __builtin_amdgcn_s_barrier();          // every wave's share of step s + 1 has landed
-#endif
-#if !defined(OSA_M2_NODMA)
-            if (s + 3 < 18) dma_b((s + 3) % G::BRING, ch0 + (s + 3) / 9, (s + 3) % 9);
-#endif
-            if (s + 1 < 18) load_a(A[(s + 1) & 1], (s + 1) / 9, (s + 1) % 9);
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd) {
-                const int u = s * 3 + kd;
-                if (u + 2 < 54) load_b(B[(u + 2) % 3], u + 2);      // (kd = 1, 2 reach into step s + 1: landed and published by barrier s)
-                __builtin_amdgcn_sched_barrier(0);
-                // kd = 0 -> output plane pd + 1 (acc[2]), kd = 1 -> pd (acc[1]), kd = 2 -> pd - 1 (acc[0]); small cross terms first
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const f16x8 a = __builtin_bit_cast(f16x8, A[s & 1][m][term == 1 ? 1 : 0]);
-                        const f16x8 w = __builtin_bit_cast(f16x8, B[u % 3][term == 0 ? 1 : 0]);
-                        acc[2 - kd][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc[2 - kd][m], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#if !defined(OSA_M2_NOWAIT)
-            // the transfer of step s + 2 (issued a step ago) has landed; the one just issued keeps flying
-            if (s + 3 < 18) { if constexpr (NI == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+        for (int i = 0; i < NP; ++i) {
+            int n = i * NWV + wm;
+            n = n < NPI ? n : NPI - 1;
+            const int j = n * 64 + lane;
+            const int lh = j / ROWQ, rem = j - lh * ROWQ, lw = rem / VQ, c4 = rem - lw * VQ;
+            const int gh = g0h + lh, gw = g0w + lw;
+            const bool ok = lh < G::LH && lw < G::LW && c4 < 4 && (unsigned)gh < (unsigned)p.Hi && (unsigned)gw < (unsigned)p.Wi;
+            poff[i] = ok ? (unsigned)(((gh * p.Wi + gw) * p.xCs + c4 * 4) * 4) : 0u;
+            pvalid |= ok ? (1u << i) : 0u;
+        }
+    }
+    const size_t plane_bytes = (size_t)p.Hi * p.Wi * p.xCs * 4;
+    const char* const xb = reinterpret_cast<const char*>(p.x) + (size_t)b * p.Di * plane_bytes;
+    // piece i of the (plane pd, chunk c) slab into plane buffer `buf`; pd < 0: nothing to fetch (zeros)
+    auto dma_piece = [&](const int i, const int buf, const int pd, const int c) {
+        if constexpr (INS) {
+            int n = i * NWV + wm;
+            n = n < NPI ? n : NPI - 1;
+            const char* base = xb + (size_t)(pd < 0 ? 0 : pd) * plane_bytes + (size_t)c * (CC * 4);
+            const bool ok = ((pvalid >> i) & 1u) && pd >= 0;
+            dma(ok ? base + poff[i] : zsrc, smem_lds + (unsigned)((buf * PLANEQ + n * 64) * 16));
         }
     };
 
     // ---- epilogue of the finished output plane `od` (accumulator set 0): BN affine + residual + activation, NDHWC store
-    auto epilogue = [&](const int od) {
+    auto epilogue = [&](const int od, float* const tb) {
         // folded-BN scale / shift of the channels this lane finalises (re-read per plane from L2: 4 registers x 4 not held across the tap loop)
         float4 sc[2], sh[2];
 #pragma unroll
@@ -288,45 +277,100 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
         }
     };
 
-    for (int pd = d0 - 1; pd <= d1; ++pd) {
-        const bool v2 = (pd - 1 >= d0) && (pd - 1 < d1);      // output plane pd - 1 completes with this input plane
-        if (pd >= 0 && pd < p.Di) {                       // (planes outside the tensor are zero: nothing to add)
-            for (int pass = 0; pass < npass; ++pass) {
-                __syncthreads();                          // the previous pass's readers (planes and B ring) / the epilogue's tiles are done
-                dma_b(0, pass * G::CPP, 0);
-                dma_b(1, pass * G::CPP, 1);
-                dma_b(2, pass * G::CPP, 2);
-#if !defined(OSA_M2_NOSTAGE)
-                stage_brick<NTHR, PREC_F16X3, 2, 8>(p, smem, PLANEQ, b, pass * (G::CPP * CC), pd, g0h, g0w, tid, s_in);
-#endif
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                run_pass(pass * G::CPP);
-            }
-        }
-#if defined(OSA_M2_NOEPI)
-        if (v2) {
-            float t_ = 0.f;
+
+    // ---- pass sequence.  Planes pf .. pl of the input are walked (those outside [0, Di) are zero: skipped); pass q = (plane pf + q / nch,
+    // chunk q % nch) reads plane buffer q & 1; global step t = 9 q + s lives in ring slot t % 4 = (q + s) % 4.
+    const int pf = (d0 - 1 > 0) ? d0 - 1 : 0, pl = (d1 < p.Di - 1) ? d1 : p.Di - 1;
+    const int npass = (pl - pf + 1) * nch;
+    // prologue: plane-chunk of pass 0 and the B operands of steps 0..2, all in flight together
+    if constexpr (INS) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t_ += acc[0][m][r];
-            if (t_ == 12345.678f) yb[0] = t_;
-        }
-#else
-        if (v2) {
-            __syncthreads();                              // every wave is past its taps: the plane buffer becomes the transpose tiles
-            epilogue(pd - 1);
-        }
-#endif
-        // rotate: the plane that was pd becomes pd - 1 of the next step
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            acc[0][m] = acc[1][m]; acc[1][m] = acc[2][m];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[2][m][r] = 0.f;
-        }
+        for (int i = 0; i < NP; ++i) dma_piece(i, 0, pf, 0);
     }
+    dma_b(0, 0, 0); dma_b(1, 0, 1); dma_b(2, 0, 2);
+
+    int pd = pf, c = 0;
+    for (int q = 0; q < npass; ++q) {
+        const int cn = (c + 1 < nch) ? c + 1 : 0;                       // chunk of pass q + 1
+        const int pdn = (q + 1 < npass) ? ((c + 1 < nch) ? pd : pd + 1) : -1;   // its plane (-1: there is none -- zeros are fetched)
+        const int sb = q & 3, cur = q & 1;
+        if constexpr (!INS) {
+            __syncthreads();                              // the previous pass's readers of buffer `cur` are done
+            stage_brick<NTHR, PREC_F16X3, 1, 4>(p, smem + cur * PLANEQ, PLANEQ, b, c * CC, pd, g0h, g0w, tid, s_in);
+        }
+        if (!INS || q == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (INS: pass 0's plane; later passes arrive with their planes home: the waits of steps 2..8)
+        __syncthreads();
+        int ab[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ab[m] = abase[m] + cur * PLANEQ;
+        int bq[4];                                        // ring slot of step s + k: bq[(s + k) & 3]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = (((sb + k) & 3) * 6) * 64 + lane;
+        float4 A[2][MT][2], B[3][2];           // A: ping-pong per step; B: 3-deep rotation over (step, kd) micro-steps -- [hi, lo] of one kd, read 2 micro-steps ahead
+        auto load_a = [&](float4 (&An)[MT][2], const int khw) {
+            const int off = (khw / 3) * ROWQ + (khw % 3) * VQ;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { An[m][0] = smem[ab[m] + off]; An[m][1] = smem[ab[m] + off + 2]; }
+        };
+        auto load_b = [&](float4 (&Bn)[2], const int u) {       // micro-step u = step * 3 + kd of this pass
+            const int kd = u % 3;
+            Bn[0] = bring[bq[(u / 3) & 3] + (kd * 2) * 64]; Bn[1] = bring[bq[(u / 3) & 3] + (kd * 2 + 1) * 64];
+        };
+        load_b(B[0], 0);
+        load_b(B[1], 1);
+        load_a(A[0], 0);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            if (s > 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // every wave's share of step s + 1 has landed
+            // B operands of step s + 3 (of the next pass from s = 6 on), then one piece of the next pass's plane: the piece is YOUNGER than
+            // the B transfer the end-of-step wait is after, so it stays in flight across two more steps
+            if (s + 3 < 9) dma_b((sb + s + 3) & 3, c, s + 3);
+            else dma_b((sb + s + 3) & 3, cn, s + 3 - 9);
+            if (s < NP) dma_piece(s, cur ^ 1, pdn, cn);
+            if (s + 1 < 9) load_a(A[(s + 1) & 1], s + 1);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const int u = s * 3 + kd;
+                if (u + 2 < 27) load_b(B[(u + 2) % 3], u + 2);      // (kd = 1, 2 reach into step s + 1: landed and published by barrier s)
+                __builtin_amdgcn_sched_barrier(0);
+                // kd = 0 -> output plane pd + 1 (acc[2]), kd = 1 -> pd (acc[1]), kd = 2 -> pd - 1 (acc[0]); small cross terms first
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const f16x8 a = __builtin_bit_cast(f16x8, A[s & 1][m][term == 1 ? 1 : 0]);
+                        const f16x8 w = __builtin_bit_cast(f16x8, B[u % 3][term == 0 ? 1 : 0]);
+                        acc[2 - kd][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc[2 - kd][m], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // everything up to the B transfer of step s + 2 (issued a step ago) is home; younger: the piece of step s - 1, this step's B
+            // transfer (NI instructions) and this step's piece
+            constexpr int PCS = INS ? 1 : 0;
+            wait_vmcnt(NI + ((s < NP) ? PCS : 0) + ((s >= 1 && s - 1 < NP) ? PCS : 0));
+        }
+        // ---- plane complete?  (last chunk of plane pd)
+        if (c + 1 == nch) {
+            const bool v2 = (pd - 1 >= d0) && (pd - 1 < d1);     // output plane pd - 1 completes with input plane pd
+            if (v2) {
+                __syncthreads();                              // every wave is past its taps: buffer `cur` becomes the transpose tiles
+                epilogue(pd - 1, reinterpret_cast<float*>(smem + cur * PLANEQ) + wm * (32 * 36));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {                    // rotate: the plane that was pd becomes pd - 1 of the next step
+                acc[0][m] = acc[1][m]; acc[1][m] = acc[2][m];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[2][m][r] = 0.f;
+            }
+            if (q + 1 == npass && pd + 1 == d1 && pd + 1 >= p.Di) {
+                // the segment ends at the tensor's last plane: plane Di is zero, so output Di - 1 (now accumulator set 0) is complete too
+                __syncthreads();
+                epilogue(pd, reinterpret_cast<float*>(smem + cur * PLANEQ) + wm * (32 * 36));
+            }
+            ++pd; c = 0;
+        } else ++c;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the zero pieces / spare B transfers of the last pass)
     if (p.out_meta) {
         __syncthreads();
         publish_amax(p.out_meta, am, amax_seen, reinterpret_cast<float*>(smem));

@@ -10,18 +10,18 @@ namespace osa {
 static long long g_march_launches = 0;
 long long march_launches() { return g_march_launches; }
 
-struct MarchCfg { int nwv, tw, th; size_t lds; void (*fn[2])(const ConvArgs, int, int); };
+struct MarchCfg { int nwv, tw, th; size_t lds; void (*fn[2][2])(const ConvArgs, int, int); };   // [split output][split input]
 #define OSA_MARCH_CFG(NWV, TW) { NWV, TW, MarchGeo<NWV, TW>::TH, MarchGeo<NWV, TW>::lds_bytes(),                      \
-                                 { conv_march_kernel<NWV, TW, 0>, conv_march_kernel<NWV, TW, 1> } }
+                                 { { conv_march_kernel<NWV, TW, 0, 0>, conv_march_kernel<NWV, TW, 0, 1> },            \
+                                   { conv_march_kernel<NWV, TW, 1, 0>, conv_march_kernel<NWV, TW, 1, 1> } } }
 static const MarchCfg g_march_cfgs[] = {
-    OSA_MARCH_CFG(2, 16),     // 0:  8 x 16 pixel column, 2 waves, 4 workgroups per CU
-    OSA_MARCH_CFG(4, 32),     // 1:  8 x 32, 4 waves, 2 per CU
-    OSA_MARCH_CFG(4, 16),     // 2: 16 x 16, 4 waves, 2 per CU
+    OSA_MARCH_CFG(4, 16),     // 0: 16 x 16 pixel column, 4 waves, 2 workgroups per CU
+    OSA_MARCH_CFG(4, 32),     // 1:  8 x 32
 };
 
 int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     if (!exp_int("OSA_MARCH", 1)) return 0;
-    if (a.T != 27 || a.Co != 32 || a.CoP != 32 || a.nchunks % 2 != 0 || a.Di < 3 || a.gate || a.rx) return 0;
+    if (a.T != 27 || a.Co != 32 || a.CoP != 32 || a.Di < 3 || a.gate || a.rx) return 0;
     const int actk = a.act & 15;
     if (actk > OSA_ACT_LEAKY || (a.act & (OSA_GATE_RAW | OSA_RES_AFTER_ACT)) || ((unsigned)a.act >> 16)) return 0;
     if ((a.yCs & 3) || ((size_t)a.y & 15) || (a.res && ((a.rCs & 3) || ((size_t)a.res & 15)))) return 0;
@@ -36,10 +36,9 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     // pixel-column shape: least padded area among the 4-wave columns (16 x 16 first: measured 2-4 % ahead of 8 x 32 at 544x960,
     // profiles/round4/march_v3_ring4_ablation_ab.txt; the 2-wave 8 x 16 column loses 20 % since the B ring costs it a workgroup per CU)
     int gi = exp_int("OSA_MARCH_GEO", -1);
-    if (gi < 0 || gi > 2) {
+    if (gi < 0 || gi > 1) {
         long long best = -1;
-        static const int order[2] = {2, 1};
-        for (int i : order) {
+        for (int i = 0; i < 2; ++i) {
             const MarchCfg& g = g_march_cfgs[i];
             const long long area = (long long)cdiv(a.Ho, g.th) * g.th * cdiv(a.Wo, g.tw) * g.tw;
             if (best < 0 || area < best) { best = area; gi = i; }
@@ -51,11 +50,11 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     a.LD = 1; a.LH = g.th + 2; a.LW = g.tw + 2;
     a.VQ = 5;
     a.RowQ = (g.tw == 16) ? ((a.LW * 5 + 15) / 16 * 16) : a.LW * 5;
-    a.PlaneQ = a.LH * a.RowQ;
+    a.PlaneQ = a.LH * a.RowQ;          // (one plane per pass: LD = 1; only the fp32-input variant stages through ConvArgs geometry)
     a.magicW = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
     a.magicH = (unsigned)((0x100000000ull + a.LH - 1) / a.LH);
     a.magicHW = (unsigned)((0x100000000ull + (unsigned long long)a.LH * a.LW - 1) / ((unsigned long long)a.LH * a.LW));
-    a.cps = 2; a.dma = 0; a.dbg = exp_int("OSA_DBG", 0);
+    a.cps = 1; a.dma = 0; a.dbg = exp_int("OSA_DBG", 0);
     // D segments: a workgroup walks dseg output planes (+ 2 boundary planes that are staged for one third of their taps).  Cost model in
     // plane-steps: rounds of resident workgroups x (dseg + 2 boundary planes of a cut column, staged and multiplied in full); the fewest segments win a tie.
     const long long cols = (long long)a.B * a.tilesH * a.tilesW;
@@ -77,9 +76,9 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     const int dseg = cdiv(a.Di, nseg);
     nseg = cdiv(a.Di, dseg);
     OSA_REQUIRE(cols * nseg < (1ll << 31), "%s: grid too large", what);
-    void (*fn)(const ConvArgs, int, int) = g.fn[(a.act & OSA_OUT_SPLIT) ? 1 : 0];
-    static bool attr_set[3][2];
-    bool& done = attr_set[gi][(a.act & OSA_OUT_SPLIT) ? 1 : 0];
+    void (*fn)(const ConvArgs, int, int) = g.fn[(a.act & OSA_OUT_SPLIT) ? 1 : 0][(a.act & OSA_IN_SPLIT) ? 1 : 0];
+    static bool attr_set[2][2][2];
+    bool& done = attr_set[gi][(a.act & OSA_OUT_SPLIT) ? 1 : 0][(a.act & OSA_IN_SPLIT) ? 1 : 0];
     if (!done && g.lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds); }
     done = true;
     hipLaunchKernelGGL(fn, dim3((unsigned)(cols * nseg)), dim3(g.nwv * 64), g.lds, st, a, dseg, nseg);

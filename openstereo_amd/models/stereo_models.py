@@ -140,6 +140,21 @@ class StubFeature(nn.Module):
         return out
 
 
+def _pick_feature(feature, which):
+    """The 2-D feature pyramid of an end-to-end class: a module (the reference's own, or any shape-compatible one), None = the light
+    5-conv stand-in the round-2/3 fixtures were generated with (`StubFeature`), or "mobilenetv2" = the reference's pyramid --
+    feature_pyramid.Feature / IGEVFeature / LightStereoBackbone: MobileNetV2-100 trunk mirror (unpinned: timm absent) + the reference's FPN
+    decoder (pinned), full `feature.*` / `backbone.*` checkpoint keys."""
+    if isinstance(feature, str):
+        if feature != "mobilenetv2":
+            raise ValueError(f"unknown feature pyramid '{feature}' (only 'mobilenetv2')")
+        from . import feature_pyramid as FP
+        return {"stereobase": FP.Feature, "igev": FP.IGEVFeature, "lightstereo": FP.LightStereoBackbone}[which]()
+    if feature is not None:
+        return feature
+    return StubFeature((24, 32, 96, 160) if which == "lightstereo" else (48, 64, 192, 160))
+
+
 class StubContext(nn.Module):
     """Shape-compatible stand-in for MultiBasicEncoder (stereobase/gru_blocks.py, igev/extractor.py): image ->
     [(net, inp)] at 1/4, 1/8, 1/16 with hidden_dims / context_dims channels.  `forward(x, num_layers)` like the reference."""
@@ -244,7 +259,7 @@ class StereoBase(StereoBaseCostStage):
         inter_ch = g("INTERLACED_CHANNELS", 8) if use_inter else 0
         if groups + self_concat + use_sub + inter_ch == 0:
             raise ValueError("StereoBase: every volume switch is off (USE_GWC_VOLUME / USE_CONCAT_VOLUME / USE_SUB_VOLUME / USE_INTERLACED_VOLUME)")
-        feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
+        feature = _pick_feature(feature, "stereobase")
         bc = list(getattr(feature, "output_channels", (48, 64, 192, 160)))
         bc[0] += 48
         super().__init__(max_disp=cfgs.MAX_DISP, num_groups=groups, concat_channels=self_concat, backbone_channels=bc,
@@ -410,7 +425,7 @@ class IGEVStereo(IGEVCostStage):
         self.args = args
         hd = list(args.HIDDEN_DIMS)
         IN, LR = nn.InstanceNorm2d, nn.LeakyReLU
-        self.feature = feature if feature is not None else StubFeature((48, 64, 192, 160))
+        self.feature = _pick_feature(feature, "igev")
         self.cnet = cnet if cnet is not None else MultiBasicEncoder(output_dim=[hd, hd], norm_fn="batch", downsample=getattr(args, "N_DOWNSAMPLE", 2))
         self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hd)
         self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hd[i], hd[i] * 3, 3, padding=1) for i in range(args.N_GRU_LAYERS)])
@@ -477,7 +492,7 @@ class LightStereo(LightStereoCostStage):
     """lightstereo.py:13-71.  `cfgs`: MAX_DISP, LEFT_ATT, AGGREGATION_BLOCKS, EXPANSE_RATIO."""
 
     def __init__(self, cfgs, backbone=None):
-        backbone = backbone if backbone is not None else StubFeature((24, 32, 96, 160))
+        backbone = _pick_feature(backbone, "lightstereo")
         oc = list(backbone.output_channels)
         super().__init__(max_disp=cfgs.MAX_DISP, left_att=cfgs.LEFT_ATT, blocks=tuple(cfgs.AGGREGATION_BLOCKS),
                          expanse_ratio=cfgs.EXPANSE_RATIO, backbone_channels=oc)

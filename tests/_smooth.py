@@ -46,3 +46,56 @@ def smooth_activations(k: float = 4.0):
     finally:
         for o, n, f in saved:
             setattr(o, n, f)
+
+
+class KinkCount:
+    """how many pre-activations of a run sit within `tau` x max |x| of a kink of their activation (ReLU / LeakyReLU: 0; ReLU6 / hardtanh:
+    both ends) -- the elements whose mask a second correct fp32 implementation may decide the other way"""
+    def __init__(self):
+        self.near, self.total, self.calls = 0, 0, 0
+
+
+@contextlib.contextmanager
+def count_kinks(tau: float = 2e-6):
+    """Leaves the activations as they are and counts the at-risk elements (KinkCount).  r3 measured the mechanism: one pre-activation of
+    -2.9e-7 vs +1.5e-7 (relative to a tensor maximum of ~1) flipped between two implementations and moved an upstream weight gradient by
+    6e-3 of its max.  A run with NO at-risk element has a gradient that is locally smooth in the forward values and can be held to the
+    tight bound; every at-risk element buys one such flip's worth of tolerance (tests/test_gpu_models_e2e.py)."""
+    kc = KinkCount()
+    depth = [0]
+
+    def tally(x, kinks):
+        with torch.no_grad():
+            xf = x.detach().float()
+            m = float(xf.abs().max()) if xf.numel() else 0.0
+            if m > 0:
+                for kv in kinks:        # (values exactly ON the kink are structural -- zero padding -- and identical in every implementation)
+                    d = (xf - kv).abs()
+                    kc.near += int(((d < tau * m) & (d > 0)).sum())
+            kc.total += xf.numel(); kc.calls += 1
+
+    def wrap(fn, kinks_of):
+        def f(x, *a, **k):
+            if depth[0] == 0:           # F.relu calls torch.relu: count the outermost entry only
+                tally(x, kinks_of(*a, **k))
+            depth[0] += 1
+            try:
+                return fn(x, *a, **k)
+            finally:
+                depth[0] -= 1
+        return f
+
+    zero = lambda *a, **k: (0.0,)
+    ht = lambda min_val=-1.0, max_val=1.0, inplace=False: (min_val, max_val)
+    six = lambda *a, **k: (0.0, 6.0)
+    targets = [(F, "relu", zero), (F, "relu_", zero), (torch, "relu", zero), (torch, "relu_", zero), (torch.Tensor, "relu", zero),
+               (torch.Tensor, "relu_", zero), (F, "leaky_relu", zero), (F, "leaky_relu_", zero), (F, "hardtanh", ht), (F, "hardtanh_", ht),
+               (F, "relu6", six)]
+    saved = [(o, n, getattr(o, n)) for o, n, _ in targets]
+    try:
+        for (o, n, kinks_of), (_, _, orig) in zip(targets, saved):
+            setattr(o, n, wrap(orig, kinks_of))
+        yield kc
+    finally:
+        for o, n, f in saved:
+            setattr(o, n, f)

@@ -477,6 +477,79 @@ def gen_e2e_train(feat, cnet):
     save("e2e_reference_train.npz", **out)
 
 
+def gen_e2e_train_at_size():
+    """BASELINE configs[2] AT SIZE: the reference's own StereoBase class, training mode, at the SceneFlow crop 320x736
+    with MAX_DISP 192 and TRAIN_ITERS 22 (cfgs/stereobase/stereobase_sceneflow.yaml:15-16,27,40): forward, the reference's get_loss and
+    CPU autograd, frozen BatchNorm.  Smoothed activations (tests/_smooth.py) like the tight half of gen_e2e_train -- a 22-iteration
+    gradient through real ReLUs has thousands of ~0 pre-activations and cannot be pinned across implementations -- and contractive
+    update-block weights (gain 0.8, as the at-size inference fixtures).  Stored: loss, final / first-iteration / initial disparities
+    (sub-sampled), and the first 20000 elements of the gradients of parameters across all stages."""
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    from openstereo_amd.models.stereo_models import StubFeature
+    import torch.nn as nn
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from _smooth import smooth_activations
+    H, W = 320, 736
+    feat = lambda *a, **k: StubFeature((48, 64, 192, 160))
+    L, R = synth_images(1, H, W, seed=33, max_shift=40.0)
+    gt = torch.from_numpy(np.random.default_rng(5).uniform(1.0, 120.0, (1, H, W)).astype(np.float32))
+    cfg = Cfg(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, USE_GWC_VOLUME=True, USE_SUB_VOLUME=False, USE_INTERLACED_VOLUME=False,
+              CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_DOWNSAMPLE=2, N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2,
+              SLOW_FAST_GRU=False, TRAIN_ITERS=22, EVAL_ITERS=32)
+    net = _reference_model("stereo.modeling.models.stereobase.stereobase_gru", "StereoBase", cfg, {"Feature": feat})
+    sd = synth_state_dict(net, seed=41, head_gain=20.0, gain=0.9)
+    sd.update({k: v for k, v in synth_state_dict(net, seed=41, head_gain=20.0, gain=0.8).items() if k.startswith("update_block.")})
+    net.load_state_dict(sd)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.eval()
+    t = time.time()
+    with torch.enable_grad(), smooth_activations():
+        pred = net({"left": L, "right": R})
+        loss, _ = net.get_loss(pred, {"disp": gt})
+        loss.backward()
+    print(f"StereoBase 320x736 x22 training step (reference autograd, smoothed activations): {time.time() - t:.1f} s, loss {loss.item():.4f}, "
+          f"disp {pred['disp_pred'].min().item():.2f}..{pred['disp_pred'].max().item():.2f}")
+    out = {"loss": loss.detach(), "disp_sub": pred["disp_pred"].detach()[..., ::4, ::4], "init_disp_sub": pred["init_disp"].detach()[..., ::2, ::2],
+           "it1_sub": pred["disp_preds"][0].detach()[..., ::4, ::4], "n_preds": torch.tensor(len(pred["disp_preds"]))}
+    params = dict(net.named_parameters())
+    for k in E2E_TRAIN_KEYS["stereobase"]:
+        g = params[k].grad
+        assert g is not None and float(g.abs().max()) > 0, k
+        out[f"grad::{k}"] = g.reshape(-1)[:20000].clone()
+        out[f"gmax::{k}"] = g.abs().max()
+    save("e2e_reference_train_at_size.npz", **out)
+
+
+def gen_feature_pyramid():
+    """The reference's OWN feature-pyramid classes -- `Feature` of StereoBase (models/stereobase/backbone.py:32-73) and IGEV-Stereo
+    (models/igev/extractor.py:320-355), `Backbone` of LightStereo (models/lightstereo/backbone.py:29-75) -- with `timm.create_model`
+    answered by openstereo_amd.models.feature_pyramid.create_model (the key-compatible MobileNetV2-100 mirror; timm itself is not available
+    offline: the TRUNK is therefore unpinned, the FPN decoders -- Conv2xUp / Conv2x_IN / FPNLayer, InstanceNorm, replicate-padded
+    out_conv -- and the forward wiring are the reference's code).  128x256 image; outputs at 1/4 .. 1/32 and the state_dict key list."""
+    import importlib
+    from openstereo_amd.models import feature_pyramid as FP
+    from openstereo_amd.utils.weights import synth_state_dict, synth_images
+    fake = sys.modules.setdefault("timm", types.ModuleType("timm"))
+    fake.create_model = FP.create_model
+    img, _ = synth_images(2, 128, 256, seed=37)
+    out = {}
+    for tag, modname, clsname, seed in (("stereobase", "stereo.modeling.models.stereobase.backbone", "Feature", 61),
+                                        ("igev", "stereo.modeling.models.igev.extractor", "Feature", 62),
+                                        ("lightstereo", "stereo.modeling.models.lightstereo.backbone", "Backbone", 63)):
+        mod = importlib.import_module(modname)
+        mod.timm = fake                                   # (the module did `import timm` at import time)
+        net = getattr(mod, clsname)().eval()
+        net.load_state_dict(synth_state_dict(net, seed=seed, gain=0.9))
+        outs = net(img)
+        for i, t in enumerate(outs):
+            out[f"{tag}_out{i}"] = t
+        out[f"{tag}_keys"] = np.array(sorted(net.state_dict().keys()))
+        print(f"{tag} pyramid: {[tuple(t.shape) for t in outs]}, std {[round(float(t.std()), 3) for t in outs]}, {len(net.state_dict())} keys")
+    save("feature_pyramid.npz", **out)
+
+
 def gen_e2e_dormant():
     """StereoBase with the dormant volume switches (stereobase_gru.py:22-23,152-159; no shipped config sets them): the reference's own class,
     (a) USE_SUB_VOLUME + USE_INTERLACED_VOLUME on top of gwc + concat (8 + 16 + 1 + 8 = 33 volume channels), (b) gwc + interlaced only
@@ -522,7 +595,7 @@ def gen_e2e_dormant():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
-    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | e2e_dormant | unit_gain | context_encoder")
+    ap.add_argument("--only", default="", help="regenerate a single fixture group: lightstereo | igev_update | at_size | preprocess | dormant | e2e | e2e_dormant | e2e_train_at_size | feature_pyramid | unit_gain | context_encoder")
     args = ap.parse_args()
     import_reference()
     torch.set_grad_enabled(False)
@@ -547,6 +620,12 @@ def main():
         return
     if args.only == "e2e_dormant":
         gen_e2e_dormant()
+        return
+    if args.only == "feature_pyramid":
+        gen_feature_pyramid()
+        return
+    if args.only == "e2e_train_at_size":
+        gen_e2e_train_at_size()
         return
     if args.only == "unit_gain":
         gen_unit_gain()

@@ -232,8 +232,9 @@ def test_training_step_matches_reference_autograd(which, activations):
     per tensor (measured ~1e-6 .. 1e-5).  "reference": the reference's real activations; every ReLU whose pre-activation is ~0 is a
     discontinuity of the gradient, and two correct fp32 implementations do not agree on the sign of a 1e-7 pre-activation (measured: one
     flipped mask element in the first iteration's disparity head moves IGEVStereo's conv.conv.weight gradient by 6e-3 of its max,
-    tools/diag_e2e_grad7.py; the stock PyTorch-ROCm convolutions show the same effect against the CPU), so the bound there is the
-    kink-tolerant 3e-2 -- still far below what a wiring error produces (the avg_pool2d backward bug this test found was 2-5e-2 ... 1)."""
+    profiles/round3/diag; the stock PyTorch-ROCm convolutions show the same effect against the CPU), so the bound there is derived
+    from the number of at-risk pre-activations of the run (tests/_smooth.py::count_kinks): 5e-4 when there is none, one measured flip's
+    worth per at-risk element otherwise, never more than the old flat 3e-2; plus a per-tensor norm check that a mis-scaled layer fails."""
     import contextlib
     import numpy as np
     import torch.nn as nn
@@ -258,11 +259,20 @@ def test_training_step_matches_reference_autograd(which, activations):
     if which == "igev":
         L, Rr = (L * 40 + 128).clamp(0, 255), (Rr * 40 + 128).clamp(0, 255)
     gt = torch.from_numpy(np.random.default_rng(3).uniform(1.0, 30.0, (1, 64, 128)).astype(np.float32)).cuda()
-    tag, ctx, bound = (which + "_smooth", smooth_activations, 5e-4) if activations == "smooth" else (which, contextlib.nullcontext, 3e-2)
-    with ctx():
+    from _smooth import count_kinks
+    tag, ctx = (which + "_smooth", smooth_activations) if activations == "smooth" else (which, count_kinks)
+    with ctx() as kinks:
         out = m({"left": L.cuda(), "right": Rr.cuda()})
         loss, _ = m.get_loss(out, {"disp": gt})
         loss.backward()
+    # smooth activations: 5e-4.  The reference's real activations (r4, VERDICT r3 weak #2: no flat 3e-2 any more): the same 5e-4 when NO
+    # pre-activation of this run sits within 2e-6 x max of a kink; otherwise one measured flip's worth (6e-3 of max |grad|, r3
+    # diag/e2e_grad_relu_flip.txt) per at-risk element, capped at the old 3e-2 -- a 2 % mis-scaled layer no longer passes a kink-free run,
+    # and the norm check below catches a uniform mis-scaling even when kinks are present.
+    bound = 5e-4
+    if activations != "smooth":
+        print(f"[kinks] {kinks.near} at-risk pre-activations of {kinks.total} in {kinks.calls} activation calls")
+        bound = min(3e-2, 5e-4 + 6e-3 * kinks.near)
     want_loss = float(g[f"{tag}_loss"])
     assert abs(float(loss.detach()) - want_loss) < 2e-4 * abs(want_loss), (float(loss.detach()), want_loss)
     assert _epe(out["disp_pred"].detach(), g[f"{tag}_disp"]) < 1e-3
@@ -274,9 +284,59 @@ def test_training_step_matches_reference_autograd(which, activations):
         want = torch.from_numpy(g[f"{tag}_grad::{k}"])
         got = params[k].grad.detach().reshape(-1)[:want.numel()].cpu()
         worst[k] = float((got - want).abs().max() / (want.abs().max() + 1e-20))
+        # a flipped mask element moves single entries; a mis-scaled layer moves the whole tensor: its norm is off by the scale error
+        nr = float(got.norm() / (want.norm() + 1e-30))
+        assert abs(nr - 1.0) < max(2e-3, 0.25 * bound), f"{k}: gradient norm ratio {nr:.5f}"
     print({k: f"{v:.1e}" for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if not v < bound}
     assert not bad, bad                    # whole-model gradient error relative to max |grad| per tensor
+
+
+def test_stereobase_training_step_at_size_matches_reference_autograd():
+    """BASELINE configs[2] AT SIZE: the SceneFlow training crop 320x736, MAX_DISP 192, TRAIN_ITERS 22
+    (cfgs/stereobase/stereobase_sceneflow.yaml:15-16,27,40) -- whole-model training forward, the reference's loss, and the gradients of
+    16 parameters across every stage vs CPU autograd of the REFERENCE's own StereoBase class (tests/golden/e2e_reference_train_at_size.npz,
+    make_golden.gen_e2e_train_at_size: smoothed activations on both sides, frozen BatchNorm, contractive update-block weights)."""
+    import numpy as np
+    import torch.nn as nn
+    from conftest import golden
+    from _smooth import smooth_activations
+    from openstereo_amd.models.stereo_models import StereoBase
+    g = golden("e2e_reference_train_at_size.npz")
+    m = StereoBase(SimpleNamespace(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                                   N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=32, TRAIN_ITERS=22))
+    sd = synth_state_dict(m, seed=41, head_gain=20.0, gain=0.9)
+    sd.update({k: v for k, v in synth_state_dict(m, seed=41, head_gain=20.0, gain=0.8).items() if k.startswith("update_block.")})
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            mod.eval()
+    H, W = 320, 736
+    L, Rr = synth_images(1, H, W, seed=33, max_shift=40.0)
+    gt = torch.from_numpy(np.random.default_rng(5).uniform(1.0, 120.0, (1, H, W)).astype(np.float32)).cuda()
+    with smooth_activations():
+        out = m({"left": L.cuda(), "right": Rr.cuda()})
+        loss, _ = m.get_loss(out, {"disp": gt})
+        loss.backward()
+    assert len(out["disp_preds"]) == int(g["n_preds"]) == 22
+    want_loss = float(g["loss"])
+    assert abs(float(loss.detach()) - want_loss) < 5e-4 * abs(want_loss), (float(loss.detach()), want_loss)
+    assert _epe(out["init_disp"].detach()[..., ::2, ::2], g["init_disp_sub"]) < 1e-3
+    assert _epe(out["disp_preds"][0].detach()[..., ::4, ::4], g["it1_sub"]) < 1e-3
+    assert g["disp_sub"].std() > 2.0
+    assert _epe(out["disp_pred"].detach()[..., ::4, ::4], g["disp_sub"]) < 1e-3, _epe(out["disp_pred"].detach()[..., ::4, ::4], g["disp_sub"])
+    params = dict(m.named_parameters())
+    keys = [k.split("::", 1)[1] for k in g.files if k.startswith("grad::")]
+    assert len(keys) >= 12
+    worst = {}
+    for k in keys:
+        want = torch.from_numpy(g[f"grad::{k}"])
+        got = params[k].grad.detach().reshape(-1)[:want.numel()].cpu()
+        worst[k] = float((got - want).abs().max() / (float(g[f"gmax::{k}"]) + 1e-20))
+    print({k: f"{v:.1e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v < 2e-3}      # 22 iterations deep: 4x the 3-iteration bound of the small fixture
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
