@@ -72,3 +72,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    from openstereo_amd import _ext          # the PyTorch-ROCm C++ extension over the C ABI (csrc/torch_ext.cpp)
+    print(_ext.build(force="--force" in sys.argv))

@@ -462,6 +462,10 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 for (int n = 0; n < NT; ++n) {
                     B0[u][j][n] = wp[u * tstep + j * bstep + n * 32];
                     if constexpr (RING3) B1[u][j][n] = wp[tstep + j * bstep + n * 32];
+#ifdef OSA_DBG_NOB
+                    B2[u][j][n] = B0[u][j][n];
+                    if constexpr (!RING3) B1[u][j][n] = B0[u][j][n];
+#endif
                 }
     };
     init_b();
@@ -476,12 +480,14 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
 
     // prefetch group starting at flat tap `tn` (B: `skip` tap steps ahead of wp) into (An, Bn)
     auto prefetch = [&](float4 (&An)[TUA][JO][MT], float4 (&Bn)[TUA][JO][NT], int tn, int skip) {
+#ifndef OSA_DBG_NOB          // (-DOSA_DBG_NOB: timing-only build without the per-tap B loads -- what the weight stream through the vector-memory path costs)
 #pragma unroll
         for (int u = 0; u < TUA; ++u)
 #pragma unroll
             for (int j = 0; j < JO; ++j)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) Bn[u][j][n] = wp[(size_t)(skip + u) * tstep + j * bstep + n * 32];
+#endif
 #pragma unroll
         for (int u = 0; u < TUA; ++u) {
             const int ti = tn + u;

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import _lib, timing
+from . import _ext, _lib, timing
 from .ops import _stream, _p, empty_cl, is_cl
 
 import math
@@ -146,6 +146,17 @@ def cached_pack(owner, attr, build, mods=None):
                 cur.wait_event(ent.event)
             ent.synced[1].add(h)
     return ent.value
+
+
+_EMPTY = {}
+
+
+def _empty(device):
+    """an empty fp32 tensor on `device` (stands for a NULL pointer in the extension's tensor lists)"""
+    t = _EMPTY.get(device)
+    if t is None:
+        t = _EMPTY[device] = torch.empty(0, device=device, dtype=torch.float32)
+    return t
 
 
 def bn_scale_shift(bn):
@@ -323,8 +334,9 @@ class PackedConv3d:
             # operand ranges (device-side): scale of x / residual / redir input, bound for a split output, and the
             # output's own running maximum
             need_res = residual is not None and (out_split or is_split(residual))    # its scale (split) / its share of the output bound
-            rng = _lib.F16x3Ranges(input_meta(x).data_ptr(), input_meta(residual).data_ptr() if need_res else None,
-                                   None if redir is None else input_meta(redir[1]).data_ptr(), attach_meta(out, st).data_ptr(),
+            mx, mr, mo = input_meta(x), (input_meta(residual) if need_res else None), attach_meta(out, st)
+            rng = _lib.F16x3Ranges(mx.data_ptr(), None if mr is None else mr.data_ptr(),
+                                   None if redir is None else input_meta(redir[1]).data_ptr(), mo.data_ptr(),
                                    self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
         taps = self.k[0] * self.k[1] * self.k[2]
         macs = B * Do * Ho * Wo * self.Ci * self.Co * taps / ((4 if self.flat_deconv else 8) if self.transposed else 1)
@@ -333,7 +345,22 @@ class PackedConv3d:
                          flops=2 * macs, nbytes=nbytes):
             tail = (self.out_scale, rng, st) if self.precision == "f16x3" else (st,)
             sfx = self.precision
-            if redir is not None:
+            ext = _ext.load() if redir is None else None
+            if ext is not None:
+                # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp): one dispatcher call, tensors in, current HIP stream inside
+                if self.transposed:
+                    fam, geom = (2 if self.flat_deconv else 1), [self.k[1], self.pad[1], self.opad[1]]
+                else:
+                    fam, geom = 0, [self.k[0], self.k[1], self.k[2], self.stride[1], self.pad[0], self.pad[1], self.pad[2], self.dil[0], self.dil[1], self.dil[2]]
+                if self.precision == "f16x3":
+                    e = _empty(x.device)
+                    metas = [mx, e if mr is None else mr, e, mo, self.coef, e, e]
+                else:
+                    metas = []
+                ext.conv_ndhwc(x, x_off, self.packed, self.scale, self.shift, residual, res_off, out, out_off, gate,
+                               [B, D, H, W, Ci, Cs, self.Co, yCs, rCs, gCs], geom, fam, PRECISIONS.index(self.precision), act, self.slope,
+                               self.out_scale, metas)
+            elif redir is not None:
                 assert not h16, "the f16 mode has no fused redir branch (run the 1x1x1 layer and pass it as residual)"
                 rl, rt = redir
                 assert self.transposed and not self.flat_deconv and residual is None and gate is None

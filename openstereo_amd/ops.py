@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib, timing
+from . import _ext, _lib, timing
 from .ranges import attach_meta
 
 NCDHW, NDHWC = 0, 1
@@ -150,8 +150,12 @@ def correlation_volume(left_feature, right_feature, max_disp):
     _chk(left_feature, "left_feature", 4); _chk(right_feature, "right_feature", 4)
     l, r = _f32c(left_feature), _f32c(right_feature)
     B, Cn, H, W = l.shape
-    out = torch.empty((B, max_disp, H, W), device=l.device, dtype=torch.float32)
-    _lib.call("osa_corr_volume_f32", l.data_ptr(), r.data_ptr(), out.data_ptr(), B, Cn, H, W, max_disp, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        out = ext.corr_volume(l, r, int(max_disp))
+    else:
+        out = torch.empty((B, max_disp, H, W), device=l.device, dtype=torch.float32)
+        _lib.call("osa_corr_volume_f32", l.data_ptr(), r.data_ptr(), out.data_ptr(), B, Cn, H, W, max_disp, _stream())
     return out if left_feature.dtype == torch.float32 else out.to(left_feature.dtype)
 
 
@@ -268,8 +272,12 @@ def disparity_regression(x, maxdisp, keepdim=True):
     B, D, H, W = x.shape
     assert D == maxdisp, f"x has {D} disparity planes, maxdisp={maxdisp}"
     xs = _f32c(x)
-    out = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
-    _lib.call("osa_softargmin_f32", xs.data_ptr(), out.data_ptr(), B, D, H, W, _stream())
+    ext = _ext.load()
+    if ext is not None:                                           # torch extension: at::Tensor in / out (csrc/torch_ext.cpp)
+        out = ext.softargmin(xs)
+    else:
+        out = torch.empty((B, H, W), device=x.device, dtype=torch.float32)
+        _lib.call("osa_softargmin_f32", xs.data_ptr(), out.data_ptr(), B, D, H, W, _stream())
     out = out if _sum_dtype(x) == torch.float32 else out.to(x.dtype)
     return out.unsqueeze(1) if keepdim else out
 
@@ -282,9 +290,13 @@ def softmax_disparity_regression(cost, maxdisp=None, keepdim=True, return_prob=F
     if maxdisp is not None:
         assert D == maxdisp
     cs = _f32c(cost)
-    out = torch.empty((B, H, W), device=cost.device, dtype=torch.float32)
-    prob = torch.empty_like(cs) if return_prob else None
-    _lib.call("osa_softmax_softargmin_f32", cs.data_ptr(), _p(prob), out.data_ptr(), B, D, H, W, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        out, prob = ext.softmax_softargmin(cs, bool(return_prob))
+    else:
+        out = torch.empty((B, H, W), device=cost.device, dtype=torch.float32)
+        prob = torch.empty_like(cs) if return_prob else None
+        _lib.call("osa_softmax_softargmin_f32", cs.data_ptr(), _p(prob), out.data_ptr(), B, D, H, W, _stream())
     out = out.unsqueeze(1) if keepdim else out
     return (out, prob) if return_prob else out
 
@@ -300,8 +312,11 @@ def upsample_softargmin(cost_lowres, maxdisp, h, w, align_corners=False):
     assert cost_lowres.dim() == 4
     cs = _f32c(cost_lowres)
     B, Dl, Hl, Wl = cs.shape
-    out = torch.empty((B, h, w), device=cs.device, dtype=torch.float32)
+    ext = _ext.load()
     with timing.span("upsample_softargmin", Dl, Hl, Wl, int(maxdisp), int(h), int(w)):
+        if ext is not None:
+            return ext.upsample_softargmin(cs, int(maxdisp), int(h), int(w), bool(align_corners))
+        out = torch.empty((B, h, w), device=cs.device, dtype=torch.float32)
         _lib.call("osa_upsample_softargmin_f32", cs.data_ptr(), out.data_ptr(), B, Dl, Hl, Wl,
                   int(maxdisp), int(h), int(w), 1 if align_corners else 0, _stream())
     return out
@@ -315,10 +330,14 @@ def context_upsample(disp_low, up_weights, scale_factor=4, softmax_weights=False
     b, c, h, w = disp_low.shape
     assert c == 1 and tuple(up_weights.shape) == (b, 9, h * scale_factor, w * scale_factor)
     d, wt = _f32c(disp_low), _f32c(up_weights)
-    out = torch.empty((b, h * scale_factor, w * scale_factor), device=d.device, dtype=torch.float32)
+    ext = _ext.load()
     with timing.span("context_upsample", h, w, scale_factor):
-        _lib.call("osa_context_upsample_f32", d.data_ptr(), wt.data_ptr(), out.data_ptr(), b, h, w, int(scale_factor),
-                  1 if softmax_weights else 0, float(gain), _stream())
+        if ext is not None:
+            out = ext.context_upsample(d, wt, int(scale_factor), bool(softmax_weights), float(gain))
+        else:
+            out = torch.empty((b, h * scale_factor, w * scale_factor), device=d.device, dtype=torch.float32)
+            _lib.call("osa_context_upsample_f32", d.data_ptr(), wt.data_ptr(), out.data_ptr(), b, h, w, int(scale_factor),
+                      1 if softmax_weights else 0, float(gain), _stream())
     od = _sum_dtype(disp_low, up_weights)
     return out if od == torch.float32 else out.to(od)
 

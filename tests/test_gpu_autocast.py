@@ -220,7 +220,13 @@ def test_gwcnet_whole_model_under_autocast(dt):
     e_low = float((got - want).abs().mean())                  # vs the low-precision eager composition
     e_32 = float((got - ref32).abs().mean())                  # vs fp32: the engine does not lose precision under autocast
     e_eager = float((want - ref32).abs().mean())              # the low-precision eager composition's own error
-    assert e_32 < 1e-3, e_32
+    from openstereo_amd import engine
+    if engine.AUTOCAST_NATIVE and dt == torch.float16:
+        # r4: an fp16 region runs the native f16 mode (the reference's own autocast arithmetic, fp16 tensors between chained layers):
+        # as close to the truth as the eager fp16 composition is (measured 0.012 px vs 0.028 px), no longer fp32-class
+        assert e_32 <= 2.0 * e_eager + 1e-3, (e_32, e_eager)
+    else:
+        assert e_32 < 1e-3, e_32                              # fp32-class arithmetic: the engine does not lose precision under autocast
     assert e_low <= e_eager + e_32 + 1e-6, (e_low, e_eager)   # triangle inequality: never further from eager-AMP than eager-AMP is from fp32
 
 

@@ -9,7 +9,10 @@ import sys
 out_dir = sys.argv[1]
 BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 KERNELS = {
-    "conv3d_32_32_V0_f16x3": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
+    # r4: the V0 3x3x3 32 -> 32 layers run the d-marching kernel; its <split out, split in> instance runs dres0.2, dres1.0, dres1.2
+    # (dres0.0 reads the fp32 volume: <.., 1, 0>; classif3.0 writes fp32: <.., 0, 1>).  r3 and before: the brick kernel instance below.
+    "conv3d_32_32_V0_f16x3": os.environ.get("OSA_PMC_DOMINANT", "conv_march_kernel<4, 16, 1, 1>"),
+    "conv3d_32_32_V0_f16x3_brick": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
     "volume": "build_volume_quads_kernel<2, 8",
     "head": "upsample4_softargmin_kernel",
     "classifier": "classifier_march_kernel",
@@ -45,7 +48,7 @@ for key, sub in KERNELS.items():
     g = max(k[1] for k in fk)
     f = [v for k, v in fk.items() if k[1] == g][0]
     w = [v for k, v in wk.items() if k[1] == g][0]
-    if key.startswith("conv3d_32_32"):               # dispatch order per step: dres0.0 (64 -> 32), dres0.2, dres1.0, dres1.2: price the plain 32 -> 32 launches
+    if key.startswith("conv3d_32_32") and "conv_mfma_kernel" in sub:   # brick instance, dispatch order per step: dres0.0 (64 -> 32), dres0.2, dres1.0, dres1.2: price the plain 32 -> 32 launches
         f = [v for i, v in enumerate(f) if i % 4 in (1, 2)]
         w = [v for i, v in enumerate(w) if i % 4 in (1, 2)]
     fb, wb = sum(f) / len(f) * 1024.0, sum(w) / len(w) * 1024.0
