@@ -68,6 +68,87 @@ __global__ __launch_bounds__(256) void dwconv2d_nhwc_kernel(const DwArgs p) {
     if (p.meta) publish_amax(p.meta, am, am_seen, red);
 }
 
+// r4: pixel-run form.  The kernel above issues 2 x kh x kw 16-byte loads per output quad (input + weight per tap; the column re-reads are
+// L1 hits, but every one of them occupies the vector-memory path) and ran LightStereo's depthwise launches at ~1.3 TB/s of algorithmic
+// traffic -- 57 % of the whole cost stage (profiles/round4/amp_workloads_kernel_tables.txt).  Here a thread owns 4 channels of NPX
+// consecutive output pixels of one row: per kernel row it loads the (NPX - 1) S + KW input quads of its window ONCE into registers and
+// each tap's weight quad once; 3x3 stride 1: 27 loads per 4 outputs instead of 72, 1x21: 45 instead of 168.  Same fmaf order per
+// output as the kernel above (ky outer, kx inner): bit-identical results.  Unit dilation; compile-time (KW, S) for the shapes the
+// models use -- 3x3 (stride 1 / 2), the strip convolutions 1x7 / 7x1 / 1x11 / 11x1 / 1x21 / 21x1 -- anything else keeps the tap-loop kernel.
+template <int KW, int S, int NPX, int KC = KW>
+__global__ __launch_bounds__(256) void dwconv2d_run_kernel(const DwArgs p, const int runs) {
+    // KC: taps of a row handled per window (KC < KW: the long horizontal strips 1x11 / 1x21 walk their row in chunks of KC taps, so the
+    // register window stays (NPX - 1) S + KC quads; the chunk loop is kept rolled)
+    static_assert(KW % KC == 0, "chunks must tile the kernel row");
+    constexpr int WIN = (NPX - 1) * S + KC;
+    __shared__ float red[4];
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    float am = 0.f;
+    const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
+    if (idx < p.total) {
+        const unsigned nq = (unsigned)(p.C >> 2);
+        unsigned r = (unsigned)idx;                        // host: total < 2^31
+        const unsigned q = r % nq; r /= nq;
+        const unsigned run = r % (unsigned)runs; r /= (unsigned)runs;
+        const int oy = (int)(r % (unsigned)p.Ho);
+        const int b = (int)(r / (unsigned)p.Ho);
+        const int c = (int)q * 4, ox0 = (int)run * NPX;
+        float4 acc[NPX];
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.xCs + c;
+        const int iy0 = oy * S - p.pad_h, ix0 = ox0 * S - p.pad_w;
+        for (int ky = 0; ky < p.kh; ++ky) {
+            const int iy = iy0 + ky;
+            if ((unsigned)iy >= (unsigned)p.Hi) continue;
+            const float* row = xb + (size_t)iy * p.Wi * p.xCs;
+#pragma unroll 1
+            for (int kc = 0; kc < KW; kc += KC) {
+                float4 win[WIN];
+#pragma unroll
+                for (int i = 0; i < WIN; ++i) {
+                    const int ix = ix0 + kc + i;
+                    win[i] = ((unsigned)ix < (unsigned)p.Wi) ? *reinterpret_cast<const float4*>(row + (size_t)ix * p.xCs) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const float* wr = p.w + (size_t)(ky * KW + kc) * p.C + c;
+#pragma unroll
+                for (int kx = 0; kx < KC; ++kx) {
+                    const float4 w = *reinterpret_cast<const float4*>(wr + (size_t)kx * p.C);
+#pragma unroll
+                    for (int j = 0; j < NPX; ++j) {
+                        const float4 v = win[j * S + kx];
+                        // (a column outside the image contributes nothing in the tap-loop kernel; here it contributes v = 0: fmaf(0, w, acc) == acc
+                        // exactly, except for acc = -0 -> +0, which no later operation distinguishes)
+                        acc[j].x = fmaf(v.x, w.x, acc[j].x); acc[j].y = fmaf(v.y, w.y, acc[j].y);
+                        acc[j].z = fmaf(v.z, w.z, acc[j].z); acc[j].w = fmaf(v.w, w.w, acc[j].w);
+                    }
+                }
+            }
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c);
+        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + c);
+        const size_t opix0 = ((size_t)b * p.Ho + oy) * p.Wo + ox0;
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            if (ox0 + j >= p.Wo) break;
+            float o[4] = {fmaf(acc[j].x, sc.x, sh.x), fmaf(acc[j].y, sc.y, sh.y), fmaf(acc[j].z, sc.z, sh.z), fmaf(acc[j].w, sc.w, sh.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.act == OSA_ACT_RELU) o[e] = fmaxf(o[e], 0.f);
+                else if (p.act == OSA_ACT_RELU6) o[e] = fminf(fmaxf(o[e], 0.f), 6.f);
+            }
+            if (p.add) {
+                const float4 a = *reinterpret_cast<const float4*>(p.add + (opix0 + j) * p.aCs + c);
+                o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+            }
+            *reinterpret_cast<float4*>(p.y + (opix0 + j) * p.yCs + c) = make_float4(o[0], o[1], o[2], o[3]);
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
+    }
+    if (p.meta) publish_amax(p.meta, am, am_seen, red);
+}
+
 __global__ __launch_bounds__(256) void dwconv2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int T) {
     const int i = blockIdx.x * 256 + threadIdx.x;      // dst index t*C + c
     if (i >= C * T) return;
@@ -111,6 +192,27 @@ extern "C" int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
     a.Ho = (Hi + 2 * pad_h - dil_h * (kh - 1) - 1) / stride + 1;
     a.Wo = (Wi + 2 * pad_w - dil_w * (kw - 1) - 1) / stride + 1;
     OSA_REQUIRE(a.Ho > 0 && a.Wo > 0, "dwconv2d: empty output");
+    // pixel-run form for the shapes the models use (unit dilation; see dwconv2d_run_kernel)
+    {
+        constexpr int NPX = 4;
+        const int runs = cdiv(a.Wo, NPX);
+        const long long total = (long long)B * a.Ho * runs * (C / 4);
+        void (*fn)(const DwArgs, int) = nullptr;
+        if (dil_h == 1 && dil_w == 1 && total < (1ll << 31) && !exp_set("OSA_DW_TAPLOOP")) {
+            if (kw == 3 && stride == 1) fn = dwconv2d_run_kernel<3, 1, NPX>;
+            else if (kw == 3 && stride == 2) fn = dwconv2d_run_kernel<3, 2, NPX>;
+            else if (kw == 1 && stride == 1) fn = dwconv2d_run_kernel<1, 1, NPX>;
+            else if (kw == 7 && stride == 1) fn = dwconv2d_run_kernel<7, 1, NPX>;
+            else if (kw == 11 && stride == 1) fn = dwconv2d_run_kernel<11, 1, NPX, 11>;      // (11 is prime: one 14-quad window)
+            else if (kw == 21 && stride == 1) fn = dwconv2d_run_kernel<21, 1, NPX, 7>;       // three chunks of 7 taps: 10-quad windows
+        }
+        if (fn) {
+            a.total = total;
+            hipLaunchKernelGGL(fn, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, runs);
+            OSA_LAUNCH_CHECK("dwconv2d");
+            return 0;
+        }
+    }
     a.total = (long long)B * a.Ho * a.Wo * (C / 4);
     const long long nblk = (a.total + 255) / 256;
     OSA_REQUIRE(nblk < (1ll << 31), "dwconv2d: grid too large");
