@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--no-workloads", action="store_true", help="default workload: skip the compact measurements of the other BASELINE configs (`workloads`)")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs: nothing but warm-up + the timed configuration (no other-precision leg, no B=1 loop, no CPU leg)")
+    ap.add_argument("--force-ddp", action="store_true", help="training workloads on ONE GPU: one-rank RCCL process group + DistributedDataParallel (checks the DDP + hipGraph path without a second GPU)")
     ap.add_argument("--stub", action="store_true",
                     help="CPU plumbing self-test (tests/test_sharding_gloo.py): gloo backend, the forward replaced by a sleep")
     return ap.parse_args()
@@ -213,7 +214,7 @@ class StereoBaseTrain:
                 m.eval()
         self.raw = st
         self.model = st
-        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+        if _use_ddp():
             self.model = torch.nn.parallel.DistributedDataParallel(st, device_ids=[dev.index])
         self.opt = torch.optim.SGD([p for p in st.parameters() if p.requires_grad], lr=1e-4)
         g = torch.Generator().manual_seed(80 + rank)
@@ -332,7 +333,7 @@ class StereoBaseE2ETrain:
                 m.eval()
         self.raw = net
         self.model = net
-        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+        if _use_ddp():
             self.model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
         # capturable: the step counter lives on the device, so the optimizer step can be part of a hipGraph (no effect on the arithmetic)
         self.opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5, eps=1e-8, capturable=True)
@@ -369,7 +370,7 @@ class GwcNetTrain:
         net.load_state_dict(synth_state_dict(net, seed=0))
         self.raw = net.to(dev).train()
         self.model = self.raw
-        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+        if _use_ddp():
             self.model = torch.nn.parallel.DistributedDataParallel(self.raw, device_ids=[dev.index])
         self.opt = torch.optim.RMSprop(self.model.parameters(), lr=1e-3, capturable=True)      # cfgs/gwcnet/gwcnet_sceneflow.yaml (capturable: hipGraph-friendly, same arithmetic)
         L, R = synth_images(B, 256, 512, seed=10 + rank)
@@ -561,18 +562,27 @@ class _eager_torch_mode:
         return False
 
 
-def capture_training_step(wl):
+def _use_ddp():
+    """Training workloads wrap their model in DistributedDataParallel when the job has more than one rank -- or when --force-ddp asks
+    for the one-rank RCCL group that lets a single-GPU box exercise the DDP + hipGraph path."""
+    return int(os.environ.get("WORLD_SIZE", 1)) > 1 or os.environ.get("OSA_BENCH_FORCE_DDP") == "1"
+
+
+def capture_training_step(wl, ddp=False):
     """Whole training step as ONE hipGraph (forward, loss, backward, optimizer step, the per-step weight re-packs with their device-side
     scales): the eager step is launch-bound (1.7 K - 11 K launches of a few microseconds each).  Nothing is skipped -- every replay runs
     the same kernels on the updated weights; the loss is the static-shape form (`get_loss(..., static=True)`, same value).  PyTorch's
     whole-network capture recipe: warm-up on a side stream, grads released before capture so that backward allocates them from the
-    graph's pool.  Returns (graph, step) or None when capture is not possible (the caller then times eager steps)."""
+    graph's pool.  Under DDP (r4) the recipe's extra conditions hold too: the wrapper was constructed on a side stream (main), the RCCL
+    watchdog's asynchronous error handling is off (set before init_process_group), and 11 eager DDP steps precede the capture (the reducer
+    rebuilds its buckets during the first iterations); the gradient all-reduces are then captured as graph nodes on RCCL's stream.
+    Returns (graph, step) or None when capture is not possible (the caller then times eager steps)."""
     try:
         wl.static = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):
+            for _ in range(11 if ddp else 2):
                 wl.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -796,15 +806,30 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        if world > 1:
+        training = getattr(WORKLOADS.get(args.workload), "training", False)
+        if args.force_ddp and world == 1 and training:
+            os.environ["OSA_BENCH_FORCE_DDP"] = "1"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        if training and _use_ddp() and not args.no_graph:
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")     # DDP + graph capture (capture_training_step)
+        if world > 1 or os.environ.get("OSA_BENCH_FORCE_DDP") == "1":
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=dev)       # "nccl" == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
         from openstereo_amd import _lib, engine
         _lib.load()
         engine.set_precision(args.precision)
     from openstereo_amd.parallel import reduce_step_time, whole_job_rate
 
-    wl = (_Stub if args.stub else WORKLOADS[args.workload])(args, dev, rank)
+    ddp_graph = (not args.stub) and dev.type == "cuda" and _use_ddp() and getattr(WORKLOADS.get(args.workload), "training", False) and not args.no_graph
+    if ddp_graph:
+        # DDP wrappers that will be captured into a hipGraph are constructed on a side stream (PyTorch's DDP + CUDA-graphs recipe)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            wl = WORKLOADS[args.workload](args, dev, rank)
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        wl = (_Stub if args.stub else WORKLOADS[args.workload])(args, dev, rank)
     B = wl.B
     if args.amp and not wl.training and not args.stub:
         wl.step = _amp_step(wl.step)
@@ -825,8 +850,16 @@ def main():
     # inner loop -> one graph launch per step).  Warm-up has packed every weight, so only kernels (and the caching allocator's
     # graph pool) are recorded.
     graph = None
-    if wl.training and world == 1 and not args.no_graph and dev.type == "cuda":
-        cap = capture_training_step(wl)
+    if wl.training and not args.no_graph and dev.type == "cuda":
+        cap = capture_training_step(wl, ddp=ddp_graph)
+        if dist is not None and world > 1:
+            # every rank replays or every rank launches eagerly: a mixed job would dead-lock in the first all-reduce
+            ok = torch.tensor([1.0 if cap is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok) == 0.0 and cap is not None:
+                print("[bench] another rank could not capture its step: running eagerly", file=sys.stderr)
+                cap = None
+                wl.static = False
         if cap is not None:
             graph, step = cap
             step()

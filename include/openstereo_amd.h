@@ -543,6 +543,27 @@ int osa_instnorm_nhwc_f32(const float* x, float* y, int B, long long HW, int C, 
  * order).  This counter tells how many calls of this process took that form (tests assert that the intended layers do). */
 long long osa_conv3d_march_launches(void);
 
+/* ---- B (weight) operands through an LDS ring (r4, csrc/conv_kernel.h BL = 1; f16x3 and f16 modes) ----
+ * Every convolution / transposed convolution entry point above (the MFMA tiles behind nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d of
+ * gwcnet/hourglass.py:19-56, gwcnet_disp_processor.py:40-81, gwcnet_backbone.py:38-91) fetches a tap step's weight fragments once per
+ * workgroup by LDS-DMA instead of once per wave.  Same products, same order: results are bit-identical either way.  The mask selects the
+ * tile configurations that take the ring (bit i = entry i of csrc/conv_cfgs.def, bit 30 = the fused transposed convs; default: the
+ * tiles where it measured faster, csrc/conv3d.hip g_b_ring_mask; -1 = every tile that has the form, 0 = none); it exists for A/B
+ * measurements and for the parity test that proves the two forms identical.  Returns the previous mask.
+ * osa_conv_b_ring_launches: launches of this process that took the ring form. */
+int osa_conv_b_ring_mask(int mask);
+long long osa_conv_b_ring_launches(void);
+
+/* ---- d-walking form of the fused NDHWC volume builder (r4, csrc/volume.hip build_volume_walk_kernel) ----
+ * osa_build_volume_nhwc_f32 (build_gwc_volume + build_concat_volume + torch.cat, cost_volume.py:59-105, gwcnet_cost_processor.py:65) runs
+ * eligible calls (NHWC features with 16-byte aligned channel quads, quad-lane channel counts, maps at least 2 x 32 pixels wide) as
+ * workgroups that own a (row, 32-pixel tile) and walk along d: left features stay in registers for all disparities, the right window is a
+ * ring in LDS that a loader wave refills by LDS-DMA `step` pixels at a time while the other waves compute and store.  Bit-identical output.
+ * osa_volume_walk_step(step): 8 (default) or 4 disparities per step, 0 = the chunked kernel; returns the previous value (A/B runs and the
+ * parity test).  osa_volume_walk_launches: calls of this process that took the walking form. */
+int osa_volume_walk_step(int step);
+long long osa_volume_walk_launches(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,6 +174,10 @@ SIGNATURES = {
     "osa_instnorm_workspace_floats": (C.c_size_t, [c_i, c_ll, c_i]),
     "osa_instnorm_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_f, c_i, c_f, c_fp, c_fp, c_st]),
     "osa_conv3d_march_launches": (c_ll, []),
+    "osa_conv_b_ring_mask": (c_i, [c_i]),
+    "osa_conv_b_ring_launches": (c_ll, []),
+    "osa_volume_walk_step": (c_i, [c_i]),
+    "osa_volume_walk_launches": (c_ll, []),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
@@ -208,6 +212,10 @@ def load():
             fn.argtypes = args
         if lib.osa_abi_version() != 4:
             raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}")
+        if os.environ.get("OSA_B_RING_MASK") and hasattr(lib, "osa_conv_b_ring_mask"):
+            lib.osa_conv_b_ring_mask(int(os.environ["OSA_B_RING_MASK"], 0))     # A/B runs: which tiles take their weights through the LDS ring
+        if os.environ.get("OSA_VOL_WALK") and hasattr(lib, "osa_volume_walk_step"):
+            lib.osa_volume_walk_step(int(os.environ["OSA_VOL_WALK"]))               # A/B runs: 0 = chunked volume builder, 4 / 8 = d-walking form
         _lib = lib
     return _lib
 

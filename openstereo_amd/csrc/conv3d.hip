@@ -225,6 +225,17 @@ static void set_stagger(ConvArgs& a, const KernelCfg& k, void (*fn)(const ConvAr
 // d-marching form of the 3x3x3 stride-1 32-output-channel layers (f16x3): conv_march.hip.  1 = launched, 0 = not eligible, -1 = error
 int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
 
+// Which tile configurations take their B operands through the LDS ring (osa_conv_b_ring_mask; bit i = conv_cfgs.def entry i, bit 30 = the
+// fused transposed convs).  Default = the tiles where the ring measured ahead at 8 AND at 4 pairs per launch (profiles/round4/
+// b_ring_layers_ab.txt, b_ring_ablation_and_tiles.txt): the stride-1 tiles with 64 output channels or more per workgroup whose four waves
+// share every fragment -- 1 (256 x 64: GwcNet conv2 1.067 -> 1.001 ms), 2 (128 x 128: conv4 0.619 -> 0.569), 3 / 4 (few-tap launches: redir 1x1x1
+// +3-7 %), 13 (2-D 128 x 64: the 31 quarter-resolution 64 -> 64 layers 0.157 -> 0.152).  Left on the per-wave stream: the stride-2 tiles 5 / 6 /
+// 14 / 15 (3-6 MFMAs per step: one barrier + one transfer per 96-192 matrix cycles costs more than the stream, conv3 -36 %), the 32-channel
+// tiles 0 / 7 / 12 (first 32 -> 32: -11 %), 9 (2 x 2 waves share a fragment only pairwise: 128 -> 128 @1/4 -3 ... +1 %), 11 (no sharing at
+// all), the fused transposed convs (+-1 %).
+static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13);
+static long long g_b_ring_launches = 0;
+
 static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what,
                        const KernelCfg* forced = nullptr) {
 #ifdef OSA_EXPERIMENTS
@@ -326,6 +337,16 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         OSA_REQUIRE(fn != nullptr, "%s: this tile configuration has no split- / fp16-output variant", what);
     }
     OSA_REQUIRE(fn != nullptr, "%s: tile configuration %s is not built for this arithmetic mode", what, k.name);
+    // B operands through the LDS ring (conv_kernel.h, BL = 1; f16x3 / f16 modes): a 4-slot ring of one tap step's fragments
+    // (2 KB per 32 output channels of the workgroup) above the bricks and the epilogue tiles.  Bit-identical results.
+    a.ringQ = 0;
+    {
+        void (*fb)(const ConvArgs) = (a.act & OSA_OUT_SPLIT) ? kf.fnbs : kf.fnb;
+        const size_t ring = (size_t)4 * 2 * (k.N / 32) * 1024;
+        const int bit = (k.table == 0) ? (int)(&k - g_cfgs) : 30;     // osa_conv_b_ring_mask: conv_cfgs.def index, 30 = the fused transposed convs
+        const bool use = fb != nullptr && k.ks <= 1 && ((g_b_ring_mask >> bit) & 1) && lds + ring <= 160 * 1024;
+        if (use) { fn = fb; a.ringQ = (int)(lds / 16); lds += ring; ++g_b_ring_launches; }
+    }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)nblk, a.CoP / k.N), block(k.threads);
@@ -1141,3 +1162,6 @@ extern "C" int osa_debug_trace_read(unsigned long long* dst, size_t n_words) {
     return (int)n_words;
 }
 #endif
+
+extern "C" int osa_conv_b_ring_mask(int mask) { const int prev = osa::g_b_ring_mask; osa::g_b_ring_mask = mask; return prev; }
+extern "C" long long osa_conv_b_ring_launches(void) { return osa::g_b_ring_launches; }

@@ -7,8 +7,9 @@ namespace osa {
 
 typedef void (*ConvFn)(const ConvArgs);
 // fn: ping-pong operand pipeline; fn3: B-ring pipeline (tap counts % 3 == 0) or null; fns / fns3: the same with OUTS = 1 (the output
-// is a split tensor in the f16x3 mode, an fp16 tensor in the f16 mode) or null
-struct KernelFns { ConvFn fn, fn3, fns, fns3; };
+// is a split tensor in the f16x3 mode, an fp16 tensor in the f16 mode) or null; fnb / fnbs: B operands through the LDS ring (BL = 1; f16x3 and
+// f16 modes, tiles whose waves can split a step's fragments evenly) or null
+struct KernelFns { ConvFn fn, fn3, fns, fns3, fnb, fnbs; };
 struct ConvFnTables {
     const KernelFns* cfgs; int n_cfgs;     // conv_cfgs.def order
     const KernelFns* ks;                   // the 4 split-K tiles

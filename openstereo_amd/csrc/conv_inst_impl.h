@@ -15,11 +15,20 @@ namespace osa {
 #endif
 #define OSA_RING_0(x) nullptr
 #define OSA_RING_1(x) x
+// BL = 1 variants (B operands through the LDS ring): every mode but exact f32, tiles with (2 * JO * WN * NT) % (WM * WN) == 0
+template <int NCLS, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR, int OUTS>
+static constexpr ConvFn bl_fn() {
+    if constexpr (OSA_INST_PREC != PREC_F32 && (OUTS == 0 || OSA_INST_OUTS) && (2 * JO * WN * NT) % (WM * WN) == 0)
+        return conv_mfma_kernel<OSA_INST_PREC, NCLS, 1, MT, NT, WM, WN, TH, TW, REDIR, OUTS, 0, 1, 1>;
+    else return nullptr;
+}
+#define OSA_KB(NCLS, MT, NT, WM, WN, TH, TW, REDIR, OUTS) bl_fn<NCLS, MT, NT, WM, WN, TH, TW, REDIR, OUTS>()
 
 static const KernelFns g_cfg_fns[] = {
 #define OSA_CFG_X(RING, MT, NT, WM, WN, TH, TW)                                                                          \
     { OSA_K(1, 1, MT, NT, WM, WN, TH, TW, 0, 0, 1), OSA_RING_##RING(OSA_K(1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 1)),       \
-      OSA_KO(1, 1, MT, NT, WM, WN, TH, TW, 0, 1), OSA_RING_##RING(OSA_KO(1, 3, MT, NT, WM, WN, TH, TW, 0, 1)) },
+      OSA_KO(1, 1, MT, NT, WM, WN, TH, TW, 0, 1), OSA_RING_##RING(OSA_KO(1, 3, MT, NT, WM, WN, TH, TW, 0, 1)),           \
+      OSA_KB(1, MT, NT, WM, WN, TH, TW, 0, 0), OSA_KB(1, MT, NT, WM, WN, TH, TW, 0, 1) },
 #define OSA_KS_X(MT, NT, WM, WN, TH, TW, KS)
 #include "conv_cfgs.def"
 #undef OSA_CFG_X
@@ -29,7 +38,7 @@ static const KernelFns g_cfg_fns[] = {
 static const KernelFns g_ks_fns[] = {
 #define OSA_CFG_X(RING, MT, NT, WM, WN, TH, TW)
 #define OSA_KS_X(MT, NT, WM, WN, TH, TW, KS)                                                                             \
-    { OSA_K(1, 1, MT, NT, WM, WN, TH, TW, 0, 0, KS), OSA_K(1, 3, MT, NT, WM, WN, TH, TW, 0, 0, KS), nullptr, nullptr },
+    { OSA_K(1, 1, MT, NT, WM, WN, TH, TW, 0, 0, KS), OSA_K(1, 3, MT, NT, WM, WN, TH, TW, 0, 0, KS), nullptr, nullptr, nullptr, nullptr },
 #include "conv_cfgs.def"
 #undef OSA_CFG_X
 #undef OSA_KS_X
@@ -38,13 +47,13 @@ static const KernelFns g_ks_fns[] = {
 // fused transposed convs: 128 input-resolution positions x 32 channels x 8 parity classes per workgroup (brick 4x4x8); 2-D: 4 classes, 8x16
 static const KernelFns g_deconv_fns[] = {
 #if OSA_INST_REDIR
-    { OSA_K(8, 1, 1, 1, 4, 1, 4, 8, 1, 0, 1), nullptr, OSA_KO(8, 1, 1, 1, 4, 1, 4, 8, 1, 1), nullptr },
-    { OSA_K(8, 1, 1, 1, 4, 1, 4, 8, 2, 0, 1), nullptr, OSA_KO(8, 1, 1, 1, 4, 1, 4, 8, 2, 1), nullptr },
+    { OSA_K(8, 1, 1, 1, 4, 1, 4, 8, 1, 0, 1), nullptr, OSA_KO(8, 1, 1, 1, 4, 1, 4, 8, 1, 1), nullptr, OSA_KB(8, 1, 1, 4, 1, 4, 8, 1, 0), OSA_KB(8, 1, 1, 4, 1, 4, 8, 1, 1) },
+    { OSA_K(8, 1, 1, 1, 4, 1, 4, 8, 2, 0, 1), nullptr, OSA_KO(8, 1, 1, 1, 4, 1, 4, 8, 2, 1), nullptr, OSA_KB(8, 1, 1, 4, 1, 4, 8, 2, 0), OSA_KB(8, 1, 1, 4, 1, 4, 8, 2, 1) },
 #else
-    { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr },
+    { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr },
 #endif
-    { OSA_K(8, 1, 1, 1, 4, 1, 4, 8, 0, 0, 1), nullptr, OSA_KO(8, 1, 1, 1, 4, 1, 4, 8, 0, 1), nullptr },
-    { OSA_K(4, 1, 1, 1, 4, 1, 8, 16, 0, 0, 1), nullptr, nullptr, nullptr },
+    { OSA_K(8, 1, 1, 1, 4, 1, 4, 8, 0, 0, 1), nullptr, OSA_KO(8, 1, 1, 1, 4, 1, 4, 8, 0, 1), nullptr, OSA_KB(8, 1, 1, 4, 1, 4, 8, 0, 0), OSA_KB(8, 1, 1, 4, 1, 4, 8, 0, 1) },
+    { OSA_K(4, 1, 1, 1, 4, 1, 8, 16, 0, 0, 1), nullptr, nullptr, nullptr, OSA_KB(4, 1, 1, 4, 1, 8, 16, 0, 0), nullptr },
 };
 
 const ConvFnTables& OSA_INST_FUNC() {

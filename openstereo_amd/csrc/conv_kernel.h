@@ -83,6 +83,7 @@ struct ConvArgs {
     unsigned magicW, magicHW;     // ceil(2^32/LW), ceil(2^32/(LH*LW)) : exact for operands < 2^16
     unsigned magicH;              // ceil(2^32/LH)
     int dma;                      // 1: split input + compact LDS image -> stage rows by LDS-DMA (global_load_lds_dwordx4)
+    int ringQ;                    // BL kernels: first float4 slot of the B-operand ring inside the workgroup's LDS (above bricks and epilogue tiles)
     int stag_ticks, stag_n, stag_cus;   // start-up stagger: workgroups with linear id < stag_n wait (id / stag_cus) * stag_ticks 10-ns ticks (0: off)
     // f16x3 range tracking (see osa_f16x3_ranges in the header); every pointer may be NULL.  A "meta" block is
     // OSA_META_FLOATS floats of device memory per tensor: running max |value| in 8 slots (osa_common.h),
@@ -293,6 +294,19 @@ __device__ __forceinline__ void stage_brick_dma(const ConvArgs& p, float4* smem,
     }
 }
 
+// s_waitcnt vmcnt(n): the immediates of the LDS-DMA protocols are instruction counts; n is a constant after unrolling, the switch folds
+__device__ __forceinline__ void wait_vmcnt(const int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
+}
+
 // In-kernel timeline (build with -DOSA_EXPERIMENTS -DOSA_TRACE_ON, run with OSA_DBG & 256): wave `w` of every 97th workgroup stamps the 100 MHz wall clock at its
 // phase boundaries into g_trace[slot][wave][event]; tools/trace_conv.py reads it back (osa_debug_trace_read).
 #ifdef OSA_TRACE_ON
@@ -309,7 +323,9 @@ static __device__ unsigned long long g_trace[TRACE_SLOTS * TRACE_WAVES * TRACE_E
 // NCLS = 8: stride-2 transposed convolution, all 8 output-parity classes in one launch: the input
 //           brick is staged once, every class has its own accumulator set and its own run of taps
 //           (class-major tap order, one linear B stream), outputs go to o = 2a + parity.
-template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0, int OUTS = 0, int PIPE = 0, int KS = 1>
+template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR = 0, int OUTS = 0, int PIPE = 0, int KS = 1, int BL = 0>
+// BL = 1 (r4): the B (weight) operands of a tap step reach the waves through an LDS ring filled by LDS-DMA -- ONE fetch per workgroup and
+// step instead of one per wave (see the BL block below).  Same products in the same order: bit-identical to BL = 0.
 // OUTS = 1: the output is a split tensor (OSA_OUT_SPLIT) -- separate instantiation: a lane finalises 8
 // channels of 2 voxels (16-byte hi and lo stores) instead of 4 channels of 4 voxels.
 // Registers: the fused transposed convs need 2 waves per SIMD; the 256-voxel x 32-channel tiles
@@ -340,6 +356,7 @@ template <int PREC, int NCLS, int TU, int MT, int NT, int WM, int WN, int TH, in
 #define OSA_MIN_BLOCKS OSA_WAVES_PER_SIMD          // HIP: the second __launch_bounds__ argument is waves per SIMD (execution unit)
 __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM * WN * KS / 4) : OSA_MIN_BLOCKS) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(KS == 1 || (NCLS == 1 && !PIPE && !REDIR), "split-K: plain convolutions");
+    static_assert(!BL || (KS == 1 && !PIPE && TU == 1), "B ring: one B stream per workgroup, per-tap steps");
     constexpr int NW = WM * WN;
     constexpr int TD = WM * MT * 32 / (TH * TW);
     static_assert(TD * TH * TW == WM * MT * 32, "brick must hold WM*MT*32 voxels");
@@ -468,7 +485,69 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
 #endif
                 }
     };
-    init_b();
+    if constexpr (!BL) init_b();
+
+    // ---- BL = 1: B operands through an LDS ring (r4).  The r4 ablations (profiles/round4/brick_kernel_without_B_loads_and_amax_retest.txt,
+    // march_v1_ablation_and_f16_tests.txt) found the tap loop bound by its weight stream: every wave pulls its own 1 KB fragments through
+    // the vector-memory path, which delivers ~37 B/clk/CU of 16-byte-per-lane loads whether they hit L1 or not -- a 64 x 32 wave (6 MFMAs
+    // = 192 cycles per tap) asks for 42 B/clk/CU.  Here a tap step's FR = JO * WN * NT fragments are fetched ONCE per workgroup by
+    // LDS-DMA (global_load_lds_dwordx4, every wave issues its share: HP 512-byte half fragments) into slot (step & 3) of a 4-slot ring,
+    // three steps ahead of their use; every wave reads its operands from there with lane-contiguous (conflict-free) ds_read_b128 one
+    // step ahead, into the same two register sets the A operands ping-pong through.  ds_read_b128 runs at 256 B/clk/CU, so the ring's
+    // reads ride on top of the A fragments without touching the vector-memory path.  Protocol per consumed step g (conv_march.h's):
+    //   s_barrier            publishes DMA(g + 1): every wave waited for its share at the end of step g - 1
+    //   issue DMA(g + 3)     into slot (g + 3) & 3 = (g - 1) & 3, whose last readers finished with step g - 1 (everyone is past the barrier)
+    //   ds_read A(tap + 1), B(g + 1) -> other register set;  MFMAs of step g
+    //   s_waitcnt vmcnt(NIW) DMA(g + 2) is home (vmcnt retires in order), DMA(g + 3) stays in flight
+    // The B stream is the ordinary packed buffer walked linearly ([chunk][tap]: g = chunk * T + tap), so the ring runs on across chunk
+    // and parity-class boundaries; the 3 steps it runs past the end fall into the buffer's slack (slack_floats).  Inline asm for the
+    // DMA (through the builtin this compiler waits vmcnt(0) right after the issue); the saddr form keeps the 64-bit base scalar.
+    constexpr int BL_NBT = WN * NT;                          // N tiles of the workgroup
+    constexpr int BL_FR = JO * BL_NBT;                       // 1 KB fragments per tap step
+    constexpr int BL_HP = BL ? (2 * BL_FR) / NW : 2;         // 512-byte half fragments per wave and step
+    constexpr int BL_NIW = (BL_HP + 1) / 2;                  // DMA instructions per wave and step
+    constexpr int BL_SLOTQ = BL_FR * 64;                     // float4 slots per ring step
+    static_assert(!BL || ((2 * BL_FR) % NW == 0 && BL_HP >= 1 && BL_NIW <= 3), "B ring: the waves split a step's fragments evenly");
+    [[maybe_unused]] const float4* const bring = smem + p.ringQ;
+    [[maybe_unused]] unsigned bl_voff[BL_NIW], bl_loff[BL_NIW];
+    [[maybe_unused]] const float4* bl_next = p.w + n0;       // wave-uniform: start of the next step to fetch (this workgroup's N columns)
+    [[maybe_unused]] int bl_gi = 0, bl_gs = 0;               // steps issued / steps consumed
+    [[maybe_unused]] const unsigned bl_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)p.ringQ * 16u;
+    if constexpr (BL) {
+#pragma unroll
+        for (int i = 0; i < BL_NIW; ++i) {
+            // fragment f = j * NBT + nt of the step; HP == 1: wave w fetches half (w & 1) of fragment w >> 1 with its lower 32 lanes
+            const int f = (BL_HP == 1) ? (wave >> 1) : (wave * BL_NIW + i);
+            const int khalf = (BL_HP == 1) ? (wave & 1) : hh;
+            bl_voff[i] = (unsigned)(((f / BL_NBT) * (2 * p.CoP) + khalf * p.CoP + (f % BL_NBT) * 32 + col) * 16);
+            bl_loff[i] = (unsigned)((f * 64 + ((BL_HP == 1) ? (wave & 1) * 32 : 0)) * 16);
+        }
+    }
+    auto bl_issue = [&]() {
+        if constexpr (BL) {
+            const unsigned slot = bl_lds + (unsigned)(bl_gi & 3) * (BL_SLOTQ * 16u);
+#pragma unroll
+            for (int i = 0; i < BL_NIW; ++i) {
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(slot + bl_loff[i]);
+                if (BL_HP > 1 || lane < 32) {
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(bl_voff[i]), "s"(bl_next), "s"(m0v) : "memory");
+                }
+            }
+            bl_next += (size_t)JO * 2 * p.CoP;
+            ++bl_gi;
+        }
+    };
+    // this wave's B operands of ring step g
+    auto bl_read = [&](float4 (&Bn)[1][JO][NT], const int g) {
+        const float4* const sl = bring + (g & 3) * BL_SLOTQ + lane;
+#pragma unroll
+        for (int j = 0; j < JO; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) Bn[0][j][n] = sl[(j * BL_NBT + wn * NT + n) * 64];
+    };
+    if constexpr (BL) { bl_issue(); bl_issue(); bl_issue(); }     // steps 0..2 land while the first brick is staged
 
     const int brickQ = p.LD * p.PlaneQ;          // float4s per staged chunk
     const int Tm1 = p.T - 1;
@@ -571,7 +650,46 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 for (int m = 0; m < MT; ++m) A0[u][j][m] = sm[abase[m] + to + j * 2];
         }
         t = 0;
-        if constexpr (RING3) {
+        if constexpr (BL) {
+            // set 0 holds the A operands of the chunk's first tap; its B operands (ring step bl_gs) were published one step ago at the
+            // latest (first chunk: by the staging barrier, after the prologue's transfers were waited for)
+            bl_read(B0, bl_gs);
+            auto bl_step = [&](float4 (&An)[TUA][JO][MT], float4 (&Bn)[TUA][JO][NT], const int ta,
+                               const float4 (&Ac)[TUA][JO][MT], const float4 (&Bc)[TUA][JO][NT], f32x16 (&ac)[MT][NT]) {
+                // (timing-only ablations, experiments build: dbg 1024 no barrier, 2048 no transfers, 4096 no end-of-step wait)
+                if (!(p.dbg & 1024)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+                if (!(p.dbg & 2048)) bl_issue();
+                const int to = __builtin_amdgcn_readlane(toff_v, (ta < Tm1) ? ta : Tm1);
+#pragma unroll
+                for (int j = 0; j < JO; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) An[0][j][m] = sm[abase[m] + to + j * 2];
+                bl_read(Bn, bl_gs + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Ac, Bc, ac, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(p.dbg & 4096)) wait_vmcnt(BL_NIW);
+                ++bl_gs;
+            };
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const int tend = (NCLS == 1) ? p.T : p.cls_end[c];
+                while (t < tend) {
+                    hook();
+                    bl_step(A1, B1, t + 1, A0, B0, acc[c]); ++t;
+                    if (t < tend) { hook(); bl_step(A0, B0, t + 1, A1, B1, acc[c]); ++t; }
+                    else {
+                        // odd run: the next tap's operands sit in set 1 -- read them again into set 0 (same LDS words)
+                        const int to = __builtin_amdgcn_readlane(toff_v, (t < Tm1) ? t : Tm1);
+#pragma unroll
+                        for (int j = 0; j < JO; ++j)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) A0[0][j][m] = sm[abase[m] + to + j * 2];
+                        bl_read(B0, bl_gs);
+                    }
+                }
+            }
+        } else if constexpr (RING3) {
             // invariant at the top: A0 = tap t, B0 = tap t, B1 = tap t+1 (stream positions wp, wp+1).
             // Three steps are one full turn of the B ring, so leaving after the first triple keeps
             // the invariant for the next chunk (whose A0 is reloaded anyway).
@@ -688,6 +806,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 stage_brick<NW * 64, PREC, 1, SU>(p, smem + cl * brickQ, brickQ, b, (ch0 + cl) * CC, g0d, g0h, g0w, tid, s_in);
         }
         OSA_TRACE(trace_ev); ++trace_ev;                 // own staging loads issued + written
+        if constexpr (BL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ring transfers issued through inline asm: invisible to the compiler's own counts
         __syncthreads();
         OSA_TRACE(trace_ev); ++trace_ev;                 // brick complete
         for (int cl = 0; cl < ncl; ++cl) {
@@ -725,6 +844,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
         scv[n] = sc; shv[n] = sh;
     }
     if (p.out_meta) amax_seen = amax_peek(p.out_meta);   // early: its latency hides behind the epilogue
+    if constexpr (BL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead transfers: the fast path below counts its own loads only
     if constexpr (!PIPE) __syncthreads();              // everyone is done reading the input brick (PIPE: the chunk's end barrier)
     OSA_TRACE(20);
     if (KS > 1 && kg != 0) return;                     // split-K: group 0 holds the sums (the others rejoin at publish_amax)

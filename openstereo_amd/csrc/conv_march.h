@@ -48,19 +48,6 @@ struct MarchGeo {
     static_assert(NP <= 7, "one piece per wave and step, all of them forced home by the waits of steps 2..8");
 };
 
-// s_waitcnt vmcnt(n): the immediates of the LDS-DMA protocol are instruction counts; n is a constant after unrolling, the switch folds
-__device__ __forceinline__ void wait_vmcnt(const int n) {
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    }
-}
-
 __device__ const float4 g_march_zeros[4] = {};       // source of the LDS-DMA lanes that fill padding / out-of-image slots
 
 // INS = 1: the input is a split tensor (16-byte quads are the LDS image: asynchronous LDS-DMA staging); INS = 0: fp32 input, split while

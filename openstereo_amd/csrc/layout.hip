@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void to_ncdhw_kernel(const float* __restrict__
 // max |x| of a dense fp32 tensor into a (zeroed or partially filled) range block: what `torch.linalg.vector_norm(x, inf)` did for every
 // operand that reaches an f16x3 layer from a torch op (training: ~120 reductions per GwcNet step at 17 us each).  Grid-stride float4
 // loads, one atomic max per workgroup, spread over the block's 8 slots (osa_common.h).
+// (r4: the slots are cleared by device-scope atomic exchanges, i.e. at the same point of the memory system the producers' atomicMax
+// operations execute at -- a plain store leaves a dirty zero line in ONE XCD's L2 that is only ordered against the other XCDs' atomics by
+// the kernel-boundary write-back)
 __global__ void amax_clear_kernel(float* meta) {
-    if (threadIdx.x < OSA_AMAX_SLOTS) meta[threadIdx.x * OSA_AMAX_STRIDE] = 0.f;
+    if (threadIdx.x < OSA_AMAX_SLOTS) atomicExch(reinterpret_cast<unsigned*>(meta) + threadIdx.x * OSA_AMAX_STRIDE, 0u);
 }
 
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, float* meta) {

@@ -374,6 +374,183 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
     if (p.meta) publish_amax(p.meta, am, am_seen, reinterpret_cast<float*>(smq));
 }
 
+// ---- NDHWC, quad lanes, d-walking form (r4) ----
+// The quad-lane kernel above is bound by latency at the occupancy its 70 KB right window allows (2 workgroups per CU): every workgroup
+// loads its left features, stages the window, and only then starts to store -- three phases that two workgroups per CU do not overlap
+// (ablation in DESIGN.md 3.1: stores 0.05 + staging 0.035 + products 0.02 + launch / left loads / loop 0.05 ms of 0.154).  Here a workgroup
+// owns ONE (b, h, 32-pixel tile) and WALKS along d in steps of DS disparities:
+//   * the left features of a lane stay in registers for all D disparities (loaded once instead of once per disparity chunk);
+//   * the right window is a RING of NB = WT / DS + 2 blocks of DS pixels in LDS (pixel x lives in slot (x - (w0 + 1)) mod (NB * DS)): step
+//     s needs the pixels [w0 + 1 - (s + 1) DS, w0 + WT - 1 - s DS] -- DS new pixels on the left per step, which a LOADER WAVE (wave NWV of the
+//     workgroup, no other duty) fetches by LDS-DMA (global_load_lds_dwordx4, per-lane source = the permuted quad the slot holds) while the NWV
+//     compute waves run the dot products and the stores of step s.  One barrier per step hands the block over (the loader waits for its
+//     transfers first; the compute waves never wait on vmcnt, so their stores stay in flight across steps).  The block a transfer
+//     overwrites was last read at least one step -- one barrier -- earlier (derivation next to the kernel).
+//   * staged bytes per output byte fall from (WT + DCH - 1) / (WT DCH) to (WT + D - 1) / (WT D) pixels per voxel row (0.36 -> 0.26 of the
+//     window per output for GwcNet), and there is no second pass over the left features.
+// Same lanes, same k-ordered fmaf chains, same stores as the kernel above: bit-identical output (tests/test_gpu_parity.py).
+// NHWC features with 16-byte aligned quads only (the engine's backbone output); everything else keeps the kernel above.
+__device__ const float4 g_vol_zeros[64] = {};        // source of the ring slots outside the image / beyond a pixel's quads
+
+template <int QG, int NWV, int DS>
+__global__ __launch_bounds__((NWV + 1) * 64) void build_volume_walk_kernel(const VolQArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float4 smq[];
+    const VolArgs& p = q.v;
+    const int vpw = 64 >> q.lgNQ, WT = NWV * vpw;
+    const int NB = WT / DS + 2, NRING = NB * DS;            // ring capacity in pixels (host: WT % DS == 0)
+    const int BLKQ = DS * q.RSq;                            // float4 slots per block
+    const int NI = (BLKQ + 63) / 64;                        // LDS-DMA instructions per block
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wt = bid % p.nWt;   bid /= p.nWt;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    const int w0 = wt * WT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G4 = p.G >> 2;
+    const int nq_g = QG * p.G, nq_c = p.Cc >> 2, nq = nq_g + nq_c;
+    const size_t rowpix = ((size_t)b * p.H + h) * p.W;
+    const int nsteps = (p.D + DS - 1) / DS;
+    float* const red = reinterpret_cast<float*>(smq + (size_t)NRING * q.RSq);      // publish_amax scratch (NWV + 1 floats) above the ring
+
+    // ---- LDS-DMA of ring block `blk` <- right pixels [x0, x0 + DS).  Slot j of the block = (pixel j / RSq, position j % RSq); the
+    // position -> source quad map is the inverse of the staging permutation of the kernel above.  Issued by `nw` waves, wave `iw` of them.
+    const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smq;
+    auto dma_block = [&](const int blk, const int x0, const int iw, const int nw) {
+        for (int i = iw; i < NI; i += nw) {
+            const int j = i * 64 + lane;
+            const int px = j / q.RSq, pos = j - px * q.RSq;
+            const int x = x0 + px;
+            const char* src = reinterpret_cast<const char*>(g_vol_zeros) + lane * 16;
+            if (j < BLKQ && pos < nq && x >= 0 && x < p.W) {
+                if (pos < nq_g) {
+                    const int a = pos / G4, ghi = pos - a * G4;
+                    const int g = ghi * 4 + a / QG, kq = a - (a / QG) * QG;
+                    src = reinterpret_cast<const char*>(p.rg + (rowpix + x) * p.gstride + g * p.K + kq * 4);
+                } else src = reinterpret_cast<const char*>(p.rc + (rowpix + x) * p.cstride + (pos - nq_g) * 4);
+            }
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((blk * BLKQ + i * 64) * 16));
+            if (j < BLKQ) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+            }
+        }
+    };
+    // block index of the pixels [w0 + 1 + k DS, w0 + (k + 1) DS], k may be negative
+    auto blk_of = [&](int k) { k %= NB; return k < 0 ? k + NB : k; };
+
+    // ---- prologue: every wave requests its left features (compute waves), then all NWV + 1 waves share the initial window:
+    // blocks 0 .. WT / DS - 1 (pixels w0 + 1 .. w0 + WT) and block -1 (step 0's left pixels w0 + 1 - DS .. w0)
+    const int cq = lane & (q.NQ - 1), wsub = lane >> q.lgNQ;
+    const bool compute = wave < NWV;
+    const int w = w0 + wave * vpw + wsub;
+    const bool wlive = compute && w < p.W;
+    const int role = (cq < G4) ? 0 : ((cq < G4 + nq_c) ? 1 : 2);
+    float4 Lr[4 * QG];
+    float4 lcat = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4 * QG; ++i) Lr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wlive && role == 0) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int kq = 0; kq < QG; ++kq)
+                Lr[gi * QG + kq] = *reinterpret_cast<const float4*>(p.lg + (rowpix + w) * p.gstride + (cq * 4 + gi) * p.K + kq * 4);
+    } else if (wlive && role == 1) {
+        const float* src = p.lc + (rowpix + w) * p.cstride + (cq - G4) * 4;
+        lcat = make_float4(src[0], src[1], src[2], src[3]);
+    }
+    {
+        const int nbi = WT / DS + 1;                      // blocks of the initial window
+        for (int t = wave; t < nbi * NI; t += NWV + 1) {  // (block, instruction) pairs round-robin over the waves
+            const int kb = t / NI, i = t - kb * NI;
+            const int k = (kb < WT / DS) ? kb : -1;
+            // one instruction: reuse dma_block's body through a 1-wave slice
+            const int j = i * 64 + lane;
+            const int px = j / q.RSq, pos = j - px * q.RSq;
+            const int x = w0 + 1 + k * DS + px;
+            const char* src = reinterpret_cast<const char*>(g_vol_zeros) + lane * 16;
+            if (j < BLKQ && pos < nq && x >= 0 && x < p.W) {
+                if (pos < nq_g) {
+                    const int a = pos / G4, ghi = pos - a * G4;
+                    const int g = ghi * 4 + a / QG, kq = a - (a / QG) * QG;
+                    src = reinterpret_cast<const char*>(p.rg + (rowpix + x) * p.gstride + g * p.K + kq * 4);
+                } else src = reinterpret_cast<const char*>(p.rc + (rowpix + x) * p.cstride + (pos - nq_g) * 4);
+            }
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((blk_of(k) * BLKQ + i * 64) * 16));
+            if (j < BLKQ) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (also the left features: requested above, needed below)
+    __syncthreads();
+
+    float am = 0.f;
+    const unsigned am_seen = (p.meta && compute) ? amax_peek(p.meta) : 0u;
+    if (!compute) {
+        // ================= loader wave: block of step s + 1 while the compute waves run step s =================
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) dma_block(blk_of(-(s + 2)), w0 + 1 - (s + 2) * DS, 0, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ================= compute waves =================
+        const float Kf = (float)p.K;
+        const bool kpow2 = (p.K & (p.K - 1)) == 0;
+        const float Kinv = 1.0f / Kf;
+        const int rq = nq_g + (cq - G4 - nq_c);
+        float* vout = p.vol + p.coff + cq * 4;
+        int ri = w - (w0 + 1);                                // ring slot of pixel w - d, d = 0 (in [-1, WT - 2])
+        if (ri < 0) ri += NRING;
+        for (int s = 0; s < nsteps; ++s) {
+#pragma unroll 4
+            for (int dd = 0; dd < DS; ++dd) {
+                const int d = s * DS + dd;
+                if (d >= p.D) break;
+                const bool valid = (w >= d);
+                const float4* rrow = smq + (size_t)ri * q.RSq;
+                ri = (ri == 0) ? NRING - 1 : ri - 1;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (role == 0) {
+                    float sv[4];
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int kq = 0; kq < QG; ++kq) {
+                            const float4 r = rrow[(gi * QG + kq) * G4 + cq];
+                            const float4 l = Lr[gi * QG + kq];
+                            sacc = fmaf(l.x, r.x, sacc); sacc = fmaf(l.y, r.y, sacc);
+                            sacc = fmaf(l.z, r.z, sacc); sacc = fmaf(l.w, r.w, sacc);
+                        }
+                        sv[gi] = valid ? (kpow2 ? sacc * Kinv : sacc / Kf) : 0.f;
+                    }
+                    o = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                } else if (role == 1) {
+                    if (valid || !p.mask_left) o = lcat;
+                } else {
+                    if (valid) o = rrow[rq];
+                }
+                if (wlive) {
+                    const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
+                    store16(vout + vox * p.VC, o);
+                    am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                }
+            }
+            // step s is read; block s + 1 has landed (the loader waited for it).  s_barrier only: no vmcnt wait, the stores stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (p.meta) publish_amax(p.meta, am, am_seen, red);
+}
+
 // ------------------------------------------------------------------ NCDHW ----
 // One thread per output element, w fastest. grid.y = channel, grid.z = b*D+d.
 struct VolNArgs {
@@ -502,6 +679,16 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
                              float* vol, int layout, int vol_channels, int c_off,
                              int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta = nullptr);
 
+// d-walking form of the NDHWC builder (build_volume_walk_kernel): disparities per step (4 or 8), 0 = the chunked kernel
+static int g_vol_walk_ds = 8;
+static long long g_vol_walk_launches = 0;
+extern "C" int osa_volume_walk_step(int ds) {
+    const int prev = g_vol_walk_ds;
+    if (ds == 0 || ds == 4 || ds == 8) g_vol_walk_ds = ds;
+    return prev;
+}
+extern "C" long long osa_volume_walk_launches(void) { return g_vol_walk_launches; }
+
 extern "C" int osa_build_volume_f32(const float* left_gwc, const float* right_gwc, int C, int num_groups,
                                     const float* left_cat, const float* right_cat, int Cc,
                                     float* vol, int layout, int vol_channels, int c_off,
@@ -607,6 +794,35 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             } while (0)
 #define OSA_VOLQ_LAUNCH(Q) do { if (px2) { if (nwv == 8) OSA_VOLQ_LAUNCH1P(Q, 8); else OSA_VOLQ_LAUNCH1P(Q, 4); }    \
                                 else if (nwv == 8) OSA_VOLQ_LAUNCH1(Q, 8); else OSA_VOLQ_LAUNCH1(Q, 4); } while (0)
+            // d-walking form (build_volume_walk_kernel): NHWC features with 16-byte aligned quads, 8-wave pixel tiles
+            if (g_vol_walk_ds > 0 && !px2 && nwv == 8 && (G == 0 || gwc_stride > 0) && (Cc == 0 || (cat_stride > 0 && cat_stride % 4 == 0 &&
+                ((size_t)left_cat & 15) == 0 && ((size_t)right_cat & 15) == 0)) && WT % g_vol_walk_ds == 0 && maxdisp > g_vol_walk_ds) {
+                const int DS = g_vol_walk_ds;
+                a.nWt = cdiv(W, WT); a.nDch = 1;
+                qa.DCH = DS; qa.dbg = 0;
+                const size_t wlds = (size_t)(WT / DS + 2) * DS * qa.RSq * 16 + 64;
+                const long long wblk = (long long)B * H * a.nWt;
+                OSA_REQUIRE(wlds <= 160 * 1024 && wblk < (1ll << 31), "build_volume: walk form does not fit (%zu B of LDS)", wlds);
+#define OSA_VOLW_LAUNCH1(Q, DSV)                                                                    \
+                do {                                                                                \
+                    if (wlds > 64 * 1024)                                                           \
+                        (void)hipFuncSetAttribute((const void*)build_volume_walk_kernel<Q, 8, DSV>, \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
+                    hipLaunchKernelGGL((build_volume_walk_kernel<Q, 8, DSV>), dim3((unsigned)wblk), dim3(9 * 64), wlds, st, qa); \
+                } while (0)
+#define OSA_VOLW_LAUNCH(Q) do { if (DS == 4) OSA_VOLW_LAUNCH1(Q, 4); else OSA_VOLW_LAUNCH1(Q, 8); } while (0)
+                switch (QG) {
+                    case 1: OSA_VOLW_LAUNCH(1); break;
+                    case 2: OSA_VOLW_LAUNCH(2); break;
+                    case 3: OSA_VOLW_LAUNCH(3); break;
+                    default: OSA_VOLW_LAUNCH(4); break;
+                }
+#undef OSA_VOLW_LAUNCH
+#undef OSA_VOLW_LAUNCH1
+                OSA_LAUNCH_CHECK("build_volume_walk");
+                ++g_vol_walk_launches;
+                return 0;
+            }
             switch (QG) {
                 case 1: OSA_VOLQ_LAUNCH(1); break;
                 case 2: OSA_VOLQ_LAUNCH(2); break;

@@ -995,3 +995,98 @@ def test_hidden_state_resampling_kernels(shape):
         want_i = F.interpolate(x, (Ho, Wo), mode="bilinear", align_corners=True)
         dest = ops.empty_cl(B, C, 1, Ho, Wo, DEV)
         close(cl_to_nchw(interp(nchw_to_cl(x.to(DEV)), dest)), want_i, 2e-6, 1e-6, f"interp -> {Ho}x{Wo}")
+
+
+# ----------------------------------------------------------------------------- B operands through the LDS ring (r4)
+BRING_CASES = [
+    # name, kind, Ci, Co, k, stride, (D, H, W), out_split
+    ("3d 48-32 s1", "conv", 48, 32, 3, 1, (2, 19, 20), False),          # 27 taps (odd run), 3 chunks, ragged bricks (D >= 3 would take the marching form)
+    ("3d 64-64 s1 split out", "conv", 64, 64, 3, 1, (5, 9, 17), True),
+    ("3d 128-128 s1", "conv", 128, 128, 3, 1, (3, 9, 10), False),       # 2 x 2 waves, 4 N tiles per workgroup: two transfers per wave
+    ("3d 32-64 s2", "conv", 32, 64, 3, 2, (8, 12, 20), False),
+    ("3d 64-128 s2", "conv", 64, 128, 3, 2, (6, 10, 14), False),
+    ("3d 48-24 s2", "conv", 48, 24, 3, 2, (8, 8, 12), False),           # 2-wave tile
+    ("1x1x1 64-64", "conv", 64, 64, 1, 1, (3, 4, 7), False),            # a single tap per chunk
+    ("2d 64-64", "conv", 64, 64, 3, 1, (1, 40, 50), False),
+    ("2d 128-128", "conv", 128, 128, 3, 1, (1, 60, 110), False),        # 32-pixel x 128-channel tile (1 x 4 waves), no split-K at this size
+    ("2d 128-128 large map", "conv", 128, 128, 3, 1, (1, 200, 260), False),   # 128 x 128 tile (2 x 2 waves)
+    ("2d 32-32", "conv", 32, 32, 3, 1, (1, 33, 47), False),
+    ("2d 320-128", "conv", 320, 128, 3, 1, (1, 60, 110), False),         # 20 chunks, several staging passes
+    ("2d 32-64 s2", "conv", 32, 64, 3, 2, (1, 30, 44), False),
+    ("deconv 64-32", "deconv", 64, 32, 3, 2, (4, 6, 9), False),          # 8 parity classes: runs of 1 / 2 / 4 / 8 taps
+    ("deconv 128-64 split out", "deconv", 128, 64, 3, 2, (3, 5, 7), True),
+    ("deconv k4 48-24", "deconv4", 48, 24, 4, 2, (3, 4, 6), False),
+]
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("case", BRING_CASES, ids=[c[0] for c in BRING_CASES])
+def test_conv_b_ring_is_bit_identical(case, prec):
+    """conv_kernel.h BL = 1: weight fragments fetched once per workgroup through the LDS ring instead of once per wave -- the same
+    products in the same order, so every output bit equals the per-wave form's (osa_conv_b_ring_mask(0))."""
+    from openstereo_amd import _lib, ops
+    from openstereo_amd.engine import PackedConv3d
+    lib = _lib.load()
+    name, kind, Ci, Co, k, s, (D, H, W), out_split = case
+    if prec == "f16" and out_split:
+        pytest.skip("fp16 outputs are covered by the f16-mode chain tests")
+    if kind == "conv":
+        m = nn.Conv3d(Ci, Co, (1 if D == 1 else k, k, k), (1 if D == 1 else s, s, s), (0 if D == 1 else k // 2, k // 2, k // 2), bias=False)
+    elif kind == "deconv":
+        m = nn.ConvTranspose3d(Ci, Co, 3, stride=2, padding=1, output_padding=1, bias=False)
+    else:
+        m = nn.ConvTranspose3d(Ci, Co, 4, stride=2, padding=1, bias=False)
+    m.weight.data = synth_tensor(name + ".w", m.weight.shape, 1)
+    bn = _bn_for(Co, 2, name)
+    x = ops.to_cl(T(np.random.default_rng(3).normal(0, 1, (2, Ci, D, H, W)).astype(np.float32)).to(DEV))
+    pc = PackedConv3d(m.to(DEV), bn.to(DEV), 1, precision=prec)
+    kw = {"out_split": True} if out_split else {}
+    prev = lib.osa_conv_b_ring_mask(0)
+    try:
+        n0 = lib.osa_conv_b_ring_launches()
+        y_wave = pc(x, **kw).clone()
+        assert lib.osa_conv_b_ring_launches() == n0
+        lib.osa_conv_b_ring_mask(-1)
+        y_ring = pc(x, **kw)
+        assert lib.osa_conv_b_ring_launches() == n0 + 1, "the ring form did not run"
+    finally:
+        lib.osa_conv_b_ring_mask(prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_ring.float()).all()
+    assert torch.equal(y_wave, y_ring), f"{name} [{prec}]: ring form differs by {(y_wave.float() - y_ring.float()).abs().max().item():.3e}"
+
+
+# ----------------------------------------------------------------------------- d-walking volume builder (r4)
+@pytest.mark.parametrize("step", [8, 4])
+@pytest.mark.parametrize("case", [
+    # name, B, gwc channels, groups, concat channels, H, W, D, mask_left
+    ("gwcnet", 2, 320, 40, 12, 9, 96, 48, True),
+    ("gwcnet ragged", 1, 320, 40, 12, 5, 75, 21, True),            # W % 32 != 0, D % step != 0
+    ("gwcnet D > W", 1, 320, 40, 12, 3, 70, 90, True),              # disparities beyond the map width: zero planes
+    ("unmasked concat", 1, 320, 40, 12, 4, 80, 24, False),          # IGEV-style copy (left concat not masked)
+    ("K = 4", 1, 64, 16, 8, 6, 140, 17, True),                       # 4 + 4 quads = 8 per voxel: 64-pixel tiles
+    ("concat only", 1, 0, 0, 16, 4, 130, 12, True),
+], ids=lambda c: c[0])
+def test_volume_walking_form_is_bit_identical(case, step):
+    """csrc/volume.hip build_volume_walk_kernel (a workgroup walks along d, right window as an LDS ring refilled by a loader wave through
+    LDS-DMA): the same lanes run the same fmaf chains and stores as the chunked kernel -- every output bit equal, maximum tracked too."""
+    from openstereo_amd import _lib, ops, ranges
+    lib = _lib.load()
+    name, B, C, G, Cc, H, W, D, mask_left = case
+    rng = np.random.default_rng(5)
+    gf = ops.empty_cl(2 * B, max(C, 4), 1, H, W, DEV); gf.copy_(T(rng.normal(0, 1, tuple(gf.shape)).astype(np.float32)))
+    cf = ops.empty_cl(2 * B, Cc, 1, H, W, DEV); cf.copy_(T(rng.normal(0, 1, tuple(cf.shape)).astype(np.float32)))
+    run = lambda: ops.build_cost_volume_from_cl(gf, G, cf, B, D, gwc_channels=C, mask_left=mask_left)
+    prev = lib.osa_volume_walk_step(0)
+    try:
+        n0 = lib.osa_volume_walk_launches()
+        v_chunk = run()
+        assert lib.osa_volume_walk_launches() == n0
+        lib.osa_volume_walk_step(step)
+        v_walk = run()
+        assert lib.osa_volume_walk_launches() == n0 + 1, "the walking form did not run"
+    finally:
+        lib.osa_volume_walk_step(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(v_chunk, v_walk), f"{name}: walking form differs by {(v_chunk - v_walk).abs().max().item():.3e}"
+    assert float(ranges.meta_of(v_walk)[::16][:8].max()) == float(v_walk.abs().max()) == float(ranges.meta_of(v_chunk)[::16][:8].max())

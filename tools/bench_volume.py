@@ -11,7 +11,12 @@ cf = ops.empty_cl(2 * B, 12, 1, H, W, dev); cf.normal_()
 def run():
     return ops.build_cost_volume_from_cl(gf, 40, cf, B, D)
 outs = {}
-for mode in ("quads", "perchannel", "quads", "px2", "quads", "px2", "w4", "w8", "w8lds160", "dbg1", "dbg2", "dbg4", "dbg7", "px2dbg1", "px2dbg7"):
+from openstereo_amd import _lib
+LIB = _lib.load()
+MODES = os.environ.get("VOL_MODES", "quads,perchannel,quads,px2,quads,px2,w4,w8,w8lds160,dbg1,dbg2,dbg4,dbg7,px2dbg1,px2dbg7").split(",")
+for mode in MODES:
+    if hasattr(LIB, "osa_volume_walk_step"):      # walk8 / walk4: the d-walking form (r4); every other mode measures the chunked kernel
+        LIB.osa_volume_walk_step(int(mode[4:]) if mode.startswith("walk") else 0)
     for k in ("OSA_VOL_PERCHANNEL", "OSA_VOL_DBG", "OSA_VOL_WAVES", "OSA_VOL_LDS", "OSA_VOL_PX2"):
         os.environ.pop(k, None)
     if mode.startswith("w") and not mode.startswith("px2"):
@@ -29,4 +34,6 @@ for mode in ("quads", "perchannel", "quads", "px2", "quads", "px2", "w4", "w8", 
     ms = e0.elapsed_time(e1) / 20
     outs[mode] = v.clone()
     print(f"{mode}: {ms:.3f} ms  {(487.8e6 * B / ms / 1e9):.2f} TB/s (algorithmic 487.8 MB)")
-print("bit-identical:", torch.equal(outs["quads"], outs["perchannel"]), "px2 bit-identical:", torch.equal(outs["quads"], outs["px2"]))
+for a in ("perchannel", "px2", "walk8", "walk4"):
+    if a in outs and "quads" in outs:
+        print(f"quads vs {a} bit-identical:", torch.equal(outs["quads"], outs[a]))
