@@ -12,15 +12,16 @@ KERNELS = {
     # r4: the V0 3x3x3 32 -> 32 layers run the d-marching kernel; its <split out, split in> instance runs dres0.2, dres1.0, dres1.2
     # (dres0.0 reads the fp32 volume: <.., 1, 0>; classif3.0 writes fp32: <.., 0, 1>).  r3 and before: the brick kernel instance below.
     "conv3d_32_32_V0_f16x3": os.environ.get("OSA_PMC_DOMINANT", "conv_march_kernel<4, 16, 1, 1>"),
-    "conv3d_32_32_V0_f16x3_brick": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1>",
-    "volume": "build_volume_quads_kernel<2, 8",
+    "conv3d_32_32_V0_f16x3_brick": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1, 0>",
+    # (r4, later: every conv_mfma_kernel name carries a 14th template argument, BL -- 1 = weight fragments through the LDS ring)
+    "volume": "build_volume_walk_kernel<2, 8, 8",
     "head": "upsample4_softargmin_kernel",
     "classifier": "classifier_march_kernel",
-    "deconv_64_32_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1, 0, 1>",
-    "deconv_128_64_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 2, 1, 0, 1>",
-    "conv_s2_32_64": "conv_mfma_kernel<1, 1, 3, 1, 1, 2, 2, 4, 8, 0, 1, 0, 1>",
-    "backbone_64ch_quarter": "conv_mfma_kernel<1, 1, 3, 1, 2, 4, 1, 8, 16, 0, 1, 0, 1>",
-    "backbone_128ch_quarter": "conv_mfma_kernel<1, 1, 3, 2, 2, 2, 2, 8, 16, 0, 1, 0, 1>",
+    "deconv_64_32_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1, 0, 1, 0>",
+    "deconv_128_64_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 2, 1, 0, 1, 0>",
+    "conv_s2_32_64": "conv_mfma_kernel<1, 1, 3, 1, 1, 2, 2, 4, 8, 0, 1, 0, 1, 0>",
+    "backbone_64ch_quarter": "conv_mfma_kernel<1, 1, 1, 1, 2, 4, 1, 8, 16, 0, 1, 0, 1, 1>",
+    "backbone_128ch_quarter": "conv_mfma_kernel<1, 1, 3, 2, 2, 2, 2, 8, 16, 0, 1, 0, 1, 0>",
 }
 
 
