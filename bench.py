@@ -72,8 +72,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: the best-throughput batch of the sweep in DESIGN.md 6 -- 8 GwcNet / LightStereo, 4 IGEV, 1 training; single-pair latency is reported next to it)")
-    ap.add_argument("--streams", type=int, default=2, help="GwcNet inference: independent sub-batches on this many concurrent HIP streams (1 = one stream)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per step (default: the best-throughput batch of the sweeps in DESIGN.md 6 -- 9 GwcNet, 8 LightStereo, 4 IGEV, 1 training; single-pair latency is reported next to it)")
+    ap.add_argument("--streams", type=int, default=None, help="GwcNet inference: independent sub-batches on this many concurrent HIP streams (1 = one stream; default: 3 when the batch divides by 3 -- sub-batches of 3 pairs measured best, profiles/round4/substreams_x_batch_sweep.txt --, else 2, else 1)")
     ap.add_argument("--workload", default="gwcnet",
                     choices=("gwcnet", "lightstereo_kitti15", "igev_refine32", "stereobase_train", "stereobase_e2e_train", "gwcnet_train",
                              "stereobase_e2e", "igev_e2e", "lightstereo_e2e"))
@@ -100,7 +100,7 @@ class GwcNetInference:
     def __init__(self, args, dev, rank):
         from openstereo_amd.models.gwcnet import GwcNet
         from openstereo_amd.utils.weights import synth_state_dict, synth_images
-        self.B = args.batch or 8
+        self.B = args.batch or 9
         net = GwcNet()
         self.sd = synth_state_dict(net, seed=0)
         net.load_state_dict(self.sd)
@@ -110,7 +110,8 @@ class GwcNetInference:
         pad = lambda t: torch.nn.functional.pad(t, (0, W_PAD - W_IMG, H_PAD - H_IMG, 0), mode="replicate")
         self.L, self.R = pad(L0).to(dev), pad(R0).to(dev)        # inputs resident in HBM before timing starts
         from openstereo_amd.parallel import SubBatchStreams
-        self.nstreams = args.streams if (args.streams and self.B % args.streams == 0) else 1
+        want = args.streams if args.streams else (3 if self.B % 3 == 0 else (2 if self.B % 2 == 0 else 1))
+        self.nstreams = want if self.B % want == 0 else 1
         self.sub = SubBatchStreams(self.nstreams)                # independent sub-batches on concurrent HIP streams (fork / join inside the hipGraph)
 
     def step(self):

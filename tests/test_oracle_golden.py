@@ -182,7 +182,9 @@ def test_at_size_fixtures_against_reference():
     st, x, feats = stereobase_at_size_case()
     with torch.no_grad():
         d, prob, geo = O.stereobase_cost_stage(*x, feats, st.state_dict(), 192, 8)
-    assert (d - torch.from_numpy(g["init_disp"])).abs().max().item() <= 1e-5
+    # (5e-5 px: the fixture was generated on another host CPU; oneDNN picks its convolution code path -- and with it the fp32 summation
+    # order -- by ISA and thread count, which moves this soft-argmin by up to ~10 ulp of its ~25 px values)
+    assert (d - torch.from_numpy(g["init_disp"])).abs().max().item() <= 5e-5
     assert (geo[:, :, ::4, ::4, ::4] - torch.from_numpy(g["geo_sub"])).abs().max().item() <= 1e-5 * float(np.abs(g["geo_sub"]).max())
     g = golden("igev_at_size.npz")
     ref, ml, mr, gvol, net, inp, d0 = igev_at_size_case()
