@@ -334,9 +334,9 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
     void (*fn)(const ConvArgs) = (kf.fn3 && a.T % 3 == 0 && !no_ring) ? kf.fn3 : kf.fn;
     if (a.act & OSA_OUT_SPLIT) {
         fn = (kf.fns3 && a.T % 3 == 0 && !no_ring) ? kf.fns3 : kf.fns;
-        OSA_REQUIRE(fn != nullptr, "%s: this tile configuration has no split- / fp16-output variant", what);
+        OSA_REQUIRE(fn != nullptr || kf.fnbs != nullptr, "%s: this tile configuration has no split- / fp16-output variant", what);
     }
-    OSA_REQUIRE(fn != nullptr, "%s: tile configuration %s is not built for this arithmetic mode", what, k.name);
+    OSA_REQUIRE(fn != nullptr || kf.fnb != nullptr, "%s: tile configuration %s is not built for this arithmetic mode", what, k.name);
     // B operands through the LDS ring (conv_kernel.h, BL = 1; f16x3 / f16 modes): a 4-slot ring of one tap step's fragments
     // (2 KB per 32 output channels of the workgroup) above the bricks and the epilogue tiles.  Bit-identical results.
     a.ringQ = 0;
@@ -344,8 +344,9 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         void (*fb)(const ConvArgs) = (a.act & OSA_OUT_SPLIT) ? kf.fnbs : kf.fnb;
         const size_t ring = (size_t)4 * 2 * (k.N / 32) * 1024;
         const int bit = (k.table == 0) ? (int)(&k - g_cfgs) : 30;     // osa_conv_b_ring_mask: conv_cfgs.def index, 30 = the fused transposed convs
-        const bool use = fb != nullptr && k.ks <= 1 && ((g_b_ring_mask >> bit) & 1) && lds + ring <= 160 * 1024;
+        const bool use = fb != nullptr && k.ks <= 1 && (((g_b_ring_mask >> bit) & 1) || fn == nullptr) && lds + ring <= 160 * 1024;   // (fn == nullptr: a ring-only tile)
         if (use) { fn = fb; a.ringQ = (int)(lds / 16); lds += ring; ++g_b_ring_launches; }
+        OSA_REQUIRE(fn != nullptr, "%s: tile configuration %s exists in the ring form only and its ring does not fit", what, k.name);
     }
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

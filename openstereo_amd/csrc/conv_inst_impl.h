@@ -15,6 +15,11 @@ namespace osa {
 #endif
 #define OSA_RING_0(x) nullptr
 #define OSA_RING_1(x) x
+#define OSA_RING_2(x) nullptr
+// RING = 2: a tile that exists in the ring form (BL = 1) only
+#define OSA_BASE_0(x) x
+#define OSA_BASE_1(x) x
+#define OSA_BASE_2(x) nullptr
 // BL = 1 variants (B operands through the LDS ring): every mode but exact f32, tiles with (2 * JO * WN * NT) % (WM * WN) == 0
 template <int NCLS, int MT, int NT, int WM, int WN, int TH, int TW, int REDIR, int OUTS>
 static constexpr ConvFn bl_fn() {
@@ -26,8 +31,8 @@ static constexpr ConvFn bl_fn() {
 
 static const KernelFns g_cfg_fns[] = {
 #define OSA_CFG_X(RING, MT, NT, WM, WN, TH, TW)                                                                          \
-    { OSA_K(1, 1, MT, NT, WM, WN, TH, TW, 0, 0, 1), OSA_RING_##RING(OSA_K(1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 1)),       \
-      OSA_KO(1, 1, MT, NT, WM, WN, TH, TW, 0, 1), OSA_RING_##RING(OSA_KO(1, 3, MT, NT, WM, WN, TH, TW, 0, 1)),           \
+    { OSA_BASE_##RING(OSA_K(1, 1, MT, NT, WM, WN, TH, TW, 0, 0, 1)), OSA_RING_##RING(OSA_K(1, 3, MT, NT, WM, WN, TH, TW, 0, 0, 1)),       \
+      OSA_BASE_##RING(OSA_KO(1, 1, MT, NT, WM, WN, TH, TW, 0, 1)), OSA_RING_##RING(OSA_KO(1, 3, MT, NT, WM, WN, TH, TW, 0, 1)),           \
       OSA_KB(1, MT, NT, WM, WN, TH, TW, 0, 0), OSA_KB(1, MT, NT, WM, WN, TH, TW, 0, 1) },
 #define OSA_KS_X(MT, NT, WM, WN, TH, TW, KS)
 #include "conv_cfgs.def"

@@ -654,8 +654,12 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             // set 0 holds the A operands of the chunk's first tap; its B operands (ring step bl_gs) were published one step ago at the
             // latest (first chunk: by the staging barrier, after the prologue's transfers were waited for)
             bl_read(B0, bl_gs);
+            // BL_B1 (128 x 64 register tiles: 8 accumulator tiles = 128 registers): ONE B register set -- step g + 1's operands are read into
+            // it after step g's MFMAs were issued (the barrier, the transfer and the A reads at the top of the next step cover the LDS
+            // latency); with two sets the tile spills
+            constexpr bool BL_B1 = (MT * NT >= 8);
             auto bl_step = [&](float4 (&An)[TUA][JO][MT], float4 (&Bn)[TUA][JO][NT], const int ta,
-                               const float4 (&Ac)[TUA][JO][MT], const float4 (&Bc)[TUA][JO][NT], f32x16 (&ac)[MT][NT]) {
+                               const float4 (&Ac)[TUA][JO][MT], float4 (&Bc)[TUA][JO][NT], f32x16 (&ac)[MT][NT]) {
                 // (timing-only ablations, experiments build: dbg 1024 no barrier, 2048 no transfers, 4096 no end-of-step wait)
                 if (!(p.dbg & 1024)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
                 if (!(p.dbg & 2048)) bl_issue();
@@ -664,10 +668,11 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 for (int j = 0; j < JO; ++j)
 #pragma unroll
                     for (int m = 0; m < MT; ++m) An[0][j][m] = sm[abase[m] + to + j * 2];
-                bl_read(Bn, bl_gs + 1);
+                if constexpr (!BL_B1) bl_read(Bn, bl_gs + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(Ac, Bc, ac, 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BL_B1) bl_read(Bc, bl_gs + 1);
                 if (!(p.dbg & 4096)) wait_vmcnt(BL_NIW);
                 ++bl_gs;
             };
@@ -676,8 +681,13 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                 const int tend = (NCLS == 1) ? p.T : p.cls_end[c];
                 while (t < tend) {
                     hook();
-                    bl_step(A1, B1, t + 1, A0, B0, acc[c]); ++t;
-                    if (t < tend) { hook(); bl_step(A0, B0, t + 1, A1, B1, acc[c]); ++t; }
+                    if constexpr (BL_B1) bl_step(A1, B0, t + 1, A0, B0, acc[c]); else bl_step(A1, B1, t + 1, A0, B0, acc[c]);
+                    ++t;
+                    if (t < tend) {
+                        hook();
+                        if constexpr (BL_B1) bl_step(A0, B0, t + 1, A1, B0, acc[c]); else bl_step(A0, B0, t + 1, A1, B1, acc[c]);
+                        ++t;
+                    }
                     else {
                         // odd run: the next tap's operands sit in set 1 -- read them again into set 0 (same LDS words)
                         const int to = __builtin_amdgcn_readlane(toff_v, (t < Tm1) ? t : Tm1);
