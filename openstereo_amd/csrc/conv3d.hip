@@ -50,7 +50,8 @@ static const KernelFns& fns_of(const KernelCfg& k, int prec) {
     return t.deconv[k.idx];
 }
 
-static int pick_cfg(const ConvArgs& a, int stride) {
+static int g_b_ring_mask_value();         // (defined below, next to the mask)
+static int pick_cfg(const ConvArgs& a, int stride, int prec = PREC_F32) {
     {
         const int v = exp_int("OSA_CONV_CFG", -1);
         if (v >= 0 && v < N_CFGS && a.CoP % g_cfgs[v].N == 0) return v;
@@ -76,6 +77,10 @@ static int pick_cfg(const ConvArgs& a, int stride) {
     // measured on MI355X (tools/bench_layers.py): few-tap launches (1x1x1, transposed-conv parity
     // classes) and sub-megavoxel volumes prefer the 128-voxel bricks (more workgroups in flight)
     if (a.T <= 8) return (a.CoP % 64 == 0) ? 4 : 3;
+    // r4: with the weight fragments coming through the LDS ring (f16x3 / f16 modes, tile 4 in the ring mask) the 128-voxel x 64-channel tile --
+    // four waves of 32 x 64 that share every fragment -- is ahead of the 256 x 64 and the 128 x 128 tiles on the stride-1 layers with 64 / 128
+    // output channels (profiles/round4/tiles_128x64_ring.txt, 8 and 4 pairs: conv2 @V1 1.008-1.024 -> 0.980-0.985 ms, conv4 @V2 0.550-0.571 -> 0.522-0.526)
+    if (prec != PREC_F32 && a.CoP % 64 == 0 && ((g_b_ring_mask_value() >> 4) & 1)) return 4;
     if (a.CoP % 128 == 0) return 2;                                // 128 voxels x 128 channels, 2x2 waves
     if (vox < (1ll << 20)) return (a.CoP % 64 == 0) ? 4 : 3;
     return (a.CoP % 64 == 0) ? 1 : 0;
@@ -235,6 +240,7 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
 // all), the fused transposed convs (+-1 %).
 static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13);
 static long long g_b_ring_launches = 0;
+static int g_b_ring_mask_value() { return g_b_ring_mask; }
 
 static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const char* what,
                        const KernelCfg* forced = nullptr) {
@@ -244,7 +250,7 @@ static int launch_conv(ConvArgs& a, int stride, int prec, hipStream_t st, const 
         if (r != 0) return r < 0 ? r : 0;
     }
 #endif
-    int ci = forced ? 0 : pick_cfg(a, stride);
+    int ci = forced ? 0 : pick_cfg(a, stride, prec);
     if (!forced && brick_bytes(a, g_cfgs[ci]) > 160 * 1024) {
         // e.g. a stride-2 3x3x3 layer whose output depth collapses to 1: fall back to the small bricks
         static const int fallback[] = {5, 15, 3, 11};
