@@ -564,6 +564,26 @@ long long osa_conv_b_ring_launches(void);
 int osa_volume_walk_step(int step);
 long long osa_volume_walk_launches(void);
 
+/* ---- the fused volume written as a split tensor (r4, f16x3 chains) ----
+ * Same construction and arguments as osa_build_volume_nhwc_f32 (build_gwc_volume + build_concat_volume + torch.cat: cost_volume.py:59-105,
+ * gwcnet_cost_processor.py:41-65), but the NDHWC volume is stored in the split activation format of the f16x3 convolution chain (every
+ * 16-channel chunk [16 x fp16 hi | 16 x fp16 lo], the bytes of fp32; see osa_f16x3_ranges) so that the first aggregation layer
+ * (dres0, gwcnet_disp_processor.py:40-47) stages it by LDS-DMA like every later layer instead of splitting fp32 values through registers.
+ * The power-of-two scale of the halves must be known before the first voxel exists, so it comes from a BOUND: |gwc| <= max|f|^2 and
+ * |concat| <= max|f_cat| with the maxima read from the features' range blocks gwc_meta / cat_meta (one block per feature tensor, left and
+ * right images together); it is stored in vol_meta[1], the volume's running maximum in vol_meta's slots as usual.  Decoded values
+ * (float(hi) + float(lo)) / scale equal the fp32 volume to 2^-22 relative (elements below 2^-18 of the bound: 2^-25 / scale absolute).
+ * Only the d-walking form writes this layout: osa_build_volume_nhwc_split_eligible(...) == 1 tells whether a call qualifies (NHWC features
+ * with 16-byte aligned quads, quad-lane channel counts, vol_channels / c_off / G + 2 Cc multiples of 16, map at least two 8-wave tiles wide,
+ * maxdisp > osa_volume_walk_step); otherwise build the fp32 volume. */
+int osa_build_volume_nhwc_split_eligible(const float* left_cat, const float* right_cat, const float* vol, int C, int num_groups,
+                                         int gwc_stride, int Cc, int cat_stride, int vol_channels, int c_off, int W, int maxdisp);
+int osa_build_volume_nhwc_split_f16x3(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
+                                      const float* left_cat, const float* right_cat, int Cc, int cat_stride,
+                                      float* vol, int vol_channels, int c_off,
+                                      int B, int H, int W, int maxdisp, int mask_left_concat,
+                                      const float* gwc_meta, const float* cat_meta, float* vol_meta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,9 @@ SIGNATURES = {
     "osa_conv_b_ring_launches": (c_ll, []),
     "osa_volume_walk_step": (c_i, [c_i]),
     "osa_volume_walk_launches": (c_ll, []),
+    "osa_build_volume_nhwc_split_eligible": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "osa_build_volume_nhwc_split_f16x3": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_fp, c_i, c_i,
+                                                c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_st]),
     "osa_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_softmax_softargmin_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_st]),
     "osa_upsample_softargmin_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -31,7 +31,6 @@ namespace osa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Arithmetic modes of the implicit GEMM:
@@ -97,37 +96,8 @@ struct ConvArgs {
 
 // Stage CC channels [c0, c0+CC) of the input brick into LDS (zero outside the tensor / beyond Ci).
 // Loads are issued U at a time before the first LDS write so a thread keeps U 16-byte loads in flight.
-typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
 
-// x = hi + lo with hi, lo fp16.  hi uses the packed round-toward-zero convert (2 floats per
-// instruction): any rounding is fine for hi because lo = x - float(hi) is exact in fp32 and carries
-// the remainder; lo is rounded to nearest, error <= 2^-12 |lo| <= 2^-22 |x|.
-// No saturation: operands are brought into range by the per-tensor power-of-two scale below (pow2_scale);
-// a value that still exceeds the fp16 range becomes inf and poisons the result visibly instead of being
-// clamped silently.
-__device__ __forceinline__ void split_f16(const float4 v, uint2& hi, uint2& lo) {
-    const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-    const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-    // lo is rounded to nearest (unbiased): its error is what remains of the split
-    const f16x4 l = {(_Float16)(x0 - (float)h01[0]), (_Float16)(x1 - (float)h01[1]),
-                     (_Float16)(x2 - (float)h23[0]), (_Float16)(x3 - (float)h23[1])};
-    hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-    lo = __builtin_bit_cast(uint2, l);
-}
-
-// Power-of-two scale s with amax * s in [2^14, 2^15): the largest operand sits one binade under the fp16
-// maximum and every element down to 2^-18 * amax keeps a NORMAL lo half (22 significant bits); smaller
-// elements degrade gracefully (absolute error <= 2^-25 / s, i.e. 2^-39 * amax).  Exact to undo (1 / s).
-// amax == 0, denormal, inf or NaN: unscaled.
-__device__ __forceinline__ float pow2_scale(float amax) {
-    const unsigned b = __builtin_bit_cast(unsigned, amax);
-    const int eb = (int)((b >> 23) & 0xffu);
-    if (eb == 0 || eb == 255) return 1.f;
-    int k = 15 - (eb - 126);
-    k = k < -60 ? -60 : (k > 60 ? 60 : k);
-    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
-}
-__device__ __forceinline__ float4 mul4(const float4 v, const float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+// (split_f16, pow2_scale, mul4: osa_common.h -- the volume builder writes split tensors too)
 
 // Thread-linear item order (every lane busy on every load).  A row-wise variant with wave-uniform
 // row arithmetic (2x fewer VALU instructions) was measured slower overall on MI355X: rows of 10-18

@@ -12,6 +12,7 @@
 //  * NCDHW kernel (reference layout, drop-in functions): lanes run along w, so loads and
 //    stores are coalesced rows; operands come from L1/L2.
 #include "osa_common.h"
+#include <type_traits>
 
 namespace osa {
 
@@ -166,6 +167,12 @@ struct VolQArgs {
     VolArgs v;
     int NQ, lgNQ, DCH, RSq;
     int dbg;               // timing experiments only (OSA_VOL_DBG): 1 = no stores, 2 = no dot products, 4 = no window staging
+    // d-walking form, split output (f16x3 chains): the volume is written as a split tensor -- every 16-channel chunk [16 x fp16 hi | 16 x fp16 lo],
+    // the bytes of fp32 NDHWC -- scaled by a power of two derived from the FEATURES' range blocks (a bound, known before the first voxel
+    // exists: |gwc| <= max|f|^2, |concat| <= max|f_cat|), so that the first aggregation layer stages it by LDS-DMA like every other layer of
+    // the chain instead of splitting fp32 values through registers.  split = 0: fp32 output.
+    int split;
+    const float* gmeta; const float* cmeta;     // range blocks of the gwc / concat feature tensors (left and right images in one tensor)
 };
 
 // PX2: a lane owns TWO pixels, w and w + vpw.  out(w, d) and out(w + vpw, d + vpw) read the same right vector R[w - d], so walking the
@@ -506,9 +513,22 @@ __global__ __launch_bounds__((NWV + 1) * 64) void build_volume_walk_kernel(const
         const float Kinv = 1.0f / Kf;
         const int rq = nq_g + (cq - G4 - nq_c);
         float* vout = p.vol + p.coff + cq * 4;
+        // split output: scale from the features' ranges (wave-uniform); lanes (cq even, cq + 1) of a voxel pair up -- the even lane stores the
+        // 16 bytes of hi halves of both quads, the odd lane the 16 bytes of lo halves (one 16-byte store per lane, as for fp32)
+        float s_out = 1.f;
+        if (q.split) {
+            const float ag = (p.G > 0 && q.gmeta) ? amax_read(q.gmeta) : 0.f, ac = (p.Cc > 0 && q.cmeta) ? amax_read(q.cmeta) : 0.f;
+            s_out = pow2_scale(fmaxf(ag * ag, ac) * 1.0625f);
+            if (p.meta && blockIdx.x == 0 && tid == 0) p.meta[1] = s_out;
+        }
+        const int cch = p.coff + cq * 4;                       // first channel of this lane's quad
+        float* const vsplit = p.vol + (cch >> 4) * 16 + ((cq & 1) ? 8 : 0) + (((cch & 15) >> 3) * 4);
         int ri = w - (w0 + 1);                                // ring slot of pixel w - d, d = 0 (in [-1, WT - 2])
         if (ri < 0) ri += NRING;
-        for (int s = 0; s < nsteps; ++s) {
+        // one step of DS disparities.  SPLIT is a compile-time branch: the fp32 loop keeps its unrolled form (the cross-lane exchange of the
+        // split stores is a convergent operation, which the unroller will not duplicate past the early exit)
+        auto run_step = [&](auto SPLIT_T, const int s) {
+            constexpr bool SPLIT = decltype(SPLIT_T)::value;
 #pragma unroll 4
             for (int dd = 0; dd < DS; ++dd) {
                 const int d = s * DS + dd;
@@ -537,12 +557,27 @@ __global__ __launch_bounds__((NWV + 1) * 64) void build_volume_walk_kernel(const
                 } else {
                     if (valid) o = rrow[rq];
                 }
-                if (wlive) {
+                if constexpr (SPLIT) {
+                    uint2 h2, l2;
+                    split_f16(mul4(o, s_out), h2, l2);
+                    const bool odd = (cq & 1) != 0;
+                    const uint2 send = odd ? h2 : l2;            // what the partner lane stores
+                    const uint2 recv = make_uint2((unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xf, 0xf, true),     // quad_perm [1, 0, 3, 2]
+                                                  (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xf, 0xf, true));
+                    if (wlive) {
+                        const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
+                        store16(vsplit + vox * p.VC, odd ? make_uint4(recv.x, recv.y, l2.x, l2.y) : make_uint4(h2.x, h2.y, recv.x, recv.y));
+                        am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                    }
+                } else if (wlive) {
                     const size_t vox = (((size_t)b * p.D + d) * p.H + h) * p.W + w;
                     store16(vout + vox * p.VC, o);
                     am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
                 }
             }
+        };
+        for (int s = 0; s < nsteps; ++s) {
+            if (q.split) run_step(std::true_type{}, s); else run_step(std::false_type{}, s);
             // step s is read; block s + 1 has landed (the loader waited for it).  s_barrier only: no vmcnt wait, the stores stay in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -677,10 +712,23 @@ extern "C" int osa_pair_volume_f32(const float* left, const float* right, float*
 static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                              const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                              float* vol, int layout, int vol_channels, int c_off,
-                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta = nullptr);
+                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta = nullptr,
+                             int split = 0, const float* gwc_meta = nullptr, const float* cat_meta = nullptr);
 
 // d-walking form of the NDHWC builder (build_volume_walk_kernel): disparities per step (4 or 8), 0 = the chunked kernel
 static int g_vol_walk_ds = 8;
+static bool walk_eligible(int G, int K, int Cc, int gwc_stride, int cat_stride, const float* left_cat, const float* right_cat,
+                          const float* vol, int vol_channels, int c_off, int W, int maxdisp) {
+    const int nch = G + 2 * Cc, nq4 = nch / 4;
+    if (!(G == 0 || (K % 4 == 0 && K / 4 <= 4))) return false;
+    if (!((G % 4 == 0) && (Cc % 4 == 0) && nq4 >= 1 && nq4 <= 64 && (nq4 & (nq4 - 1)) == 0 && (vol_channels % 4 == 0) && (c_off % 4 == 0) &&
+          (((size_t)vol & 15) == 0))) return false;
+    const int WT = 8 * (64 / nq4);
+    if (W < 2 * WT) return false;                                   // 8-wave pixel tiles
+    if (!(G == 0 || gwc_stride > 0)) return false;
+    if (!(Cc == 0 || (cat_stride > 0 && cat_stride % 4 == 0 && ((size_t)left_cat & 15) == 0 && ((size_t)right_cat & 15) == 0))) return false;
+    return g_vol_walk_ds > 0 && WT % g_vol_walk_ds == 0 && maxdisp > g_vol_walk_ds;
+}
 static long long g_vol_walk_launches = 0;
 extern "C" int osa_volume_walk_step(int ds) {
     const int prev = g_vol_walk_ds;
@@ -711,10 +759,36 @@ extern "C" int osa_build_volume_nhwc_f32(const float* left_gwc, const float* rig
                              mask_left_concat, stream, vol_meta);
 }
 
+extern "C" int osa_build_volume_nhwc_split_eligible(const float* left_cat, const float* right_cat, const float* vol, int C, int num_groups,
+                                                    int gwc_stride, int Cc, int cat_stride, int vol_channels, int c_off, int W, int maxdisp) {
+    const int G = (C > 0) ? num_groups : 0;
+    if (C > 0 && (num_groups <= 0 || C % num_groups)) return 0;
+    const int K = G ? C / G : 0;
+    if (vol_channels % 16 || c_off % 16 || (G + 2 * Cc) % 16) return 0;
+    return walk_eligible(G, K, Cc, gwc_stride ? gwc_stride : C, cat_stride ? cat_stride : Cc, left_cat, right_cat, vol, vol_channels, c_off, W, maxdisp) ? 1 : 0;
+}
+
+extern "C" int osa_build_volume_nhwc_split_f16x3(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
+                                                 const float* left_cat, const float* right_cat, int Cc, int cat_stride,
+                                                 float* vol, int vol_channels, int c_off,
+                                                 int B, int H, int W, int maxdisp, int mask_left_concat,
+                                                 const float* gwc_meta, const float* cat_meta, float* vol_meta, void* stream) {
+    OSA_REQUIRE(vol_meta != nullptr && (C == 0 || gwc_meta != nullptr) && (Cc == 0 || cat_meta != nullptr),
+                "build_volume_nhwc_split: the range blocks of the features and of the volume are required (the scale of the split halves is derived from them)");
+    OSA_REQUIRE((C == 0 || (gwc_stride >= C && gwc_stride % 4 == 0 && ((size_t)left_gwc & 15) == 0 && ((size_t)right_gwc & 15) == 0)),
+                "build_volume_nhwc_split: gwc features need stride >= C, stride %% 4 == 0 and 16-byte alignment");
+    OSA_REQUIRE((Cc == 0 || cat_stride >= Cc), "build_volume_nhwc_split: concat stride %d < Cc %d", cat_stride, Cc);
+    OSA_REQUIRE(C == 0 || (C / (num_groups > 0 ? num_groups : 1)) % 4 == 0, "build_volume_nhwc_split: channels per group must be a multiple of 4");
+    return build_volume_impl(left_gwc, right_gwc, C, num_groups, gwc_stride ? gwc_stride : C, left_cat, right_cat, Cc,
+                             cat_stride ? cat_stride : Cc, vol, OSA_NDHWC, vol_channels, c_off, B, H, W, maxdisp,
+                             mask_left_concat, stream, vol_meta, 1, gwc_meta, cat_meta);
+}
+
 static int build_volume_impl(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
                              const float* left_cat, const float* right_cat, int Cc, int cat_stride,
                              float* vol, int layout, int vol_channels, int c_off,
-                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta) {
+                             int B, int H, int W, int maxdisp, int mask_left_concat, void* stream, float* vol_meta,
+                             int split, const float* gwc_meta, const float* cat_meta) {
     OSA_REQUIRE(vol != nullptr, "build_volume: vol is NULL");
     OSA_REQUIRE(B > 0 && H > 0 && W > 0 && maxdisp > 0, "build_volume: bad dims B=%d H=%d W=%d D=%d", B, H, W, maxdisp);
     OSA_REQUIRE(C >= 0 && Cc >= 0 && (C > 0 || Cc > 0), "build_volume: nothing to build (C=%d Cc=%d)", C, Cc);
@@ -795,8 +869,11 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
 #define OSA_VOLQ_LAUNCH(Q) do { if (px2) { if (nwv == 8) OSA_VOLQ_LAUNCH1P(Q, 8); else OSA_VOLQ_LAUNCH1P(Q, 4); }    \
                                 else if (nwv == 8) OSA_VOLQ_LAUNCH1(Q, 8); else OSA_VOLQ_LAUNCH1(Q, 4); } while (0)
             // d-walking form (build_volume_walk_kernel): NHWC features with 16-byte aligned quads, 8-wave pixel tiles
-            if (g_vol_walk_ds > 0 && !px2 && nwv == 8 && (G == 0 || gwc_stride > 0) && (Cc == 0 || (cat_stride > 0 && cat_stride % 4 == 0 &&
-                ((size_t)left_cat & 15) == 0 && ((size_t)right_cat & 15) == 0)) && WT % g_vol_walk_ds == 0 && maxdisp > g_vol_walk_ds) {
+            const bool walk = !px2 && nwv == 8 && walk_eligible(G, K, Cc, gwc_stride, cat_stride, left_cat, right_cat, vol, vol_channels, c_off, W, maxdisp);
+            OSA_REQUIRE(!split || (walk && vol_channels % 16 == 0 && c_off % 16 == 0 && nch % 16 == 0),
+                        "build_volume: split output needs the d-walking form and 16-channel aligned volume channels (osa_build_volume_nhwc_split_eligible)");
+            qa.split = split; qa.gmeta = gwc_meta; qa.cmeta = cat_meta;
+            if (walk) {
                 const int DS = g_vol_walk_ds;
                 a.nWt = cdiv(W, WT); a.nDch = 1;
                 qa.DCH = DS; qa.dbg = 0;
@@ -835,6 +912,7 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
             OSA_LAUNCH_CHECK("build_volume_quads");
             return 0;
         }
+        OSA_REQUIRE(!split, "build_volume: split output needs the quad-lane d-walking form (osa_build_volume_nhwc_split_eligible)");
         VolArgs a;
         a.lg = left_gwc; a.rg = right_gwc; a.lc = left_cat; a.rc = right_cat; a.vol = vol; a.meta = vol_meta;
         a.B = B; a.C = C; a.Cc = Cc; a.H = H; a.W = W; a.D = maxdisp; a.G = G; a.K = K;

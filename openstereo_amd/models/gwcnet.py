@@ -48,6 +48,7 @@ def _cb2(cin, cout, k, stride, pad, dil):
 
 _FUSE_REDIR = os.environ.get("OSA_FUSE_REDIR", "1") != "0"
 _SPLIT_ACT = os.environ.get("OSA_SPLIT_ACT", "1") != "0"     # f16x3: 3-D activations stored pre-split between engine layers
+_VOL_SPLIT = os.environ.get("OSA_VOL_SPLIT", "1") != "0"     # f16x3: the cost volume itself is written in the split format (r4; A/B switch)
 
 class _ResBlock(nn.Module):
     def __init__(self, cin, cout, stride, shortcut, pad, dil):
@@ -392,9 +393,11 @@ class GwcNet(nn.Module):
             B = inputs["left"].shape[0]
             gwc, catf = self.Backbone.forward_cl(inputs["left"], inputs["right"])
             cp = self.CostProcessor
+            # f16x3 chains: the volume is written in the chain's split format, so dres0 stages it like every later layer (ops docstring)
             vol = ops.build_cost_volume_from_cl(gwc, cp.num_groups, catf if cp.use_concat_volume else None, B,
                                                 cp.maxdisp // cp.downsample,
-                                                cat_channels=self.Backbone.concat_channels or None)
+                                                cat_channels=self.Backbone.concat_channels or None,
+                                                out_split=_SPLIT_ACT and _VOL_SPLIT and self.DispProcessor._pack()["d00"].precision == "f16x3")
             inputs["cost_volume"] = vol
         else:
             inputs.update(self.Backbone(inputs))

@@ -238,9 +238,12 @@ def build_cost_volume_cl(gwc_left, gwc_right, num_groups, cat_left=None, cat_rig
 
 
 def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_channels=None, cat_channels=None,
-                              gwc_off=0, mask_left=True):
+                              gwc_off=0, mask_left=True, out_split=False):
     """Volume from the engine backbone's channels-last feature maps.  gwc_feat / cat_feat: logical
-    [2B, Cs, 1, H, W] NDHWC tensors holding the left images first ([0:B]) and the right images last."""
+    [2B, Cs, 1, H, W] NDHWC tensors holding the left images first ([0:B]) and the right images last.
+    out_split=True (f16x3 chains): when the call qualifies (osa_build_volume_nhwc_split_eligible) and both feature tensors carry range
+    blocks, the volume is written as a split tensor (tagged `_osa_split`, scale from the features' ranges) for the aggregation chain;
+    otherwise the fp32 volume is returned as always -- the consumer recognises the format by the tag."""
     assert is_cl(gwc_feat) and gwc_feat.shape[0] == 2 * B and gwc_feat.shape[2] == 1
     _, Gs, _, H, W = gwc_feat.shape
     C = Gs - gwc_off if gwc_channels is None else gwc_channels
@@ -258,9 +261,19 @@ def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_ch
     out = empty_cl(B, VC, maxdisp, H, W, gwc_feat.device)
     if VC != nch:
         out.zero_()
+    gm = getattr(gwc_feat, "_osa_meta", None) if C > 0 else None
+    cm = getattr(cat_feat, "_osa_meta", None) if (cat_feat is not None and Cc > 0) else None
+    split = bool(out_split) and VC == nch and (C == 0 or gm is not None) and (Cc == 0 or cm is not None) and \
+        _lib.load().osa_build_volume_nhwc_split_eligible(lc, rc, out.data_ptr(), C, num_groups, Gs, Cc, cs, VC, 0, W, maxdisp) == 1
     with timing.span("build_volume", C, num_groups, Cc, NDHWC, maxdisp, H, W):
-        _lib.call("osa_build_volume_nhwc_f32", lg, rg, C, num_groups, Gs, lc, rc, Cc, cs, out.data_ptr(), VC, 0,
-                  B, H, W, maxdisp, 1 if mask_left else 0, attach_meta(out).data_ptr(), _stream())
+        if split:
+            _lib.call("osa_build_volume_nhwc_split_f16x3", lg, rg, C, num_groups, Gs, lc, rc, Cc, cs, out.data_ptr(), VC, 0,
+                      B, H, W, maxdisp, 1 if mask_left else 0, None if gm is None else gm.data_ptr(), None if cm is None else cm.data_ptr(),
+                      attach_meta(out).data_ptr(), _stream())
+            out._osa_split = True
+        else:
+            _lib.call("osa_build_volume_nhwc_f32", lg, rg, C, num_groups, Gs, lc, rc, Cc, cs, out.data_ptr(), VC, 0,
+                      B, H, W, maxdisp, 1 if mask_left else 0, attach_meta(out).data_ptr(), _stream())
     return out
 
 

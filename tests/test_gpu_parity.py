@@ -1090,3 +1090,37 @@ def test_volume_walking_form_is_bit_identical(case, step):
     torch.cuda.synchronize()
     assert torch.equal(v_chunk, v_walk), f"{name}: walking form differs by {(v_chunk - v_walk).abs().max().item():.3e}"
     assert float(ranges.meta_of(v_walk)[::16][:8].max()) == float(v_walk.abs().max()) == float(ranges.meta_of(v_chunk)[::16][:8].max())
+
+
+@pytest.mark.parametrize("case", [("gwcnet", 2, 320, 40, 12, 9, 96, 48), ("gwcnet ragged", 1, 320, 40, 12, 5, 75, 21), ("concat only", 1, 0, 0, 16, 4, 130, 12)],
+                         ids=lambda c: c[0])
+def test_volume_written_as_split_tensor(case):
+    """osa_build_volume_nhwc_split_f16x3: the fused volume in the f16x3 chain's split format (hi / lo fp16 halves per 16-channel chunk, power-of-
+    two scale from the FEATURES' range blocks).  Decoded, it equals the fp32 volume to 2^-21 relative (+ the absolute floor of elements far
+    below the bound); the scale is the documented bound; a consumer layer gives the same result from either format."""
+    from openstereo_amd import ops, ranges
+    from openstereo_amd.engine import PackedConv3d, is_split
+    name, B, C, G, Cc, H, W, D = case
+    rng = np.random.default_rng(6)
+    gf = ops.empty_cl(2 * B, max(C, 4), 1, H, W, DEV); gf.copy_(T(rng.normal(0, 1.5, tuple(gf.shape)).astype(np.float32)))
+    cf = ops.empty_cl(2 * B, Cc, 1, H, W, DEV); cf.copy_(T(rng.normal(0, 3.0, tuple(cf.shape)).astype(np.float32)))
+    ranges.ensure_meta(gf); ranges.ensure_meta(cf)
+    v32 = ops.build_cost_volume_from_cl(gf, G, cf, B, D, gwc_channels=C)
+    vs = ops.build_cost_volume_from_cl(gf, G, cf, B, D, gwc_channels=C, out_split=True)
+    assert is_split(vs) and not is_split(v32), "the call qualifies for the split form"
+    meta = ranges.meta_of(vs)
+    scale = float(meta[1])
+    bound = max(float(gf.abs().max()) ** 2 if C else 0.0, float(cf.abs().max())) * 1.0625
+    assert scale == 2.0 ** (15 - (int(np.floor(np.log2(bound))) + 1)), (scale, bound)          # bound * scale in [2^14, 2^15)
+    raw = vs.permute(0, 2, 3, 4, 1).contiguous().view(torch.float16)                           # [B, D, H, W, 2 * VC] halves
+    raw = raw.reshape(*raw.shape[:4], -1, 2, 16).float()                                       # [..., chunk, hi | lo, 16]
+    dec = ((raw[..., 0, :] + raw[..., 1, :]) / scale).reshape(*raw.shape[:4], -1).permute(0, 4, 1, 2, 3)
+    err = (dec - v32).abs()
+    tol = v32.abs() * 2.0 ** -21 + 2.0 ** -24 / scale
+    assert bool((err <= tol).all()), f"{name}: decoded split volume off by {float((err - tol).max()):.3e}"
+    assert float(meta[::16][:8].max()) == float(v32.abs().max())                               # the running maximum tracks the fp32 values
+    if (G + 2 * Cc) % 16 == 0 and D >= 3:
+        conv = nn.Conv3d(G + 2 * Cc, 32, 3, 1, 1, bias=False)
+        conv.weight.data = synth_tensor("vsplit.w", conv.weight.shape, 1)
+        pc = PackedConv3d(conv.to(DEV), None, 1, precision="f16x3")
+        close(pc(vs), pc(v32), atol=3e-5, rtol=3e-5, what=f"{name}: consumer of the split volume vs of the fp32 volume")

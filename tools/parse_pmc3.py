@@ -49,6 +49,11 @@ for key, sub in KERNELS.items():
     g = max(k[1] for k in fk)
     f = [v for k, v in fk.items() if k[1] == g][0]
     w = [v for k, v in wk.items() if k[1] == g][0]
+    if key == "conv3d_32_32_V0_f16x3" and "conv_march_kernel<4, 16, 1, 1>" in sub and len(f) % 4 == 0 and os.environ.get("OSA_PMC_VOLUME_SPLIT", "1") == "1":
+        # late r4: the volume is a split tensor, so dres0.0 (64 -> 32) runs this instance too -- dispatch order per step dres0.0, dres0.2, dres1.0,
+        # dres1.2: price the three 32 -> 32 launches (OSA_PMC_VOLUME_SPLIT=0: traces taken with OSA_VOL_SPLIT=0 / before that change)
+        f = [v for i, v in enumerate(f) if i % 4 != 0]
+        w = [v for i, v in enumerate(w) if i % 4 != 0]
     if key.startswith("conv3d_32_32") and "conv_mfma_kernel" in sub:   # brick instance, dispatch order per step: dres0.0 (64 -> 32), dres0.2, dres1.0, dres1.2: price the plain 32 -> 32 launches
         f = [v for i, v in enumerate(f) if i % 4 in (1, 2)]
         w = [v for i, v in enumerate(w) if i % 4 in (1, 2)]
