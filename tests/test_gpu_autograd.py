@@ -517,9 +517,12 @@ def test_ddp_two_ranks_average_gradients_through_engine_functions():
         singles.append((net.DispProcessor.dres0[0][0].weight.grad.detach().cpu().clone(),
                         net.Backbone.feature_extraction.layer2[0].conv1[0][0].weight.grad.detach().cpu().clone()))
     assert abs(losses[0] - l0) < 1e-4 * abs(l0) and abs(losses[1] - l1) < 1e-4 * abs(l1)
-    for got, a, b in ((g0, singles[0][0], singles[1][0]), (h0, singles[0][1], singles[1][1])):
+    # dres0's weight gradient sees engine kernels only (deterministic): 1e-4.  The backbone's stride-2 layer2[0].conv1 stays a torch module in
+    # training (autograd._shape_eligible), i.e. MIOpen -- whose solver choice (find mode, workspace-dependent: the GemmWrwUniversal / GemmBwdRest
+    # warnings in the log) differs between the DDP worker processes and this one on some boxes and moves that gradient by ~2e-4: 1e-3.
+    for got, a, b, tol in ((g0, singles[0][0], singles[1][0], 1e-4), (h0, singles[0][1], singles[1][1], 1e-3)):
         want = 0.5 * (a + b)
-        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-12, float((got - want).abs().max() / want.abs().max())
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max()) + 1e-12, float((got - want).abs().max() / want.abs().max())
 
 
 def test_geo_lookup_gradients_vs_oracle_autograd():
