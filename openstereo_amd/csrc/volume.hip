@@ -399,7 +399,9 @@ __global__ __launch_bounds__(NWV * 64) void build_volume_quads_kernel(const VolQ
 // NHWC features with 16-byte aligned quads only (the engine's backbone output); everything else keeps the kernel above.
 __device__ const float4 g_vol_zeros[64] = {};        // source of the ring slots outside the image / beyond a pixel's quads
 
-template <int QG, int NWV, int DS>
+// SPLIT: the volume is written as a split tensor (VolQArgs::split; a kernel of its own -- compiled into one kernel behind a run-time branch the
+// fp32 loop lost 20 %: 70 -> 92 registers and two unrolled loop bodies, profiles/round4/volume_walk_after_split_support.txt)
+template <int QG, int NWV, int DS, bool SPLIT = false>
 __global__ __launch_bounds__((NWV + 1) * 64) void build_volume_walk_kernel(const VolQArgs q) {
     extern __shared__ __attribute__((aligned(16))) float4 smq[];
     const VolArgs& p = q.v;
@@ -515,24 +517,21 @@ __global__ __launch_bounds__((NWV + 1) * 64) void build_volume_walk_kernel(const
         float* vout = p.vol + p.coff + cq * 4;
         // split output: scale from the features' ranges (wave-uniform); lanes (cq even, cq + 1) of a voxel pair up -- the even lane stores the
         // 16 bytes of hi halves of both quads, the odd lane the 16 bytes of lo halves (one 16-byte store per lane, as for fp32)
-        float s_out = 1.f;
-        if (q.split) {
+        [[maybe_unused]] float s_out = 1.f;
+        if constexpr (SPLIT) {
             const float ag = (p.G > 0 && q.gmeta) ? amax_read(q.gmeta) : 0.f, ac = (p.Cc > 0 && q.cmeta) ? amax_read(q.cmeta) : 0.f;
             s_out = pow2_scale(fmaxf(ag * ag, ac) * 1.0625f);
             if (p.meta && blockIdx.x == 0 && tid == 0) p.meta[1] = s_out;
         }
         const int cch = p.coff + cq * 4;                       // first channel of this lane's quad
-        float* const vsplit = p.vol + (cch >> 4) * 16 + ((cq & 1) ? 8 : 0) + (((cch & 15) >> 3) * 4);
+        [[maybe_unused]] float* const vsplit = p.vol + (cch >> 4) * 16 + ((cq & 1) ? 8 : 0) + (((cch & 15) >> 3) * 4);
         int ri = w - (w0 + 1);                                // ring slot of pixel w - d, d = 0 (in [-1, WT - 2])
         if (ri < 0) ri += NRING;
-        // one step of DS disparities.  SPLIT is a compile-time branch: the fp32 loop keeps its unrolled form (the cross-lane exchange of the
-        // split stores is a convergent operation, which the unroller will not duplicate past the early exit)
-        auto run_step = [&](auto SPLIT_T, const int s) {
-            constexpr bool SPLIT = decltype(SPLIT_T)::value;
-#pragma unroll 4
-            for (int dd = 0; dd < DS; ++dd) {
-                const int d = s * DS + dd;
-                if (d >= p.D) break;
+        // (measured and NOT kept: walking the ring offset and the output pointer incrementally instead of recomputing them per disparity --
+        // fewer VALU instructions, but a loop-carried chain through the unrolled body: 0.97 -> 1.17 ms at 8 pairs, profiles/round4/volume_walk_incremental_addresses.txt)
+        // one disparity of this lane's voxel column
+        auto emit = [&](const int d) {
+            {
                 const bool valid = (w >= d);
                 const float4* rrow = smq + (size_t)ri * q.RSq;
                 ri = (ri == 0) ? NRING - 1 : ri - 1;
@@ -577,7 +576,24 @@ __global__ __launch_bounds__((NWV + 1) * 64) void build_volume_walk_kernel(const
             }
         };
         for (int s = 0; s < nsteps; ++s) {
-            if (q.split) run_step(std::true_type{}, s); else run_step(std::false_type{}, s);
+            if constexpr (SPLIT) {
+                // (the cross-lane exchange of the split stores is a convergent operation: the unroller will not duplicate it past an early exit,
+                // so full steps run a fixed-trip loop and only the last, partial step a counted one)
+                const int nd = (p.D - s * DS < DS) ? p.D - s * DS : DS;
+                if (nd == DS) {
+#pragma unroll 4
+                    for (int dd = 0; dd < DS; ++dd) emit(s * DS + dd);
+                } else {
+                    for (int dd = 0; dd < nd; ++dd) emit(s * DS + dd);
+                }
+            } else {
+#pragma unroll 4
+                for (int dd = 0; dd < DS; ++dd) {
+                    const int d = s * DS + dd;
+                    if (d >= p.D) break;
+                    emit(d);
+                }
+            }
             // step s is read; block s + 1 has landed (the loader waited for it).  s_barrier only: no vmcnt wait, the stores stay in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -880,14 +896,15 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
                 const size_t wlds = (size_t)(WT / DS + 2) * DS * qa.RSq * 16 + 64;
                 const long long wblk = (long long)B * H * a.nWt;
                 OSA_REQUIRE(wlds <= 160 * 1024 && wblk < (1ll << 31), "build_volume: walk form does not fit (%zu B of LDS)", wlds);
-#define OSA_VOLW_LAUNCH1(Q, DSV)                                                                    \
+#define OSA_VOLW_LAUNCH1(Q, DSV, SP)                                                                \
                 do {                                                                                \
                     if (wlds > 64 * 1024)                                                           \
-                        (void)hipFuncSetAttribute((const void*)build_volume_walk_kernel<Q, 8, DSV>, \
+                        (void)hipFuncSetAttribute((const void*)build_volume_walk_kernel<Q, 8, DSV, SP>, \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds); \
-                    hipLaunchKernelGGL((build_volume_walk_kernel<Q, 8, DSV>), dim3((unsigned)wblk), dim3(9 * 64), wlds, st, qa); \
+                    hipLaunchKernelGGL((build_volume_walk_kernel<Q, 8, DSV, SP>), dim3((unsigned)wblk), dim3(9 * 64), wlds, st, qa); \
                 } while (0)
-#define OSA_VOLW_LAUNCH(Q) do { if (DS == 4) OSA_VOLW_LAUNCH1(Q, 4); else OSA_VOLW_LAUNCH1(Q, 8); } while (0)
+#define OSA_VOLW_LAUNCH(Q) do { if (split) { if (DS == 4) OSA_VOLW_LAUNCH1(Q, 4, true); else OSA_VOLW_LAUNCH1(Q, 8, true); }   \
+                                else { if (DS == 4) OSA_VOLW_LAUNCH1(Q, 4, false); else OSA_VOLW_LAUNCH1(Q, 8, false); } } while (0)
                 switch (QG) {
                     case 1: OSA_VOLW_LAUNCH(1); break;
                     case 2: OSA_VOLW_LAUNCH(2); break;

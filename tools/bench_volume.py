@@ -8,15 +8,19 @@ dev = "cuda:0"
 B, H, W, D = int(os.environ.get("VOL_B", 1)), 136, 240, 48
 gf = ops.empty_cl(2 * B, 320, 1, H, W, dev); gf.normal_()
 cf = ops.empty_cl(2 * B, 12, 1, H, W, dev); cf.normal_()
+from openstereo_amd import ranges
+ranges.ensure_meta(gf); ranges.ensure_meta(cf)          # (the split form derives its scale from the features' range blocks)
+SPLIT = False
 def run():
-    return ops.build_cost_volume_from_cl(gf, 40, cf, B, D)
+    return ops.build_cost_volume_from_cl(gf, 40, cf, B, D, out_split=SPLIT)
 outs = {}
 from openstereo_amd import _lib
 LIB = _lib.load()
 MODES = os.environ.get("VOL_MODES", "quads,perchannel,quads,px2,quads,px2,w4,w8,w8lds160,dbg1,dbg2,dbg4,dbg7,px2dbg1,px2dbg7").split(",")
 for mode in MODES:
     if hasattr(LIB, "osa_volume_walk_step"):      # walk8 / walk4: the d-walking form (r4); every other mode measures the chunked kernel
-        LIB.osa_volume_walk_step(int(mode[4:]) if mode.startswith("walk") else 0)
+        LIB.osa_volume_walk_step(int(mode[4:5]) if mode.startswith("walk") else 0)
+    SPLIT = mode.endswith("split")                      # walk8split: the volume written as a split tensor (f16x3 chains)
     for k in ("OSA_VOL_PERCHANNEL", "OSA_VOL_DBG", "OSA_VOL_WAVES", "OSA_VOL_LDS", "OSA_VOL_PX2"):
         os.environ.pop(k, None)
     if mode.startswith("w") and not mode.startswith("px2"):
