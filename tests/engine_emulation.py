@@ -127,7 +127,7 @@ def build_cost_volume_cl(gwc_left, gwc_right, num_groups, cat_left=None, cat_rig
 
 
 def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_channels=None, cat_channels=None, gwc_off=0,
-                              mask_left=True):
+                              mask_left=True, out_split=False):          # (out_split: a storage format of the GPU engine, same values)
     C = gwc_feat.shape[1] - gwc_off if gwc_channels is None else gwc_channels
     g = gwc_feat[:, gwc_off:gwc_off + C, 0]
     c = None if cat_feat is None else cat_feat[:, :(cat_feat.shape[1] if cat_channels is None else cat_channels), 0]
