@@ -559,8 +559,8 @@ long long osa_conv_b_ring_launches(void);
  * eligible calls (NHWC features with 16-byte aligned channel quads, quad-lane channel counts, maps at least 2 x 32 pixels wide) as
  * workgroups that own a (row, 32-pixel tile) and walk along d: left features stay in registers for all disparities, the right window is a
  * ring in LDS that a loader wave refills by LDS-DMA `step` pixels at a time while the other waves compute and store.  Bit-identical output.
- * osa_volume_walk_step(step): 8 (default) or 4 disparities per step, 0 = the chunked kernel; returns the previous value (A/B runs and the
- * parity test).  osa_volume_walk_launches: calls of this process that took the walking form. */
+ * osa_volume_walk_step(step): 8 or 4 disparities per step for both output forms, 0 = the chunked kernel (fp32 output); returns the previous
+ * fp32-form value (A/B runs and the parity test).  Defaults: 8 for the fp32 output, 4 for the split output (csrc/volume.hip).  osa_volume_walk_launches: calls of this process that took the walking form. */
 int osa_volume_walk_step(int step);
 long long osa_volume_walk_launches(void);
 

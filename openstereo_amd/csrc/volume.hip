@@ -733,8 +733,12 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
 
 // d-walking form of the NDHWC builder (build_volume_walk_kernel): disparities per step (4 or 8), 0 = the chunked kernel
 static int g_vol_walk_ds = 8;
+// ... of the split-output kernel: 4 (72 registers and a 53 KB ring -> 3 workgroups per CU; 84 / 64 KB / 2 at 8).  Measured at 3 pairs per launch,
+// the sub-batch of the default line: 0.466-0.506 -> 0.418-0.424 ms, whole model +0.7 % (profiles/round4/volume_walk_step_split.txt); the fp32
+// kernel is indifferent at 3 pairs and 2-3 % better with 8 at 8 pairs.
+static int g_vol_walk_split_ds = 4;
 static bool walk_eligible(int G, int K, int Cc, int gwc_stride, int cat_stride, const float* left_cat, const float* right_cat,
-                          const float* vol, int vol_channels, int c_off, int W, int maxdisp) {
+                          const float* vol, int vol_channels, int c_off, int W, int maxdisp, int ds) {
     const int nch = G + 2 * Cc, nq4 = nch / 4;
     if (!(G == 0 || (K % 4 == 0 && K / 4 <= 4))) return false;
     if (!((G % 4 == 0) && (Cc % 4 == 0) && nq4 >= 1 && nq4 <= 64 && (nq4 & (nq4 - 1)) == 0 && (vol_channels % 4 == 0) && (c_off % 4 == 0) &&
@@ -743,12 +747,12 @@ static bool walk_eligible(int G, int K, int Cc, int gwc_stride, int cat_stride, 
     if (W < 2 * WT) return false;                                   // 8-wave pixel tiles
     if (!(G == 0 || gwc_stride > 0)) return false;
     if (!(Cc == 0 || (cat_stride > 0 && cat_stride % 4 == 0 && ((size_t)left_cat & 15) == 0 && ((size_t)right_cat & 15) == 0))) return false;
-    return g_vol_walk_ds > 0 && WT % g_vol_walk_ds == 0 && maxdisp > g_vol_walk_ds;
+    return ds > 0 && WT % ds == 0 && maxdisp > ds;
 }
 static long long g_vol_walk_launches = 0;
 extern "C" int osa_volume_walk_step(int ds) {
     const int prev = g_vol_walk_ds;
-    if (ds == 0 || ds == 4 || ds == 8) g_vol_walk_ds = ds;
+    if (ds == 0 || ds == 4 || ds == 8) { g_vol_walk_ds = ds; g_vol_walk_split_ds = ds ? ds : 4; }     // (0: the fp32 output falls back to the chunked kernel; the split form exists as a walk only)
     return prev;
 }
 extern "C" long long osa_volume_walk_launches(void) { return g_vol_walk_launches; }
@@ -781,7 +785,8 @@ extern "C" int osa_build_volume_nhwc_split_eligible(const float* left_cat, const
     if (C > 0 && (num_groups <= 0 || C % num_groups)) return 0;
     const int K = G ? C / G : 0;
     if (vol_channels % 16 || c_off % 16 || (G + 2 * Cc) % 16) return 0;
-    return walk_eligible(G, K, Cc, gwc_stride ? gwc_stride : C, cat_stride ? cat_stride : Cc, left_cat, right_cat, vol, vol_channels, c_off, W, maxdisp) ? 1 : 0;
+    return walk_eligible(G, K, Cc, gwc_stride ? gwc_stride : C, cat_stride ? cat_stride : Cc, left_cat, right_cat, vol, vol_channels, c_off, W, maxdisp,
+                         g_vol_walk_split_ds) ? 1 : 0;
 }
 
 extern "C" int osa_build_volume_nhwc_split_f16x3(const float* left_gwc, const float* right_gwc, int C, int num_groups, int gwc_stride,
@@ -885,12 +890,13 @@ static int build_volume_impl(const float* left_gwc, const float* right_gwc, int 
 #define OSA_VOLQ_LAUNCH(Q) do { if (px2) { if (nwv == 8) OSA_VOLQ_LAUNCH1P(Q, 8); else OSA_VOLQ_LAUNCH1P(Q, 4); }    \
                                 else if (nwv == 8) OSA_VOLQ_LAUNCH1(Q, 8); else OSA_VOLQ_LAUNCH1(Q, 4); } while (0)
             // d-walking form (build_volume_walk_kernel): NHWC features with 16-byte aligned quads, 8-wave pixel tiles
-            const bool walk = !px2 && nwv == 8 && walk_eligible(G, K, Cc, gwc_stride, cat_stride, left_cat, right_cat, vol, vol_channels, c_off, W, maxdisp);
+            const int walk_ds = split ? g_vol_walk_split_ds : g_vol_walk_ds;
+            const bool walk = !px2 && nwv == 8 && walk_eligible(G, K, Cc, gwc_stride, cat_stride, left_cat, right_cat, vol, vol_channels, c_off, W, maxdisp, walk_ds);
             OSA_REQUIRE(!split || (walk && vol_channels % 16 == 0 && c_off % 16 == 0 && nch % 16 == 0),
                         "build_volume: split output needs the d-walking form and 16-channel aligned volume channels (osa_build_volume_nhwc_split_eligible)");
             qa.split = split; qa.gmeta = gwc_meta; qa.cmeta = cat_meta;
             if (walk) {
-                const int DS = g_vol_walk_ds;
+                const int DS = walk_ds;
                 a.nWt = cdiv(W, WT); a.nDch = 1;
                 qa.DCH = DS; qa.dbg = 0;
                 const size_t wlds = (size_t)(WT / DS + 2) * DS * qa.RSq * 16 + 64;
