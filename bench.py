@@ -53,7 +53,7 @@ VOLUME_MB, HEAD_MB, CLASSIF_MB = 487.8, 8.36, 200.5 + 6.27
 KERNEL_NAMES = {
     ("conv", "f16x3"): "void osa::conv_march_kernel<4, 16, 1, 1>(osa::ConvArgs, int, int)   [d-marching form, csrc/conv_march.h]",
     ("conv", "f32"): "void osa::conv_mfma_kernel<0, 1, 1, 2, 1, 4, 1, 8, 8, 0, 0, 0, 1, 0>(osa::ConvArgs)",
-    "volume": "void osa::build_volume_walk_kernel<2, 8, 8>(osa::VolQArgs)   [d-walking form, csrc/volume.hip]",
+    "volume": "void osa::build_volume_walk_kernel<2, 8, 4, true>(osa::VolQArgs)   [d-walking form, split output for the f16x3 chain; fp32 output: <2, 8, 8, false>; csrc/volume.hip]",
     "head": "osa::upsample4_softargmin_kernel(osa::UpArgs)",
     "classifier": "osa::classifier_march_kernel(osa::ConvArgs, float const*, float const*, int, int)",
 }

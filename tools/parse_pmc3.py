@@ -14,7 +14,7 @@ KERNELS = {
     "conv3d_32_32_V0_f16x3": os.environ.get("OSA_PMC_DOMINANT", "conv_march_kernel<4, 16, 1, 1>"),
     "conv3d_32_32_V0_f16x3_brick": "conv_mfma_kernel<1, 1, 1, 2, 1, 4, 1, 8, 8, 0, 1, 0, 1, 0>",
     # (r4, later: every conv_mfma_kernel name carries a 14th template argument, BL -- 1 = weight fragments through the LDS ring)
-    "volume": "build_volume_walk_kernel<2, 8, 8",
+    "volume": "build_volume_walk_kernel<2, 8, ",
     "head": "upsample4_softargmin_kernel",
     "classifier": "classifier_march_kernel",
     "deconv_64_32_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1, 0, 1, 0>",
