@@ -239,6 +239,8 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
 // tiles 0 / 7 / 12 (first 32 -> 32: -11 %), 9 (2 x 2 waves share a fragment only pairwise: 128 -> 128 @1/4 -3 ... +1 %), 11 (no sharing at
 // all), the fused transposed convs (+-1 %).
 static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13);
+// (measured and not kept: tile 9 on the ring for long K loops only, >= 16 input chunks -- the GRU gate convs 384 -> 128 / 256 @1/4 gain 0 ... +5 % as
+// single layers, and the IGEV x 32 loop LOSES 1.3 % with it, StereoBase 0.4 %: profiles/round4/b_ring_tile9_long_k.txt)
 static long long g_b_ring_launches = 0;
 static int g_b_ring_mask_value() { return g_b_ring_mask; }
 

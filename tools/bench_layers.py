@@ -126,8 +126,8 @@ def main():
             elif cfg is not None:
                 os.environ["OSA_CONV_CFG"] = str(cfg)
             from openstereo_amd import _lib as _L
-            if hasattr(_L.load(), "osa_conv_b_ring_mask"):      # OSA_B_RING_MASK is a run-time switch of the shipped library (C ABI)
-                _L.load().osa_conv_b_ring_mask(int(os.environ.get("OSA_B_RING_MASK", "-1"), 0))
+            if hasattr(_L.load(), "osa_conv_b_ring_mask") and os.environ.get("OSA_B_RING_MASK"):   # a run-time switch of the shipped library (C ABI); unset: its built-in default
+                _L.load().osa_conv_b_ring_mask(int(os.environ["OSA_B_RING_MASK"], 0))
             try:
                 call = (lambda: layer(x, out_split=True)) if split else (lambda: layer(x))
                 for _ in range(3):
