@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU call 20: the ring-only 128 x 64 register tiles (configurations 16 / 17) against the tiles in use, ring on everywhere
+# (run when those tiles were entries 16 / 17 of conv_cfgs.def; they live in the experiments block as 20 / 21 since -- profiles/round4/tiles_128x64_ring.txt)
 cd "$(dirname "$0")/../.."
 V=openstereo_amd/lib/variants
 export OSA_B_RING_MASK=-1

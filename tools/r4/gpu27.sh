@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, GPU call 27: tile 9 takes the weight ring for long K loops (>= 16 chunks) under the default mask: GRU layers, backbone check, IGEV / StereoBase workloads
+# RECORD ONLY: the long-K rule lost 1.3 % on the IGEV loop and was reverted -- profiles/round4/b_ring_tile9_long_k.txt.
 cd "$(dirname "$0")/../.."
 export OSA_PRECISION=f16x3
 echo "== gru / backbone layers: explicit default mask (no tile 9) vs built-in default (tile 9 for long K)"
