@@ -613,6 +613,52 @@ def capture_training_step(wl, ddp=False):
         return None
 
 
+def capture_inference_step(eager_step):
+    """The inference forwards are fixed sequences of launches on static buffers: capture the (already warmed-up) step once into a
+    hipGraph.  Returns (graph, step); (None, eager_step) when capture is unsupported.  The step returns the graph's static output."""
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = eager_step()
+
+        def step():
+            graph.replay()
+            return graph_out
+        step()
+        torch.cuda.synchronize()
+        return graph, step
+    except Exception as ex:                      # capture unsupported -> eager launches
+        print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        return None, eager_step
+
+
+def gwcnet_timed_config_parity(wl, step, replays=3):
+    """Parity of the TIMED configuration itself: the step as it is timed -- all B pairs, `nstreams` concurrent
+    sub-batch streams, hipGraph replay, split-format volume -- replayed `replays` times and compared, for EVERY pair, with
+    (a) the previous replay (a race between sub-batch streams or a stale arena slot shows up as run-to-run differences),
+    (b) the same sub-batches launched eagerly one after the other on ONE stream (same arithmetic, same tiles: bit for bit),
+    (c) B single-pair single-stream forwards (f16x3: the per-tensor power-of-two operand scales follow the batch, so agreement is to
+        ~1e-6 relative, not bitwise; exact-f32 mode: bitwise).
+    Returns the maxima over pairs; tests/test_gpu_timed_config.py asserts on them, bench.py prints them in `config.timed_config_parity`."""
+    outs = []
+    for _ in range(replays):
+        outs.append(step().clone())
+    torch.cuda.synchronize()
+    per = wl.B // wl.nstreams
+    with torch.no_grad():
+        seq = torch.cat([wl.net({"left": wl.L[i:i + per], "right": wl.R[i:i + per]})["disp_pred"] for i in range(0, wl.B, per)], 0)
+        one = torch.cat([wl.net({"left": wl.L[i:i + 1], "right": wl.R[i:i + 1]})["disp_pred"] for i in range(wl.B)], 0)
+    torch.cuda.synchronize()
+    out = outs[-1]
+    d1 = (out - one).abs().flatten(1)
+    return {"pairs": wl.B, "streams": wl.nstreams, "replays": replays,
+            "replay_vs_replay_max_px": max([float((o - outs[0]).abs().max()) for o in outs[1:]] + [0.0]),
+            "vs_same_sub_batches_on_one_stream_max_px": float((out - seq).abs().max()),
+            "vs_single_pair_runs_max_px": float(d1.max()), "vs_single_pair_runs_worst_pair_epe_px": float(d1.mean(1).max()),
+            "all_finite": bool(torch.isfinite(out).all()), "disp_std_min_over_pairs": float(out.flatten(1).std(1).min())}
+
+
 def _time_steps(step, steps, warmup):
     for _ in range(warmup):
         step()
@@ -871,20 +917,7 @@ def main():
             step()
             sync()
     if wl.graphable and not args.no_graph and dev.type == "cuda":
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                graph_out = eager_step()
-
-            def step():
-                graph.replay()
-                return graph_out
-            step()
-            sync()
-        except Exception as ex:                      # capture unsupported -> eager launches
-            print(f"[bench] hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly", file=sys.stderr)
-            graph, step = None, eager_step
-            torch.cuda.synchronize()
+        graph, step = capture_inference_step(eager_step)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -906,6 +939,8 @@ def main():
     if args.workload == "gwcnet" and not args.stub and rank == 0:
         from openstereo_amd import engine
         roofs, alt, latency_1, cpu = [], None, None, None
+        if not args.timed_only and world == 1:
+            cfg["timed_config_parity"] = gwcnet_timed_config_parity(wl, step)      # every pair of the timed step vs single-pair single-stream runs
         if not args.timed_only:
             nrep = max(2, min(args.steps, 5))
             if graph is not None and world == 1:

@@ -537,7 +537,7 @@ int osa_instnorm_nhwc_f32(const float* x, float* y, int B, long long HW, int C, 
                           float* workspace, float* y_meta, void* stream);
 
 /* ---- d-marching form of the 3x3x3 stride-1 convolutions with 32 output channels (r4, csrc/conv_march.h) ----
- * osa_conv3d_ndhwc_f16x3 runs eligible layers (3x3x3, stride 1, padding 1, Ci % 32 == 0, Co == 32, no gate: GwcNet / PSMNet dres0,
+ * osa_conv3d_ndhwc_f16x3 runs eligible layers (3x3x3, stride 1, padding 1, Ci % 16 == 0, Co == 32, no gate: GwcNet / PSMNet dres0,
  * dres1, classif*.0 -- gwcnet_disp_processor.py:40-81) as workgroups that own a pixel column and walk along d, each staged input plane
  * feeding three output planes.  Same arguments, same semantics; results agree with the brick form to fp32 rounding (different summation
  * order).  This counter tells how many calls of this process took that form (tests assert that the intended layers do). */

@@ -53,7 +53,7 @@ def load():
     _lib.load()              # the C-ABI library first: a missing / stale one is reported by its own loader
     torch.ops.load_library(EXT_PATH)
     ns = torch.ops.osa_native
-    if int(ns.abi_version()) != 4:
+    if int(ns.abi_version()) != _lib.abi_version():
         raise _lib.EngineError(f"libosa_torch_ext.so was built against ABI {int(ns.abi_version())}: rebuild with `python -m openstereo_amd.build`")
     ops = ns
     return ops

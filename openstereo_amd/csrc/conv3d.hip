@@ -821,6 +821,18 @@ static void set_ranges(ConvArgs& a, const osa_f16x3_ranges* r) {
     a.wscale_dev = r->weight_scale;
 }
 
+// f16x3 split tensors cannot be decoded without their range blocks (scale of a split input / residual / redir input; bound
+// coefficients + input range for a split output).  Checked once, in front of BOTH kernel forms (brick and d-marching).
+static int check_split_ranges(const ConvArgs& a, int prec, const char* what) {
+    if (prec != PREC_F16X3) return 0;
+    if (a.act & OSA_IN_SPLIT) OSA_REQUIRE(a.in_meta, "%s: a split input needs its range block (osa_f16x3_ranges.x_meta)", what);
+    if ((a.act & OSA_RES_SPLIT) && a.res) OSA_REQUIRE(a.res_meta, "%s: a split residual needs its range block (residual_meta)", what);
+    if ((a.act & OSA_REDIR_SPLIT) && a.rx) OSA_REQUIRE(a.rx_meta, "%s: a split redir input needs its range block (redir_meta)", what);
+    if (a.act & OSA_OUT_SPLIT) OSA_REQUIRE(a.out_meta && a.coef && a.in_meta,
+                                           "%s: a split output needs y_meta, bound_coef and x_meta (its scale is derived from them)", what);
+    return 0;
+}
+
 static int check_common(const char* what, const float* x, const float* w, float* y,
                         int B, int Di, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs,
                         const float* residual) {
@@ -894,6 +906,7 @@ static int conv3d_impl(const float* x, const float* w_packed,
     a.act = act; a.slope = slope; a.oscale = oscale;
     if (prec == PREC_F16 && f16_units(a, "conv3d")) return -1;
     set_ranges(a, rng);
+    if (check_split_ranges(a, prec, "conv3d")) return -1;
     if (prec == PREC_F16X3 && kd == 3 && kh == 3 && kw == 3 && stride == 1 && a.isd == 1 && pad_d == 1 && pad_h == 1 && pad_w == 1 &&
         dil_d == 1 && dil_h == 1 && dil_w == 1) {
         const int r = launch_conv_march(a, (hipStream_t)stream, "conv3d (march)");
@@ -972,6 +985,7 @@ static int deconv3d_impl(const float* x, const float* w_packed,
         a.rscale = rscale; a.rshift = rshift; a.roscale = roscale;
     }
     set_ranges(a, rng);
+    if (check_split_ranges(a, prec, flat ? "deconv2d" : "deconv3d")) return -1;
     return launch_conv(a, 1, prec, (hipStream_t)stream, flat ? "deconv2d" : "deconv3d",
                        flat ? &g_deconv_flat_cfg : (rx ? (rCi > 32 ? &g_deconv_redir64_cfg : &g_deconv_redir_cfg) : &g_deconv_cfg));
 }

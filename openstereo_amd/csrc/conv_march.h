@@ -111,6 +111,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
     const int c8 = (lane & 3) * 8, vs2 = lane >> 2;         // split output: 8 channels of 2 voxels
     const int actk = p.act & 15;
     const float act_ns = (actk == OSA_ACT_NONE) ? 1.f : ((actk == OSA_ACT_LEAKY) ? p.slope : 0.f);    // slope for v < 0 (none / relu / leaky)
+    const bool act_relu = actk == OSA_ACT_RELU;
     const size_t ovox_b = (size_t)b * p.Do * p.Ho * p.Wo;
     float* const yb = p.y + ovox_b * p.yCs;
     const float* const resb = p.res ? p.res + ovox_b * p.rCs : nullptr;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
                     float o[4] = {fmaf(a.x, sc[0].x, sh[0].x) + r.x, fmaf(a.y, sc[0].y, sh[0].y) + r.y,
                                   fmaf(a.z, sc[0].z, sh[0].z) + r.z, fmaf(a.w, sc[0].w, sh[0].w) + r.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (o[e] < 0.f) ? o[e] * act_ns : o[e];
+                    for (int e = 0; e < 4; ++e) o[e] = (o[e] < 0.f) ? (act_relu ? 0.f : o[e] * act_ns) : o[e];    // relu(-inf) = 0 as in the brick form, not -inf * 0
                     if (ok) {
                         am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                         store16(yb + vox * p.yCs + cq, make_float4(o[0], o[1], o[2], o[3]));
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs 
                         float o[4] = {fmaf(a.x, sc[h2].x, sh[h2].x) + r.x, fmaf(a.y, sc[h2].y, sh[h2].y) + r.y,
                                       fmaf(a.z, sc[h2].z, sh[h2].z) + r.z, fmaf(a.w, sc[h2].w, sh[h2].w) + r.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (o[e] < 0.f) ? o[e] * act_ns : o[e];
+                        for (int e = 0; e < 4; ++e) o[e] = (o[e] < 0.f) ? (act_relu ? 0.f : o[e] * act_ns) : o[e];    // relu(-inf) = 0 as in the brick form, not -inf * 0
                         if (ok) am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
                         split_f16(make_float4(o[0] * s_out, o[1] * s_out, o[2] * s_out, o[3] * s_out), hq[h2], lq[h2]);
                     }

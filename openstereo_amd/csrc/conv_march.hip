@@ -21,7 +21,10 @@ static const MarchCfg g_march_cfgs[] = {
 
 int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     if (!exp_int("OSA_MARCH", 1)) return 0;
+    // (argument validation shared with the brick form -- check_common, check_split_ranges -- has run in conv3d_impl; what follows is
+    // ELIGIBILITY: a layer this form does not cover falls through to the brick kernel, it is not an error)
     if (a.T != 27 || a.Co != 32 || a.CoP != 32 || a.Di < 3 || a.gate || a.rx) return 0;
+    if (a.Ci % 16 != 0) return 0;                          // whole 16-channel chunks (the staging reads 16-channel rows, the split form is per chunk)
     const int actk = a.act & 15;
     if (actk > OSA_ACT_LEAKY || (a.act & (OSA_GATE_RAW | OSA_RES_AFTER_ACT)) || ((unsigned)a.act >> 16)) return 0;
     if ((a.yCs & 3) || ((size_t)a.y & 15) || (a.res && ((a.rCs & 3) || ((size_t)a.res & 15)))) return 0;

@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import amp
 from .. import autograd as AG
 from .. import ops
-from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU
+from ..engine import cached_pack, foldable_bn, PackedConv3d, ACT_NONE, ACT_RELU
 from ..ops import on_engine
 from .lightstereo import cl_to_nchw
 
@@ -49,7 +49,7 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def packs(self):
-        bn = lambda n: n if isinstance(n, nn.BatchNorm2d) else None
+        bn = foldable_bn          # any _BatchNorm (nn.SyncBatchNorm after convert_sync_batchnorm included); raises on a norm it cannot fold
         return cached_pack(self, "_eng", lambda: (
             PackedConv3d(self.conv1, bn(self.norm1), ACT_RELU), PackedConv3d(self.conv2, bn(self.norm2), ACT_RELU),
             None if self.downsample is None else PackedConv3d(self.downsample[0], bn(self.norm3), ACT_NONE)))

@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, amp
-from ..engine import (ACT_LEAKY, ACT_NONE, ACT_RELU6, DepthwiseConv2d, PackedConv3d, cached_pack)
+from ..engine import (ACT_LEAKY, ACT_NONE, ACT_RELU6, DepthwiseConv2d, PackedConv3d, cached_pack, norm_kind)
 from ..ops import _stream, empty_cl, is_cl, on_engine
 from ..ranges import attach_meta, combine_meta, input_meta, meta_of
 from .igev_style import BasicConv2d
@@ -136,7 +136,7 @@ class _ConvNormAct:
     (lightstereo/backbone.py:57 `padding_mode="replicate"`): the map is padded first (one small torch op), the conv runs unpadded."""
 
     def __init__(self, conv, norm, act, slope):
-        self.inorm = isinstance(norm, nn.InstanceNorm2d)
+        self.inorm = norm_kind(norm) == "in"
         self.replicate = getattr(conv, "padding_mode", "zeros") == "replicate"
         self.act, self.slope = act, slope
         c = conv
@@ -165,8 +165,10 @@ def _unit(block, slope_default=0.01):
     if hasattr(block, "block"):
         layers = list(block.block)
         conv = layers[0]
-        norm = next((l for l in layers[1:] if isinstance(l, (nn.BatchNorm2d, nn.InstanceNorm2d))), None)
         actl = next((l for l in layers[1:] if isinstance(l, (nn.LeakyReLU, nn.ReLU))), None)
+        norms = [l for l in layers[1:] if l is not actl]
+        assert len(norms) <= 1, "BasicConv2d / BasicDeconv2d block = [conv, norm?, act?]"
+        norm = norms[0] if norms else None      # classified by engine.norm_kind in _ConvNormAct: any _BatchNorm (SyncBatchNorm too) folds, unknown norms raise
         if actl is None:
             return _ConvNormAct(conv, norm, ACT_NONE, 0.0)
         if isinstance(actl, nn.LeakyReLU):

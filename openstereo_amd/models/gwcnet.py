@@ -398,6 +398,14 @@ class GwcNet(nn.Module):
                                                 cp.maxdisp // cp.downsample,
                                                 cat_channels=self.Backbone.concat_channels or None,
                                                 out_split=_SPLIT_ACT and _VOL_SPLIT and self.DispProcessor._pack()["d00"].precision == "f16x3")
+            if getattr(vol, "_osa_split", False):
+                # the split (hi | lo fp16 halves in fp32 storage) volume is an engine-chain format: it never leaves this function.  The
+                # reference publishes a real fp32 volume under "cost_volume" (inputs.update(cost_out), gwcnet.py:33-35); a tensor that
+                # reports float32 but holds split halves would be silently misread by any other consumer, so the key stays
+                # absent in this mode (OSA_VOL_SPLIT=0 or the exact-f32 mode publish the fp32 NDHWC volume).
+                dp = self.DispProcessor
+                h, w = inputs["left"].shape[2:]
+                return {"disp_pred": ops.upsample_softargmin(dp.aggregate_cl(vol), dp.maxdisp, h, w, align_corners=False)}
             inputs["cost_volume"] = vol
         else:
             inputs.update(self.Backbone(inputs))

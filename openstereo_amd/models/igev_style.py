@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import amp, ops
-from ..engine import cached_pack, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_LEAKY
+from ..engine import cached_pack, foldable_bn, PackedConv3d, SmallCoConv3d, ACT_NONE, ACT_LEAKY, ACT_RELU
 from ..ops import empty_cl
 
 
@@ -82,10 +82,14 @@ class FeatureAtt(nn.Module):
 def _pack_sb(m):
     """BasicConv3d/BasicDeconv3d -> PackedConv3d (BN and LeakyReLU(0.01) fused when present)."""
     conv = m.block[0]
-    bn = m.block[1] if len(m.block) > 1 and isinstance(m.block[1], nn.BatchNorm3d) else None
-    act = ACT_LEAKY if isinstance(m.block[-1], nn.LeakyReLU) else ACT_NONE
-    slope = m.block[-1].negative_slope if act == ACT_LEAKY else 0.01
-    return PackedConv3d(conv, bn, act, slope)
+    rest = list(m.block)[1:]
+    norms = [l for l in rest if not isinstance(l, (nn.LeakyReLU, nn.ReLU))]
+    acts = [l for l in rest if isinstance(l, (nn.LeakyReLU, nn.ReLU))]
+    assert len(norms) <= 1 and len(acts) <= 1, "BasicConv3d / BasicDeconv3d block = [conv, norm?, act?]"
+    bn = foldable_bn(norms[0]) if norms else None        # nn.SyncBatchNorm is a _BatchNorm but not a BatchNorm3d; unknown norms raise
+    if acts and isinstance(acts[0], nn.LeakyReLU):
+        return PackedConv3d(conv, bn, ACT_LEAKY, acts[0].negative_slope)
+    return PackedConv3d(conv, bn, ACT_RELU if acts else ACT_NONE)
 
 
 # ----------------------------------------------------------------------------- shared engine forward

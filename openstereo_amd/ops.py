@@ -100,6 +100,8 @@ def to_ncdhw(x: torch.Tensor, channels: int | None = None) -> torch.Tensor:
     _chk(x, "x", 5)
     if not is_cl(x):
         return x.contiguous()
+    if x.dtype != torch.float32:         # fp16 chain tensors of the f16 mode: the layout kernel counts the channel stride in floats
+        raise _lib.EngineError(f"to_ncdhw takes an fp32 NDHWC tensor, got {x.dtype} (an f16-mode chain tensor is internal to its layer chain)")
     B, Cs, D, H, W = x.shape
     Cn = Cs if channels is None else channels
     y = torch.empty((B, Cn, D, H, W), device=x.device, dtype=torch.float32)

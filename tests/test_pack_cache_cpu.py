@@ -22,13 +22,21 @@ def test_cached_pack_invalidation_rules():
     assert get() == 6
     old = engine.get_precision()
     try:
-        engine.set_precision("f16x3" if old == "f32" else "f32")               # arithmetic mode is part of the key
-        assert get() == 7
+        engine.set_precision("f16x3" if old == "f32" else "f32")               # one slot per arithmetic mode
+        assert get() == 7 and get() == 7
     finally:
         engine.set_precision(old)
-    assert get() == 8 and get() == 8
+    assert get() == 6 and len(builds) == 7                                     # flipping back neither rebuilds nor frees the other mode's packs
+    with torch.no_grad():
+        m[0].weight.add_(1.0)                                                  # a parameter update invalidates EVERY mode's slot
+    assert get() == 8
+    try:
+        engine.set_precision("f16x3" if old == "f32" else "f32")
+        assert get() == 9
+    finally:
+        engine.set_precision(old)
     m._packed = None                                                           # reset_engine() protocol still works
-    assert get() == 9
+    assert get() == 10
 
 
 def test_autograd_weight_memo_follows_the_parameter_not_its_fp32_copy(monkeypatch):

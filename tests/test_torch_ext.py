@@ -11,11 +11,11 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def test_extension_builds_loads_and_has_no_cpu_backend(lib):
-    from openstereo_amd import _ext
+    from openstereo_amd import _ext, _lib
     path = _ext.build()
     assert os.path.exists(path)
     ns = _ext.load()
-    assert ns is not None and int(ns.abi_version()) == lib.osa_abi_version() == 4
+    assert ns is not None and int(ns.abi_version()) == lib.osa_abi_version() == _lib.abi_version()
     for name in ("gwc_volume", "concat_volume", "corr_volume", "softargmin", "softmax_softargmin", "upsample_softargmin", "context_upsample", "conv_ndhwc"):
         assert hasattr(ns, name), name
     x = torch.zeros(1, 8, 4, 8)
