@@ -36,8 +36,9 @@ def _with_precision(prec, fn):
 def _sync(m):
     n_bn = sum(isinstance(x, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)) for x in m.modules())
     m = nn.SyncBatchNorm.convert_sync_batchnorm(m)
-    n_sync = sum(isinstance(x, nn.SyncBatchNorm) for x in m.modules())
-    assert n_bn > 0 and n_sync == n_bn and not any(isinstance(x, (nn.BatchNorm2d, nn.BatchNorm3d)) for x in m.modules())
+    n_sync = sum(isinstance(x, nn.SyncBatchNorm) for x in m.modules())      # (>= n_bn: a BatchNorm registered under two names -- ResidualBlock's norm3 /
+    # downsample[1] -- is converted once per name; the copies share its parameters and statistics)
+    assert n_sync >= n_bn > 0 and not any(isinstance(x, (nn.BatchNorm2d, nn.BatchNorm3d)) for x in m.modules())
     return m
 
 
