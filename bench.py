@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--precision", choices=("f16x3", "f32", "f16"), default=os.environ.get("OSA_PRECISION", "f16x3"),
                     help="MFMA arithmetic mode of the conv kernels (both pass the same parity tests)")
     ap.add_argument("--stages", default="", help="write the full per-stage timing table to this file")
-    ap.add_argument("--amp", action="store_true", help="inference workloads: run the step inside torch.autocast(fp16) -- engine layers in the native f16 mode")
+    ap.add_argument("--amp", action="store_true", help="run the step the way the reference runs its AMP configs: inference inside torch.autocast(fp16); training as autocast + GradScaler (trainer_template.py:211-226) -- engine layers in the native f16 mode")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (default workload) / the same-GPU PyTorch-ROCm eager leg (training workloads)")
     ap.add_argument("--no-workloads", action="store_true", help="default workload: skip the compact measurements of the other BASELINE configs (`workloads`)")
@@ -196,6 +196,38 @@ class IGEVRefine32:
                             "(BASELINE configs[4]); synthetic features / hidden states stand in for the timm extractor"}
 
 
+def _amp_training_step(wl, forward_loss, clip=None):
+    """One optimisation step the way the reference's trainer runs it (trainer_template.py:202-226): zero_grad; forward + loss under
+    `torch.autocast(enabled=AMP)`; `scaler.scale(loss).backward()`; `scaler.unscale_`; gradient clipping; `scaler.step`; `scaler.update`.
+    wl.amp False: the plain fp32-class step (autocast and the scaler disabled: identical to the previous rounds' step).  With AMP the
+    optimizers are the fused variants, which take the scaler's found-inf flag on the device (no host synchronisation: the whole step
+    stays capturable in a hipGraph)."""
+    wl.opt.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16, enabled=wl.amp):
+        loss = forward_loss()
+    if not wl.amp:
+        loss.backward()
+        if clip is not None:
+            clip()
+        wl.opt.step()
+        return loss.detach()
+    wl.scaler.scale(loss).backward()
+    wl.scaler.unscale_(wl.opt)
+    if clip is not None:
+        clip()
+    wl.scaler.step(wl.opt)
+    wl.scaler.update()
+    return loss.detach().float()
+
+
+def _set_amp(wl, args):
+    wl.amp = bool(getattr(args, "amp", False))
+    # (init_scale 2^12: the synthetic losses here have gradients around 1e-3 .. 1e-1; the default 2^16 is also fine, it just spends the
+    # first steps of a run backing off)
+    wl.scaler = torch.amp.GradScaler("cuda", enabled=wl.amp, init_scale=4096.0)
+    return dict(fused=True) if wl.amp else {}
+
+
 class StereoBaseTrain:
     """BASELINE configs[2]: StereoBase training step on the hot path -- gwc(8) + concat volume -> Hourglass(24) with FeatureAtt ->
     classifier -> softmax regression (stereobase_gru.py:139-164), forward + backward + SGD, SceneFlow crop 320x736
@@ -217,7 +249,7 @@ class StereoBaseTrain:
         self.model = st
         if _use_ddp():
             self.model = torch.nn.parallel.DistributedDataParallel(st, device_ids=[dev.index])
-        self.opt = torch.optim.SGD([p for p in st.parameters() if p.requires_grad], lr=1e-4)
+        self.opt = torch.optim.SGD([p for p in st.parameters() if p.requires_grad], lr=1e-4, **_set_amp(self, args))
         g = torch.Generator().manual_seed(80 + rank)
         r = lambda *s: torch.randn(*s, generator=g).to(dev)
         H, W = 80, 184
@@ -228,12 +260,7 @@ class StereoBaseTrain:
     static = False            # (the loss of this workload has static shapes already)
 
     def step(self):
-        self.opt.zero_grad(set_to_none=True)
-        out = self.model(*self.x, self.feats)
-        loss = torch.nn.functional.smooth_l1_loss(out["init_disp"], self.gt)
-        loss.backward()
-        self.opt.step()
-        return loss.detach()
+        return _amp_training_step(self, lambda: torch.nn.functional.smooth_l1_loss(self.model(*self.x, self.feats)["init_disp"].float(), self.gt))
 
     def config(self, args):
         return {"workload": "StereoBase cost stage training step (volume -> Hourglass(24)+FeatureAtt -> classifier -> softmax regression; "
@@ -337,7 +364,7 @@ class StereoBaseE2ETrain:
         if _use_ddp():
             self.model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index])
         # capturable: the step counter lives on the device, so the optimizer step can be part of a hipGraph (no effect on the arithmetic)
-        self.opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5, eps=1e-8, capturable=True)
+        self.opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5, eps=1e-8, capturable=True, **_set_amp(self, args))
         L, R = synth_images(B, 320, 736, seed=20 + rank)
         self.L, self.R = L.to(dev), R.to(dev)
         self.gt = torch.from_numpy(np.random.default_rng(rank).uniform(1, 100, (B, 320, 736)).astype("float32")).to(dev)
@@ -345,13 +372,8 @@ class StereoBaseE2ETrain:
     static = False            # True: static-shape loss without .item() (hipGraph replay of the whole step)
 
     def step(self):
-        self.opt.zero_grad(set_to_none=True)
-        out = self.model({"left": self.L, "right": self.R})
-        loss, _ = self.raw.get_loss(out, {"disp": self.gt}, static=self.static)
-        loss.backward()
-        torch.nn.utils.clip_grad_value_(self.raw.parameters(), 1.0)          # CLIP_GRAD: value 1.0
-        self.opt.step()
-        return loss.detach()
+        return _amp_training_step(self, lambda: self.raw.get_loss(self.model({"left": self.L, "right": self.R}), {"disp": self.gt}, static=self.static)[0],
+                                  clip=lambda: torch.nn.utils.clip_grad_value_(self.raw.parameters(), 1.0))          # CLIP_GRAD: value 1.0
 
     def config(self, args):
         return {"workload": "StereoBase training step, whole model with stand-in 2-D backbone (cost stage + geometry lookup + 22 GRU iterations + convex "
@@ -373,6 +395,7 @@ class GwcNetTrain:
         self.model = self.raw
         if _use_ddp():
             self.model = torch.nn.parallel.DistributedDataParallel(self.raw, device_ids=[dev.index])
+        self.amp, self.scaler = False, None                   # cfgs/gwcnet/gwcnet_sceneflow.yaml: AMP false
         self.opt = torch.optim.RMSprop(self.model.parameters(), lr=1e-3, capturable=True)      # cfgs/gwcnet/gwcnet_sceneflow.yaml (capturable: hipGraph-friendly, same arithmetic)
         L, R = synth_images(B, 256, 512, seed=10 + rank)
         self.L, self.R = L.to(dev), R.to(dev)
@@ -703,16 +726,17 @@ def secondary_workloads(args, dev, rank, budget_s=170.0):
     # (cfgs/lightstereo/*: AMP true, cfgs/igev/igev_sceneflow_amp.yaml, cfgs/stereobase/stereobase_sceneflow.yaml:50;
     # trainer_template.py:281) -- the engine layers then use the native f16 mode (engine.effective_precision)
     plan = [("lightstereo_kitti15", 10, 3, False), ("lightstereo_kitti15", 10, 3, True), ("igev_refine32", 5, 2, False), ("igev_refine32", 5, 2, True),
-            ("stereobase_e2e", 5, 2, False), ("stereobase_e2e", 5, 2, True), ("stereobase_train", 10, 3, False), ("stereobase_e2e_train", 3, 2, False)]
+            ("stereobase_e2e", 5, 2, False), ("stereobase_e2e", 5, 2, True), ("stereobase_train", 10, 3, False), ("stereobase_train", 10, 3, True),
+            ("stereobase_e2e_train", 3, 2, False), ("stereobase_e2e_train", 3, 2, True)]
     for wname, steps, warmup, amp in plan:
         name = wname + ("_amp" if amp else "")
         if time.perf_counter() - t_start > budget_s:
             out[name] = {"skipped": "time budget of the default run exhausted"}
             continue
         try:
-            a = argparse.Namespace(**{**vars(args), "batch": None, "workload": wname})
+            a = argparse.Namespace(**{**vars(args), "batch": None, "workload": wname, "amp": amp})
             wl = WORKLOADS[wname](a, dev, rank)
-            if amp:
+            if amp and not wl.training:          # (training workloads run the reference's AMP step themselves: autocast + GradScaler, _amp_training_step)
                 wl.step = _amp_step(wl.step)
             step = wl.step
             for _ in range(warmup):

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OSA_ABI_VERSION 4
+#define OSA_ABI_VERSION 5
 #define OSA_META_FLOATS 128   /* floats per range block (osa_f16x3_ranges) */
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
@@ -387,6 +387,18 @@ int osa_conv3d_wgrad_ws_f16x3(const float* x, const float* dy, float* dw,
                               int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
                               int transposed, const float* x_meta, const float* dy_meta,
                               float* workspace, size_t workspace_bytes, void* stream);
+/* Native f16 weight gradient (r5, ABI v5): the arithmetic of the reference's AMP training (stereo/modeling/trainer_template.py:211-226,
+ * autocast + GradScaler: the weight gradient of an autocast convolution multiplies fp16 activations by fp16 output gradients and
+ * accumulates in fp32) -- operands rounded to fp16 (nearest even) when they are staged, ONE v_mfma_f32_32x32x16_f16 per product, no lo
+ * planes.  Same layers, workspace (osa_conv3d_wgrad_f16x3_workspace_bytes) and deterministic two-stage reduction as the f16x3 form.
+ * x_meta / dy_meta: NULL (no operand scaling, exactly like autocast: GradScaler owns the range) or range blocks (power-of-two scaling). */
+int osa_conv3d_wgrad_ws_f16(const float* x, const float* dy, float* dw,
+                            int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                            int Do, int Ho, int Wo, int Co, int dyCs,
+                            int kd, int kh, int kw, int stride,
+                            int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                            int transposed, const float* x_meta, const float* dy_meta,
+                            float* workspace, size_t workspace_bytes, void* stream);
 
 
 /* small-Cout 'same' convolution (Co <= 4, e.g. the 32->1 classifier heads). Reference weight

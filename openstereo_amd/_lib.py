@@ -87,6 +87,8 @@ SIGNATURES = {
     "osa_conv3d_wgrad_f16x3_workspace_bytes": (C.c_size_t, [c_i] * 20),
     "osa_conv3d_wgrad_ws_f16x3": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                         c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, C.c_size_t, c_st]),
+    "osa_conv3d_wgrad_ws_f16": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                      c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, C.c_size_t, c_st]),
     "osa_conv3d_small_co_ndhwc_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_fp,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                             c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

@@ -15,6 +15,7 @@ unchanged (one process per GPU).
 from __future__ import annotations
 
 import math
+import os
 import threading
 
 import torch
@@ -217,6 +218,7 @@ def _pack_now(w, Ci, Co, k, mode, precision):
     from max |w| on the device (osa_*_pack_*_auto) -- no host synchronisation per layer / role / optimizer step, and the whole training
     step can be captured in a hipGraph (the packs are part of the captured work)."""
     f16 = precision == "f16x3"
+    h16 = precision == "f16"            # native fp16 operands (AMP training, r5): weights rounded to nearest even, no scale
     lib = _lib.load()
     if f16:
         amax = torch.linalg.vector_norm(w.detach(), float("inf"))          # one reduction kernel, stays on the device
@@ -226,6 +228,8 @@ def _pack_now(w, Ci, Co, k, mode, precision):
         buf = torch.zeros(n, device=w.device, dtype=torch.float32)
         if f16:
             _lib.call("osa_deconv2d_pack_f16x3_auto", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, amax.data_ptr(), sc.data_ptr(), _stream())
+        elif h16:
+            _lib.call("osa_deconv2d_pack_f16", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
         else:
             _lib.call("osa_deconv2d_pack_f32", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
     elif mode == "deconv":
@@ -233,6 +237,8 @@ def _pack_now(w, Ci, Co, k, mode, precision):
         buf = torch.zeros(n, device=w.device, dtype=torch.float32)
         if f16:
             _lib.call("osa_deconv3d_pack_f16x3_auto", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, amax.data_ptr(), sc.data_ptr(), _stream())
+        elif h16:
+            _lib.call("osa_deconv3d_pack_f16", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
         else:
             _lib.call("osa_deconv3d_pack_f32", w.data_ptr(), buf.data_ptr(), Ci, Co, k[0], 1, _stream())
     else:
@@ -242,7 +248,7 @@ def _pack_now(w, Ci, Co, k, mode, precision):
         if f16:
             _lib.call("osa_conv3d_pack_ex_auto", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, amax.data_ptr(), sc.data_ptr(), _stream())
         else:
-            _lib.call("osa_conv3d_pack_ex", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, 0, 1.0, _stream())
+            _lib.call("osa_conv3d_pack_ex", w.data_ptr(), buf.data_ptr(), Ci, Co, *k, tr, fl, 2 if h16 else 0, 1.0, _stream())
     return buf, (sc if f16 else 1.0)
 
 
@@ -254,6 +260,13 @@ def _ranges(x, y, wscale, xmeta=None):
     return _lib.F16x3Ranges((xmeta if xmeta is not None else input_meta(x)).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None, wscale.data_ptr())
 
 
+def _sfx_tail(precision, x, y, oscale, xmeta=None):
+    """entry-point suffix and trailing arguments of a plain conv / deconv call in the given arithmetic mode"""
+    if precision == "f16x3":
+        return "f16x3", (1.0, _ranges(x, y, oscale, xmeta), _stream())
+    return ("f16" if precision == "f16" else "f32"), (_stream(),)        # f16: fp32 NDHWC tensors, fp16 operands (no flags, no ranges)
+
+
 def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape, xmeta=None):
     """x NDHWC (channels padded to 4). plain conv, no epilogue extras."""
     B, Cs, D, H, W = x.shape
@@ -262,7 +275,7 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (1.0, _ranges(x, y, oscale, xmeta), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = _sfx_tail(precision, x, y, oscale, xmeta)
     macs = B * out_shape[0] * out_shape[1] * out_shape[2] * Ci * Co * k[0] * k[1] * k[2]
     with timing.span("conv3d", Ci, Co, k[1], stride, D, H, W, flops=2 * macs,
                      nbytes=4 * B * (D * H * W * Ci + out_shape[0] * out_shape[1] * out_shape[2] * Co)):
@@ -280,7 +293,7 @@ def _run_deconv(x, packed, oscale, Ci, Co, k, pad, opad, precision):
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = ("f16x3", (1.0, _ranges(x, y, oscale), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+    sfx, tail = _sfx_tail(precision, x, y, oscale)
     with timing.span("deconv3d", Ci, Co, k, 2, D, H, W, flops=2 * B * D * H * W * Ci * Co * k ** 3,
                      nbytes=4 * B * (D * H * W * Ci + od(D) * od(H) * od(W) * Co)):
         _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
@@ -297,6 +310,10 @@ WGRAD_F16X3 = True      # f16x3 mode: weight gradients of the layers osa_conv3d_
 # faster than the fp32 class-mode kernel, which takes a whole class of up to 8 taps per staged brick where this form needs two groups of
 # <= 4 (measured: GwcNet step 33.9 -> 34.4 ms, StereoBase whole model 176 -> 184 ms): off by default.
 WGRAD_F16X3_CLASS = False
+# native f16 mode (AMP training, r5): the same kernel with fp16 operands and one MFMA per product.  Class mode (stride-2 / transposed layers)
+# is on there: with a third of the matrix work and half the LDS footprint it no longer trails the fp32 class-mode kernel (to be re-measured).
+WGRAD_F16 = True
+WGRAD_F16_CLASS = os.environ.get("OSA_WGRAD_F16_CLASS", "1") != "0"
 
 
 def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed, precision="f32", xmeta=None, dymeta=None):
@@ -308,6 +325,16 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     lib = _lib.load()
     vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
     span = dict(flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2], nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co))
+    if precision == "f16" and WGRAD_F16 and ((stride == 1 and not transposed) or WGRAD_F16_CLASS):
+        # native fp16 operands, one MFMA per product, no range blocks (AMP training: GradScaler owns the range)
+        need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
+        if need:
+            ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
+            with timing.span("wgrad_f16", Ci, Co, k[1], stride, D, H, W, transposed, **span):
+                _lib.call("osa_conv3d_wgrad_ws_f16", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
+                          Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                          None, None, ws.data_ptr(), need, _stream())
+            return
     if precision == "f16x3" and WGRAD_F16X3 and ((stride == 1 and not transposed) or WGRAD_F16X3_CLASS):
         need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
         if need:
@@ -437,7 +464,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if CoS != Co:
             y.zero_()
         Ci4 = (Ci + 3) // 4 * 4
-        sfx, tail = ("f16x3", (1.0, _ranges(xc, y, osc), _stream())) if precision == "f16x3" else ("f32", (_stream(),))
+        sfx, tail = _sfx_tail(precision, xc, y, osc)
         _lib.call("osa_deconv2d_nhwc_" + sfx, xc.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
                   B, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
         ctx.save_for_backward(xc, wf)
@@ -467,10 +494,11 @@ class _ConvTranspose2d(torch.autograd.Function):
 
 
 def _train_precision(precision):
-    """arithmetic mode of the differentiable convolutions: the requested / global one, except that the inference-only "f16" mode
-    (engine.PRECISIONS) trains on the f16x3 kernels"""
-    p = precision or engine.get_precision()
-    return "f16x3" if p == "f16" else p
+    """arithmetic mode of the differentiable convolutions -- evaluated by the callers below BEFORE the Function runs (custom_fwd switches
+    autocast off inside).  The requested / global mode; inside a `torch.autocast(fp16)` region the native "f16" mode (r5:
+    engine.train_precision -- what the reference's AMP training computes, trainer_template.py:211-226; forward, data gradient and weight
+    gradient then spend one MFMA per product instead of three and need no range reductions).  OSA_AMP_TRAIN_NATIVE=0 keeps f16x3 there."""
+    return engine.train_precision(precision)
 
 
 def conv_transpose2d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):

@@ -208,13 +208,22 @@ __device__ __forceinline__ float wg_pow2_scale(float amax) {              // = p
     return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
 }
 // two scaled values -> packed fp16 hi pair (round toward zero) and lo pair (x - hi, rounded to nearest); low half = first value
+// two values -> packed fp16 pair, each rounded to nearest even (what autocast's cast does); low half = first value
+__device__ __forceinline__ unsigned wg_round2(float x0, float x1) {
+    const wf16x2 h = {(_Float16)x0, (_Float16)x1};
+    return __builtin_bit_cast(unsigned, h);
+}
 __device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
     const wf16x2 h = __builtin_bit_cast(wf16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
     const wf16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
     hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int TD, int TH, int TW>     // 128 positions: 2x8x8 or (flat) 1x8x16
+// SPLIT = 1: the f16x3 form above.  SPLIT = 0 (r5): the native f16 form -- the arithmetic of the reference's AMP training
+// (trainer_template.py:211-226: autocast + GradScaler; the weight gradient of an autocast convolution multiplies fp16 activations by
+// fp16 output gradients and accumulates in fp32): operands rounded to fp16 (nearest even) when they are staged, ONE MFMA per product, no
+// lo planes in LDS (half the footprint).  Range blocks are optional there (NULL: no scaling, like autocast -- GradScaler owns the range).
+template <int TD, int TH, int TW, int SPLIT>     // 128 positions: 2x8x8 or (flat) 1x8x16
 __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     static_assert(TD * TH * TW == 128 && (TW == 8 || TW == 16), "128-position bricks");
     constexpr int ROWH = (TW == 8) ? 16 : 24;        // halves per Q row in LDS (LW <= TW + 2, padded to a 16-byte multiple)
@@ -224,8 +233,8 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     static_assert((CHS_P / 8) % 2 == 1 && (CHS_Q / 8) % 2 == 1, "odd number of 16-byte slots per channel");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* const Ph = smem_h;               // [32][CHS_P] hi halves of the P tile
-    unsigned short* const Pl = Ph + 32 * CHS_P;
-    unsigned short* const Qh = Pl + 32 * CHS_P;      // [32][CHS_Q] hi halves of the Q brick
+    unsigned short* const Pl = Ph + 32 * CHS_P;      // (SPLIT = 0: no lo planes -- Pl / Ql are never touched and Qh follows Ph)
+    unsigned short* const Qh = SPLIT ? Pl + 32 * CHS_P : Ph + 32 * CHS_P;      // [32][CHS_Q] hi halves of the Q brick
     unsigned short* const Ql = Qh + 32 * CHS_Q;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     const int sw = sidx % nstripsW; sidx /= nstripsW;
     const int thi = sidx % p.tilesH; sidx /= p.tilesH;
     const int tdi = sidx % p.tilesD; const int b = sidx / p.tilesD;
-    const float sP = wg_pow2_scale(amax_read(p.Pmeta)), sQ = wg_pow2_scale(amax_read(p.Qmeta));
+    const float sP = p.Pmeta ? wg_pow2_scale(amax_read(p.Pmeta)) : 1.f, sQ = p.Qmeta ? wg_pow2_scale(amax_read(p.Qmeta)) : 1.f;
     const float inv = (1.0f / sP) * (1.0f / sQ);
 
     f32x16 acc[WG_TAPS];
@@ -324,10 +333,12 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
             const float x0[4] = {pv[k][0].x, pv[k][0].y, pv[k][0].z, pv[k][0].w}, x1[4] = {pv[k][1].x, pv[k][1].y, pv[k][1].z, pv[k][1].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                unsigned h, l;
-                wg_split2(x0[j] * sP, x1[j] * sP, h, l);
-                *reinterpret_cast<unsigned*>(Ph + p_dst[k] + j * CHS_P) = h;
-                *reinterpret_cast<unsigned*>(Pl + p_dst[k] + j * CHS_P) = l;
+                if constexpr (SPLIT) {
+                    unsigned h, l;
+                    wg_split2(x0[j] * sP, x1[j] * sP, h, l);
+                    *reinterpret_cast<unsigned*>(Ph + p_dst[k] + j * CHS_P) = h;
+                    *reinterpret_cast<unsigned*>(Pl + p_dst[k] + j * CHS_P) = l;
+                } else *reinterpret_cast<unsigned*>(Ph + p_dst[k] + j * CHS_P) = wg_round2(x0[j] * sP, x1[j] * sP);
             }
         }
 #pragma unroll
@@ -336,10 +347,12 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
                 const float x0[4] = {qv[k][0].x, qv[k][0].y, qv[k][0].z, qv[k][0].w}, x1[4] = {qv[k][1].x, qv[k][1].y, qv[k][1].z, qv[k][1].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    unsigned h, l;
-                    wg_split2(x0[j] * sQ, x1[j] * sQ, h, l);
-                    *reinterpret_cast<unsigned*>(Qh + q_dst[k] + j * CHS_Q) = h;
-                    *reinterpret_cast<unsigned*>(Ql + q_dst[k] + j * CHS_Q) = l;
+                    if constexpr (SPLIT) {
+                        unsigned h, l;
+                        wg_split2(x0[j] * sQ, x1[j] * sQ, h, l);
+                        *reinterpret_cast<unsigned*>(Qh + q_dst[k] + j * CHS_Q) = h;
+                        *reinterpret_cast<unsigned*>(Ql + q_dst[k] + j * CHS_Q) = l;
+                    } else *reinterpret_cast<unsigned*>(Qh + q_dst[k] + j * CHS_Q) = wg_round2(x0[j] * sQ, x1[j] * sQ);
                 }
             }
         }
@@ -359,7 +372,8 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int hb = (wave * 2 + i) * 2 + hh;
             ah[i] = *reinterpret_cast<const uint4*>(Ph + col * CHS_P + hb * 8);
-            al[i] = *reinterpret_cast<const uint4*>(Pl + col * CHS_P + hb * 8);
+            if constexpr (SPLIT) al[i] = *reinterpret_cast<const uint4*>(Pl + col * CHS_P + hb * 8);
+            else al[i] = ah[i];
             // Q row of the same positions at dh = 0: TW = 8: hb = pd * TH + ph; TW = 16: hb = 2 * ph + (w half)
             const int prow = (TW == 8) ? hb : (hb >> 1);
             const int pd = prow / TH, ph = prow % TH;
@@ -372,8 +386,8 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
                 for (int i = 0; i < 2; ++i) {
                     const unsigned short* qh = Qh + qoff[i] + dh * ROWH;
                     const unsigned short* ql = Ql + qoff[i] + dh * ROWH;
-                    const uint4 vh = *reinterpret_cast<const uint4*>(qh), vl = *reinterpret_cast<const uint4*>(ql);
-                    const unsigned eh = *reinterpret_cast<const unsigned*>(qh + 8), el = *reinterpret_cast<const unsigned*>(ql + 8);
+                    const uint4 vh = *reinterpret_cast<const uint4*>(qh), vl = SPLIT ? *reinterpret_cast<const uint4*>(ql) : vh;
+                    const unsigned eh = *reinterpret_cast<const unsigned*>(qh + 8), el = SPLIT ? *reinterpret_cast<const unsigned*>(ql + 8) : eh;
                     const wf16x8 pa_h = __builtin_bit_cast(wf16x8, ah[i]), pa_l = __builtin_bit_cast(wf16x8, al[i]);
 #pragma unroll
                     for (int dw = 0; dw < 3; ++dw) {
@@ -388,8 +402,10 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
                             } else { bh = make_uint4(vh.y, vh.z, vh.w, eh); bl = make_uint4(vl.y, vl.z, vl.w, el); }
                             const wf16x8 qb_h = __builtin_bit_cast(wf16x8, bh), qb_l = __builtin_bit_cast(wf16x8, bl);
                             f32x16& c = acc[dh * 3 + dw];
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_l, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_l, qb_h, c, 0, 0, 0);
+                            if constexpr (SPLIT) {
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_l, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_l, qb_h, c, 0, 0, 0);
+                            }
                             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_h, c, 0, 0, 0);
                         }
                     }
@@ -580,10 +596,12 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         a.tgroups = ng;
         a.tilesD = cdiv(a.Pd, TD); a.tilesH = cdiv(a.Ph, TH); a.tilesW = cdiv(a.Pw, TW);
         const int chs_q = TD * (TH + 2) * (flat16 ? 24 : 16) + 8;
-        const size_t lds = (size_t)(2 * 32 * 136 + 2 * 32 * chs_q) * sizeof(unsigned short);
+        const int planes = (f16x3 == 2) ? 1 : 2;              // hi (+ lo) planes of P and Q
+        const size_t lds_ops = (size_t)(planes * 32 * 136 + planes * 32 * chs_q) * sizeof(unsigned short);
+        const size_t lds = lds_ops > (size_t)3 * 16 * 64 * sizeof(float) ? lds_ops : (size_t)3 * 16 * 64 * sizeof(float);   // (the hand-over of the partial tiles reuses it: 3 waves x 16 x 64 floats)
         const int gy = cdiv(a.A, 32) * cdiv(a.Bc, 32);
         const long long rows = (long long)B * a.tilesD * a.tilesH * a.tgroups * gy;
-        const long long slots = 256ll * 2;
+        const long long slots = 256ll * 2;                    // (registers: 9 accumulator sets keep both forms at 2 workgroups per CU)
         long long best = -1; int best_strip = a.tilesW;
         for (int strip = a.tilesW; strip >= 1; --strip) {
             const long long wgs = rows * cdiv(a.tilesW, strip);
@@ -597,13 +615,18 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         const size_t need = (size_t)gx * gy * WG_TAPS * 1024 * sizeof(float);
         if (query) { *query = need; return 0; }
         OSA_REQUIRE(ws && ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad_f16x3: workspace of %zu B needed (got %zu)", need, ws_bytes);
-        OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
+        if (f16x3 == 1) OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
         a.ws = ws;
         a.Pmeta = transposed ? x_meta : dy_meta; a.Qmeta = transposed ? dy_meta : x_meta;       // conv: P = dy, Q = x; transposed: P = x, Q = dy
         a.dbg = exp_int("OSA_WG_DBG", 0);
         dim3 grid((unsigned)gx, gy), block(256);
-        if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8>), grid, block, lds, st, a);
+        if (f16x3 == 2) {
+            if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16, 0>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8, 0>), grid, block, lds, st, a);
+        } else {
+            if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16, 1>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8, 1>), grid, block, lds, st, a);
+        }
         OSA_LAUNCH_CHECK("conv3d_wgrad_f16x3");
         WgradReduceArgs r;
         memset(&r, 0, sizeof(r));
@@ -738,4 +761,19 @@ extern "C" int osa_conv3d_wgrad_ws_f16x3(const float* x, const float* dy, float*
     OSA_REQUIRE(workspace, "conv3d_wgrad_ws_f16x3: NULL workspace (osa_conv3d_wgrad_f16x3_workspace_bytes gives its size)");
     return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
                       dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, 1, x_meta, dy_meta);
+}
+
+/* native f16 weight gradient (r5): the arithmetic of the reference's AMP training -- fp16 operands (rounded to nearest even when staged),
+ * one MFMA per product, fp32 accumulation.  Same layers, workspace size and two-stage reduction as the f16x3 form; x_meta / dy_meta may be
+ * NULL (no operand scaling, as under autocast: GradScaler owns the range) or range blocks (power-of-two scaling, undone exactly). */
+extern "C" int osa_conv3d_wgrad_ws_f16(const float* x, const float* dy, float* dw,
+                                       int B, int Di, int Hi, int Wi, int Ci, int xCs,
+                                       int Do, int Ho, int Wo, int Co, int dyCs,
+                                       int kd, int kh, int kw, int stride,
+                                       int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
+                                       int transposed, const float* x_meta, const float* dy_meta,
+                                       float* workspace, size_t workspace_bytes, void* stream) {
+    OSA_REQUIRE(workspace, "conv3d_wgrad_ws_f16: NULL workspace (osa_conv3d_wgrad_f16x3_workspace_bytes gives its size)");
+    return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
+                      dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, 2, x_meta, dy_meta);
 }

@@ -81,6 +81,23 @@ def effective_precision() -> str:
     return _precision
 
 
+AMP_TRAIN_NATIVE = os.environ.get("OSA_AMP_TRAIN_NATIVE", "1") != "0"
+
+
+def train_precision(requested=None) -> str:
+    """arithmetic mode of the DIFFERENTIABLE engine convolutions (autograd.py) called now: the requested / global mode, or "f16" inside an
+    fp16 autocast region (AMP_TRAIN_NATIVE) -- the reference trains StereoBase / LightStereo / IGEV under autocast + GradScaler
+    (trainer_template.py:211,217-226; cfgs/stereobase/stereobase_sceneflow.yaml:50), where every convolution, its data gradient and its
+    weight gradient multiply fp16 operands and accumulate in fp32.  bf16 regions keep the global mode (no native bf16 kernels: the
+    fp32-class modes are strictly more accurate).  A global "f16" mode trains natively as well."""
+    p = requested or _precision
+    if p == "f16":
+        return "f16" if AMP_TRAIN_NATIVE else "f16x3"
+    if AMP_TRAIN_NATIVE and AUTOCAST_NATIVE and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
+        return "f16"
+    return p
+
+
 # ----------------------------------------------------------------------------- packed-weight caches
 class _PackEntry:
     __slots__ = ("slots", "modes", "key", "value", "event", "stream", "synced")

@@ -1,0 +1,197 @@
+"""Training at the reference's own arithmetic (VERDICT r4 missing #2 / next #3a).
+
+The reference trains StereoBase / LightStereo / IGEV under `torch.autocast` + `GradScaler` (stereo/modeling/trainer_template.py:211,217-226;
+cfgs/stereobase/stereobase_sceneflow.yaml:50): every convolution, its data gradient and its weight gradient multiply fp16 operands and
+accumulate in fp32.  Since r5 the differentiable engine convolutions (openstereo_amd/autograd.py) do the same inside an fp16 autocast
+region -- the native "f16" mode: operands rounded to fp16 (nearest even) when they are staged, ONE MFMA per product, no range reductions --
+instead of spending the f16x3 mode's three MFMAs on accuracy autocast has given up.
+
+Pinned here: (1) forward / data gradient / weight gradient of every layer kind against torch run on the SAME fp16-rounded operands in
+fp32 (the products of fp16 numbers are exact in fp32, so only the summation order differs); (2) an autocast region with grad enabled
+selects that mode; (3) a whole AMP training step (StereoBase cost stage: the configs[2] hot path) drifts from the fp32 step no more than
+twice what the PyTorch-ROCm eager composition under the same autocast does."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from openstereo_amd.utils.weights import synth_state_dict, synth_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rn(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).normal(0, 1, shape) * scale).astype(np.float32))
+
+
+def r16(t):
+    """what the kernels do to an operand: round to fp16 (nearest even), compute with that value"""
+    return t.half().float()
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+
+
+LAYERS = [  # name, kind, Ci, Co, k, stride, pad, opad, dims
+    ("conv 32-32 s1", "conv3d", 32, 32, 3, 1, 1, 0, (6, 9, 12)),
+    ("conv 64-40 s1 ragged", "conv3d", 64, 40, 3, 1, 1, 0, (5, 7, 11)),
+    ("conv 32-64 s2", "conv3d", 32, 64, 3, 2, 1, 0, (8, 12, 16)),
+    ("conv 1x1x1 48-32", "conv3d", 48, 32, 1, 1, 0, 0, (3, 9, 10)),
+    ("conv2d 3x3 384-128 (gru)", "conv2d", 384, 128, 3, 1, 1, 0, (1, 20, 46)),
+    ("conv2d 3x3 36-7 ragged", "conv2d", 36, 7, 3, 1, 1, 0, (1, 9, 33)),
+    ("deconv3d k3 64-32", "deconv3d", 64, 32, 3, 2, 1, 1, (3, 5, 7)),
+    ("deconv3d k4 48-24", "deconv3d", 48, 24, 4, 2, 1, 0, (4, 5, 9)),
+    ("deconv2d k4 64-9", "deconv2d", 64, 9, 4, 2, 1, 0, (1, 20, 46)),
+]
+
+
+def _fns(kind, s, p, op):
+    from openstereo_amd import autograd as AG
+    if kind == "conv3d":
+        return (lambda x, w: F.conv3d(x, w, None, s, p)), (lambda x, w, prec: AG.conv3d(x, w, None, s, p, 1, precision=prec)), False
+    if kind == "conv2d":
+        return (lambda x, w: F.conv2d(x, w, None, s, p)), (lambda x, w, prec: AG.conv2d(x, w, None, s, p, 1, precision=prec)), False
+    if kind == "deconv3d":
+        return (lambda x, w: F.conv_transpose3d(x, w, None, 2, p, op)), (lambda x, w, prec: AG.conv_transpose3d(x, w, None, 2, p, op, precision=prec)), True
+    return (lambda x, w: F.conv_transpose2d(x, w, None, 2, p, op)), (lambda x, w, prec: AG.conv_transpose2d(x, w, None, 2, p, op, precision=prec)), True
+
+
+@pytest.mark.parametrize("case", LAYERS, ids=[c[0] for c in LAYERS])
+def test_f16_training_kernels_vs_torch_on_rounded_operands(case):
+    """forward, dx and dW of the native f16 mode = torch (fp32) on the fp16-rounded x, w and dy: fp32 accumulation of exact products, so
+    the two agree to summation-order rounding; and deterministic (two runs bit-identical).  The gradient dy has GradScaler-sized magnitude."""
+    name, kind, Ci, Co, k, s, p, op, (D, H, W) = case
+    ref, eng, transposed = _fns(kind, s, p, op)
+    two_d = kind.endswith("2d")
+    wshape = ((Ci, Co) if transposed else (Co, Ci)) + ((k, k) if two_d else (k, k, k))
+    w = (synth_tensor(name + ".w", wshape, 1) * 3.0).to(DEV)
+    x = (rn((2, Ci, H, W) if two_d else (2, Ci, D, H, W), 21) * 2.0).to(DEV)
+    xr, wr = r16(x).requires_grad_(), r16(w).requires_grad_()
+    y = ref(xr, wr)
+    gy = (torch.randn(y.shape, generator=torch.Generator().manual_seed(5)) * 7.0).to(DEV)     # "scaled" gradients: O(10), far from fp16's edges
+    y.backward(r16(gy))
+    outs = []
+    for _ in range(2):
+        xe, we = x.clone().requires_grad_(), w.clone().requires_grad_()
+        ye = eng(xe, we, "f16")
+        ye.backward(gy)
+        outs.append((ye.detach(), xe.grad, we.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), "deterministic"
+    ye, dx, dw = outs[0]
+    assert rel(ye, y) < 2e-6, ("fwd", rel(ye, y))
+    assert rel(dx, xr.grad) < 2e-6, ("dx", rel(dx, xr.grad))
+    assert rel(dw, wr.grad) < 5e-6, ("dw", rel(dw, wr.grad))
+    # and it IS a different arithmetic from the fp32-class modes: the distance to the unrounded fp32 result is fp16-sized
+    xf, wf = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref(xf, wf).backward(gy)
+    assert 1e-5 < rel(dw, wf.grad) < 5e-3
+
+
+def test_autocast_region_with_grad_selects_the_native_f16_mode():
+    """engine.train_precision: inside torch.autocast(fp16) the differentiable convolutions run the f16 mode (bit-identical to an explicit
+    precision="f16" call), outside -- and inside a bf16 region -- the global mode; the results come back in the dtype the reference's
+    convolution would return there."""
+    from openstereo_amd import autograd as AG, engine
+    x = (rn((1, 32, 4, 9, 12), 3) * 2.0).to(DEV)
+    w = (synth_tensor("sel.w", (32, 32, 3, 3, 3), 1) * 3.0).to(DEV).requires_grad_()
+    old = engine.get_precision()
+    engine.set_precision("f16x3")
+    try:
+        assert engine.train_precision() == "f16x3"
+        explicit16 = AG.conv3d(x, w, None, 1, 1, 1, precision="f16")
+        x3 = AG.conv3d(x, w, None, 1, 1, 1)
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert engine.train_precision() == "f16" and torch.is_grad_enabled()
+            inside = AG.conv3d(x, w, None, 1, 1, 1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert engine.train_precision() == "f16x3"
+            inside_bf = AG.conv3d(x, w, None, 1, 1, 1)
+        assert torch.equal(inside.float(), explicit16.float().to(inside.dtype).float())
+        assert not torch.equal(explicit16, x3) and rel(explicit16, x3) < 2e-3
+        assert torch.equal(inside_bf.float(), x3.to(inside_bf.dtype).float())
+    finally:
+        engine.set_precision(old)
+
+
+def test_stereobase_cost_stage_amp_step_drifts_no_more_than_the_eager_autocast_composition():
+    """configs[2] hot path, one AMP training step (autocast + GradScaler, frozen BN): gradients of the engine's native f16 path vs the fp32
+    step, against the same distance for the PyTorch-ROCm eager composition (stock conv / conv_transpose kernels) under the same autocast."""
+    from openstereo_amd import autograd as AG, engine
+    from openstereo_amd.models.igev_style import StereoBaseCostStage
+
+    def build():
+        st = StereoBaseCostStage(max_disp=64, num_groups=8, concat_channels=8, backbone_channels=[48, 64, 192, 120])
+        st.load_state_dict(synth_state_dict(st, seed=8, head_gain=20.0))
+        st = st.to(DEV).train()
+        for m in st.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                m.eval()
+        return st
+    g = torch.Generator().manual_seed(80)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    B, H, W = 1, 32, 64
+    x = [r(B, 96, H, W), r(B, 96, H, W), r(B, 8, H, W), r(B, 8, H, W)]
+    feats = [None, r(B, 64, H // 2, W // 2), r(B, 192, H // 4, W // 4), r(B, 120, H // 8, W // 8)]
+    gt = torch.rand(B, 1, H, W, generator=g).to(DEV) * 12
+
+    def step(st, amp, eager=False):
+        scaler = torch.amp.GradScaler("cuda", enabled=amp, init_scale=1024.0)
+        opt = torch.optim.SGD(st.parameters(), lr=0.0)
+        ctx = _stock_torch_convs() if eager else _null()
+        with ctx:
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                out = st(*x, feats)
+                loss = F.smooth_l1_loss(out["init_disp"].float(), gt)
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+        gr = {k: p.grad.detach().float().clone() for k, p in st.named_parameters() if p.grad is not None}
+        assert all(torch.isfinite(v).all() for v in gr.values()), "scaled fp16 gradients overflowed at init_scale 1024"
+        return float(loss), gr
+
+    old = engine.get_precision()
+    engine.set_precision("f16x3")
+    try:
+        l32, g32 = step(build(), False)
+        l16, g16 = step(build(), True)
+        le, ge = step(build(), True, eager=True)
+    finally:
+        engine.set_precision(old)
+    assert abs(l16 - l32) < 2e-2 * abs(l32) and len(g32) > 20 and g16.keys() == g32.keys() == ge.keys()
+    worst = 0.0
+    for k in g32:
+        s = float(g32[k].abs().max()) + 1e-20
+        e_eng, e_ref = float((g16[k] - g32[k]).abs().max()) / s, float((ge[k] - g32[k]).abs().max()) / s
+        worst = max(worst, e_eng)
+        assert e_eng <= 2.0 * e_ref + 2e-2, (k, e_eng, e_ref)
+    print(f"[amp step] worst relative gradient distance to the fp32 step: {worst:.3e}")
+    assert worst > 1e-5, "the AMP step must have run the fp16 arithmetic (distance to fp32 is fp16-sized, not zero)"
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _stock_torch_convs:
+    """run the model's convolutions on stock PyTorch-ROCm kernels: the engine's differentiable conv entry points replaced by torch's"""
+
+    def __enter__(self):
+        from openstereo_amd import autograd as AG
+        self.AG, self.saved = AG, {n: getattr(AG, n) for n in ("conv3d", "conv_transpose3d", "conv2d", "conv_transpose2d")}
+        AG.conv3d = lambda x, w, b=None, stride=1, padding=0, dilation=1, precision=None: F.conv3d(x, w, b, stride, padding, dilation)
+        AG.conv2d = lambda x, w, b=None, stride=1, padding=0, dilation=1, precision=None: F.conv2d(x, w, b, stride, padding, dilation)
+        AG.conv_transpose3d = lambda x, w, b=None, stride=2, padding=1, output_padding=0, precision=None: F.conv_transpose3d(x, w, b, stride, padding, output_padding)
+        AG.conv_transpose2d = lambda x, w, b=None, stride=2, padding=1, output_padding=0, precision=None: F.conv_transpose2d(x, w, b, stride, padding, output_padding)
+        return self
+
+    def __exit__(self, *a):
+        for n, f in self.saved.items():
+            setattr(self.AG, n, f)
+        return False
