@@ -675,6 +675,15 @@ def gwcnet_timed_config_parity(wl, step, replays=3):
     torch.cuda.synchronize()
     out = outs[-1]
     d1 = (out - one).abs().flatten(1)
+    if os.environ.get("OSA_PARITY_DIAG"):            # which pairs / how many pixels differ between replays and against the one-stream run
+        for r, o in enumerate(outs[1:], 1):
+            d = (o - outs[0]).abs().flatten(1)
+            print(f"[parity diag] replay {r} vs 0: per-pair max {[round(float(v), 4) for v in d.max(1).values]}, pixels > 1e-3: {[int(v) for v in (d > 1e-3).sum(1)]}", file=sys.stderr)
+        d = (out - seq).abs().flatten(1)
+        print(f"[parity diag] last replay vs one-stream sub-batches: per-pair max {[round(float(v), 4) for v in d.max(1).values]}, pixels > 1e-3: {[int(v) for v in (d > 1e-3).sum(1)]}", file=sys.stderr)
+        from openstereo_amd import ranges
+        print(f"[parity diag] sub-batch streams {[hex(s.cuda_stream) for s in wl.sub.streams]}, current {hex(torch.cuda.current_stream().cuda_stream)}, "
+              f"arenas {[(hex(k[1]), a[1], a[2]) for k, a in ranges._arenas.items()]}", file=sys.stderr)
     return {"pairs": wl.B, "streams": wl.nstreams, "replays": replays,
             "replay_vs_replay_max_px": max([float((o - outs[0]).abs().max()) for o in outs[1:]] + [0.0]),
             "vs_same_sub_batches_on_one_stream_max_px": float((out - seq).abs().max()),

@@ -29,6 +29,9 @@ def test_timed_configuration_every_pair(prec):
     engine.set_precision(prec)
     try:
         dev = torch.device("cuda", 0)
+        if os.environ.get("OSA_TEST_RESET_ARENAS"):
+            from openstereo_amd import ranges
+            ranges.reset_arenas()
         wl = bench.GwcNetInference(argparse.Namespace(batch=None, streams=None), dev, 0)
         assert wl.B == 9 and wl.nstreams == 3, "bench.py's default line: 9 pairs as 3 sub-batch streams of 3"
         # pair 0 := the input of tests/golden/gwcnet_full_disp.npz (the reference's own forward at 544x960, D=192); same weights (seed 0)
