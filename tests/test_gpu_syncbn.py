@@ -146,17 +146,24 @@ def test_freeze_bn_training_step_converted_equals_unconverted(which):
     conv = _sync(_freeze_bn(m.train())).to(DEV)
     assert all(not x.training for x in conv.modules() if isinstance(x, nn.SyncBatchNorm))      # convert keeps the frozen (eval) flag
     losses, grads = [], []
-    for net in (plain, conv):
+    for net in (plain, conv, plain):           # the third run (the unconverted model again) measures the step's own run-to-run spread
+        net.zero_grad(set_to_none=True)
         out = net({"left": L, "right": R})
         loss = sum(p.float().abs().mean() for p in out["disp_preds"]) + (out["init_disp"].abs().mean() if "init_disp" in out else 0.0)
         loss.backward()
         losses.append(float(loss))
         grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
-    assert np.isfinite(losses[0]) and abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
-    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 10
+    assert np.isfinite(losses[0]) and abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0]), losses
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 10, (len(grads[0]), len(grads[1]))
+    worst = 0.0
     for k in grads[0]:
-        a, b = grads[0][k], grads[1][k]
-        assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(a.abs().max())), k
+        a, b, a2 = grads[0][k], grads[1][k], grads[2][k]
+        s = max(1e-6, float(a.abs().max()))
+        noise = float((a - a2).abs().max()) / s          # float atomics in torch's own backward kernels (BatchNorm / interpolate) are order dependent
+        err = float((a - b).abs().max()) / s
+        worst = max(worst, err)
+        assert err <= 1e-5 + 4.0 * noise, (k, err, noise)
+    print(f"[{which}] converted vs unconverted FREEZE_BN step: worst relative gradient difference {worst:.2e}")
 
 
 def test_unfoldable_norm_raises_instead_of_being_dropped():
