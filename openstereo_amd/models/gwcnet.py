@@ -288,6 +288,9 @@ class Hourglass(nn.Module):
         return ops.to_ncdhw(self.forward_cl(ops.to_cl(x)), channels=x.shape[1])
 
 
+STAGE_STASH = None          # a list: GwcDispProcessor.aggregate_cl / GwcNet.forward append (stage name, clone) of every stage (diagnostics only)
+
+
 class GwcDispProcessor(nn.Module):
     """gwcnet_disp_processor.py:29-146, inference branch, on the engine."""
 
@@ -326,6 +329,15 @@ class GwcDispProcessor(nn.Module):
         p = self._pack()
         split = _SPLIT_ACT and chains(p["d00"].precision)
         s = dict(out_split=True) if split else {}
+        if STAGE_STASH is not None:        # diagnostics (tools/diag_timed_config.py --stages): bit copies of every stage of this call
+            k = lambda name, t: (STAGE_STASH.append((name, t.clone())), t)[1]
+            d00 = k("dres0.0", p["d00"](k("volume", volume), **s))
+            cost0 = k("dres0.2", p["d02"](d00, **s))
+            cost0 = k("dres1", p["d12"](k("dres1.0", p["d10"](cost0, **s)), residual=cost0, **s))
+            out1 = k("hourglass1", self.dres2.forward_cl(cost0, split))
+            out2 = k("hourglass2", self.dres3.forward_cl(out1, split))
+            out3 = k("hourglass3", self.dres4.forward_cl(out2, split))
+            return k("classif3.2", p["k2"](k("classif3.0", p["k0"](out3))))
         cost0 = p["d02"](p["d00"](volume, **s), **s)
         cost0 = p["d12"](p["d10"](cost0, **s), residual=cost0, **s)      # dres1(cost0) + cost0
         out3 = self.dres4.forward_cl(self.dres3.forward_cl(self.dres2.forward_cl(cost0, split), split), split)
@@ -392,6 +404,10 @@ class GwcNet(nn.Module):
             # fused engine path: NHWC features never leave the engine layout
             B = inputs["left"].shape[0]
             gwc, catf = self.Backbone.forward_cl(inputs["left"], inputs["right"])
+            if STAGE_STASH is not None:
+                STAGE_STASH.append(("backbone gwc", gwc.clone()))
+                if catf is not None:
+                    STAGE_STASH.append(("backbone concat", catf.clone()))
             cp = self.CostProcessor
             # f16x3 chains: the volume is written in the chain's split format, so dres0 stages it like every later layer (ops docstring)
             vol = ops.build_cost_volume_from_cl(gwc, cp.num_groups, catf if cp.use_concat_volume else None, B,
