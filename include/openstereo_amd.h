@@ -322,6 +322,31 @@ int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
 int osa_gru_combine_f32(const float* z, const float* q, const float* h, float* out,
                         long long npix, int C, int zCs, int qCs, int hCs, int oCs, float* out_meta, void* stream);
 
+/* ConvGRU gate arithmetic of the TRAINING path, fused (r5, ABI v5; csrc/gru_train.hip).  Reference: models/igev/update.py:36-45 ==
+ * models/stereobase/gru_blocks.py:261-268
+ *     z = sigmoid(convz(hx) + cz);  r = sigmoid(convr(hx) + cr);  q = tanh(convq(cat([r * h, x])) + cq);  h' = (1 - z) * h + z * q.
+ * The three convolutions run through the conv / dgrad / wgrad entry points; these four calls replace the ~13 forward and ~20 backward
+ * elementwise launches per cell of the torch composition (66 cells per StereoBase training step):
+ *   rz_fwd: pre = [convz(hx) | convr(hx)] WITHOUT bias (2C channels), bias_z / bias_r (C floats each, or NULL), cz, cr, h -> z, r * h
+ *   rz_bwd: the same inputs + dz, d(r*h) -> dpre = [d pre_z | d pre_r] (2C channels; its halves are also the gradients of cz and cr, and
+ *           summed over the pixels those of the biases) and the part of dh that flows through r * h
+ *   q_fwd : z, qpre = convq([r*h, x]) without bias, bias_q, cq, h -> h'
+ *   q_bwd : the same inputs + dh' -> dz, dqpre (= dcq; summed: dbias_q), the direct part of dh
+ * sigmoid / tanh are recomputed from the saved pre-activations in the backward calls.  Every tensor is NHWC over npix pixels with its own
+ * channel stride (elements, % 4 == 0) and element type: fp32 (16-byte aligned) or fp16 (f16 = 1, 8-byte aligned) -- under autocast the
+ * context features and the hidden state arrive in fp16 next to fp32 conv results.  fp32 arithmetic, one rounding at the store.  C % 4 == 0. */
+typedef struct osa_nhwc_ref { void* ptr; int cs; int f16; } osa_nhwc_ref;
+int osa_gru_gates_rz_fwd(const osa_nhwc_ref* pre, const float* bias_z, const float* bias_r, const osa_nhwc_ref* cz, const osa_nhwc_ref* cr,
+                         const osa_nhwc_ref* h, const osa_nhwc_ref* z_out, const osa_nhwc_ref* rh_out, long long npix, int C, void* stream);
+int osa_gru_gates_rz_bwd(const osa_nhwc_ref* pre, const float* bias_z, const float* bias_r, const osa_nhwc_ref* cz, const osa_nhwc_ref* cr,
+                         const osa_nhwc_ref* h, const osa_nhwc_ref* dz, const osa_nhwc_ref* drh, const osa_nhwc_ref* dpre_out,
+                         const osa_nhwc_ref* dh_out, long long npix, int C, void* stream);
+int osa_gru_gates_q_fwd(const osa_nhwc_ref* z, const osa_nhwc_ref* qpre, const float* bias_q, const osa_nhwc_ref* cq, const osa_nhwc_ref* h,
+                        const osa_nhwc_ref* out, long long npix, int C, void* stream);
+int osa_gru_gates_q_bwd(const osa_nhwc_ref* z, const osa_nhwc_ref* qpre, const float* bias_q, const osa_nhwc_ref* cq, const osa_nhwc_ref* h,
+                        const osa_nhwc_ref* dout, const osa_nhwc_ref* dz_out, const osa_nhwc_ref* dqpre_out, const osa_nhwc_ref* dh_out,
+                        long long npix, int C, void* stream);
+
 /* Disparity update of the GRU loop (igev_stereo.py:201 `disp = disp + delta_disp`) with the copies its consumers read:
  *   disp [npix] += delta[p * delta_cs] (delta NULL: unchanged);  disp_nhwc4 [npix][4] = (disp, 0, 0, 0) (input of the motion encoder's
  *   7x7 convd1, update.py:87);  slot[p * slot_cs] = disp (the `torch.cat([out, disp])` channel of the 1/4 level, update.py:92).

@@ -30,6 +30,14 @@ class F16x3Ranges(C.Structure):
 
 c_rng = C.POINTER(F16x3Ranges)
 
+
+class NhwcRef(C.Structure):
+    """osa_nhwc_ref: an NHWC tensor operand with its own channel stride (elements) and element type (fp32 / fp16)."""
+    _fields_ = [("ptr", C.c_void_p), ("cs", C.c_int), ("f16", C.c_int)]
+
+
+c_ref = C.POINTER(NhwcRef)
+
 # name -> (restype, argtypes).  Mirrors include/openstereo_amd.h one to one; tests check that
 # every symbol declared in the header is listed here and exported by the .so.
 SIGNATURES = {
@@ -133,6 +141,10 @@ SIGNATURES = {
                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                     c_i, c_fp, c_st]),
     "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
+    "osa_gru_gates_rz_fwd": (c_i, [c_ref, c_fp, c_fp, c_ref, c_ref, c_ref, c_ref, c_ref, c_ll, c_i, c_st]),
+    "osa_gru_gates_rz_bwd": (c_i, [c_ref, c_fp, c_fp, c_ref, c_ref, c_ref, c_ref, c_ref, c_ref, c_ref, c_ll, c_i, c_st]),
+    "osa_gru_gates_q_fwd": (c_i, [c_ref, c_ref, c_fp, c_ref, c_ref, c_ref, c_ll, c_i, c_st]),
+    "osa_gru_gates_q_bwd": (c_i, [c_ref, c_ref, c_fp, c_ref, c_ref, c_ref, c_ref, c_ref, c_ref, c_ll, c_i, c_st]),
     "osa_disp_update_f32": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_ll, c_fp, c_fp, c_st]),
     "osa_conv3d_pack_ex_auto": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_deconv3d_pack_f16x3_auto": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),

@@ -212,6 +212,28 @@ def _pack(w, Ci, Co, k, mode, precision, cache=None):
     return hit
 
 
+def _memo(cache, key, build):
+    """`build()` memoised in a weight's pack cache under the same content stamp as its packs (see _pack)"""
+    if cache is None:
+        return build()
+    memo, stamp = cache.memo, cache.stamp
+    if memo.get("stamp") != stamp:
+        memo.clear()
+        memo["stamp"] = stamp
+    hit = memo.get(key)
+    if hit is None:
+        hit = memo[key] = build()
+    return hit
+
+
+def _wcache2(w, w2):
+    """pack-cache handle of a PAIR of weights packed as one layer: the dict lives on the first, the stamp covers both"""
+    a, b = _wcache(w), _wcache(w2)
+    if a is None or b is None:
+        return None
+    return _Memo(a.memo, (a.stamp, b.stamp))
+
+
 def _pack_now(w, Ci, Co, k, mode, precision):
     """mode: 'fwd' | 'dgrad_s1' (role swap + flip) | 'dgrad_of_deconv' (role swap) | 'deconv' / 'deconv2d' (parity-class packing).
     Returns (packed buffer, scale): f32 -> scale 1.0; f16x3 -> a 2-float DEVICE tensor {wscale, 1 / wscale} that the pack kernel derived
@@ -360,9 +382,12 @@ class _Conv3d(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, w, stride, pad, dil, precision, cache=None):
+    def forward(ctx, x, w, stride, pad, dil, precision, cache=None, w2=None):
         xc = to_cl(x)                               # NDHWC, channels padded to a multiple of 4 with zeros
-        wf = _f32c(w)
+        # w2: a second layer over the same input, stacked on the output axis -- ONE forward / data-gradient / weight-gradient launch for
+        # both (ConvGRU's convz | convr read the same [h | x], update.py:38-39).  The concatenation is memoised with the packs.
+        ctx.co1 = None if w2 is None else w.shape[0]
+        wf = _f32c(w) if w2 is None else _memo(cache, "wcat", lambda: torch.cat([_f32c(w.detach()), _f32c(w2.detach())], 0))
         Co, Ci = wf.shape[:2]
         k = tuple(wf.shape[2:])
         packed, osc = _pack(wf, Ci, Co, k, "fwd", precision, cache)
@@ -400,11 +425,13 @@ class _Conv3d(torch.autograd.Function):
                 packed, osc = _pack(wf, Co, Ci, k, "deconv", precision, ctx.cache)       # w [Co][Ci][k] == transposed-conv layout [Cin_t][Cout_t]
                 dxc = _run_deconv(dyc, packed, osc, Co, Ci, 3, 1, 1, precision)
             dx = dxc[:, :Ci].to(xdt)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[7]):
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
             _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, ctx.xmeta, dymeta)
-        return dx, dw, None, None, None, None, None
+        if ctx.co1 is not None:
+            return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, None, None, (None if dw is None else dw[ctx.co1:])
+        return dx, dw, None, None, None, None, None, None
 
 
 class _ConvTranspose3d(torch.autograd.Function):
@@ -542,6 +569,131 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight))
     y = y[:, :, 0]
     return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+def conv2d_pair(x, weight_a, weight_b, padding=0, dilation=1, precision=None):
+    """[conv2d(x, weight_a) | conv2d(x, weight_b)] (no bias, stride 1) as ONE engine layer with the two weights stacked on the output axis:
+    one forward, one data-gradient and one weight-gradient launch for both; the gradients come back per weight."""
+    p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    assert weight_a.shape[1:] == weight_b.shape[1:]
+    y = _Conv3d.apply(x.unsqueeze(2), weight_a.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision),
+                      _wcache2(weight_a, weight_b), weight_b.unsqueeze(2))
+    return y[:, :, 0]
+
+
+# ----------------------------------------------------------------------------- fused ConvGRU gates (training path, csrc/gru_train.hip)
+def _nhwc_ref(t, C):
+    """(tensor to keep alive, _lib.NhwcRef) for a logical [B, >=C, H, W] CUDA tensor read / written as NHWC with a channel stride: engine
+    outputs (channel-sliced NDHWC views), channels_last tensors and anything whose strides are (H*W*cs, 1, W*cs, cs) pass as they are;
+    other layouts / dtypes are converted once (differentiable torch ops; callers memoise per tensor object where an operand repeats)."""
+    memo = getattr(t, "_osa_nhwc", None)            # operands that repeat (the context features cz / cr / cq: the same objects in all 22
+    if memo is not None and memo[0] == t._version:  # GRU iterations of a step) are converted once
+        t = memo[1]
+    src = t
+    if t.dtype not in (torch.float32, torch.float16):
+        t = t.float()
+    B, _, H, W = t.shape
+    cs = t.stride(3)
+    el = t.element_size()
+    ok = t.stride(1) == 1 and cs >= C and cs % 4 == 0 and t.stride(2) == W * cs and t.stride(0) == H * W * cs and (t.data_ptr() % (4 * el)) == 0
+    if not ok:
+        t = t.contiguous(memory_format=torch.channels_last)
+        if t.shape[1] % 4 or t.stride(1) != 1:          # (C % 4 == 0 is asserted by the callers; size-1 dims can leave ambiguous strides)
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        cs = t.stride(3)
+    if t is not src:
+        try:
+            src._osa_nhwc = (src._version, t)
+        except Exception:
+            pass
+    return t, _lib.NhwcRef(t.data_ptr(), int(cs), 1 if t.dtype == torch.float16 else 0)
+
+
+def _new_nhwc(B, C, H, W, device, dtype):
+    return torch.empty((B, H, W, C), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def _bias_ptr(b):
+    return None if b is None else b.data_ptr()
+
+
+class _GruGatesRZ(torch.autograd.Function):
+    """z, r * h = sigmoid(pre_z + bz + cz), sigmoid(pre_r + br + cr) * h  (update.py:38-40), pre = [pre_z | pre_r] from conv2d_pair."""
+
+    @staticmethod
+    def forward(ctx, pre, bz, br, cz, cr, h, rh_dtype):
+        B, C2, H, W = pre.shape
+        C = C2 // 2
+        keep = [_nhwc_ref(t, n) for t, n in ((pre, C2), (cz, C), (cr, C), (h, C))]
+        bzf, brf = (None if bz is None else _f32c(bz.detach())), (None if br is None else _f32c(br.detach()))
+        z = _new_nhwc(B, C, H, W, pre.device, torch.float32)             # internal: only the q kernel reads it
+        rh = _new_nhwc(B, C, H, W, pre.device, rh_dtype)
+        zr, rhr = _nhwc_ref(z, C), _nhwc_ref(rh, C)
+        _lib.call("osa_gru_gates_rz_fwd", keep[0][1], _bias_ptr(bzf), _bias_ptr(brf), keep[1][1], keep[2][1], keep[3][1], zr[1], rhr[1],
+                  B * H * W, C, _stream())
+        ctx.save_for_backward(keep[0][0], keep[1][0], keep[2][0], keep[3][0], *([] if bzf is None else [bzf]), *([] if brf is None else [brf]))
+        ctx.has_b = (bzf is not None, brf is not None)
+        ctx.dt = (pre.dtype, cz.dtype, cr.dtype, h.dtype, None if bz is None else bz.dtype, None if br is None else br.dtype)
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, dz, drh):
+        sv = list(ctx.saved_tensors)
+        pre, cz, cr, h = sv[:4]
+        rest = sv[4:]
+        bzf = rest.pop(0) if ctx.has_b[0] else None
+        brf = rest.pop(0) if ctx.has_b[1] else None
+        B, C2, H, W = pre.shape
+        C = C2 // 2
+        refs = [_nhwc_ref(t, n) for t, n in ((pre, C2), (cz, C), (cr, C), (h, C), (dz, C), (drh, C))]
+        dpre = _new_nhwc(B, C2, H, W, pre.device, torch.float32)
+        dh = _new_nhwc(B, C, H, W, pre.device, torch.float32)
+        _lib.call("osa_gru_gates_rz_bwd", refs[0][1], _bias_ptr(bzf), _bias_ptr(brf), refs[1][1], refs[2][1], refs[3][1], refs[4][1], refs[5][1],
+                  _nhwc_ref(dpre, C2)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
+        pdt, czdt, crdt, hdt, bzdt, brdt = ctx.dt
+        db = dpre.sum((0, 2, 3)) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None       # one reduction for both biases
+        return (dpre.to(pdt), None if bzdt is None or db is None else db[:C].to(bzdt), None if brdt is None or db is None else db[C:].to(brdt),
+                dpre[:, :C].to(czdt) if ctx.needs_input_grad[3] else None, dpre[:, C:].to(crdt) if ctx.needs_input_grad[4] else None,
+                dh.to(hdt) if ctx.needs_input_grad[5] else None, None)
+
+
+class _GruGatesQ(torch.autograd.Function):
+    """h' = (1 - z) * h + z * tanh(qpre + bq + cq)  (update.py:41-44)"""
+
+    @staticmethod
+    def forward(ctx, z, qpre, bq, cq, h, out_dtype):
+        B, C, H, W = qpre.shape
+        keep = [_nhwc_ref(t, C) for t in (z, qpre, cq, h)]
+        bqf = None if bq is None else _f32c(bq.detach())
+        out = _new_nhwc(B, C, H, W, qpre.device, out_dtype)
+        _lib.call("osa_gru_gates_q_fwd", keep[0][1], keep[1][1], _bias_ptr(bqf), keep[2][1], keep[3][1], _nhwc_ref(out, C)[1], B * H * W, C, _stream())
+        ctx.save_for_backward(keep[0][0], keep[1][0], keep[2][0], keep[3][0], *([] if bqf is None else [bqf]))
+        ctx.dt = (z.dtype, qpre.dtype, cq.dtype, h.dtype, None if bq is None else bq.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sv = list(ctx.saved_tensors)
+        z, qpre, cq, h = sv[:4]
+        bqf = sv[4] if len(sv) > 4 else None
+        B, C, H, W = qpre.shape
+        refs = [_nhwc_ref(t, C) for t in (z, qpre, cq, h, dout)]
+        dz, dq, dh = (_new_nhwc(B, C, H, W, qpre.device, torch.float32) for _ in range(3))
+        _lib.call("osa_gru_gates_q_bwd", refs[0][1], refs[1][1], _bias_ptr(bqf), refs[2][1], refs[3][1], refs[4][1],
+                  _nhwc_ref(dz, C)[1], _nhwc_ref(dq, C)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
+        zdt, qdt, cqdt, hdt, bqdt = ctx.dt
+        return (dz.to(zdt), dq.to(qdt), None if bqdt is None or not ctx.needs_input_grad[2] else dq.sum((0, 2, 3)).to(bqdt),
+                dq.to(cqdt) if ctx.needs_input_grad[3] else None, dh.to(hdt) if ctx.needs_input_grad[4] else None, None)
+
+
+def gru_gates_rz(pre, bias_z, bias_r, cz, cr, h, rh_dtype=None):
+    with torch.autocast("cuda", enabled=False):
+        return _GruGatesRZ.apply(pre, bias_z, bias_r, cz, cr, h, rh_dtype or h.dtype)
+
+
+def gru_gates_q(z, qpre, bias_q, cq, h, out_dtype=None):
+    with torch.autocast("cuda", enabled=False):
+        return _GruGatesQ.apply(z, qpre, bias_q, cq, h, out_dtype or h.dtype)
 
 
 def _wgrad_ok(m, x):

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIBNAME = "libopenstereo_amd.so"
-SOURCES = ["api.hip", "volume.hip", "conv3d.hip", "conv_inst_f32.hip", "conv_inst_f16x3.hip", "conv_inst_f16.hip", "conv_march.hip", "softargmin.hip", "layout.hip", "refine.hip", "backward.hip", "wgrad.hip", "geometry.hip", "dwconv.hip", "norm.hip"]
+SOURCES = ["api.hip", "volume.hip", "conv3d.hip", "conv_inst_f32.hip", "conv_inst_f16x3.hip", "conv_inst_f16.hip", "conv_march.hip", "softargmin.hip", "layout.hip", "refine.hip", "backward.hip", "wgrad.hip", "geometry.hip", "dwconv.hip", "norm.hip", "gru_train.hip"]
 ARCH = "gfx950"
 HIPCC_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]

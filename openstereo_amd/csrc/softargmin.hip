@@ -151,9 +151,22 @@ __global__ __launch_bounds__(256) void upsample4_softargmin_kernel(const UpArgs 
     const int plane = p.Hl * p.Wl;
     const float* c = p.cost + (size_t)b * p.Dl * plane;
     const int o00 = y0 * p.Wl + x0, o01 = y0 * p.Wl + x1, o10 = y1 * p.Wl + x0, o11 = y1 * p.Wl + x1;
+#ifndef OSA_HEAD_EXP
+#define OSA_HEAD_EXP 0          // r5 diagnosis builds (tools/build_head_variant.sh): 1 = L1-bypassing loads, 2 = L1 invalidate at kernel start
+#endif
+#if OSA_HEAD_EXP == 2
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    auto tap = [&](const float* q) {
+#if OSA_HEAD_EXP == 1
+        return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
+        return *q;
+#endif
+    };
     auto bil = [&](int k) {
         const float* cp = c + (size_t)k * plane;
-        return w00 * cp[o00] + w01 * cp[o01] + w10 * cp[o10] + w11 * cp[o11];
+        return w00 * tap(cp + o00) + w01 * tap(cp + o01) + w10 * tap(cp + o10) + w11 * tap(cp + o11);
     };
     float vm = 0.f, vc = bil(0), vn = (p.Dl > 1) ? bil(1) : vc;
     float m = -INFINITY, se = 0.f, sd = 0.f;

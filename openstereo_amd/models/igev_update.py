@@ -19,6 +19,8 @@ forward() takes and returns the reference's NCHW tensors; forward_cl() is the ch
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -151,6 +153,9 @@ class DispHead(nn.Module):
         return cl_to_nchw(self.forward_cl(nchw_to_cl(x)), self.conv2.out_channels)
 
 
+FUSED_GRU_TRAIN = os.environ.get("OSA_FUSED_GRU_TRAIN", "1") != "0"      # training: paired r|z conv + fused gate kernels (ConvGRU.forward_train)
+
+
 class ConvGRU(nn.Module):
     """update.py:29-45"""
 
@@ -208,14 +213,30 @@ class ConvGRU(nn.Module):
         return inherit_meta(out, lv.T)
 
     def forward_train(self, h, cz, cr, cq, *x_list):
-        """update.py:36-45: the three 3x3 convolutions on the engine (forward, dgrad, wgrad), gating in torch."""
-        with AG.engine_convs():
-            x = torch.cat(x_list, dim=1)
-            hx = torch.cat([h, x], dim=1)
-            z = torch.sigmoid(self.convz(hx) + cz)
-            r = torch.sigmoid(self.convr(hx) + cr)
-            q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
-        return (1 - z) * h + z * q
+        """update.py:36-45 in training mode.  r5: convz | convr as ONE engine layer (they read the same [h | x]: one forward, one data
+        gradient, one weight gradient), convq as another, and the gate arithmetic in two fused kernels forward and two backward
+        (csrc/gru_train.hip) instead of ~13 + ~20 torch elementwise launches per cell -- 66 cells per StereoBase training step.
+        FUSED_GRU_TRAIN = False (or operands the fused form does not cover) keeps the torch composition."""
+        hd = self.hidden_dim
+        x = torch.cat(x_list, dim=1) if len(x_list) > 1 else x_list[0]
+        fused = FUSED_GRU_TRAIN and hd % 4 == 0 and h.is_cuda and all(t.dtype in (torch.float16, torch.float32) for t in (h, cz, cr, cq, x)) \
+            and tuple(self.convz.stride) == (1, 1) and tuple(self.convz.dilation) == (1, 1) and (h.shape[1] + x.shape[1]) % 4 == 0
+        if not fused:
+            with AG.engine_convs():
+                hx = torch.cat([h, x], dim=1)
+                z = torch.sigmoid(self.convz(hx) + cz)
+                r = torch.sigmoid(self.convr(hx) + cr)
+                q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
+            return (1 - z) * h + z * q
+        cdt = amp.conv_out_dtype(h)                                   # dtype the reference's convolutions return here (autocast: fp16)
+        pad = self.convz.padding
+        hx = torch.cat([h, x], dim=1)
+        pre = AG.conv2d_pair(hx, self.convz.weight, self.convr.weight, padding=pad)                   # [convz(hx) | convr(hx)], fp32, no bias
+        z, rh = AG.gru_gates_rz(pre, self.convz.bias, self.convr.bias, cz, cr, h,
+                                rh_dtype=torch.promote_types(torch.promote_types(cdt, cr.dtype), h.dtype))   # r * h as the reference rounds it
+        qpre = AG.conv2d(torch.cat([rh, x], dim=1), self.convq.weight, None, 1, pad)
+        out_dt = torch.promote_types(torch.promote_types(torch.promote_types(cdt, cz.dtype), cq.dtype), h.dtype)
+        return AG.gru_gates_q(z, qpre, self.convq.bias, cq, h, out_dtype=out_dt)
 
     @amp.contract("gru")
     def forward(self, h, cz, cr, cq, *x_list):

@@ -143,10 +143,11 @@ def test_freeze_bn_training_step_converted_equals_unconverted(which):
         L, R = synth_images(1, 64, 128, seed=1)
         L, R = L.to(DEV), R.to(DEV)
     plain = _freeze_bn(copy.deepcopy(m).train()).to(DEV)
+    plain2 = _freeze_bn(copy.deepcopy(m).train()).to(DEV)          # a second unconverted instance: the spread between two model OBJECTS
     conv = _sync(_freeze_bn(m.train())).to(DEV)
     assert all(not x.training for x in conv.modules() if isinstance(x, nn.SyncBatchNorm))      # convert keeps the frozen (eval) flag
     losses, grads = [], []
-    for net in (plain, conv, plain):           # the third run (the unconverted model again) measures the step's own run-to-run spread
+    for net in (plain, conv, plain2):          # the third run (another unconverted instance) measures the step's own instance-to-instance spread
         net.zero_grad(set_to_none=True)
         out = net({"left": L, "right": R})
         loss = sum(p.float().abs().mean() for p in out["disp_preds"]) + (out["init_disp"].abs().mean() if "init_disp" in out else 0.0)
