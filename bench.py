@@ -899,7 +899,15 @@ def main():
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")     # DDP + graph capture (capture_training_step)
         if world > 1 or os.environ.get("OSA_BENCH_FORCE_DDP") == "1":
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
+            own_port = world == 1 and "RANK" not in os.environ          # --force-ddp picked MASTER_PORT itself: another process may grab it first
+            for attempt in range(4):
+                try:
+                    dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
+                    break
+                except Exception as ex:                                  # (DistNetworkError EADDRINUSE between _free_port() and the bind)
+                    if not own_port or attempt == 3 or "EADDRINUSE" not in str(ex):
+                        raise
+                    os.environ["MASTER_PORT"] = str(_free_port())
         from openstereo_amd import _lib, engine
         _lib.load()
         engine.set_precision(args.precision)

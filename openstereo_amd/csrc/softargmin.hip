@@ -69,11 +69,23 @@ struct UpArgs {
 // exp(x) for x <= 0 on the transcendental unit with a compensated argument: t = x * log2(e) is formed as
 // hi + lo (lo = the rounding error of the product plus the low bits of the constant), exp2(hi) comes from
 // v_exp_f32 and the lo part is applied to first order.  ~1.5 ulp, 6 VALU operations (expf: ~20).
+__device__ __forceinline__ float exp2_poly(float t) {         // 2^t for t <= 0 without the transcendental unit (r5 diagnosis, OSA_HEAD_EXP == 6)
+    const float tc = fmaxf(t, -150.f);
+    const float fl = floorf(tc), f = tc - fl;
+    float p = 1.530277e-4f;
+    p = fmaf(p, f, 1.339887e-3f); p = fmaf(p, f, 9.618437e-3f); p = fmaf(p, f, 5.550357e-2f);
+    p = fmaf(p, f, 2.402265e-1f); p = fmaf(p, f, 6.931472e-1f); p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)fl);
+}
 __device__ __forceinline__ float exp_neg(float x) {
     const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
     const float t = x * L2E;
     const float lo = fmaf(x, L2E, -t) + x * L2E_LO;
+#if defined(OSA_HEAD_EXP) && OSA_HEAD_EXP == 6
+    const float e = exp2_poly(t);
+#else
     const float e = __builtin_amdgcn_exp2f(t);
+#endif
     return (t < -126.f) ? e : fmaf(e, lo * 0.693147182464599609375f, e);     // x = -inf: e = 0 (lo would be NaN)
 }
 
