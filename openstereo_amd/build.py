@@ -23,6 +23,15 @@ SOURCES = ["api.hip", "volume.hip", "conv3d.hip", "conv_inst_f32.hip", "conv_ins
 ARCH = "gfx950"
 HIPCC_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
+# Per-file flags.  softargmin.hip is built WITHOUT the SLP vectoriser, i.e. without packed-fp32 VALU instructions (v_pk_mul / add / fma_f32):
+# r5 found the fused head returning wrong disparities in isolated quarter waves (16 pixels of one row, errors up to tens of pixels)
+# whenever the d-marching conv kernel (250-256 VGPRs, 16-pass f16 MFMAs) runs on another stream of the same GPU -- the timed
+# configuration's sub-batch streams.  Its loads are right (checksum of everything it loads: clean), its arithmetic is not (checksum of its
+# exponentials: dirty; polynomial exp2 instead of v_exp_f32: still dirty), and the same source compiled without packed math is clean:
+# 0 differing elements in 40 launches under that load against 40 of 40 launches with ~600 wrong pixels each
+# (profiles/round5/head_packed_math_under_march_load.txt, tools/diag_head_under_load.py).  Same arithmetic, same
+# order (-ffp-contract=off): results are bit-identical to the packed build on an otherwise idle GPU.
+EXTRA_FLAGS = {"softargmin.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -52,8 +61,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc, *HIPCC_FLAGS, "-c", s, "-o", o]
+        if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
+            cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

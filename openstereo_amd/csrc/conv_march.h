@@ -52,13 +52,8 @@ __device__ const float4 g_march_zeros[4] = {};       // source of the LDS-DMA la
 
 // INS = 1: the input is a split tensor (16-byte quads are the LDS image: asynchronous LDS-DMA staging); INS = 0: fp32 input, split while
 // it is staged through registers at the start of every pass (GwcNet: dres0.0 only, which reads the volume builder's fp32 output).
-#ifdef OSA_MARCH_VGPR      // r5 diagnosis builds: cap the kernel's register allocation below the 256 it takes by itself
-#define OSA_MARCH_ATTR __attribute__((amdgpu_num_vgpr(OSA_MARCH_VGPR)))
-#else
-#define OSA_MARCH_ATTR
-#endif
 template <int NWV, int TW, int OUTS, int INS>
-__global__ __launch_bounds__(NWV * 64, 2) OSA_MARCH_ATTR void conv_march_kernel(const ConvArgs p, const int dseg, const int nseg) {
+__global__ __launch_bounds__(NWV * 64, 2) void conv_march_kernel(const ConvArgs p, const int dseg, const int nseg) {
     using G = MarchGeo<NWV, TW>;
     constexpr int MT = G::MT, TH = G::TH, ROWQ = G::ROWQ, VQ = G::VQ, PLANEQ = G::PLANEQ, NTHR = G::NTHR, NP = G::NP, NPI = G::NPI;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];

@@ -48,27 +48,11 @@ static inline bool exp_set(const char*) { return false; }
 // means a redundant atomic) already covers their maximum.  Values are uint bit patterns of floats >= 0, so
 // integer order == float order; the atomics are fire-and-forget.
 constexpr int OSA_AMAX_SLOTS = 8, OSA_AMAX_STRIDE = 16;
-// -DOSA_AMAX_ATOMIC_READ=1 (r5 experiment, tools/build_variant.sh): the consumer reads the slots with device-scope atomic loads -- at the
-// point of the memory system where the producers' atomicMax / the clear's atomicExch execute -- instead of plain loads that may be
-// served from a line this XCD's L2 kept from an earlier launch (the open osa_amax_f32 defect).
-#ifndef OSA_AMAX_ATOMIC_READ
-#define OSA_AMAX_ATOMIC_READ 0
-#endif
 __device__ __forceinline__ float amax_read(const float* meta) {          // consumer side (after the producer kernel ended)
-#if OSA_AMAX_ATOMIC_READ
-    unsigned mb = 0u;
-#pragma unroll
-    for (int s = 0; s < OSA_AMAX_SLOTS; ++s) {
-        const unsigned v = __hip_atomic_load(reinterpret_cast<const unsigned*>(meta) + s * OSA_AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mb = v > mb ? v : mb;                                            // non-negative floats: integer order == float order (NaN bits win)
-    }
-    return __builtin_bit_cast(float, mb);
-#else
     float m = meta[0];
 #pragma unroll
     for (int s = 1; s < OSA_AMAX_SLOTS; ++s) m = fmaxf(m, meta[s * OSA_AMAX_STRIDE]);
     return m;
-#endif
 }
 __device__ __forceinline__ float* amax_slot(float* meta) { return meta + (blockIdx.x & (OSA_AMAX_SLOTS - 1)) * OSA_AMAX_STRIDE; }
 __device__ __forceinline__ unsigned amax_peek(float* meta) {

@@ -69,23 +69,11 @@ struct UpArgs {
 // exp(x) for x <= 0 on the transcendental unit with a compensated argument: t = x * log2(e) is formed as
 // hi + lo (lo = the rounding error of the product plus the low bits of the constant), exp2(hi) comes from
 // v_exp_f32 and the lo part is applied to first order.  ~1.5 ulp, 6 VALU operations (expf: ~20).
-__device__ __forceinline__ float exp2_poly(float t) {         // 2^t for t <= 0 without the transcendental unit (r5 diagnosis, OSA_HEAD_EXP == 6)
-    const float tc = fmaxf(t, -150.f);
-    const float fl = floorf(tc), f = tc - fl;
-    float p = 1.530277e-4f;
-    p = fmaf(p, f, 1.339887e-3f); p = fmaf(p, f, 9.618437e-3f); p = fmaf(p, f, 5.550357e-2f);
-    p = fmaf(p, f, 2.402265e-1f); p = fmaf(p, f, 6.931472e-1f); p = fmaf(p, f, 1.0f);
-    return ldexpf(p, (int)fl);
-}
 __device__ __forceinline__ float exp_neg(float x) {
     const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
     const float t = x * L2E;
     const float lo = fmaf(x, L2E, -t) + x * L2E_LO;
-#if defined(OSA_HEAD_EXP) && OSA_HEAD_EXP == 6
-    const float e = exp2_poly(t);
-#else
     const float e = __builtin_amdgcn_exp2f(t);
-#endif
     return (t < -126.f) ? e : fmaf(e, lo * 0.693147182464599609375f, e);     // x = -inf: e = 0 (lo would be NaN)
 }
 
@@ -163,29 +151,9 @@ __global__ __launch_bounds__(256) void upsample4_softargmin_kernel(const UpArgs 
     const int plane = p.Hl * p.Wl;
     const float* c = p.cost + (size_t)b * p.Dl * plane;
     const int o00 = y0 * p.Wl + x0, o01 = y0 * p.Wl + x1, o10 = y1 * p.Wl + x0, o11 = y1 * p.Wl + x1;
-#ifndef OSA_HEAD_EXP
-#define OSA_HEAD_EXP 0          // r5 diagnosis builds (tools/build_head_variant.sh): 1 = L1-bypassing loads, 2 = L1 invalidate at kernel start
-#endif
-#if OSA_HEAD_EXP == 2
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-#if OSA_HEAD_EXP == 4 || OSA_HEAD_EXP == 5
-    unsigned chk = 0u;            // 4: the kernel returns the XOR of the bit patterns of everything it LOADED instead of the disparity;
-#endif                            // 5: the XOR of the bit patterns of every exponential it computed (loads vs arithmetic under concurrent load)
-    auto tap = [&](const float* q) {
-#if OSA_HEAD_EXP == 4
-        const float v = *q;
-        chk ^= __builtin_bit_cast(unsigned, v) * 2654435761u + (chk >> 7);
-        return v;
-#elif OSA_HEAD_EXP == 1
-        return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#else
-        return *q;
-#endif
-    };
     auto bil = [&](int k) {
         const float* cp = c + (size_t)k * plane;
-        return w00 * tap(cp + o00) + w01 * tap(cp + o01) + w10 * tap(cp + o10) + w11 * tap(cp + o11);
+        return w00 * cp[o00] + w01 * cp[o01] + w10 * cp[o10] + w11 * cp[o11];
     };
     float vm = 0.f, vc = bil(0), vn = (p.Dl > 1) ? bil(1) : vc;
     float m = -INFINITY, se = 0.f, sd = 0.f;
@@ -201,20 +169,12 @@ __global__ __launch_bounds__(256) void upsample4_softargmin_kernel(const UpArgs 
         const float r = exp_neg(m - mn);                               // m = -inf at k = 0: r = 0
         const float e0 = exp_neg(s0 - mn), e1 = exp_neg(s1 - mn), e2 = exp_neg(s2 - mn), e3 = exp_neg(s3 - mn);
         const float d0 = (float)(4 * k);
-#if OSA_HEAD_EXP == 5
-        chk ^= (__builtin_bit_cast(unsigned, e0) + 3u * __builtin_bit_cast(unsigned, e1) + 5u * __builtin_bit_cast(unsigned, e2) + 7u * __builtin_bit_cast(unsigned, e3)
-                + 11u * __builtin_bit_cast(unsigned, r)) * 2654435761u + (chk >> 7);
-#endif
         se = fmaf(se, r, (e0 + e1) + (e2 + e3));
         sd = fmaf(sd, r, fmaf(e0, d0, fmaf(e1, d0 + 1.f, fmaf(e2, d0 + 2.f, e3 * (d0 + 3.f)))));
         m = mn;
         vm = vc; vc = vn; vn = vnn;
     }
-#if OSA_HEAD_EXP == 4 || OSA_HEAD_EXP == 5
-    p.out[i] = __builtin_bit_cast(float, chk);
-#else
     p.out[i] = sd / se;
-#endif
 }
 
 }  // namespace osa
