@@ -282,6 +282,24 @@ def _ranges(x, y, wscale, xmeta=None):
     return _lib.F16x3Ranges((xmeta if xmeta is not None else input_meta(x)).data_ptr(), None, None, attach_meta(y).data_ptr(), None, None, wscale.data_ptr())
 
 
+_PREC_ID = {"f32": 0, "f16x3": 1, "f16": 2}
+
+
+def _ext_conv(family, x, packed, y, dims, geom, precision, oscale, xmeta=None):
+    """The plain conv / transposed-conv launch of the training path through the PyTorch-ROCm C++ extension (torch.ops.osa_native.conv_ndhwc:
+    one dispatcher call, tensors in, current HIP stream inside) -- False when the extension is not loaded (the caller then goes through
+    ctypes; same entry point of the C ABI, bit-identical)."""
+    ext = engine._ext.load()
+    if ext is None:
+        return False
+    metas = []
+    if precision == "f16x3":
+        e = engine._empty(x.device)
+        metas = [xmeta if xmeta is not None else input_meta(x), e, e, attach_meta(y), e, e, oscale]
+    ext.conv_ndhwc(x, 0, packed, None, None, None, 0, y, 0, None, dims, geom, family, _PREC_ID[precision], 0, 0.0, 1.0, metas)
+    return True
+
+
 def _sfx_tail(precision, x, y, oscale, xmeta=None):
     """entry-point suffix and trailing arguments of a plain conv / deconv call in the given arithmetic mode"""
     if precision == "f16x3":
@@ -297,13 +315,15 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = _sfx_tail(precision, x, y, oscale, xmeta)
     macs = B * out_shape[0] * out_shape[1] * out_shape[2] * Ci * Co * k[0] * k[1] * k[2]
     with timing.span("conv3d", Ci, Co, k[1], stride, D, H, W, flops=2 * macs,
                      nbytes=4 * B * (D * H * W * Ci + out_shape[0] * out_shape[1] * out_shape[2] * Co)):
-        _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
-                  B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
-                  None, 0, 0, 0.0, *tail)
+        if not _ext_conv(0, x, packed, y, [B, D, H, W, Ci4, Cs, Co, CoS, 0, 0],
+                         [k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2]], precision, oscale, xmeta):
+            sfx, tail = _sfx_tail(precision, x, y, oscale, xmeta)
+            _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+                      B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
+                      None, 0, 0, 0.0, *tail)
     return y
 
 
@@ -315,11 +335,12 @@ def _run_deconv(x, packed, oscale, Ci, Co, k, pad, opad, precision):
     if CoS != Co:
         y.zero_()
     Ci4 = (Ci + 3) // 4 * 4
-    sfx, tail = _sfx_tail(precision, x, y, oscale)
     with timing.span("deconv3d", Ci, Co, k, 2, D, H, W, flops=2 * B * D * H * W * Ci * Co * k ** 3,
                      nbytes=4 * B * (D * H * W * Ci + od(D) * od(H) * od(W) * Co)):
-        _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
-                  B, D, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
+        if not _ext_conv(1, x, packed, y, [B, D, H, W, Ci4, Cs, Co, CoS, 0, 0], [k, pad, opad], precision, oscale):
+            sfx, tail = _sfx_tail(precision, x, y, oscale)
+            _lib.call("osa_deconv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+                      B, D, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
     return y
 
 
@@ -347,6 +368,21 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     lib = _lib.load()
     vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
     span = dict(flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2], nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co))
+    ext = engine._ext.load()
+    if ext is not None:
+        # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp conv_wgrad): workspace query, allocation and launch in one dispatcher call
+        ed = [B, D, H, W, Ci, xc.shape[1], Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed]
+        if precision == "f16" and WGRAD_F16 and ((stride == 1 and not transposed) or WGRAD_F16_CLASS):
+            with timing.span("wgrad_f16", Ci, Co, k[1], stride, D, H, W, transposed, **span):
+                if ext.conv_wgrad(xc, dyc, dw, ed, 2, None, None):
+                    return
+        if precision == "f16x3" and WGRAD_F16X3 and ((stride == 1 and not transposed) or WGRAD_F16X3_CLASS):
+            with timing.span("wgrad_f16x3", Ci, Co, k[1], stride, D, H, W, transposed, **span):
+                if ext.conv_wgrad(xc, dyc, dw, ed, 1, xmeta if xmeta is not None else input_meta(xc), dymeta if dymeta is not None else input_meta(dyc)):
+                    return
+        with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
+            ext.conv_wgrad(xc, dyc, dw, ed, 0, None, None)
+        return
     if precision == "f16" and WGRAD_F16 and ((stride == 1 and not transposed) or WGRAD_F16_CLASS):
         # native fp16 operands, one MFMA per product, no range blocks (AMP training: GradScaler owns the range)
         need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
@@ -491,6 +527,10 @@ class _ConvTranspose2d(torch.autograd.Function):
         if CoS != Co:
             y.zero_()
         Ci4 = (Ci + 3) // 4 * 4
+        if _ext_conv(2, xc, packed, y, [B, 1, H, W, Ci4, Cs, Co, CoS, 0, 0], [k, pad, opad], precision, osc):
+            ctx.save_for_backward(xc, wf)
+            ctx.meta = (pad, opad, precision, x.dtype)
+            return y[:, :Co, 0]
         sfx, tail = _sfx_tail(precision, xc, y, osc)
         _lib.call("osa_deconv2d_nhwc_" + sfx, xc.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
                   B, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)

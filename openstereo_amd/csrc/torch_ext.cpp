@@ -12,6 +12,7 @@
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
+#include <torch/csrc/autograd/custom_function.h>
 
 #include "../../include/openstereo_amd.h"
 
@@ -177,6 +178,270 @@ void conv_ndhwc(const at::Tensor& x, int64_t x_off, const at::Tensor& packed, co
         OSA_CALL(osa_deconv2d_nhwc_f16(xp, w, fpo(scale), fpo(shift), rp, yp, B, H, W, Ci, xCs, Co, yCs, rCs, k, pad, opad, gp, gCs, (int)act, (float)slope, st));
 }
 
+// ---- backward kernels of the memory-bound ops (r5: SURVEY 8b last row "*_fwd / *_bwd") --------------------------------------------------
+// d(gwc_volume) / d(corr_volume: groups = 1, dvol [B,1,D,H,W]) need the forward features; d(concat_volume) needs only their shape.
+std::tuple<at::Tensor, at::Tensor> volume_bwd(const at::Tensor& dvol, const c10::optional<at::Tensor>& left, const c10::optional<at::Tensor>& right,
+                                              at::IntArrayRef shape, int64_t maxdisp, int64_t groups, bool concat, bool mask_left) {
+    gpu_f32(dvol, "dvol");
+    TORCH_CHECK(shape.size() == 4, "volume_bwd: shape = [B, C, H, W] of one feature map");
+    const int64_t B = shape[0], C = shape[1], H = shape[2], W = shape[3];
+    const auto dv = dvol.contiguous();
+    auto dl = at::empty({B, C, H, W}, dv.options()), dr = at::empty({B, C, H, W}, dv.options());
+    if (concat) {
+        TORCH_CHECK(dv.dim() == 5 && dv.size(1) == 2 * C && dv.size(2) == maxdisp, "volume_bwd: dvol must be [B, 2C, maxdisp, H, W]");
+        OSA_CALL(osa_build_volume_bwd_f32(fp(dv), nullptr, nullptr, dl.data_ptr<float>(), dr.data_ptr<float>(), (int)B, (int)C, (int)H, (int)W, (int)maxdisp, 0, 1,
+                                          mask_left ? 1 : 0, (int)(2 * C), 0, cur_stream()));
+    } else {
+        TORCH_CHECK(left.has_value() && right.has_value(), "volume_bwd: the group-wise correlation gradient needs the forward features");
+        TORCH_CHECK(dv.dim() == 5 && dv.size(1) == groups && dv.size(2) == maxdisp, "volume_bwd: dvol must be [B, groups, maxdisp, H, W]");
+        const auto l = gpu_f32(*left, "left").contiguous(), r = gpu_f32(*right, "right").contiguous();
+        OSA_CALL(osa_build_volume_bwd_f32(fp(dv), fp(l), fp(r), dl.data_ptr<float>(), dr.data_ptr<float>(), (int)B, (int)C, (int)H, (int)W, (int)maxdisp, (int)groups, 0, 1,
+                                          (int)groups, 0, cur_stream()));
+    }
+    return {dl, dr};
+}
+
+at::Tensor softargmin_bwd(const at::Tensor& dout, int64_t D) {
+    gpu_f32(dout, "dout");
+    TORCH_CHECK(dout.dim() == 3, "softargmin_bwd: dout must be [B,H,W]");
+    const auto g = dout.contiguous();
+    auto dp = at::empty({g.size(0), D, g.size(1), g.size(2)}, g.options());
+    OSA_CALL(osa_softargmin_bwd_f32(fp(g), dp.data_ptr<float>(), (int)g.size(0), (int)D, (int)g.size(1), (int)g.size(2), cur_stream()));
+    return dp;
+}
+
+at::Tensor softmax_softargmin_bwd(const at::Tensor& cost, const at::Tensor& dout) {
+    gpu_f32(cost, "cost"); gpu_f32(dout, "dout");
+    TORCH_CHECK(cost.dim() == 4 && dout.dim() == 3, "softmax_softargmin_bwd: cost [B,D,H,W], dout [B,H,W]");
+    const auto c = cost.contiguous(), g = dout.contiguous();
+    auto dc = at::empty_like(c);
+    OSA_CALL(osa_softmax_softargmin_bwd_f32(fp(c), fp(g), dc.data_ptr<float>(), (int)c.size(0), (int)c.size(1), (int)c.size(2), (int)c.size(3), cur_stream()));
+    return dc;
+}
+
+// deterministic two-pass form (fold per output pixel, fixed-order gather per low-res cell); the scratch tensor comes from the caching allocator
+at::Tensor upsample_softargmin_bwd(const at::Tensor& cost_lowres, const at::Tensor& dout, int64_t maxdisp, int64_t h, int64_t w, bool align_corners) {
+    gpu_f32(cost_lowres, "cost_lowres"); gpu_f32(dout, "dout");
+    TORCH_CHECK(cost_lowres.dim() == 4 && dout.dim() == 3, "upsample_softargmin_bwd: cost [B,Dl,Hl,Wl], dout [B,h,w]");
+    const auto c = cost_lowres.contiguous(), g = dout.contiguous();
+    auto dc = at::empty_like(c);
+    const size_t need = osa_upsample_softargmin_bwd_workspace_bytes((int)c.size(0), (int)c.size(1), (int)h, (int)w);
+    auto ws = at::empty({(int64_t)((need + 3) / 4)}, c.options());
+    OSA_CALL(osa_upsample_softargmin_bwd_ws_f32(fp(c), fp(g), dc.data_ptr<float>(), (int)c.size(0), (int)c.size(1), (int)c.size(2), (int)c.size(3), (int)maxdisp,
+                                                (int)h, (int)w, align_corners ? 1 : 0, ws.data_ptr<float>(), need, cur_stream()));
+    return dc;
+}
+
+// ---- the fused NDHWC cost-volume builder the engine models run (ops.build_cost_volume_from_cl) -----------------------------------------
+// gwc_feat / cat_feat: NHWC feature maps of the 2B images (left images first), logical [2B, Cs, 1, H, W] with channels_last_3d strides.
+// Returns the [B, G + 2 Cc, maxdisp, H, W] NDHWC volume; out_split asks for the f16x3 chain's split format (taken when the call is
+// eligible and both range blocks are there: the second result says which format was written).  out_meta: the volume's range block.
+std::tuple<at::Tensor, bool> cost_volume_cl(const at::Tensor& gwc_feat, const c10::optional<at::Tensor>& cat_feat, int64_t B, int64_t num_groups, int64_t maxdisp,
+                                            int64_t gwc_channels, int64_t cat_channels, int64_t gwc_off, bool mask_left, bool out_split,
+                                            const c10::optional<at::Tensor>& gwc_meta, const c10::optional<at::Tensor>& cat_meta, const at::Tensor& out_meta) {
+    gpu_f32(gwc_feat, "gwc_feat"); gpu_f32(out_meta, "out_meta");
+    TORCH_CHECK(gwc_feat.dim() == 5 && gwc_feat.size(0) == 2 * B && gwc_feat.size(2) == 1 && gwc_feat.stride(1) == 1, "cost_volume_cl: gwc_feat must be NHWC [2B, Cs, 1, H, W]");
+    const int64_t Gs = gwc_feat.size(1), H = gwc_feat.size(3), W = gwc_feat.size(4);
+    const int64_t C = gwc_channels > 0 ? gwc_channels : Gs - gwc_off;
+    const float* lg = fp(gwc_feat) + gwc_off;
+    const float* rg = lg + B * H * W * Gs;
+    const float *lc = nullptr, *rc = nullptr;
+    int64_t Cc = 0, cs = 0;
+    if (cat_feat.has_value() && cat_feat->defined()) {
+        gpu_f32(*cat_feat, "cat_feat");
+        TORCH_CHECK(cat_feat->dim() == 5 && cat_feat->size(0) == 2 * B && cat_feat->size(3) == H && cat_feat->size(4) == W && cat_feat->stride(1) == 1,
+                    "cost_volume_cl: cat_feat must be NHWC [2B, cs, 1, H, W] at the gwc features' resolution");
+        cs = cat_feat->size(1); Cc = cat_channels > 0 ? cat_channels : cs;
+        lc = fp(*cat_feat); rc = lc + B * H * W * cs;
+    }
+    const int64_t nch = num_groups + 2 * Cc, VC = (nch + 3) / 4 * 4;
+    auto out = at::empty({B, maxdisp, H, W, VC}, gwc_feat.options()).permute({0, 4, 1, 2, 3});        // logical NCDHW, NDHWC in memory
+    if (VC != nch) out.zero_();
+    const float* gm = fpo(gwc_meta); const float* cm = fpo(cat_meta);
+    const bool split = out_split && VC == nch && (C == 0 || gm) && (Cc == 0 || cm) &&
+        osa_build_volume_nhwc_split_eligible(lc, rc, out.data_ptr<float>(), (int)C, (int)num_groups, (int)Gs, (int)Cc, (int)cs, (int)VC, 0, (int)W, (int)maxdisp) == 1;
+    if (split)
+        OSA_CALL(osa_build_volume_nhwc_split_f16x3(lg, rg, (int)C, (int)num_groups, (int)Gs, lc, rc, (int)Cc, (int)cs, out.data_ptr<float>(), (int)VC, 0, (int)B, (int)H, (int)W,
+                                                   (int)maxdisp, mask_left ? 1 : 0, gm, cm, out_meta.data_ptr<float>(), cur_stream()));
+    else
+        OSA_CALL(osa_build_volume_nhwc_f32(lg, rg, (int)C, (int)num_groups, (int)Gs, lc, rc, (int)Cc, (int)cs, out.data_ptr<float>(), (int)VC, 0, (int)B, (int)H, (int)W,
+                                           (int)maxdisp, mask_left ? 1 : 0, out_meta.data_ptr<float>(), cur_stream()));
+    return {out, split};
+}
+
+// ---- weight gradient of the training path (autograd._wgrad): two-stage deterministic form, workspace from the caching allocator -----------
+// dims: [B, D, H, W, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w, dil_d, dil_h, dil_w, transposed].  prec: 0 exact
+// fp32, 1 f16x3 (x_meta / dy_meta required), 2 native f16 (metas optional).  Returns false when the split-precision forms do not cover the layer
+// (the caller then asks for prec 0); dw is written in place ([Co][Ci][k] or, transposed, [Ci][Co][k]).
+bool conv_wgrad(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, at::IntArrayRef dims, int64_t prec, const c10::optional<at::Tensor>& x_meta,
+                const c10::optional<at::Tensor>& dy_meta) {
+    gpu_f32(x, "x"); gpu_f32(dy, "dy"); gpu_f32(dw, "dw");
+    TORCH_CHECK(dims.size() == 22, "conv_wgrad: dims = [B, D, H, W, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad x3, dil x3, transposed]");
+    int d[22];
+    for (int i = 0; i < 22; ++i) d[i] = (int)dims[i];
+    const size_t need = prec == 0
+        ? osa_conv3d_wgrad_workspace_bytes(d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21])
+        : osa_conv3d_wgrad_f16x3_workspace_bytes(d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21]);
+    if (need == 0) {
+        TORCH_CHECK(prec != 0, "conv_wgrad: unsupported layer");
+        return false;
+    }
+    auto ws = at::empty({(int64_t)((need + 3) / 4)}, x.options());
+    void* st = cur_stream();
+#define OSA_WG_ARGS fp(x), fp(dy), dw.data_ptr<float>(), d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21]
+    if (prec == 0) OSA_CALL(osa_conv3d_wgrad_ws_f32(OSA_WG_ARGS, ws.data_ptr<float>(), need, st));
+    else if (prec == 1) OSA_CALL(osa_conv3d_wgrad_ws_f16x3(OSA_WG_ARGS, fpo(x_meta), fpo(dy_meta), ws.data_ptr<float>(), need, st));
+    else OSA_CALL(osa_conv3d_wgrad_ws_f16(OSA_WG_ARGS, fpo(x_meta), fpo(dy_meta), ws.data_ptr<float>(), need, st));
+#undef OSA_WG_ARGS
+    return true;
+}
+
+// ---- Meta kernels (shape / dtype inference in C++: FakeTensor tracing, torch.export, torch.compile need no Python shim) --------------------
+at::Tensor gwc_volume_meta(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, int64_t groups) {
+    TORCH_CHECK(l.dim() == 4 && l.sizes() == r.sizes() && groups > 0 && l.size(1) % groups == 0, "gwc_volume: [B,C,H,W] features of equal shape, C % groups == 0");
+    return at::empty({l.size(0), groups, maxdisp, l.size(2), l.size(3)}, l.options());
+}
+at::Tensor concat_volume_meta(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, bool) {
+    TORCH_CHECK(l.dim() == 4 && l.sizes() == r.sizes(), "concat_volume: [B,C,H,W] features of equal shape");
+    return at::empty({l.size(0), 2 * l.size(1), maxdisp, l.size(2), l.size(3)}, l.options());
+}
+at::Tensor corr_volume_meta(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp) {
+    TORCH_CHECK(l.dim() == 4 && l.sizes() == r.sizes(), "corr_volume: [B,C,H,W] features of equal shape");
+    return at::empty({l.size(0), maxdisp, l.size(2), l.size(3)}, l.options());
+}
+at::Tensor softargmin_meta(const at::Tensor& p) { TORCH_CHECK(p.dim() == 4, "softargmin: [B,D,H,W]"); return at::empty({p.size(0), p.size(2), p.size(3)}, p.options()); }
+std::tuple<at::Tensor, at::Tensor> softmax_softargmin_meta(const at::Tensor& c, bool return_prob) {
+    TORCH_CHECK(c.dim() == 4, "softmax_softargmin: [B,D,H,W]");
+    return {at::empty({c.size(0), c.size(2), c.size(3)}, c.options()), return_prob ? at::empty_like(c) : at::empty({0}, c.options())};
+}
+at::Tensor upsample_softargmin_meta(const at::Tensor& c, int64_t, int64_t h, int64_t w, bool) {
+    TORCH_CHECK(c.dim() == 4, "upsample_softargmin: [B,Dl,Hl,Wl]");
+    return at::empty({c.size(0), h, w}, c.options());
+}
+at::Tensor context_upsample_meta(const at::Tensor& d, const at::Tensor& wt, int64_t scale, bool, double) {
+    TORCH_CHECK(d.dim() == 4 && d.size(1) == 1 && wt.dim() == 4 && wt.size(1) == 9, "context_upsample: disp [B,1,h,w], weights [B,9,s*h,s*w]");
+    return at::empty({d.size(0), scale * d.size(2), scale * d.size(3)}, d.options());
+}
+std::tuple<at::Tensor, at::Tensor> volume_bwd_meta(const at::Tensor& dvol, const c10::optional<at::Tensor>&, const c10::optional<at::Tensor>&, at::IntArrayRef shape, int64_t,
+                                                   int64_t, bool, bool) {
+    return {at::empty(shape, dvol.options()), at::empty(shape, dvol.options())};
+}
+at::Tensor softargmin_bwd_meta(const at::Tensor& g, int64_t D) { return at::empty({g.size(0), D, g.size(1), g.size(2)}, g.options()); }
+at::Tensor softmax_softargmin_bwd_meta(const at::Tensor& c, const at::Tensor&) { return at::empty_like(c); }
+at::Tensor upsample_softargmin_bwd_meta(const at::Tensor& c, const at::Tensor&, int64_t, int64_t, int64_t, bool) { return at::empty_like(c); }
+
+// ---- autograd in C++ (TORCH_LIBRARY_IMPL(osa_native, Autograd, ...)): torch.ops.osa_native.* are differentiable without any Python ------
+// Each Function redispatches below the Autograd key for its forward and calls the *_bwd op in backward (so double tracing sees ops, too).
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+struct GwcVolumeFn : torch::autograd::Function<GwcVolumeFn> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, int64_t groups) {
+        at::AutoDispatchBelowADInplaceOrView g;
+        ctx->save_for_backward({l, r});
+        ctx->saved_data["maxdisp"] = maxdisp; ctx->saved_data["groups"] = groups;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::gwc_volume", "").typed<at::Tensor(const at::Tensor&, const at::Tensor&, int64_t, int64_t)>();
+        return op.call(l, r, maxdisp, groups);
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list gy) {
+        const auto sv = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::volume_bwd", "")
+            .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const c10::optional<at::Tensor>&, const c10::optional<at::Tensor>&, at::IntArrayRef, int64_t, int64_t, bool, bool)>();
+        auto [dl, dr] = op.call(gy[0].to(at::kFloat), sv[0].to(at::kFloat), sv[1].to(at::kFloat), sv[0].sizes(), ctx->saved_data["maxdisp"].toInt(), ctx->saved_data["groups"].toInt(), false, true);
+        return {dl.to(sv[0].scalar_type()), dr.to(sv[1].scalar_type()), at::Tensor(), at::Tensor()};
+    }
+};
+at::Tensor gwc_volume_autograd(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, int64_t groups) { return GwcVolumeFn::apply(l, r, maxdisp, groups); }
+
+struct ConcatVolumeFn : torch::autograd::Function<ConcatVolumeFn> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, bool mask_left) {
+        at::AutoDispatchBelowADInplaceOrView g;
+        ctx->saved_data["shape"] = l.sizes().vec(); ctx->saved_data["maxdisp"] = maxdisp; ctx->saved_data["mask_left"] = mask_left;
+        ctx->saved_data["dtype"] = (int64_t)l.scalar_type();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::concat_volume", "").typed<at::Tensor(const at::Tensor&, const at::Tensor&, int64_t, bool)>();
+        return op.call(l, r, maxdisp, mask_left);
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list gy) {
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::volume_bwd", "")
+            .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const c10::optional<at::Tensor>&, const c10::optional<at::Tensor>&, at::IntArrayRef, int64_t, int64_t, bool, bool)>();
+        const auto shape = ctx->saved_data["shape"].toIntVector();
+        auto [dl, dr] = op.call(gy[0].to(at::kFloat), c10::nullopt, c10::nullopt, shape, ctx->saved_data["maxdisp"].toInt(), 0, true, ctx->saved_data["mask_left"].toBool());
+        const auto dt = (at::ScalarType)ctx->saved_data["dtype"].toInt();
+        return {dl.to(dt), dr.to(dt), at::Tensor(), at::Tensor()};
+    }
+};
+at::Tensor concat_volume_autograd(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, bool mask_left) { return ConcatVolumeFn::apply(l, r, maxdisp, mask_left); }
+
+struct CorrVolumeFn : torch::autograd::Function<CorrVolumeFn> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& l, const at::Tensor& r, int64_t maxdisp) {
+        at::AutoDispatchBelowADInplaceOrView g;
+        ctx->save_for_backward({l, r});
+        ctx->saved_data["maxdisp"] = maxdisp;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::corr_volume", "").typed<at::Tensor(const at::Tensor&, const at::Tensor&, int64_t)>();
+        return op.call(l, r, maxdisp);
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list gy) {
+        const auto sv = ctx->get_saved_variables();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::volume_bwd", "")
+            .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const c10::optional<at::Tensor>&, const c10::optional<at::Tensor>&, at::IntArrayRef, int64_t, int64_t, bool, bool)>();
+        auto [dl, dr] = op.call(gy[0].to(at::kFloat).unsqueeze(1), sv[0].to(at::kFloat), sv[1].to(at::kFloat), sv[0].sizes(), ctx->saved_data["maxdisp"].toInt(), 1, false, true);
+        return {dl.to(sv[0].scalar_type()), dr.to(sv[1].scalar_type()), at::Tensor()};
+    }
+};
+at::Tensor corr_volume_autograd(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp) { return CorrVolumeFn::apply(l, r, maxdisp); }
+
+struct SoftargminFn : torch::autograd::Function<SoftargminFn> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& p) {
+        at::AutoDispatchBelowADInplaceOrView g;
+        ctx->saved_data["D"] = p.size(1); ctx->saved_data["dtype"] = (int64_t)p.scalar_type();
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::softargmin", "").typed<at::Tensor(const at::Tensor&)>();
+        return op.call(p);
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list gy) {
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::softargmin_bwd", "").typed<at::Tensor(const at::Tensor&, int64_t)>();
+        return {op.call(gy[0].to(at::kFloat), ctx->saved_data["D"].toInt()).to((at::ScalarType)ctx->saved_data["dtype"].toInt())};
+    }
+};
+at::Tensor softargmin_autograd(const at::Tensor& p) { return SoftargminFn::apply(p); }
+
+struct SoftmaxSoftargminFn : torch::autograd::Function<SoftmaxSoftargminFn> {
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& c, bool return_prob) {
+        at::AutoDispatchBelowADInplaceOrView g;
+        ctx->save_for_backward({c});
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::softmax_softargmin", "").typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, bool)>();
+        auto [out, prob] = op.call(c, return_prob);
+        ctx->mark_non_differentiable({prob});                 // (the probability volume is a by-product for inspection: gradients flow through `out`)
+        return {out, prob};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list gy) {
+        const auto c = ctx->get_saved_variables()[0];
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::softmax_softargmin_bwd", "").typed<at::Tensor(const at::Tensor&, const at::Tensor&)>();
+        return {op.call(c.to(at::kFloat), gy[0].to(at::kFloat)).to(c.scalar_type()), at::Tensor()};
+    }
+};
+std::tuple<at::Tensor, at::Tensor> softmax_softargmin_autograd(const at::Tensor& c, bool return_prob) {
+    auto r = SoftmaxSoftargminFn::apply(c, return_prob);
+    return {r[0], r[1]};
+}
+
+struct UpsampleSoftargminFn : torch::autograd::Function<UpsampleSoftargminFn> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& c, int64_t maxdisp, int64_t h, int64_t w, bool align) {
+        at::AutoDispatchBelowADInplaceOrView g;
+        ctx->save_for_backward({c});
+        ctx->saved_data["maxdisp"] = maxdisp; ctx->saved_data["h"] = h; ctx->saved_data["w"] = w; ctx->saved_data["align"] = align;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::upsample_softargmin", "").typed<at::Tensor(const at::Tensor&, int64_t, int64_t, int64_t, bool)>();
+        return op.call(c, maxdisp, h, w, align);
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list gy) {
+        const auto c = ctx->get_saved_variables()[0];
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("osa_native::upsample_softargmin_bwd", "")
+            .typed<at::Tensor(const at::Tensor&, const at::Tensor&, int64_t, int64_t, int64_t, bool)>();
+        auto dc = op.call(c.to(at::kFloat), gy[0].to(at::kFloat), ctx->saved_data["maxdisp"].toInt(), ctx->saved_data["h"].toInt(), ctx->saved_data["w"].toInt(),
+                          ctx->saved_data["align"].toBool());
+        return {dc.to(c.scalar_type()), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+at::Tensor upsample_softargmin_autograd(const at::Tensor& c, int64_t maxdisp, int64_t h, int64_t w, bool align) { return UpsampleSoftargminFn::apply(c, maxdisp, h, w, align); }
+
 int64_t abi_version() { return osa_abi_version(); }
 
 }  // namespace
@@ -192,6 +457,14 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("context_upsample(Tensor disp_low, Tensor up_weights, int scale=4, bool softmax_weights=False, float gain=1.0) -> Tensor");
     m.def("conv_ndhwc(Tensor x, int x_off, Tensor packed, Tensor? scale, Tensor? shift, Tensor? residual, int res_off, Tensor(a!) out, int out_off, "
           "Tensor? gate, int[] dims, int[] geom, int family, int prec, int act, float slope, float out_scale, Tensor[] metas) -> ()");
+    // r5: backward kernels, the fused NDHWC builder, the weight gradient
+    m.def("volume_bwd(Tensor dvol, Tensor? left, Tensor? right, int[] shape, int maxdisp, int groups, bool concat, bool mask_left) -> (Tensor, Tensor)");
+    m.def("softargmin_bwd(Tensor dout, int D) -> Tensor");
+    m.def("softmax_softargmin_bwd(Tensor cost, Tensor dout) -> Tensor");
+    m.def("upsample_softargmin_bwd(Tensor cost_lowres, Tensor dout, int maxdisp, int h, int w, bool align_corners=False) -> Tensor");
+    m.def("cost_volume_cl(Tensor gwc_feat, Tensor? cat_feat, int B, int num_groups, int maxdisp, int gwc_channels, int cat_channels, int gwc_off, bool mask_left, "
+          "bool out_split, Tensor? gwc_meta, Tensor? cat_meta, Tensor(a!) out_meta) -> (Tensor, bool)");
+    m.def("conv_wgrad(Tensor x, Tensor dy, Tensor(a!) dw, int[] dims, int prec, Tensor? x_meta, Tensor? dy_meta) -> bool");
 }
 
 TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers under PyTorch's CUDA dispatch key)
@@ -203,4 +476,33 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("upsample_softargmin", &upsample_softargmin);
     m.impl("context_upsample", &context_upsample);
     m.impl("conv_ndhwc", &conv_ndhwc);
+    m.impl("volume_bwd", &volume_bwd);
+    m.impl("softargmin_bwd", &softargmin_bwd);
+    m.impl("softmax_softargmin_bwd", &softmax_softargmin_bwd);
+    m.impl("upsample_softargmin_bwd", &upsample_softargmin_bwd);
+    m.impl("cost_volume_cl", &cost_volume_cl);
+    m.impl("conv_wgrad", &conv_wgrad);
+}
+
+TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference without a device: FakeTensor, torch.export, torch.compile
+    m.impl("gwc_volume", &gwc_volume_meta);
+    m.impl("concat_volume", &concat_volume_meta);
+    m.impl("corr_volume", &corr_volume_meta);
+    m.impl("softargmin", &softargmin_meta);
+    m.impl("softmax_softargmin", &softmax_softargmin_meta);
+    m.impl("upsample_softargmin", &upsample_softargmin_meta);
+    m.impl("context_upsample", &context_upsample_meta);
+    m.impl("volume_bwd", &volume_bwd_meta);
+    m.impl("softargmin_bwd", &softargmin_bwd_meta);
+    m.impl("softmax_softargmin_bwd", &softmax_softargmin_bwd_meta);
+    m.impl("upsample_softargmin_bwd", &upsample_softargmin_bwd_meta);
+}
+
+TORCH_LIBRARY_IMPL(osa_native, Autograd, m) {    // differentiable in C++: backward = the engine's *_bwd kernels (no Python autograd.Function involved)
+    m.impl("gwc_volume", &gwc_volume_autograd);
+    m.impl("concat_volume", &concat_volume_autograd);
+    m.impl("corr_volume", &corr_volume_autograd);
+    m.impl("softargmin", &softargmin_autograd);
+    m.impl("softmax_softargmin", &softmax_softargmin_autograd);
+    m.impl("upsample_softargmin", &upsample_softargmin_autograd);
 }

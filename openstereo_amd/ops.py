@@ -260,11 +260,22 @@ def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_ch
         lc, rc = cat_feat.data_ptr(), cat_feat.data_ptr() + B * H * W * cs * 4
     nch = num_groups + 2 * Cc
     VC = (nch + 3) // 4 * 4
+    gm = getattr(gwc_feat, "_osa_meta", None) if C > 0 else None
+    cm = getattr(cat_feat, "_osa_meta", None) if (cat_feat is not None and Cc > 0) else None
+    ext = _ext.load()
+    if ext is not None and gwc_feat.dtype == torch.float32 and (cat_feat is None or cat_feat.dtype == torch.float32):
+        # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp cost_volume_cl): allocation, eligibility check and launch in one dispatcher call
+        from .ranges import new_meta
+        om = new_meta(gwc_feat.device)
+        with timing.span("build_volume", C, num_groups, Cc, NDHWC, maxdisp, H, W):
+            out, split = ext.cost_volume_cl(gwc_feat, cat_feat, B, num_groups, maxdisp, C, Cc, gwc_off, bool(mask_left), bool(out_split), gm, cm, om)
+        out._osa_meta = om
+        if split:
+            out._osa_split = True
+        return out
     out = empty_cl(B, VC, maxdisp, H, W, gwc_feat.device)
     if VC != nch:
         out.zero_()
-    gm = getattr(gwc_feat, "_osa_meta", None) if C > 0 else None
-    cm = getattr(cat_feat, "_osa_meta", None) if (cat_feat is not None and Cc > 0) else None
     split = bool(out_split) and VC == nch and (C == 0 or gm is not None) and (Cc == 0 or cm is not None) and \
         _lib.load().osa_build_volume_nhwc_split_eligible(lc, rc, out.data_ptr(), C, num_groups, Gs, Cc, cs, VC, 0, W, maxdisp) == 1
     with timing.span("build_volume", C, num_groups, Cc, NDHWC, maxdisp, H, W):

@@ -50,6 +50,16 @@ out["corr"] = ops.correlation_volume(a, b, 8).cpu().numpy()
 c = torch.randn(2, 8, 6, 20, generator=g).cuda()
 out["sm"] = ops.softmax_disparity_regression(c, 8).cpu().numpy()
 out["up"] = ops.upsample_softargmin(c, 32, 24, 80).cpu().numpy()
+# training path: conv / dgrad / wgrad launches (autograd._ext_conv, conv_wgrad), in the three arithmetic modes
+from openstereo_amd import autograd as AG
+x = torch.randn(2, 32, 4, 9, 12, generator=g).cuda()
+w = (torch.randn(32, 32, 3, 3, 3, generator=g) * 0.1).cuda()
+gy = torch.randn(2, 32, 4, 9, 12, generator=g).cuda()
+for prec in ("f32", "f16x3", "f16"):
+    xe, we = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y = AG.conv3d(xe, we, None, 1, 1, 1, precision=prec)
+    y.backward(gy)
+    out["train_y_" + prec], out["train_dx_" + prec], out["train_dw_" + prec] = y.detach().cpu().numpy(), xe.grad.cpu().numpy(), we.grad.cpu().numpy()
 out["ext"] = np.array([_ext.load() is not None])
 np.savez(sys.argv[1], **out)
 ''' % ROOT
@@ -64,3 +74,84 @@ np.savez(sys.argv[1], **out)
     for k in res["ext"]:
         if k != "ext":
             assert np.array_equal(res["ext"][k], res["ctypes"][k]), k
+
+
+NEW_OPS = ("volume_bwd", "softargmin_bwd", "softmax_softargmin_bwd", "upsample_softargmin_bwd", "cost_volume_cl", "conv_wgrad")
+
+
+def test_meta_kernels_and_autograd_registration_in_cpp(lib):
+    """r5: shape inference and autograd are registered in C++ (TORCH_LIBRARY_IMPL Meta / Autograd), so a
+    FakeTensor / export trace and a backward pass need no Python shim.  Device-free: meta tensors."""
+    from openstereo_amd import _ext
+    ns = _ext.load()
+    assert ns is not None
+    for name in NEW_OPS:
+        assert hasattr(ns, name), name
+    m = lambda *s: torch.empty(*s, device="meta")
+    l = m(2, 40, 8, 16)
+    assert ns.gwc_volume(l, l, 12, 8).shape == (2, 8, 12, 8, 16)
+    assert ns.concat_volume(l, l, 12, True).shape == (2, 80, 12, 8, 16)
+    assert ns.corr_volume(l, l, 12).shape == (2, 12, 8, 16)
+    c = m(2, 12, 8, 16)
+    assert ns.softargmin(c).shape == (2, 8, 16)
+    out, prob = ns.softmax_softargmin(c, True)
+    assert out.shape == (2, 8, 16) and prob.shape == c.shape
+    assert ns.upsample_softargmin(c, 48, 32, 64, False).shape == (2, 32, 64)
+    assert ns.context_upsample(m(1, 1, 4, 5), m(1, 9, 16, 20), 4, False, 1.0).shape == (1, 16, 20)
+    dl, dr = ns.volume_bwd(m(2, 8, 12, 8, 16), l, l, [2, 40, 8, 16], 12, 8, False, True)
+    assert dl.shape == dr.shape == (2, 40, 8, 16)
+    assert ns.softargmin_bwd(m(2, 8, 16), 12).shape == (2, 12, 8, 16)
+    assert ns.upsample_softargmin_bwd(c, m(2, 32, 64), 48, 32, 64, False).shape == c.shape
+    with pytest.raises(RuntimeError):
+        ns.gwc_volume(m(2, 40, 8, 16), m(2, 40, 8, 16), 12, 7)            # cost_volume.py:61: C % groups
+    # the Autograd key: outputs of differentiable ops carry a C++ grad_fn
+    for fn in (lambda x: ns.gwc_volume(x, x, 12, 8), lambda x: ns.concat_volume(x, x, 12, True), lambda x: ns.corr_volume(x, x, 12)):
+        y = fn(torch.empty(2, 40, 8, 16, device="meta", requires_grad=True))
+        assert y.requires_grad and "CppFunction" in type(y.grad_fn).__name__ or "Backward" in type(y.grad_fn).__name__
+    cc = torch.empty(2, 12, 8, 16, device="meta", requires_grad=True)
+    assert ns.softargmin(cc).requires_grad and ns.upsample_softargmin(cc, 48, 32, 64, False).requires_grad
+    o, p_ = ns.softmax_softargmin(cc, True)
+    assert o.requires_grad and not p_.requires_grad
+    # FakeTensor tracing sees opaque ops with the right shapes
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        f = torch.empty(2, 40, 8, 16, device="cuda")
+        assert ns.gwc_volume(f, f, 12, 8).shape == (2, 8, 12, 8, 16)
+
+
+@pytest.mark.gpu
+def test_cpp_autograd_matches_the_python_custom_ops_bit_for_bit():
+    """gradients through torch.ops.osa_native.* (autograd in C++) == gradients through torch.ops.openstereo_amd.* (torch.library.custom_op +
+    Python autograd formulas over ctypes): the same backward kernels behind two registrations; and torch.library.opcheck on the C++ ops."""
+    import openstereo_amd.torch_ops  # noqa: F401
+    from openstereo_amd import _ext
+    ns, py = _ext.load(), torch.ops.openstereo_amd
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    a, b = r(2, 16, 6, 20), r(2, 16, 6, 20)
+    c = r(2, 8, 6, 20)
+    cases = [
+        ("gwc", lambda x, y: ns.gwc_volume(x, y, 8, 4), lambda x, y: py.gwc_volume(x, y, 8, 4), (a, b)),
+        ("concat", lambda x, y: ns.concat_volume(x, y, 8, True), lambda x, y: py.concat_volume(x, y, 8, True), (a, b)),
+        ("corr", lambda x, y: ns.corr_volume(x, y, 8), lambda x, y: py.corr_volume(x, y, 8), (a, b)),
+        ("softargmin", lambda x: ns.softargmin(torch.softmax(x, 1)), lambda x: py.softargmin(torch.softmax(x, 1), False), (c,)),
+        ("softmax_softargmin", lambda x: ns.softmax_softargmin(x, False)[0], lambda x: py.softmax_softargmin(x, False), (c,)),
+        ("upsample_softargmin", lambda x: ns.upsample_softargmin(x, 32, 24, 80, False), lambda x: py.upsample_softargmin(x, 32, 24, 80, False), (c,)),
+    ]
+    for name, f_cpp, f_py, args in cases:
+        res = []
+        for f in (f_cpp, f_py):
+            leaves = [t.clone().requires_grad_() for t in args]
+            y = f(*leaves)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).cuda()
+            y.backward(gy)
+            res.append((y.detach(), [t.grad for t in leaves]))
+        assert torch.equal(res[0][0], res[1][0]), name
+        for ga, gb in zip(res[0][1], res[1][1]):
+            assert ga is not None and torch.equal(ga, gb), name
+    from torch.library import opcheck
+    for op, args in ((ns.gwc_volume.default, (a.clone().requires_grad_(), b.clone().requires_grad_(), 8, 4)),
+                     (ns.concat_volume.default, (a.clone().requires_grad_(), b.clone().requires_grad_(), 8, True)),
+                     (ns.upsample_softargmin.default, (c.clone().requires_grad_(), 32, 24, 80, False)),
+                     (ns.softmax_softargmin.default, (c.clone().requires_grad_(), False))):
+        opcheck(op, args, test_utils=("test_schema", "test_autograd_registration", "test_faketensor"))
