@@ -67,6 +67,24 @@ def _free_port():
     return p
 
 
+def _pin_host_threads(local_rank, world):
+    """N ranks on one host: each rank keeps to its own contiguous share of the CPUs this job may use (cores are
+    enumerated socket by socket, so a contiguous block stays on one NUMA node for the usual 2-socket x 4-GPU layout) and sizes torch's
+    intra-op pool to it -- eight ranks would otherwise each start a 128-thread pool and migrate across sockets while they launch kernels.
+    World size 1 (the driver's N = 1 run, whose rank 0 also times the CPU baseline on ALL host cores) is left alone.  Returns the CPU set."""
+    if world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // world)
+        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus[-per:]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+        return mine
+    except OSError:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -880,6 +898,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    pinned = _pin_host_threads(local, world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or plain `python bench.py --gpus N`)"
     dist = None
     if args.stub:
@@ -972,6 +991,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": wl.scaling,
             "vs_baseline": None, "dtype": "n/a (stub)" if args.stub else DTYPES[args.precision], "data": "synthetic"}
     cfg = wl.config(args)
+    if pinned is not None:
+        cfg["host_cpus_of_rank0"] = f"{pinned[0]}-{pinned[-1]} ({len(pinned)} of the job's CPUs, {torch.get_num_threads()} intra-op threads)"
     cfg.update({"pairs_per_gpu_per_step": B, "parallelism": (f"DDP x{world} (RCCL all-reduce of gradients)" if wl.training else f"independent pairs x{world}"),
                 "precision": args.precision, "launch": ("hipGraph replay" + (" of the whole training step (forward + loss + backward + optimizer)" if wl.training else ""))
                 if graph is not None else "eager"})

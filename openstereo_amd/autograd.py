@@ -285,7 +285,7 @@ def _ranges(x, y, wscale, xmeta=None):
 _PREC_ID = {"f32": 0, "f16x3": 1, "f16": 2}
 
 
-def _ext_conv(family, x, packed, y, dims, geom, precision, oscale, xmeta=None):
+def _ext_conv(family, x, packed, y, dims, geom, precision, oscale, xmeta=None, scale=None, shift=None):
     """The plain conv / transposed-conv launch of the training path through the PyTorch-ROCm C++ extension (torch.ops.osa_native.conv_ndhwc:
     one dispatcher call, tensors in, current HIP stream inside) -- False when the extension is not loaded (the caller then goes through
     ctypes; same entry point of the C ABI, bit-identical)."""
@@ -296,7 +296,7 @@ def _ext_conv(family, x, packed, y, dims, geom, precision, oscale, xmeta=None):
     if precision == "f16x3":
         e = engine._empty(x.device)
         metas = [xmeta if xmeta is not None else input_meta(x), e, e, attach_meta(y), e, e, oscale]
-    ext.conv_ndhwc(x, 0, packed, None, None, None, 0, y, 0, None, dims, geom, family, _PREC_ID[precision], 0, 0.0, 1.0, metas)
+    ext.conv_ndhwc(x, 0, packed, scale, shift, None, 0, y, 0, None, dims, geom, family, _PREC_ID[precision], 0, 0.0, 1.0, metas)
     return True
 
 
@@ -307,8 +307,19 @@ def _sfx_tail(precision, x, y, oscale, xmeta=None):
     return ("f16" if precision == "f16" else "f32"), (_stream(),)        # f16: fp32 NDHWC tensors, fp16 operands (no flags, no ranges)
 
 
-def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape, xmeta=None):
-    """x NDHWC (channels padded to 4). plain conv, no epilogue extras."""
+_ONES = {}
+
+
+def _ones(n, device):
+    """cached all-ones scale vector: `y = acc * 1 + bias` puts a convolution's bias into the launch's epilogue (scale and shift travel together)"""
+    t = _ONES.get((n, device))
+    if t is None:
+        t = _ONES[(n, device)] = torch.ones(n, device=device, dtype=torch.float32)
+    return t
+
+
+def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_shape, xmeta=None, bias=None):
+    """x NDHWC (channels padded to 4). plain conv; bias (fp32 [Co]) is added in the epilogue."""
     B, Cs, D, H, W = x.shape
     CoS = (Co + 3) // 4 * 4
     y = empty_cl(B, CoS, *out_shape, x.device)
@@ -318,10 +329,11 @@ def _run_conv(x, packed, oscale, Ci, Co, k, stride, pad, dil, precision, out_sha
     macs = B * out_shape[0] * out_shape[1] * out_shape[2] * Ci * Co * k[0] * k[1] * k[2]
     with timing.span("conv3d", Ci, Co, k[1], stride, D, H, W, flops=2 * macs,
                      nbytes=4 * B * (D * H * W * Ci + out_shape[0] * out_shape[1] * out_shape[2] * Co)):
+        scale = None if bias is None else _ones(Co, x.device)
         if not _ext_conv(0, x, packed, y, [B, D, H, W, Ci4, Cs, Co, CoS, 0, 0],
-                         [k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2]], precision, oscale, xmeta):
+                         [k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2]], precision, oscale, xmeta, scale, bias):
             sfx, tail = _sfx_tail(precision, x, y, oscale, xmeta)
-            _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
+            _lib.call("osa_conv3d_ndhwc_" + sfx, x.data_ptr(), packed.data_ptr(), _p(scale), _p(bias), None, y.data_ptr(),
                       B, D, H, W, Ci4, Cs, Co, CoS, 0, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2],
                       None, 0, 0, 0.0, *tail)
     return y
@@ -418,7 +430,7 @@ class _Conv3d(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, w, stride, pad, dil, precision, cache=None, w2=None):
+    def forward(ctx, x, w, stride, pad, dil, precision, cache=None, w2=None, bias=None):
         xc = to_cl(x)                               # NDHWC, channels padded to a multiple of 4 with zeros
         # w2: a second layer over the same input, stacked on the output axis -- ONE forward / data-gradient / weight-gradient launch for
         # both (ConvGRU's convz | convr read the same [h | x], update.py:38-39).  The concatenation is memoised with the packs.
@@ -432,7 +444,9 @@ class _Conv3d(torch.autograd.Function):
         oshape = (_out(D, k[0], pad[0], dil[0], sd), _out(H, k[1], pad[1], dil[1], stride), _out(W, k[2], pad[2], dil[2], stride))
         # one max |x| reduction serves the forward conv and (ctx.xmeta) the f16x3 weight gradient; kept on ctx, not on the tensor object
         xmeta = input_meta(xc) if precision == "f16x3" else None
-        y = _run_conv(xc, packed, osc, Ci, Co, k, stride, pad, dil, precision, oshape, xmeta)
+        # bias: added in the conv launch's epilogue (r5: one elementwise launch less per biased layer and call -- ~200 per StereoBase step)
+        ctx.bias_dt = None if bias is None else bias.dtype
+        y = _run_conv(xc, packed, osc, Ci, Co, k, stride, pad, dil, precision, oshape, xmeta, None if bias is None else _f32c(bias.detach()))
         ctx.save_for_backward(xc, wf)
         ctx.xmeta = xmeta
         ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
@@ -465,9 +479,12 @@ class _Conv3d(torch.autograd.Function):
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
             _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, ctx.xmeta, dymeta)
+        db = None
+        if ctx.bias_dt is not None and ctx.needs_input_grad[8]:
+            db = dyc[:, :Co].sum((0, 2, 3, 4)).to(ctx.bias_dt)
         if ctx.co1 is not None:
-            return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, None, None, (None if dw is None else dw[ctx.co1:])
-        return dx, dw, None, None, None, None, None, None
+            return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, None, None, (None if dw is None else dw[ctx.co1:]), db
+        return dx, dw, None, None, None, None, None, None, db
 
 
 class _ConvTranspose3d(torch.autograd.Function):
@@ -583,8 +600,7 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv3d (groups=1, isotropic stride 1|2) on the engine; output is NDHWC-strided."""
     s = _t3(stride)
     assert s[0] == s[1] == s[2]
-    y = _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), _train_precision(precision), _wcache(weight))
-    return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+    return _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), _train_precision(precision), _wcache(weight), None, bias)
 
 
 def conv_transpose3d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
@@ -606,9 +622,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv2d (groups=1, stride 1) on the engine: the D = 1 case of conv3d (forward, dgrad and wgrad kernels)."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (1, 1), "engine conv2d autograd: stride 1 (strided 2-D layers stay torch ops in training)"
-    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight))
-    y = y[:, :, 0]
-    return y if bias is None else y + bias.view(1, -1, 1, 1)
+    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight), None, bias)
+    return y[:, :, 0]
 
 
 def conv2d_pair(x, weight_a, weight_b, padding=0, dilation=1, precision=None):

@@ -58,6 +58,30 @@ def test_single_process_degenerates():
     assert whole_job_rate(2, 10, 1, 4.0) == 5.0
 
 
+def test_bench_self_launches_eight_ranks():
+    """The driver's N = 8 line (`python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...`), with the forward stubbed out:
+    eight ranks rendezvous over gloo, every rank pins its host threads to its share of the CPUs (bench._pin_host_threads), the barrier +
+    MAX-over-ranks timing picks the slowest rank (rank r sleeps 2 (r + 1) ms per step), rank 0 alone prints the line, and the whole-job
+    rate counts all eight ranks' pairs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert 16.0 <= d["ms_per_step"] < 200.0                              # rank 7: 16 ms per step
+    assert abs(d["value"] - 8 * 2 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-2
+    if hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) >= 8:
+        assert "host_cpus_of_rank0" in d["config"], d["config"]
+
+
 def test_bench_self_launches_n_ranks_and_reports_whole_job_rate():
     """`python bench.py --gpus 2` re-executes itself under torch.distributed.run with 2 ranks (the flag
     used to be ignored).  --stub swaps the GPU forward for a sleep and RCCL for gloo, everything else is the real script:
