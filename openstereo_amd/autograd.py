@@ -307,6 +307,11 @@ def _sfx_tail(precision, x, y, oscale, xmeta=None):
     return ("f16" if precision == "f16" else "f32"), (_stream(),)        # f16: fp32 NDHWC tensors, fp16 operands (no flags, no ranges)
 
 
+def _alias(t):
+    """a tensor object over t's storage and geometry that autograd does not regard as a view of anything"""
+    return torch.empty(0, device=t.device, dtype=t.dtype).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
 _ONES = {}
 
 
@@ -430,7 +435,12 @@ class _Conv3d(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, w, stride, pad, dil, precision, cache=None, w2=None, bias=None):
+    def forward(ctx, x, w, stride, pad, dil, precision, cache=None, w2=None, bias=None, flat=False):
+        # flat: the 2-D case -- x is [B,Ci,H,W], w [Co,Ci,kh,kw] (the D = 1 case of the same kernels), the result [B,Co,H,W]
+        ctx.flat = flat
+        if flat:
+            x, w = x.unsqueeze(2), w.unsqueeze(2)
+            w2 = None if w2 is None else w2.unsqueeze(2)
         xc = to_cl(x)                               # NDHWC, channels padded to a multiple of 4 with zeros
         # w2: a second layer over the same input, stacked on the output axis -- ONE forward / data-gradient / weight-gradient launch for
         # both (ConvGRU's convz | convr read the same [h | x], update.py:38-39).  The concatenation is memoised with the packs.
@@ -451,7 +461,11 @@ class _Conv3d(torch.autograd.Function):
         ctx.xmeta = xmeta
         ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
         ctx.cache = cache
-        return y[:, :Co]
+        # The result is a channel slice (and, flat, a squeeze) of the internal NDHWC allocation.  Returned as a view, autograd refuses
+        # in-place operations on it ("view created inside a custom Function") -- and the reference's modules put nn.ReLU(inplace=True)
+        # right behind biased convolutions (update.py:19-26); the bias add used to give them a fresh tensor.  So: a tensor object over the
+        # same storage and geometry that is not a view.
+        return _alias(y[:, :Co, 0] if flat else y[:, :Co])
 
     @staticmethod
     @_bwd
@@ -460,6 +474,8 @@ class _Conv3d(torch.autograd.Function):
         stride, pad, dil, precision, xshape, xdt = ctx.meta
         Co, Ci = wf.shape[:2]
         k = tuple(wf.shape[2:])
+        if ctx.flat:
+            dy = dy.unsqueeze(2)
         dyc = to_cl(dy)
         dymeta = input_meta(dyc) if precision == "f16x3" else None       # shared by the data gradient and the weight gradient
         B, _, D, H, W = xc.shape
@@ -474,7 +490,7 @@ class _Conv3d(torch.autograd.Function):
                     "stride-2 data gradient: 3x3x3, pad 1, even input dims (what the aggregation networks use)"
                 packed, osc = _pack(wf, Co, Ci, k, "deconv", precision, ctx.cache)       # w [Co][Ci][k] == transposed-conv layout [Cin_t][Cout_t]
                 dxc = _run_deconv(dyc, packed, osc, Co, Ci, 3, 1, 1, precision)
-            dx = dxc[:, :Ci].to(xdt)
+            dx = (dxc[:, :Ci, 0] if ctx.flat else dxc[:, :Ci]).to(xdt)
         if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[7]):
             dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
@@ -482,9 +498,11 @@ class _Conv3d(torch.autograd.Function):
         db = None
         if ctx.bias_dt is not None and ctx.needs_input_grad[8]:
             db = dyc[:, :Co].sum((0, 2, 3, 4)).to(ctx.bias_dt)
+        if dw is not None and ctx.flat:
+            dw = dw[:, :, 0]
         if ctx.co1 is not None:
-            return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, None, None, (None if dw is None else dw[ctx.co1:]), db
-        return dx, dw, None, None, None, None, None, None, db
+            return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, None, None, (None if dw is None else dw[ctx.co1:]), db, None
+        return dx, dw, None, None, None, None, None, None, db, None
 
 
 class _ConvTranspose3d(torch.autograd.Function):
@@ -622,8 +640,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv2d (groups=1, stride 1) on the engine: the D = 1 case of conv3d (forward, dgrad and wgrad kernels)."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (1, 1), "engine conv2d autograd: stride 1 (strided 2-D layers stay torch ops in training)"
-    y = _Conv3d.apply(x.unsqueeze(2), weight.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight), None, bias)
-    return y[:, :, 0]
+    return _Conv3d.apply(x, weight, 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight), None, bias, True)
 
 
 def conv2d_pair(x, weight_a, weight_b, padding=0, dilation=1, precision=None):
@@ -631,9 +648,8 @@ def conv2d_pair(x, weight_a, weight_b, padding=0, dilation=1, precision=None):
     one forward, one data-gradient and one weight-gradient launch for both; the gradients come back per weight."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert weight_a.shape[1:] == weight_b.shape[1:]
-    y = _Conv3d.apply(x.unsqueeze(2), weight_a.unsqueeze(2), 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision),
-                      _wcache2(weight_a, weight_b), weight_b.unsqueeze(2))
-    return y[:, :, 0]
+    return _Conv3d.apply(x, weight_a, 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision),
+                         _wcache2(weight_a, weight_b), weight_b, None, True)
 
 
 # ----------------------------------------------------------------------------- fused ConvGRU gates (training path, csrc/gru_train.hip)
