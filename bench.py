@@ -637,7 +637,10 @@ def capture_training_step(wl, ddp=False):
             getattr(prm, "_osa_packs", {}).clear()
         wl.opt.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # under DDP the RCCL watchdog thread keeps polling its work events (hipEventQuery) while this thread captures: in the default
+        # "global" capture mode that call from ANOTHER thread invalidates the capture / aborts the process (seen once in r5:
+        # ProcessGroupNCCL::Watchdog -> finishedGPUExecutionInternal -> HIP error); "thread_local" confines the checks to this thread
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if ddp else "global"):
             graph_out = wl.step()
 
         def step():
@@ -1050,6 +1053,19 @@ def main():
                 if not args.no_cpu_baseline:
                     cpu = gwcnet_cpu_baseline(wl, out)
         cfg["latency_ms_1_pair"] = latency_1
+        if roofs:
+            # `traffic` of every roofline record is the PMC figure of profiles/traffic.json (separate --pmc passes, tools/profile_round4.sh):
+            # say which code state it was collected at
+            try:
+                tm = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("_measured_at")
+            except Exception:
+                tm = None
+            for r in roofs:
+                if r.get("traffic") is not None:
+                    r["traffic_measured_at"] = tm
+        if cpu is not None:
+            cfg["cpu_baseline_kind"] = (f"{cpu['kind']}: " + ("the reference's own modules through the import shim" if cpu["kind"] == "reference" else
+                                        "the oracle restatement oracle/torch_ref.py (the reference checkout is not mounted on this box)"))
         line["roofline"] = roofs[0] if roofs else None
         line["rooflines"] = roofs[1:]
         line["cpu_baseline"] = cpu

@@ -233,7 +233,8 @@ at::Tensor upsample_softargmin_bwd(const at::Tensor& cost_lowres, const at::Tens
 }
 
 // ---- the fused NDHWC cost-volume builder the engine models run (ops.build_cost_volume_from_cl) -----------------------------------------
-// gwc_feat / cat_feat: NHWC feature maps of the 2B images (left images first), logical [2B, Cs, 1, H, W] with channels_last_3d strides.
+// gwc_feat / cat_feat: NHWC feature maps of the 2B images (left images first), logical [2B, Cs, 1, H, W] with channels_last_3d strides;
+// gwc_channels / cat_channels: how many of their channels enter the volume (-1: all of them from gwc_off on / all).
 // Returns the [B, G + 2 Cc, maxdisp, H, W] NDHWC volume; out_split asks for the f16x3 chain's split format (taken when the call is
 // eligible and both range blocks are there: the second result says which format was written).  out_meta: the volume's range block.
 std::tuple<at::Tensor, bool> cost_volume_cl(const at::Tensor& gwc_feat, const c10::optional<at::Tensor>& cat_feat, int64_t B, int64_t num_groups, int64_t maxdisp,
@@ -242,7 +243,7 @@ std::tuple<at::Tensor, bool> cost_volume_cl(const at::Tensor& gwc_feat, const c1
     gpu_f32(gwc_feat, "gwc_feat"); gpu_f32(out_meta, "out_meta");
     TORCH_CHECK(gwc_feat.dim() == 5 && gwc_feat.size(0) == 2 * B && gwc_feat.size(2) == 1 && gwc_feat.stride(1) == 1, "cost_volume_cl: gwc_feat must be NHWC [2B, Cs, 1, H, W]");
     const int64_t Gs = gwc_feat.size(1), H = gwc_feat.size(3), W = gwc_feat.size(4);
-    const int64_t C = gwc_channels > 0 ? gwc_channels : Gs - gwc_off;
+    const int64_t C = gwc_channels >= 0 ? gwc_channels : Gs - gwc_off;        // (0 = no group-wise part: the concat-only volumes of PSMNet)
     const float* lg = fp(gwc_feat) + gwc_off;
     const float* rg = lg + B * H * W * Gs;
     const float *lc = nullptr, *rc = nullptr;
@@ -251,7 +252,7 @@ std::tuple<at::Tensor, bool> cost_volume_cl(const at::Tensor& gwc_feat, const c1
         gpu_f32(*cat_feat, "cat_feat");
         TORCH_CHECK(cat_feat->dim() == 5 && cat_feat->size(0) == 2 * B && cat_feat->size(3) == H && cat_feat->size(4) == W && cat_feat->stride(1) == 1,
                     "cost_volume_cl: cat_feat must be NHWC [2B, cs, 1, H, W] at the gwc features' resolution");
-        cs = cat_feat->size(1); Cc = cat_channels > 0 ? cat_channels : cs;
+        cs = cat_feat->size(1); Cc = cat_channels >= 0 ? cat_channels : cs;
         lc = fp(*cat_feat); rc = lc + B * H * W * cs;
     }
     const int64_t nch = num_groups + 2 * Cc, VC = (nch + 3) / 4 * 4;
