@@ -251,9 +251,13 @@ def abi_version() -> int:
     return _abi
 
 
+CALLS = {}          # name -> number of calls that went through ctypes (the C++ extension's dispatcher calls do not pass here): tests / DESIGN.md count them
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point; turn a non-zero status into EngineError."""
     lib = load()
+    CALLS[name] = CALLS.get(name, 0) + 1
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.osa_last_error()

@@ -49,6 +49,10 @@ class _GwcVolume(torch.autograd.Function):
         maxdisp, G, dt = ctx.meta
         B, C, H, W = l.shape
         dv = _f32c(dvol)
+        ext = engine._ext.load()
+        if ext is not None:
+            dl, dr = ext.volume_bwd(dv, l, r, [B, C, H, W], maxdisp, G, False, True)
+            return dl.to(dt), dr.to(dt), None, None
         dl, dr = torch.empty_like(l), torch.empty_like(r)
         _lib.call("osa_build_volume_bwd_f32", dv.data_ptr(), l.data_ptr(), r.data_ptr(), dl.data_ptr(), dr.data_ptr(),
                   B, C, H, W, maxdisp, G, 0, 1, G, 0, _stream())
@@ -68,6 +72,10 @@ class _ConcatVolume(torch.autograd.Function):
     def backward(ctx, dvol):
         maxdisp, mask_left, dt, (B, C, H, W) = ctx.meta
         dv = _f32c(dvol)
+        ext = engine._ext.load()
+        if ext is not None:
+            dl, dr = ext.volume_bwd(dv, None, None, [B, C, H, W], maxdisp, 0, True, bool(mask_left))
+            return dl.to(dt), dr.to(dt), None, None
         dl = torch.empty((B, C, H, W), device=dv.device, dtype=torch.float32)
         dr = torch.empty_like(dl)
         _lib.call("osa_build_volume_bwd_f32", dv.data_ptr(), None, None, dl.data_ptr(), dr.data_ptr(),
@@ -101,6 +109,9 @@ class _SoftArgmin(torch.autograd.Function):
     def backward(ctx, dout):
         B, D, H, W = ctx.shape
         g = _f32c(dout)
+        ext = engine._ext.load()
+        if ext is not None:
+            return ext.softargmin_bwd(g, D)
         dp = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
         _lib.call("osa_softargmin_bwd_f32", g.data_ptr(), dp.data_ptr(), B, D, H, W, _stream())
         return dp
@@ -120,6 +131,9 @@ class _SoftmaxSoftArgmin(torch.autograd.Function):
         (c,) = ctx.saved_tensors
         B, D, H, W = c.shape
         g = _f32c(dout)
+        ext = engine._ext.load()
+        if ext is not None:
+            return ext.softmax_softargmin_bwd(c, g)
         dc = torch.empty_like(c)
         _lib.call("osa_softmax_softargmin_bwd_f32", c.data_ptr(), g.data_ptr(), dc.data_ptr(), B, D, H, W, _stream())
         return dc
@@ -141,6 +155,9 @@ class _UpsampleSoftArgmin(torch.autograd.Function):
         maxdisp, h, w, align = ctx.meta
         B, Dl, Hl, Wl = c.shape
         g = _f32c(dout)
+        ext = engine._ext.load()
+        if ext is not None:
+            return ext.upsample_softargmin_bwd(c, g, int(maxdisp), int(h), int(w), bool(align)), None, None, None, None
         dc = torch.empty_like(c)
         need = _lib.load().osa_upsample_softargmin_bwd_workspace_bytes(B, Dl, int(h), int(w))     # [B,Dl,H,W] scratch: atomic-free, deterministic
         ws = torch.empty((need + 3) // 4, device=c.device, dtype=torch.float32)
@@ -242,6 +259,24 @@ def _pack_now(w, Ci, Co, k, mode, precision):
     f16 = precision == "f16x3"
     h16 = precision == "f16"            # native fp16 operands (AMP training, r5): weights rounded to nearest even, no scale
     lib = _lib.load()
+    ext = engine._ext.load()
+    if ext is not None:
+        # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp conv_pack / deconv_pack): the same pack kernels, one dispatcher call
+        amax = sc = None
+        if f16:
+            amax = torch.linalg.vector_norm(w.detach(), float("inf")).reshape(1)
+            sc = torch.empty(2, device=w.device, dtype=torch.float32)
+        pid = _PREC_ID[precision]
+        if mode in ("deconv2d", "deconv"):
+            n = (lib.osa_deconv2d_packed_floats if mode == "deconv2d" else lib.osa_deconv3d_packed_floats)(Ci, Co, k[0])
+            buf = torch.zeros(n, device=w.device, dtype=torch.float32)
+            ext.deconv_pack(w, buf, [Ci, Co, k[0], 1, 1 if mode == "deconv2d" else 0], pid, amax, sc)
+        else:
+            n = lib.osa_conv3d_packed_floats(Ci, Co, *k)
+            buf = torch.zeros(n, device=w.device, dtype=torch.float32)
+            tr, fl = {"fwd": (0, 0), "dgrad_s1": (1, 1), "dgrad_of_deconv": (0, 0)}[mode]
+            ext.conv_pack(w, buf, [Ci, Co, k[0], k[1], k[2], tr, fl], pid, amax, sc)
+        return buf, (sc if f16 else 1.0)
     if f16:
         amax = torch.linalg.vector_norm(w.detach(), float("inf"))          # one reduction kernel, stays on the device
         sc = torch.empty(2, device=w.device, dtype=torch.float32)
@@ -699,9 +734,13 @@ class _GruGatesRZ(torch.autograd.Function):
         bzf, brf = (None if bz is None else _f32c(bz.detach())), (None if br is None else _f32c(br.detach()))
         z = _new_nhwc(B, C, H, W, pre.device, torch.float32)             # internal: only the q kernel reads it
         rh = _new_nhwc(B, C, H, W, pre.device, rh_dtype)
-        zr, rhr = _nhwc_ref(z, C), _nhwc_ref(rh, C)
-        _lib.call("osa_gru_gates_rz_fwd", keep[0][1], _bias_ptr(bzf), _bias_ptr(brf), keep[1][1], keep[2][1], keep[3][1], zr[1], rhr[1],
-                  B * H * W, C, _stream())
+        ext = engine._ext.load()
+        if ext is not None:
+            ext.gru_gates_rz_fwd(keep[0][0], bzf, brf, keep[1][0], keep[2][0], keep[3][0], z, rh)
+        else:
+            zr, rhr = _nhwc_ref(z, C), _nhwc_ref(rh, C)
+            _lib.call("osa_gru_gates_rz_fwd", keep[0][1], _bias_ptr(bzf), _bias_ptr(brf), keep[1][1], keep[2][1], keep[3][1], zr[1], rhr[1],
+                      B * H * W, C, _stream())
         ctx.save_for_backward(keep[0][0], keep[1][0], keep[2][0], keep[3][0], *([] if bzf is None else [bzf]), *([] if brf is None else [brf]))
         ctx.has_b = (bzf is not None, brf is not None)
         ctx.dt = (pre.dtype, cz.dtype, cr.dtype, h.dtype, None if bz is None else bz.dtype, None if br is None else br.dtype)
@@ -719,8 +758,12 @@ class _GruGatesRZ(torch.autograd.Function):
         refs = [_nhwc_ref(t, n) for t, n in ((pre, C2), (cz, C), (cr, C), (h, C), (dz, C), (drh, C))]
         dpre = _new_nhwc(B, C2, H, W, pre.device, torch.float32)
         dh = _new_nhwc(B, C, H, W, pre.device, torch.float32)
-        _lib.call("osa_gru_gates_rz_bwd", refs[0][1], _bias_ptr(bzf), _bias_ptr(brf), refs[1][1], refs[2][1], refs[3][1], refs[4][1], refs[5][1],
-                  _nhwc_ref(dpre, C2)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
+        ext = engine._ext.load()
+        if ext is not None:
+            ext.gru_gates_rz_bwd(refs[0][0], bzf, brf, refs[1][0], refs[2][0], refs[3][0], refs[4][0], refs[5][0], dpre, dh)
+        else:
+            _lib.call("osa_gru_gates_rz_bwd", refs[0][1], _bias_ptr(bzf), _bias_ptr(brf), refs[1][1], refs[2][1], refs[3][1], refs[4][1], refs[5][1],
+                      _nhwc_ref(dpre, C2)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
         pdt, czdt, crdt, hdt, bzdt, brdt = ctx.dt
         db = dpre.sum((0, 2, 3)) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None       # one reduction for both biases
         return (dpre.to(pdt), None if bzdt is None or db is None else db[:C].to(bzdt), None if brdt is None or db is None else db[C:].to(brdt),
@@ -737,7 +780,11 @@ class _GruGatesQ(torch.autograd.Function):
         keep = [_nhwc_ref(t, C) for t in (z, qpre, cq, h)]
         bqf = None if bq is None else _f32c(bq.detach())
         out = _new_nhwc(B, C, H, W, qpre.device, out_dtype)
-        _lib.call("osa_gru_gates_q_fwd", keep[0][1], keep[1][1], _bias_ptr(bqf), keep[2][1], keep[3][1], _nhwc_ref(out, C)[1], B * H * W, C, _stream())
+        ext = engine._ext.load()
+        if ext is not None:
+            ext.gru_gates_q_fwd(keep[0][0], keep[1][0], bqf, keep[2][0], keep[3][0], out)
+        else:
+            _lib.call("osa_gru_gates_q_fwd", keep[0][1], keep[1][1], _bias_ptr(bqf), keep[2][1], keep[3][1], _nhwc_ref(out, C)[1], B * H * W, C, _stream())
         ctx.save_for_backward(keep[0][0], keep[1][0], keep[2][0], keep[3][0], *([] if bqf is None else [bqf]))
         ctx.dt = (z.dtype, qpre.dtype, cq.dtype, h.dtype, None if bq is None else bq.dtype)
         return out
@@ -750,8 +797,12 @@ class _GruGatesQ(torch.autograd.Function):
         B, C, H, W = qpre.shape
         refs = [_nhwc_ref(t, C) for t in (z, qpre, cq, h, dout)]
         dz, dq, dh = (_new_nhwc(B, C, H, W, qpre.device, torch.float32) for _ in range(3))
-        _lib.call("osa_gru_gates_q_bwd", refs[0][1], refs[1][1], _bias_ptr(bqf), refs[2][1], refs[3][1], refs[4][1],
-                  _nhwc_ref(dz, C)[1], _nhwc_ref(dq, C)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
+        ext = engine._ext.load()
+        if ext is not None:
+            ext.gru_gates_q_bwd(refs[0][0], refs[1][0], bqf, refs[2][0], refs[3][0], refs[4][0], dz, dq, dh)
+        else:
+            _lib.call("osa_gru_gates_q_bwd", refs[0][1], refs[1][1], _bias_ptr(bqf), refs[2][1], refs[3][1], refs[4][1],
+                      _nhwc_ref(dz, C)[1], _nhwc_ref(dq, C)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
         zdt, qdt, cqdt, hdt, bqdt = ctx.dt
         return (dz.to(zdt), dq.to(qdt), None if bqdt is None or not ctx.needs_input_grad[2] else dq.sum((0, 2, 3)).to(bqdt),
                 dq.to(cqdt) if ctx.needs_input_grad[3] else None, dh.to(hdt) if ctx.needs_input_grad[4] else None, None)

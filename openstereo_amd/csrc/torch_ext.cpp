@@ -297,6 +297,107 @@ bool conv_wgrad(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, at::In
     return true;
 }
 
+// ---- layout, packing, ConvGRU gates, geometry-encoding lookup: the remaining per-step launches of the training path --------------------
+// x [B, C, ...S] contiguous NCDHW -> channels [c_off, c_off + C) of the NDHWC tensor y (voxel stride = y's channel stride)
+void to_cl(const at::Tensor& x, at::Tensor y, int64_t C, int64_t S, int64_t c_off) {
+    gpu_f32(x, "x"); gpu_f32(y, "y");
+    TORCH_CHECK(x.is_contiguous() && y.dim() == 5 && y.stride(1) == 1, "to_cl: x contiguous NCDHW, y NDHWC");
+    OSA_CALL(osa_ncdhw_to_ndhwc_f32(fp(x), y.data_ptr<float>(), (int)x.size(0), (int)C, (long long)S, (int)y.size(1), (int)c_off, cur_stream()));
+}
+void to_ncdhw(const at::Tensor& x, at::Tensor y, int64_t C, int64_t S, int64_t c_off) {
+    gpu_f32(x, "x"); gpu_f32(y, "y");
+    TORCH_CHECK(y.is_contiguous() && x.dim() == 5 && x.stride(1) == 1, "to_ncdhw: x NDHWC, y contiguous NCDHW");
+    OSA_CALL(osa_ndhwc_to_ncdhw_f32(fp(x), y.data_ptr<float>(), (int)x.size(0), (int)C, (long long)S, (int)x.size(1), (int)c_off, cur_stream()));
+}
+
+// conv weights -> MFMA operand order.  geom = [Ci, Co, kd, kh, kw, src_transposed, flip]; prec 0 f32 / 1 f16x3 / 2 f16.  f16x3: the power-of-two
+// weight scale is derived on the device from w_amax (1 float) and written to scale_out (2 floats) -- no host synchronisation.
+void conv_pack(const at::Tensor& w, at::Tensor packed, at::IntArrayRef geom, int64_t prec, const c10::optional<at::Tensor>& w_amax, const c10::optional<at::Tensor>& scale_out) {
+    gpu_f32(w, "w"); gpu_f32(packed, "packed");
+    TORCH_CHECK(geom.size() == 7 && w.is_contiguous(), "conv_pack: geom = [Ci, Co, kd, kh, kw, src_transposed, flip], w contiguous");
+    const int g[7] = {(int)geom[0], (int)geom[1], (int)geom[2], (int)geom[3], (int)geom[4], (int)geom[5], (int)geom[6]};
+    if (prec == 1) {
+        TORCH_CHECK(w_amax.has_value() && scale_out.has_value(), "conv_pack: the f16x3 mode needs w_amax and scale_out (device tensors)");
+        OSA_CALL(osa_conv3d_pack_ex_auto(fp(w), packed.data_ptr<float>(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], fpo(w_amax), const_cast<float*>(fpo(scale_out)), cur_stream()));
+    } else OSA_CALL(osa_conv3d_pack_ex(fp(w), packed.data_ptr<float>(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], prec == 2 ? 2 : 0, 1.0f, cur_stream()));
+}
+// transposed-conv weights [Ci][Co][k..] -> parity-class packing; geom = [Ci, Co, k, pad, flat (1 = 2-D)]
+void deconv_pack(const at::Tensor& w, at::Tensor packed, at::IntArrayRef geom, int64_t prec, const c10::optional<at::Tensor>& w_amax, const c10::optional<at::Tensor>& scale_out) {
+    gpu_f32(w, "w"); gpu_f32(packed, "packed");
+    TORCH_CHECK(geom.size() == 5 && w.is_contiguous(), "deconv_pack: geom = [Ci, Co, k, pad, flat], w contiguous");
+    const int Ci = (int)geom[0], Co = (int)geom[1], k = (int)geom[2], pad = (int)geom[3];
+    const bool flat = geom[4] != 0;
+    float* dst = packed.data_ptr<float>();
+    void* st = cur_stream();
+    if (prec == 1) {
+        TORCH_CHECK(w_amax.has_value() && scale_out.has_value(), "deconv_pack: the f16x3 mode needs w_amax and scale_out (device tensors)");
+        float* so = const_cast<float*>(fpo(scale_out));
+        if (flat) OSA_CALL(osa_deconv2d_pack_f16x3_auto(fp(w), dst, Ci, Co, k, pad, fpo(w_amax), so, st));
+        else OSA_CALL(osa_deconv3d_pack_f16x3_auto(fp(w), dst, Ci, Co, k, pad, fpo(w_amax), so, st));
+    } else if (prec == 2) {
+        if (flat) OSA_CALL(osa_deconv2d_pack_f16(fp(w), dst, Ci, Co, k, pad, st));
+        else OSA_CALL(osa_deconv3d_pack_f16(fp(w), dst, Ci, Co, k, pad, st));
+    } else {
+        if (flat) OSA_CALL(osa_deconv2d_pack_f32(fp(w), dst, Ci, Co, k, pad, st));
+        else OSA_CALL(osa_deconv3d_pack_f32(fp(w), dst, Ci, Co, k, pad, st));
+    }
+}
+
+// ConvGRU gate arithmetic of the training path (csrc/gru_train.hip).  Every tensor: logical [B, C', H, W] read / written as NHWC with its own
+// channel stride (stride(1) == 1, stride(3) = channel stride), fp32 or fp16.
+inline osa_nhwc_ref nref(const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.dim() == 4 && t.stride(1) == 1 && (t.scalar_type() == at::kFloat || t.scalar_type() == at::kHalf),
+                "openstereo_amd: ", name, " must be a CUDA fp32 / fp16 tensor [B,C,H,W] in NHWC memory order");
+    TORCH_CHECK(t.stride(2) == t.size(3) * t.stride(3) && t.stride(0) == t.size(2) * t.stride(2), "openstereo_amd: ", name, " is not dense over its pixels");
+    osa_nhwc_ref r;
+    r.ptr = t.data_ptr(); r.cs = (int)t.stride(3); r.f16 = t.scalar_type() == at::kHalf ? 1 : 0;
+    return r;
+}
+void gru_gates_rz_fwd(const at::Tensor& pre, const c10::optional<at::Tensor>& bz, const c10::optional<at::Tensor>& br, const at::Tensor& cz, const at::Tensor& cr,
+                      const at::Tensor& h, at::Tensor z, at::Tensor rh) {
+    const auto a = nref(pre, "pre"), b = nref(cz, "cz"), c = nref(cr, "cr"), d = nref(h, "h"), e = nref(z, "z"), f = nref(rh, "rh");
+    OSA_CALL(osa_gru_gates_rz_fwd(&a, fpo(bz), fpo(br), &b, &c, &d, &e, &f, (long long)h.size(0) * h.size(2) * h.size(3), (int)h.size(1), cur_stream()));
+}
+void gru_gates_rz_bwd(const at::Tensor& pre, const c10::optional<at::Tensor>& bz, const c10::optional<at::Tensor>& br, const at::Tensor& cz, const at::Tensor& cr,
+                      const at::Tensor& h, const at::Tensor& dz, const at::Tensor& drh, at::Tensor dpre, at::Tensor dh) {
+    const auto a = nref(pre, "pre"), b = nref(cz, "cz"), c = nref(cr, "cr"), d = nref(h, "h"), e = nref(dz, "dz"), f = nref(drh, "drh"), g = nref(dpre, "dpre"), i = nref(dh, "dh");
+    OSA_CALL(osa_gru_gates_rz_bwd(&a, fpo(bz), fpo(br), &b, &c, &d, &e, &f, &g, &i, (long long)h.size(0) * h.size(2) * h.size(3), (int)h.size(1), cur_stream()));
+}
+void gru_gates_q_fwd(const at::Tensor& z, const at::Tensor& qpre, const c10::optional<at::Tensor>& bq, const at::Tensor& cq, const at::Tensor& h, at::Tensor out) {
+    const auto a = nref(z, "z"), b = nref(qpre, "qpre"), c = nref(cq, "cq"), d = nref(h, "h"), e = nref(out, "out");
+    OSA_CALL(osa_gru_gates_q_fwd(&a, &b, fpo(bq), &c, &d, &e, (long long)h.size(0) * h.size(2) * h.size(3), (int)h.size(1), cur_stream()));
+}
+void gru_gates_q_bwd(const at::Tensor& z, const at::Tensor& qpre, const c10::optional<at::Tensor>& bq, const at::Tensor& cq, const at::Tensor& h, const at::Tensor& dout,
+                     at::Tensor dz, at::Tensor dqpre, at::Tensor dh) {
+    const auto a = nref(z, "z"), b = nref(qpre, "qpre"), c = nref(cq, "cq"), d = nref(h, "h"), e = nref(dout, "dout"), f = nref(dz, "dz"), g = nref(dqpre, "dqpre"), i = nref(dh, "dh");
+    OSA_CALL(osa_gru_gates_q_bwd(&a, &b, fpo(bq), &c, &d, &e, &f, &g, &i, (long long)h.size(0) * h.size(2) * h.size(3), (int)h.size(1), cur_stream()));
+}
+
+// geometry-encoding lookup of the GRU loop (igev/geometry.py, stereobase/gru_blocks.py:170-231): `levels` = the geo pyramid followed by the corr pyramid
+// (rows of [.., len_l] floats); forward writes out [B, (C + 1)(2r + 1) L, H, W], backward writes the gradients of every level (same shapes).
+void geo_lookup(at::TensorList levels, const at::Tensor& disp, const at::Tensor& coords_x, at::Tensor out, int64_t C, int64_t radius) {
+    const size_t L = levels.size() / 2;
+    TORCH_CHECK(L >= 1 && L <= 4 && levels.size() == 2 * L, "geo_lookup: levels = geo pyramid + corr pyramid, 1..4 levels each");
+    gpu_f32(disp, "disp"); gpu_f32(coords_x, "coords_x"); gpu_f32(out, "out");
+    const float* gp[4]; const float* cp[4]; int gl[4], cl[4];
+    for (size_t l = 0; l < L; ++l) {
+        gp[l] = fp(gpu_f32(levels[l], "geo level")); cp[l] = fp(gpu_f32(levels[L + l], "corr level"));
+        gl[l] = (int)levels[l].size(-1); cl[l] = (int)levels[L + l].size(-1);
+    }
+    OSA_CALL(osa_geo_lookup_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), out.data_ptr<float>(), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
+}
+void geo_lookup_bwd(at::TensorList dlevels, const at::Tensor& disp, const at::Tensor& coords_x, const at::Tensor& dout, int64_t C, int64_t radius) {
+    const size_t L = dlevels.size() / 2;
+    TORCH_CHECK(L >= 1 && L <= 4 && dlevels.size() == 2 * L, "geo_lookup_bwd: dlevels = gradients of the geo pyramid + of the corr pyramid");
+    gpu_f32(disp, "disp"); gpu_f32(coords_x, "coords_x"); gpu_f32(dout, "dout");
+    float* gp[4]; float* cp[4]; int gl[4], cl[4];
+    for (size_t l = 0; l < L; ++l) {
+        gp[l] = gpu_f32(dlevels[l], "dgeo level").data_ptr<float>(); cp[l] = gpu_f32(dlevels[L + l], "dcorr level").data_ptr<float>();
+        gl[l] = (int)dlevels[l].size(-1); cl[l] = (int)dlevels[L + l].size(-1);
+    }
+    OSA_CALL(osa_geo_lookup_bwd_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), fp(dout), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
+}
+
 // ---- Meta kernels (shape / dtype inference in C++: FakeTensor tracing, torch.export, torch.compile need no Python shim) --------------------
 at::Tensor gwc_volume_meta(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, int64_t groups) {
     TORCH_CHECK(l.dim() == 4 && l.sizes() == r.sizes() && groups > 0 && l.size(1) % groups == 0, "gwc_volume: [B,C,H,W] features of equal shape, C % groups == 0");
@@ -466,6 +567,16 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("cost_volume_cl(Tensor gwc_feat, Tensor? cat_feat, int B, int num_groups, int maxdisp, int gwc_channels, int cat_channels, int gwc_off, bool mask_left, "
           "bool out_split, Tensor? gwc_meta, Tensor? cat_meta, Tensor(a!) out_meta) -> (Tensor, bool)");
     m.def("conv_wgrad(Tensor x, Tensor dy, Tensor(a!) dw, int[] dims, int prec, Tensor? x_meta, Tensor? dy_meta) -> bool");
+    m.def("to_cl(Tensor x, Tensor(a!) y, int C, int S, int c_off) -> ()");
+    m.def("to_ncdhw(Tensor x, Tensor(a!) y, int C, int S, int c_off) -> ()");
+    m.def("conv_pack(Tensor w, Tensor(a!) packed, int[] geom, int prec, Tensor? w_amax, Tensor(b!)? scale_out) -> ()");
+    m.def("deconv_pack(Tensor w, Tensor(a!) packed, int[] geom, int prec, Tensor? w_amax, Tensor(b!)? scale_out) -> ()");
+    m.def("gru_gates_rz_fwd(Tensor pre, Tensor? bias_z, Tensor? bias_r, Tensor cz, Tensor cr, Tensor h, Tensor(a!) z, Tensor(b!) rh) -> ()");
+    m.def("gru_gates_rz_bwd(Tensor pre, Tensor? bias_z, Tensor? bias_r, Tensor cz, Tensor cr, Tensor h, Tensor dz, Tensor drh, Tensor(a!) dpre, Tensor(b!) dh) -> ()");
+    m.def("gru_gates_q_fwd(Tensor z, Tensor qpre, Tensor? bias_q, Tensor cq, Tensor h, Tensor(a!) out) -> ()");
+    m.def("gru_gates_q_bwd(Tensor z, Tensor qpre, Tensor? bias_q, Tensor cq, Tensor h, Tensor dout, Tensor(a!) dz, Tensor(b!) dqpre, Tensor(c!) dh) -> ()");
+    m.def("geo_lookup(Tensor[] levels, Tensor disp, Tensor coords_x, Tensor(a!) out, int C, int radius) -> ()");
+    m.def("geo_lookup_bwd(Tensor(a!)[] dlevels, Tensor disp, Tensor coords_x, Tensor dout, int C, int radius) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers under PyTorch's CUDA dispatch key)
@@ -483,6 +594,16 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("upsample_softargmin_bwd", &upsample_softargmin_bwd);
     m.impl("cost_volume_cl", &cost_volume_cl);
     m.impl("conv_wgrad", &conv_wgrad);
+    m.impl("to_cl", &to_cl);
+    m.impl("to_ncdhw", &to_ncdhw);
+    m.impl("conv_pack", &conv_pack);
+    m.impl("deconv_pack", &deconv_pack);
+    m.impl("gru_gates_rz_fwd", &gru_gates_rz_fwd);
+    m.impl("gru_gates_rz_bwd", &gru_gates_rz_bwd);
+    m.impl("gru_gates_q_fwd", &gru_gates_q_fwd);
+    m.impl("gru_gates_q_bwd", &gru_gates_q_bwd);
+    m.impl("geo_lookup", &geo_lookup);
+    m.impl("geo_lookup_bwd", &geo_lookup_bwd);
 }
 
 TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference without a device: FakeTensor, torch.export, torch.compile

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from . import _lib, ops, timing
+from . import _ext, _lib, ops, timing
 from .ops import _f32c, _stream, is_cl
 
 
@@ -30,6 +30,12 @@ class _Lookup(torch.autograd.Function):
         geo, corr = levels[:L], levels[L:]
         B, H, W = d.shape
         out = torch.empty((B, (C + 1) * (2 * radius + 1) * L, H, W), device=d.device, dtype=torch.float32)
+        ext = _ext.load()
+        if ext is not None:                               # PyTorch-ROCm C++ extension: the pyramid as a tensor list
+            ext.geo_lookup(list(levels), d, cx, out, C, radius)
+            ctx.save_for_backward(d, cx)
+            ctx.meta = (C, radius, L, [tuple(t.shape) for t in levels])
+            return out
         gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in geo])
         cp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in corr])
         gl = (ctypes.c_int * L)(*[t.shape[-1] for t in geo])
@@ -46,6 +52,10 @@ class _Lookup(torch.autograd.Function):
         C, radius, L, shapes = ctx.meta
         B, H, W = d.shape
         grads = [torch.empty(s, device=d.device, dtype=torch.float32) for s in shapes]
+        ext = _ext.load()
+        if ext is not None:
+            ext.geo_lookup_bwd(grads, d, cx, _f32c(dout), C, radius)
+            return (None, None, None, None, *grads)
         gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads[:L]])
         cp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads[L:]])
         gl = (ctypes.c_int * L)(*[s[-1] for s in shapes[:L]])

@@ -90,7 +90,11 @@ def to_cl(x: torch.Tensor, pad_to: int = 4) -> torch.Tensor:
     y = empty_cl(B, Cp, D, H, W, x.device)
     if Cp != Cn:
         y.zero_()
-    _lib.call("osa_ncdhw_to_ndhwc_f32", xs.data_ptr(), y.data_ptr(), B, Cn, D * H * W, Cp, 0, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        ext.to_cl(xs, y, Cn, D * H * W, 0)
+    else:
+        _lib.call("osa_ncdhw_to_ndhwc_f32", xs.data_ptr(), y.data_ptr(), B, Cn, D * H * W, Cp, 0, _stream())
     return y
 
 
@@ -105,7 +109,11 @@ def to_ncdhw(x: torch.Tensor, channels: int | None = None) -> torch.Tensor:
     B, Cs, D, H, W = x.shape
     Cn = Cs if channels is None else channels
     y = torch.empty((B, Cn, D, H, W), device=x.device, dtype=torch.float32)
-    _lib.call("osa_ndhwc_to_ncdhw_f32", x.data_ptr(), y.data_ptr(), B, Cn, D * H * W, Cs, 0, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        ext.to_ncdhw(x, y, Cn, D * H * W, 0)
+    else:
+        _lib.call("osa_ndhwc_to_ncdhw_f32", x.data_ptr(), y.data_ptr(), B, Cn, D * H * W, Cs, 0, _stream())
     return y
 
 

@@ -60,6 +60,25 @@ for prec in ("f32", "f16x3", "f16"):
     y = AG.conv3d(xe, we, None, 1, 1, 1, precision=prec)
     y.backward(gy)
     out["train_y_" + prec], out["train_dx_" + prec], out["train_dw_" + prec] = y.detach().cpu().numpy(), xe.grad.cpu().numpy(), we.grad.cpu().numpy()
+# fused ConvGRU training cell (paired conv, gate kernels, packs, layout kernels) and the geometry-encoding lookup, forward + backward
+from openstereo_amd.models import igev_update as U
+from openstereo_amd.geometry import _Lookup
+gru = U.ConvGRU(32, 64).cuda().train()
+gru.load_state_dict(synth_state_dict(gru, seed=3))
+h0, cc, xx = torch.tanh(torch.randn(1, 32, 8, 12, generator=g)).cuda().requires_grad_(), torch.randn(1, 96, 8, 12, generator=g).cuda(), torch.randn(1, 64, 8, 12, generator=g).cuda()
+cz, cr, cq = cc.split(32, 1)
+hn = gru(gru(h0, cz, cr, cq, xx), cz, cr, cq, xx)
+hn.square().sum().backward()
+out["gru_h"], out["gru_dh"], out["gru_dwz"] = hn.detach().cpu().numpy(), h0.grad.cpu().numpy(), gru.convz.weight.grad.cpu().numpy()
+lv = [torch.randn(1, 6, 10, 8, 12, generator=g).cuda().requires_grad_(), torch.randn(1, 6, 10, 8, 6, generator=g).cuda().requires_grad_(),
+      torch.randn(1, 6, 10, 12, generator=g).cuda().requires_grad_(), torch.randn(1, 6, 10, 6, generator=g).cuda().requires_grad_()]
+dsp = (torch.rand(1, 6, 10, generator=g) * 5).cuda()
+cxs = torch.arange(10).float().view(1, 1, 10).repeat(1, 6, 1).cuda()
+lo = _Lookup.apply(dsp, cxs, 8, 2, *lv)
+lo.square().sum().backward()
+out["geo"], out["geo_d0"], out["geo_d3"] = lo.detach().cpu().numpy(), lv[0].grad.cpu().numpy(), lv[3].grad.cpu().numpy()
+from openstereo_amd import _lib as L_
+out["ctypes_calls"] = np.array([sum(L_.CALLS.values())])
 out["ext"] = np.array([_ext.load() is not None])
 np.savez(sys.argv[1], **out)
 ''' % ROOT
@@ -72,8 +91,13 @@ np.savez(sys.argv[1], **out)
             res[tag] = dict(np.load(f))
     assert bool(res["ext"]["ext"][0]) and not bool(res["ctypes"]["ext"][0])
     for k in res["ext"]:
-        if k != "ext":
+        if k not in ("ext", "ctypes_calls"):
             assert np.array_equal(res["ext"][k], res["ctypes"][k]), k
+    # how much of the launch path still marshals through ctypes when the extension is loaded (weight packing of the inference layers,
+    # rarely used helpers): a small fraction of what the ctypes-only process issues
+    n_ext, n_ct = int(res["ext"]["ctypes_calls"][0]), int(res["ctypes"]["ctypes_calls"][0])
+    print(f"ctypes calls: {n_ext} with the extension, {n_ct} without")
+    assert n_ext < 0.5 * n_ct
 
 
 NEW_OPS = ("volume_bwd", "softargmin_bwd", "softmax_softargmin_bwd", "upsample_softargmin_bwd", "cost_volume_cl", "conv_wgrad")
