@@ -416,13 +416,15 @@ int osa_conv3d_wgrad_ws_f16x3(const float* x, const float* dy, float* dw,
  * autocast + GradScaler: the weight gradient of an autocast convolution multiplies fp16 activations by fp16 output gradients and
  * accumulates in fp32) -- operands rounded to fp16 (nearest even) when they are staged, ONE v_mfma_f32_32x32x16_f16 per product, no lo
  * planes.  Same layers, workspace (osa_conv3d_wgrad_f16x3_workspace_bytes) and deterministic two-stage reduction as the f16x3 form.
- * x_meta / dy_meta: NULL (no operand scaling, exactly like autocast: GradScaler owns the range) or range blocks (power-of-two scaling). */
-int osa_conv3d_wgrad_ws_f16(const float* x, const float* dy, float* dw,
+ * x_meta / dy_meta: NULL (no operand scaling, exactly like autocast: GradScaler owns the range) or range blocks (power-of-two scaling).
+ * x_f16 / dy_f16 = 1: that tensor holds fp16 elements (NDHWC, channel stride in elements, 8-byte aligned) -- the activations an AMP step
+ * saves and the gradients it propagates are fp16 tensors; dw stays fp32. */
+int osa_conv3d_wgrad_ws_f16(const void* x, const void* dy, float* dw,
                             int B, int Di, int Hi, int Wi, int Ci, int xCs,
                             int Do, int Ho, int Wo, int Co, int dyCs,
                             int kd, int kh, int kw, int stride,
                             int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
-                            int transposed, const float* x_meta, const float* dy_meta,
+                            int transposed, const float* x_meta, const float* dy_meta, int x_f16, int dy_f16,
                             float* workspace, size_t workspace_bytes, void* stream);
 
 

@@ -411,7 +411,9 @@ WGRAD_F16 = True
 WGRAD_F16_CLASS = os.environ.get("OSA_WGRAD_F16_CLASS", "1") != "0"
 
 
-def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed, precision="f32", xmeta=None, dymeta=None):
+def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed, precision="f32", xmeta=None, dymeta=None, xcs=None, dycs=None):
+    assert precision == "f16" or (xc.dtype == torch.float32 and dyc.dtype == torch.float32), "fp16 tensors exist in the native f16 form only"
+    xcs, dycs = (xc.shape[1] if xcs is None else xcs), (dyc.shape[1] if dycs is None else dycs)        # channel strides (rows may be wider than the tensors' logical channels)
     """Weight gradient, two-stage form: partial tiles in a scratch tensor from the caching allocator, summed in a fixed order --
     deterministic, and free of the contended float atomics of the one-stage form.  precision "f16x3": the split-precision kernel where it
     applies (unit stride / dilation, 3x3 planes: osa_conv3d_wgrad_ws_f16x3, operand ranges from the tensors' range blocks), the exact
@@ -423,7 +425,7 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     ext = engine._ext.load()
     if ext is not None:
         # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp conv_wgrad): workspace query, allocation and launch in one dispatcher call
-        ed = [B, D, H, W, Ci, xc.shape[1], Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed]
+        ed = [B, D, H, W, Ci, xcs, Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed]
         if precision == "f16" and WGRAD_F16 and ((stride == 1 and not transposed) or WGRAD_F16_CLASS):
             with timing.span("wgrad_f16", Ci, Co, k[1], stride, D, H, W, transposed, **span):
                 if ext.conv_wgrad(xc, dyc, dw, ed, 2, None, None):
@@ -432,6 +434,8 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
             with timing.span("wgrad_f16x3", Ci, Co, k[1], stride, D, H, W, transposed, **span):
                 if ext.conv_wgrad(xc, dyc, dw, ed, 1, xmeta if xmeta is not None else input_meta(xc), dymeta if dymeta is not None else input_meta(dyc)):
                     return
+        if xc.dtype != torch.float32 or dyc.dtype != torch.float32:
+            raise _lib.EngineError("the native f16 weight gradient does not cover this layer and its tensors are fp16: " + str(dims))
         with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
             ext.conv_wgrad(xc, dyc, dw, ed, 0, None, None)
         return
@@ -441,9 +445,9 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
         if need:
             ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
             with timing.span("wgrad_f16", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-                _lib.call("osa_conv3d_wgrad_ws_f16", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
-                          Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
-                          None, None, ws.data_ptr(), need, _stream())
+                _lib.call("osa_conv3d_wgrad_ws_f16", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
+                          Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                          None, None, int(xc.dtype == torch.float16), int(dyc.dtype == torch.float16), ws.data_ptr(), need, _stream())
             return
     if precision == "f16x3" and WGRAD_F16X3 and ((stride == 1 and not transposed) or WGRAD_F16X3_CLASS):
         need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
@@ -451,8 +455,8 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
             ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
             mx = xmeta if xmeta is not None else input_meta(xc)
             with timing.span("wgrad_f16x3", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-                _lib.call("osa_conv3d_wgrad_ws_f16x3", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
-                          Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                _lib.call("osa_conv3d_wgrad_ws_f16x3", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
+                          Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
                           mx.data_ptr(), (dymeta if dymeta is not None else input_meta(dyc)).data_ptr(), ws.data_ptr(), need, _stream())
             return
     need = lib.osa_conv3d_wgrad_workspace_bytes(*dims)
@@ -460,8 +464,8 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
         raise _lib.EngineError("osa_conv3d_wgrad_workspace_bytes: unsupported layer " + str(dims))
     ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
     with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-        _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xc.shape[1],
-                  Do, Ho, Wo, Co, dyc.shape[1], k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+        _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
+                  Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
                   ws.data_ptr(), need, _stream())
 
 
@@ -538,6 +542,127 @@ class _Conv3d(torch.autograd.Function):
         if ctx.co1 is not None:
             return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, None, None, (None if dw is None else dw[ctx.co1:]), db, None
         return dx, dw, None, None, None, None, None, None, db, None
+
+
+NATIVE_F16_IO = os.environ.get("OSA_NATIVE_F16_IO", "1") != "0"
+IN_F16, OUT_F16 = 32, 64           # OSA_IN_F16 / OSA_OUT_F16 of include/openstereo_amd.h
+
+
+def _cl16_ok(C):
+    return C % 8 == 0
+
+
+def _as_cl16(x):
+    """logical [B,C,D,H,W] fp16 tensor -> the same values NDHWC-dense with a channel stride % 8 == 0 (zero-copy when it already is: outputs
+    of this path, channels_last tensors; otherwise ONE torch copy -- no cast, no second layout pass).  Returns (tensor, channel stride)."""
+    B, C, D, H, W = x.shape
+    cs = x.stride(4) if W > 1 else (x.stride(3) if H > 1 else C)
+    ok = x.stride(1) == 1 and cs >= C and cs % 8 == 0 and (x.data_ptr() % 16) == 0
+    for dim, expect in ((4, cs), (3, W * cs), (2, H * W * cs), (0, D * H * W * cs)):
+        ok = ok and (x.shape[dim] == 1 or x.stride(dim) == expect)
+    if not ok:
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+        cs = C
+        if x.stride(1) != 1:                       # (degenerate shapes leave ambiguous strides)
+            x = x.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    return x, cs
+
+
+class _Conv3dF16IO(torch.autograd.Function):
+    """The stride-1 convolution in the native f16 mode with fp16 TENSORS (r5): what an AMP step of the reference moves between its layers.
+    x arrives fp16 (any layout; NDHWC-dense is taken as it is), the result leaves fp16 when the reference's convolution would return fp16
+    (`out_dtype`), the saved activation is the fp16 tensor, the data gradient is written fp16, the weight gradient reads fp16 x / dy
+    (osa_conv3d_wgrad_ws_f16 x_f16 / dy_f16) and stays fp32 for the fp32 Parameter.  No cast kernels around the launch, half the saved
+    bytes.  Same arithmetic as `_Conv3d` with precision "f16": operands are fp16 either way (there: rounded when they are staged)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad, dil, cache, w2, bias, flat, out_dtype):
+        with torch.autocast("cuda", enabled=False):
+            ctx.flat = flat
+            if flat:
+                x, w = x.unsqueeze(2), w.unsqueeze(2)
+                w2 = None if w2 is None else w2.unsqueeze(2)
+            xc, xcs = _as_cl16(x)
+            ctx.co1 = None if w2 is None else w.shape[0]
+            wf = _f32c(w) if w2 is None else _memo(cache, "wcat", lambda: torch.cat([_f32c(w.detach()), _f32c(w2.detach())], 0))
+            Co, Ci = wf.shape[:2]
+            k = tuple(wf.shape[2:])
+            packed, _ = _pack(wf, Ci, Co, k, "fwd", "f16", cache)
+            B, _, D, H, W = xc.shape
+            oshape = (_out(D, k[0], pad[0], dil[0], 1), _out(H, k[1], pad[1], dil[1], 1), _out(W, k[2], pad[2], dil[2], 1))
+            o16 = out_dtype == torch.float16 and _cl16_ok(Co)
+            CoS = Co if o16 else (Co + 3) // 4 * 4
+            y = empty_cl(B, CoS, *oshape, xc.device, torch.float16 if o16 else torch.float32)
+            if CoS != Co:
+                y.zero_()
+            bf = None if bias is None else _f32c(bias.detach())
+            ctx.bias_dt = None if bias is None else bias.dtype
+            _launch_f16(xc, xcs, packed, y, CoS, [B, D, H, W, Ci], Co, k, pad, dil, IN_F16 | (OUT_F16 if o16 else 0), bf)
+            ctx.save_for_backward(xc, wf)
+            ctx.meta = (pad, dil, xcs, x.dtype)
+            ctx.cache = cache
+            return _alias(y[:, :Co, 0] if flat else y[:, :Co])
+
+    @staticmethod
+    def backward(ctx, dy):
+        with torch.autocast("cuda", enabled=False):
+            xc, wf = ctx.saved_tensors
+            pad, dil, xcs, xdt = ctx.meta
+            Co, Ci = wf.shape[:2]
+            k = tuple(wf.shape[2:])
+            if ctx.flat:
+                dy = dy.unsqueeze(2)
+            if dy.dtype == torch.float16 and _cl16_ok(Co):
+                dyc, dycs = _as_cl16(dy)
+                fin = IN_F16
+            else:
+                dyc = to_cl(dy)
+                dycs, fin = dyc.shape[1], 0
+            B, _, D, H, W = xc.shape
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                packed, _ = _pack(wf, Co, Ci, k, "dgrad_s1", "f16", ctx.cache)
+                p2 = tuple(dil[i] * (k[i] - 1) - pad[i] for i in range(3))
+                dxc = empty_cl(B, Ci, D, H, W, xc.device, torch.float16)               # (Ci % 8 == 0: the entry condition of this path)
+                cin = Co if fin else (Co + 3) // 4 * 4                                  # (fp32 dy from to_cl: zero-padded to a channel quad)
+                _launch_f16(dyc, dycs, packed, dxc, Ci, [B, *dyc.shape[2:], cin], Ci, k, p2, dil, fin | OUT_F16, None)
+                dx = (dxc[:, :, 0] if ctx.flat else dxc).to(xdt)
+            if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[5]):
+                dw = torch.empty_like(wf)
+                Do, Ho, Wo = dyc.shape[2:]
+                _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xcs, dycs=dycs)
+                if ctx.flat:
+                    dw = dw[:, :, 0]
+            db = None
+            if ctx.bias_dt is not None and ctx.needs_input_grad[6]:
+                db = dyc[:, :Co].sum((0, 2, 3, 4), dtype=torch.float32).to(ctx.bias_dt)
+            if ctx.co1 is not None:
+                return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, (None if dw is None else dw[ctx.co1:]), db, None, None
+            return dx, dw, None, None, None, None, db, None, None
+
+
+def _launch_f16(x, xcs, packed, y, ycs, xdims, Co, k, pad, dil, act, bias):
+    """osa_conv3d_ndhwc_f16 (stride 1) on tensors of either float dtype (act carries OSA_IN_F16 / OSA_OUT_F16), bias in the epilogue"""
+    B, D, H, W, Ci = xdims
+    scale = None if bias is None else _ones(Co, x.device)
+    dims = [B, D, H, W, Ci, xcs, Co, ycs, 0, 0]
+    geom = [k[0], k[1], k[2], 1, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2]]
+    macs = B * y.shape[2] * y.shape[3] * y.shape[4] * Ci * Co * k[0] * k[1] * k[2]
+    with timing.span("conv3d", Ci, Co, k[1], 1, D, H, W, flops=2 * macs, nbytes=x.element_size() * B * D * H * W * Ci + y.element_size() * y.numel()):
+        ext = engine._ext.load()
+        if ext is not None:
+            ext.conv_ndhwc(x, 0, packed, scale, bias, None, 0, y, 0, None, dims, geom, 0, 2, act, 0.0, 1.0, [])
+        else:
+            _lib.call("osa_conv3d_ndhwc_f16", x.data_ptr(), packed.data_ptr(), _p(scale), _p(bias), None, y.data_ptr(),
+                      B, D, H, W, Ci, xcs, Co, ycs, 0, k[0], k[1], k[2], 1, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], None, 0, act, 0.0, _stream())
+
+
+def _native_f16(x, weight, stride, precision, dilation=1):
+    """entry condition of the fp16-tensor path: the f16 mode, an fp16 input, unit stride / dilation and <= 3 taps per axis (what the fp16
+    weight-gradient kernel covers: everything else keeps fp32 tensors and the exact weight gradient), input channels in whole 16-byte rows"""
+    dl = dilation if isinstance(dilation, (tuple, list)) else (dilation,)
+    return NATIVE_F16_IO and precision == "f16" and x.dtype == torch.float16 and x.is_cuda and stride == 1 and _cl16_ok(weight.shape[1]) \
+        and all(int(v) <= 3 for v in weight.shape[2:]) and all(int(v) == 1 for v in dl)
 
 
 class _ConvTranspose3d(torch.autograd.Function):
@@ -653,7 +778,10 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv3d (groups=1, isotropic stride 1|2) on the engine; output is NDHWC-strided."""
     s = _t3(stride)
     assert s[0] == s[1] == s[2]
-    return _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), _train_precision(precision), _wcache(weight), None, bias)
+    prec = _train_precision(precision)
+    if _native_f16(x, weight, s[0], prec, _t3(dilation)):
+        return _Conv3dF16IO.apply(x, weight, _t3(padding), _t3(dilation), _wcache(weight), None, bias, False, amp.conv_out_dtype(x))
+    return _Conv3d.apply(x, weight, s[0], _t3(padding), _t3(dilation), prec, _wcache(weight), None, bias)
 
 
 def conv_transpose3d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
@@ -675,7 +803,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, precision=None
     """Differentiable F.conv2d (groups=1, stride 1) on the engine: the D = 1 case of conv3d (forward, dgrad and wgrad kernels)."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (1, 1), "engine conv2d autograd: stride 1 (strided 2-D layers stay torch ops in training)"
-    return _Conv3d.apply(x, weight, 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision), _wcache(weight), None, bias, True)
+    prec = _train_precision(precision)
+    if _native_f16(x, weight, 1, prec, p2(dilation)):
+        return _Conv3dF16IO.apply(x, weight, (0,) + p2(padding), (1,) + p2(dilation), _wcache(weight), None, bias, True, amp.conv_out_dtype(x))
+    return _Conv3d.apply(x, weight, 1, (0,) + p2(padding), (1,) + p2(dilation), prec, _wcache(weight), None, bias, True)
 
 
 def conv2d_pair(x, weight_a, weight_b, padding=0, dilation=1, precision=None):
@@ -683,8 +814,11 @@ def conv2d_pair(x, weight_a, weight_b, padding=0, dilation=1, precision=None):
     one forward, one data-gradient and one weight-gradient launch for both; the gradients come back per weight."""
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert weight_a.shape[1:] == weight_b.shape[1:]
-    return _Conv3d.apply(x, weight_a, 1, (0,) + p2(padding), (1,) + p2(dilation), _train_precision(precision),
-                         _wcache2(weight_a, weight_b), weight_b, None, True)
+    prec = _train_precision(precision)
+    if _native_f16(x, weight_a, 1, prec, p2(dilation)):
+        return _Conv3dF16IO.apply(x, weight_a, (0,) + p2(padding), (1,) + p2(dilation), _wcache2(weight_a, weight_b), weight_b, None, True,
+                                  amp.conv_out_dtype(x))
+    return _Conv3d.apply(x, weight_a, 1, (0,) + p2(padding), (1,) + p2(dilation), prec, _wcache2(weight_a, weight_b), weight_b, None, True)
 
 
 # ----------------------------------------------------------------------------- fused ConvGRU gates (training path, csrc/gru_train.hip)

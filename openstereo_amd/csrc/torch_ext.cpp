@@ -276,7 +276,10 @@ std::tuple<at::Tensor, bool> cost_volume_cl(const at::Tensor& gwc_feat, const c1
 // (the caller then asks for prec 0); dw is written in place ([Co][Ci][k] or, transposed, [Ci][Co][k]).
 bool conv_wgrad(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, at::IntArrayRef dims, int64_t prec, const c10::optional<at::Tensor>& x_meta,
                 const c10::optional<at::Tensor>& dy_meta) {
-    gpu_f32(x, "x"); gpu_f32(dy, "dy"); gpu_f32(dw, "dw");
+    gpu_f32(dw, "dw");
+    const bool xh = x.scalar_type() == at::kHalf, dyh = dy.scalar_type() == at::kHalf;
+    TORCH_CHECK(x.is_cuda() && dy.is_cuda() && (xh || x.scalar_type() == at::kFloat) && (dyh || dy.scalar_type() == at::kFloat), "conv_wgrad: x / dy must be CUDA fp32 or fp16 tensors");
+    TORCH_CHECK(prec == 2 || (!xh && !dyh), "conv_wgrad: fp16 tensors exist in the native f16 form only (prec 2)");
     TORCH_CHECK(dims.size() == 22, "conv_wgrad: dims = [B, D, H, W, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad x3, dil x3, transposed]");
     int d[22];
     for (int i = 0; i < 22; ++i) d[i] = (int)dims[i];
@@ -287,12 +290,12 @@ bool conv_wgrad(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, at::In
         TORCH_CHECK(prec != 0, "conv_wgrad: unsupported layer");
         return false;
     }
-    auto ws = at::empty({(int64_t)((need + 3) / 4)}, x.options());
+    auto ws = at::empty({(int64_t)((need + 3) / 4)}, dw.options());
     void* st = cur_stream();
-#define OSA_WG_ARGS fp(x), fp(dy), dw.data_ptr<float>(), d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21]
+#define OSA_WG_ARGS static_cast<const float*>(x.data_ptr()), static_cast<const float*>(dy.data_ptr()), dw.data_ptr<float>(), d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21]
     if (prec == 0) OSA_CALL(osa_conv3d_wgrad_ws_f32(OSA_WG_ARGS, ws.data_ptr<float>(), need, st));
     else if (prec == 1) OSA_CALL(osa_conv3d_wgrad_ws_f16x3(OSA_WG_ARGS, fpo(x_meta), fpo(dy_meta), ws.data_ptr<float>(), need, st));
-    else OSA_CALL(osa_conv3d_wgrad_ws_f16(OSA_WG_ARGS, fpo(x_meta), fpo(dy_meta), ws.data_ptr<float>(), need, st));
+    else OSA_CALL(osa_conv3d_wgrad_ws_f16(OSA_WG_ARGS, fpo(x_meta), fpo(dy_meta), xh ? 1 : 0, dyh ? 1 : 0, ws.data_ptr<float>(), need, st));
 #undef OSA_WG_ARGS
     return true;
 }

@@ -51,6 +51,7 @@ struct WgradArgs {
     signed char g_od[16];                      // its d offset (class mode: delta on the sub-lattice)
     signed char g_slot[16][9];                 // accumulator slot dh * 3 + dw -> tap index inside the group, or -1
     const float* Pmeta; const float* Qmeta;   // f16x3 form: range blocks (max |.|) of the P and Q tensors
+    int Pf16, Qf16;                            // native f16 form (r5): the P / Q tensor holds fp16 elements (channel strides PCs / QCs in elements)
     int dbg;                                  // experiments build (OSA_WG_DBG): timing-only ablations of wgrad_f16x3_kernel -- 1 no global loads, 2 no LDS commit, 4 no MFMA phase, 8 no hand-over
 };
 
@@ -295,11 +296,22 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     for (int k = 0; k < PIT; ++k) pv[k][0] = pv[k][1] = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int k = 0; k < QIT; ++k) qv[k][0] = qv[k][1] = make_float4(1.f, 1.f, 1.f, 1.f);
-    auto load4 = [&](const float* src, int nc, bool ok) {
+    // four channels of one position at ELEMENT offset `off` of a tensor of fp32 or (f16 = 1: native f16 form, channel stride % 4 == 0) fp16 elements
+    auto load4 = [&](const float* base, size_t off, int nc, bool ok, int f16) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
-            if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
-            else { if (nc > 0) v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
+            if (f16) {
+                const _Float16* src = reinterpret_cast<const _Float16*>(base) + off;
+                if (nc >= 4) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(src);
+                    const wf16x2 a = __builtin_bit_cast(wf16x2, u.x), c = __builtin_bit_cast(wf16x2, u.y);
+                    v = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);
+                } else { if (nc > 0) v.x = (float)src[0]; if (nc > 1) v.y = (float)src[1]; if (nc > 2) v.z = (float)src[2]; }
+            } else {
+                const float* src = base + off;
+                if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
+                else { if (nc > 0) v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
+            }
         }
         return v;
     };
@@ -310,20 +322,20 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         for (int k = 0; k < PIT; ++k) {
             const int gd = p0d + p_d[k], gh = p0h + p_h[k], gw = p0w + p_w[k];
             const bool row = gd < p.Pd && gh < p.Ph;
-            const float* src = p.P + ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
+            const size_t off = ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
             const int nc = p.PC - (a0 + p_src[k]);
-            pv[k][0] = load4(src, nc, row && gw < p.Pw);
-            pv[k][1] = load4(src + p.PCs, nc, row && gw + 1 < p.Pw);
+            pv[k][0] = load4(p.P, off, nc, row && gw < p.Pw, SPLIT ? 0 : p.Pf16);
+            pv[k][1] = load4(p.P, off + p.PCs, nc, row && gw + 1 < p.Pw, SPLIT ? 0 : p.Pf16);
         }
         const int q0d = p0d + od, q0h = p0h + ghmin, q0w = p0w + gwmin;
 #pragma unroll
         for (int k = 0; k < QIT; ++k) {
             const int gd = qs * (q0d + q_d[k]) + pard, gh = qs * (q0h + q_h[k]) + parh, gw = qs * (q0w + q_w[k]) + parw;   // tensor coordinates
             const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
-            const float* src = p.Q + ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
+            const size_t off = ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
             const int nc = p.QC - (b0 + q_src[k]);
-            qv[k][0] = load4(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
-            qv[k][1] = load4(src + qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw);
+            qv[k][0] = load4(p.Q, off, nc, row && (unsigned)gw < (unsigned)p.Qw, SPLIT ? 0 : p.Qf16);
+            qv[k][1] = load4(p.Q, off + (size_t)qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw, SPLIT ? 0 : p.Qf16);
         }
     };
     auto commit = [&]() {                           // registers -> scaled fp16 hi / lo pairs in LDS
@@ -481,13 +493,14 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
                       int kd, int kh, int kw, int stride,
                       int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
                       int transposed, float* ws, size_t ws_bytes, size_t* query, void* stream,
-                      int f16x3 = 0, const float* x_meta = nullptr, const float* dy_meta = nullptr) {
+                      int f16x3 = 0, const float* x_meta = nullptr, const float* dy_meta = nullptr, int x_f16 = 0, int dy_f16 = 0) {
     if (!query) OSA_REQUIRE(x && dy && dw, "conv3d_wgrad: NULL pointer");
+    if (x_f16 || dy_f16) OSA_REQUIRE(f16x3 == 2, "conv3d_wgrad: fp16 tensors exist in the native f16 form only");
     const int T = kd * kh * kw;
     OSA_REQUIRE(T >= 1 && T <= 64, "conv3d_wgrad: %d taps unsupported", T);
     OSA_REQUIRE(stride == 1 || stride == 2, "conv3d_wgrad: stride %d unsupported", stride);
-    if (!query) OSA_REQUIRE(xCs % 4 == 0 && dyCs % 4 == 0 && (((size_t)x | (size_t)dy) & 15) == 0,
-                            "conv3d_wgrad: tensors must be 16-byte aligned with voxel strides %% 4 == 0");
+    if (!query) OSA_REQUIRE(xCs % 4 == 0 && dyCs % 4 == 0 && ((size_t)x & (x_f16 ? 7 : 15)) == 0 && ((size_t)dy & (dy_f16 ? 7 : 15)) == 0,
+                            "conv3d_wgrad: tensors must be 16-byte (fp16: 8-byte) aligned with voxel strides %% 4 == 0");
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.kh = kh; a.kw = kw; a.kvol = T;
@@ -618,6 +631,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         if (f16x3 == 1) OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
         a.ws = ws;
         a.Pmeta = transposed ? x_meta : dy_meta; a.Qmeta = transposed ? dy_meta : x_meta;       // conv: P = dy, Q = x; transposed: P = x, Q = dy
+        a.Pf16 = transposed ? x_f16 : dy_f16; a.Qf16 = transposed ? dy_f16 : x_f16;
         a.dbg = exp_int("OSA_WG_DBG", 0);
         dim3 grid((unsigned)gx, gy), block(256);
         if (f16x3 == 2) {
@@ -766,14 +780,15 @@ extern "C" int osa_conv3d_wgrad_ws_f16x3(const float* x, const float* dy, float*
 /* native f16 weight gradient (r5): the arithmetic of the reference's AMP training -- fp16 operands (rounded to nearest even when staged),
  * one MFMA per product, fp32 accumulation.  Same layers, workspace size and two-stage reduction as the f16x3 form; x_meta / dy_meta may be
  * NULL (no operand scaling, as under autocast: GradScaler owns the range) or range blocks (power-of-two scaling, undone exactly). */
-extern "C" int osa_conv3d_wgrad_ws_f16(const float* x, const float* dy, float* dw,
+extern "C" int osa_conv3d_wgrad_ws_f16(const void* x, const void* dy, float* dw,
                                        int B, int Di, int Hi, int Wi, int Ci, int xCs,
                                        int Do, int Ho, int Wo, int Co, int dyCs,
                                        int kd, int kh, int kw, int stride,
                                        int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
-                                       int transposed, const float* x_meta, const float* dy_meta,
+                                       int transposed, const float* x_meta, const float* dy_meta, int x_f16, int dy_f16,
                                        float* workspace, size_t workspace_bytes, void* stream) {
     OSA_REQUIRE(workspace, "conv3d_wgrad_ws_f16: NULL workspace (osa_conv3d_wgrad_f16x3_workspace_bytes gives its size)");
-    return wgrad_impl(x, dy, dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad_d, pad_h, pad_w,
-                      dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, 2, x_meta, dy_meta);
+    return wgrad_impl(static_cast<const float*>(x), static_cast<const float*>(dy), dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride,
+                      pad_d, pad_h, pad_w, dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, 2, x_meta, dy_meta,
+                      x_f16 ? 1 : 0, dy_f16 ? 1 : 0);
 }

@@ -195,3 +195,49 @@ class _stock_torch_convs:
         for n, f in self.saved.items():
             setattr(self.AG, n, f)
         return False
+
+
+F16IO = [  # name, kind, Ci, Co, k, pad, dims, input layout
+    ("conv3d 32-32 ncdhw", "conv3d", 32, 32, 3, 1, (6, 9, 12), "nchw"),
+    ("conv3d 64-40 cl", "conv3d", 64, 40, 3, 1, (5, 7, 11), "cl"),
+    ("conv3d 1x1x1 48-32 cl", "conv3d", 48, 32, 1, 0, (3, 9, 10), "cl"),
+    ("conv2d 3x3 384-128 cl (gru)", "conv2d", 384, 128, 3, 1, (1, 20, 46), "cl"),
+    ("conv2d 3x3 64-7 nchw (fp32 result)", "conv2d", 64, 7, 3, 1, (1, 9, 33), "nchw"),
+    ("conv2d slice of a wider map", "conv2d", 32, 32, 3, 1, (1, 12, 20), "slice"),
+]
+
+
+@pytest.mark.parametrize("case", F16IO, ids=[c[0] for c in F16IO])
+def test_fp16_tensor_path_vs_torch_on_the_same_fp16_tensors(case):
+    """_Conv3dF16IO: fp16 tensors in (NCHW, channels-last, or a channel slice of a wider NHWC map), fp16 result / data gradient, fp32 weight
+    gradient read from the fp16 activation and gradient -- against torch (fp32 arithmetic) on the SAME fp16 values; selected inside an fp16
+    autocast region for fp16 inputs; the saved activation is the fp16 tensor."""
+    from openstereo_amd import autograd as AG
+    name, kind, Ci, Co, k, p, (D, H, W), layout = case
+    two_d = kind == "conv2d"
+    w = (synth_tensor(name + ".w", (Co, Ci) + ((k, k) if two_d else (k, k, k)), 1) * 3.0).to(DEV)
+    bias = (rn((Co,), 3) * 0.5).to(DEV)
+    x32 = (rn((2, Ci, H, W) if two_d else (2, Ci, D, H, W), 21) * 2.0).to(DEV)
+    x16 = x32.half()
+    if layout == "cl":
+        x16 = x16.contiguous(memory_format=torch.channels_last if two_d else torch.channels_last_3d)
+    elif layout == "slice":
+        wide = torch.cat([x16, torch.zeros_like(x16)], 1).contiguous(memory_format=torch.channels_last)
+        x16 = wide[:, :Ci]
+    ref = (lambda a, b, c: F.conv2d(a, b, c, 1, p)) if two_d else (lambda a, b, c: F.conv3d(a, b, c, 1, p))
+    xr, wr, br = x16.float().detach().requires_grad_(), r16(w).requires_grad_(), bias.clone().requires_grad_()
+    y = ref(xr, wr, br)
+    gy = (torch.randn(y.shape, generator=torch.Generator().manual_seed(5)) * 7.0).to(DEV).half()
+    y.backward(gy.float())
+    xe, we, be = x16.detach().requires_grad_(), w.clone().requires_grad_(), bias.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.float16):
+        ye = (AG.conv2d if two_d else AG.conv3d)(xe, we, be, 1, p, 1)
+    assert ye.dtype == (torch.float16 if Co % 8 == 0 else torch.float32), ye.dtype
+    assert type(ye.grad_fn).__name__.startswith("_Conv3dF16IO"), type(ye.grad_fn).__name__
+    ye.backward(gy if ye.dtype == torch.float16 else gy.float())
+    assert xe.grad.dtype == torch.float16 and we.grad.dtype == torch.float32
+    # results are rounded to fp16 once (2^-11 relative); the weight gradient is fp32 sums of exact products
+    assert rel(ye, y) < 1e-3, ("fwd", rel(ye, y))
+    assert rel(xe.grad, xr.grad) < 1e-3, ("dx", rel(xe.grad, xr.grad))
+    assert rel(we.grad, wr.grad) < 5e-6, ("dw", rel(we.grad, wr.grad))
+    assert rel(be.grad, br.grad) < 1e-5, ("db", rel(be.grad, br.grad))
