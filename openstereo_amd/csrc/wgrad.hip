@@ -224,8 +224,11 @@ __device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& hi, unsi
 // (trainer_template.py:211-226: autocast + GradScaler; the weight gradient of an autocast convolution multiplies fp16 activations by
 // fp16 output gradients and accumulates in fp32): operands rounded to fp16 (nearest even) when they are staged, ONE MFMA per product, no
 // lo planes in LDS (half the footprint).  Range blocks are optional there (NULL: no scaling, like autocast -- GradScaler owns the range).
-template <int TD, int TH, int TW, int SPLIT>     // 128 positions: 2x8x8 or (flat) 1x8x16
+// PF16 / QF16 (SPLIT = 0 only): the P / Q tensor holds fp16 elements -- compile-time, so that the load sequence of every variant is
+// straight-line (a run-time dtype branch inside the back-to-back loads cost the fp32-tensor variant 25 % of its speed).
+template <int TD, int TH, int TW, int SPLIT, int PF16 = 0, int QF16 = 0>     // 128 positions: 2x8x8 or (flat) 1x8x16
 __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
+    static_assert(!SPLIT || (!PF16 && !QF16), "fp16 tensors exist in the native f16 form only");
     static_assert(TD * TH * TW == 128 && (TW == 8 || TW == 16), "128-position bricks");
     constexpr int ROWH = (TW == 8) ? 16 : 24;        // halves per Q row in LDS (LW <= TW + 2, padded to a 16-byte multiple)
     constexpr int LHM = TH + 2;                      // Q rows per plane in LDS (host: at most 2 halo rows)
@@ -297,21 +300,22 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
 #pragma unroll
     for (int k = 0; k < QIT; ++k) qv[k][0] = qv[k][1] = make_float4(1.f, 1.f, 1.f, 1.f);
     // four channels of one position at ELEMENT offset `off` of a tensor of fp32 or (f16 = 1: native f16 form, channel stride % 4 == 0) fp16 elements
-    auto load4 = [&](const float* base, size_t off, int nc, bool ok, int f16) {
+    auto load4f = [&](const float* src, int nc, bool ok) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
-            if (f16) {
-                const _Float16* src = reinterpret_cast<const _Float16*>(base) + off;
-                if (nc >= 4) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(src);
-                    const wf16x2 a = __builtin_bit_cast(wf16x2, u.x), c = __builtin_bit_cast(wf16x2, u.y);
-                    v = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);
-                } else { if (nc > 0) v.x = (float)src[0]; if (nc > 1) v.y = (float)src[1]; if (nc > 2) v.z = (float)src[2]; }
-            } else {
-                const float* src = base + off;
-                if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
-                else { if (nc > 0) v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
-            }
+            if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
+            else { if (nc > 0) v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
+        }
+        return v;
+    };
+    auto load4h = [&](const _Float16* src, int nc, bool ok) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            if (nc >= 4) {
+                const uint2 u = *reinterpret_cast<const uint2*>(src);
+                const wf16x2 a = __builtin_bit_cast(wf16x2, u.x), c = __builtin_bit_cast(wf16x2, u.y);
+                v = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);
+            } else { if (nc > 0) v.x = (float)src[0]; if (nc > 1) v.y = (float)src[1]; if (nc > 2) v.z = (float)src[2]; }
         }
         return v;
     };
@@ -324,8 +328,15 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
             const bool row = gd < p.Pd && gh < p.Ph;
             const size_t off = ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
             const int nc = p.PC - (a0 + p_src[k]);
-            pv[k][0] = load4(p.P, off, nc, row && gw < p.Pw, SPLIT ? 0 : p.Pf16);
-            pv[k][1] = load4(p.P, off + p.PCs, nc, row && gw + 1 < p.Pw, SPLIT ? 0 : p.Pf16);
+            if constexpr (PF16) {
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.P) + off;
+                pv[k][0] = load4h(src, nc, row && gw < p.Pw);
+                pv[k][1] = load4h(src + p.PCs, nc, row && gw + 1 < p.Pw);
+            } else {
+                const float* src = p.P + off;
+                pv[k][0] = load4f(src, nc, row && gw < p.Pw);
+                pv[k][1] = load4f(src + p.PCs, nc, row && gw + 1 < p.Pw);
+            }
         }
         const int q0d = p0d + od, q0h = p0h + ghmin, q0w = p0w + gwmin;
 #pragma unroll
@@ -334,8 +345,15 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
             const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
             const size_t off = ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
             const int nc = p.QC - (b0 + q_src[k]);
-            qv[k][0] = load4(p.Q, off, nc, row && (unsigned)gw < (unsigned)p.Qw, SPLIT ? 0 : p.Qf16);
-            qv[k][1] = load4(p.Q, off + (size_t)qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw, SPLIT ? 0 : p.Qf16);
+            if constexpr (QF16) {
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.Q) + off;
+                qv[k][0] = load4h(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
+                qv[k][1] = load4h(src + qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw);
+            } else {
+                const float* src = p.Q + off;
+                qv[k][0] = load4f(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
+                qv[k][1] = load4f(src + qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw);
+            }
         }
     };
     auto commit = [&]() {                           // registers -> scaled fp16 hi / lo pairs in LDS
@@ -635,8 +653,15 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         a.dbg = exp_int("OSA_WG_DBG", 0);
         dim3 grid((unsigned)gx, gy), block(256);
         if (f16x3 == 2) {
-            if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16, 0>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8, 0>), grid, block, lds, st, a);
+#define OSA_WG_F16(TD_, TH_, TW_)                                                                                                    \
+            switch (a.Pf16 * 2 + a.Qf16) {                                                                                           \
+                case 0: hipLaunchKernelGGL((wgrad_f16x3_kernel<TD_, TH_, TW_, 0, 0, 0>), grid, block, lds, st, a); break;              \
+                case 1: hipLaunchKernelGGL((wgrad_f16x3_kernel<TD_, TH_, TW_, 0, 0, 1>), grid, block, lds, st, a); break;              \
+                case 2: hipLaunchKernelGGL((wgrad_f16x3_kernel<TD_, TH_, TW_, 0, 1, 0>), grid, block, lds, st, a); break;              \
+                default: hipLaunchKernelGGL((wgrad_f16x3_kernel<TD_, TH_, TW_, 0, 1, 1>), grid, block, lds, st, a); break;             \
+            }
+            if (flat16) { OSA_WG_F16(1, 8, 16) } else { OSA_WG_F16(2, 8, 8) }
+#undef OSA_WG_F16
         } else {
             if (flat16) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, 8, 16, 1>), grid, block, lds, st, a);
             else hipLaunchKernelGGL((wgrad_f16x3_kernel<2, 8, 8, 1>), grid, block, lds, st, a);
