@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-5 final pass on the GPU box (through gpurun), everything at ONE code state:
+#   1. the whole GPU suite                                   -> gpurun_out/r5_final/suite.log
+#   2. tools/profile_round4.sh r5 (kernel stats + FETCH_SIZE / WRITE_SIZE / SQ passes of `bench.py --timed-only --no-graph --streams 1`)
+#   3. the default bench line as the driver runs it          -> gpurun_out/r5_final/bench_default.json
+#   4. replay-to-replay determinism of the timed configuration and of the head next to the marching kernel (tools/diag_*.py)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5_final; mkdir -p $O
+python -m pytest tests -m gpu -q 2>&1 | grep -v GridwiseOp > $O/suite.log; tail -4 $O/suite.log
+bash tools/profile_round4.sh r5 > $O/profile.log 2>&1; tail -3 $O/profile.log
+cd $GRAFT_REPO_ROOT
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; head -c 700 $O/bench_default.json; echo
+for i in 1 2 3; do python tools/diag_timed_config.py --tag final_$i 2>&1 | grep "^\[" ; done > $O/determinism.txt
+python tools/diag_head_under_load.py --load f16x3 --iters 60 --tag "shipped head next to the marching kernel" 2>&1 | grep "^\[" >> $O/determinism.txt
+cat $O/determinism.txt
