@@ -222,6 +222,54 @@ __global__ __launch_bounds__(256) void geo_lookup_bwd_kernel(const LookupBwdArgs
     }
 }
 
+// r5: the same gradient in GATHER form.  The scatter kernel above gives every pixel ONE thread that read-modify-writes 324 scattered floats
+// of its (memset) rows: 0.54 ms per call at the 80 x 184 training map, 22 calls per StereoBase step (12 ms, the largest single item of the AMP
+// step's kernel census).  Here a thread owns one OUTPUT element (pixel, level, row, position j) and sums the taps that land on
+// it: tap k contributes dout_k * w0_k if x0_k == j and dout_k * w1_k if x0_k + 1 == j.  The taps are evaluated with the same tap_of() and
+// visited in the same order k = 0 .. 2r as the scatter kernel adds them, so the result is bit-identical; every element is written (zeros
+// included): no memset, no read-modify-write, consecutive threads write consecutive floats.
+struct LookupBwdGatherArgs {
+    float* dgeo[4]; float* dcorr[4];
+    const float* disp; const float* coords; const float* dout;
+    int B, H, W, C, levels, radius;
+    int Dl[4], Wl[4];
+    long long seg_end[8];            // running end of segment 2 l (geo rows of level l) / 2 l + 1 (corr rows) in the flat element index
+};
+__global__ __launch_bounds__(256) void geo_lookup_bwd_gather_kernel(const LookupBwdGatherArgs p) {
+    const long long HW = (long long)p.H * p.W;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nseg = 2 * p.levels;
+    if (t >= p.seg_end[nseg - 1]) return;
+    int sgm = 0;
+    while (t >= p.seg_end[sgm]) ++sgm;
+    const long long e = t - (sgm ? p.seg_end[sgm - 1] : 0);
+    const int l = sgm >> 1;
+    const bool is_corr = sgm & 1;
+    const int n = is_corr ? p.Wl[l] : p.Dl[l];
+    const int rows = is_corr ? 1 : p.C;
+    const int j = (int)(e % n);
+    const long long r = e / n;
+    const int c = is_corr ? p.C : (int)(r % rows);
+    const long long i = is_corr ? r : r / rows;                        // pixel
+    const long long b = i / HW, hw = i - b * HW;
+    const int taps = 2 * p.radius + 1;
+    const int per_level = (p.C + 1) * taps;
+    float scale = 1.f;
+    for (int q = 0; q < l; ++q) scale *= 0.5f;
+    const float d = p.disp[i], cx = p.coords[i];
+    const float xg = d * scale, xc = cx * scale - d * scale;
+    const float* o = p.dout + (size_t)b * per_level * p.levels * HW + hw + ((size_t)l * per_level + (size_t)c * taps) * HW;
+    float v = 0.f;
+    for (int k = 0; k < taps; ++k) {
+        const float dx = (float)(k - p.radius);
+        const Tap tp = is_corr ? tap_of(xc + dx, n) : tap_of(dx + xg, n);
+        if (tp.x0 == j) v += o[(size_t)k * HW] * tp.w0;
+        if (tp.x0 + 1 == j) v += o[(size_t)k * HW] * tp.w1;
+    }
+    float* dst = is_corr ? p.dcorr[l] : p.dgeo[l];
+    dst[e] = v;
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -232,8 +280,25 @@ extern "C" int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* d
                                       int B, int H, int W, int C, int radius, void* stream) {
     OSA_REQUIRE(dgeo_levels && dcorr_levels && geo_len && corr_len && disp && coords_x && dout, "geo_lookup_bwd: NULL pointer");
     OSA_REQUIRE(levels >= 1 && levels <= 4, "geo_lookup_bwd: %d levels unsupported (1..4)", levels);
-    LookupBwdArgs a;
     const long long total = (long long)B * H * W;
+    if (!exp_int("OSA_GEO_BWD_SCATTER", 0)) {                              // gather form (r5): one thread per output element, no memset
+        LookupBwdGatherArgs g;
+        long long end = 0;
+        for (int l = 0; l < levels; ++l) {
+            OSA_REQUIRE(dgeo_levels[l] && dcorr_levels[l] && geo_len[l] > 0 && corr_len[l] > 0, "geo_lookup_bwd: level %d missing", l);
+            g.dgeo[l] = dgeo_levels[l]; g.dcorr[l] = dcorr_levels[l]; g.Dl[l] = geo_len[l]; g.Wl[l] = corr_len[l];
+            end += total * C * geo_len[l]; g.seg_end[2 * l] = end;
+            end += total * corr_len[l]; g.seg_end[2 * l + 1] = end;
+        }
+        for (int q = 2 * levels; q < 8; ++q) g.seg_end[q] = end;
+        g.disp = disp; g.coords = coords_x; g.dout = dout;
+        g.B = B; g.H = H; g.W = W; g.C = C; g.levels = levels; g.radius = radius;
+        OSA_REQUIRE((end + 255) / 256 < (1ll << 31), "geo_lookup_bwd: grid too large");
+        hipLaunchKernelGGL(geo_lookup_bwd_gather_kernel, dim3((unsigned)((end + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
+        OSA_LAUNCH_CHECK("geo_lookup_bwd (gather)");
+        return 0;
+    }
+    LookupBwdArgs a;
     for (int l = 0; l < levels; ++l) {
         OSA_REQUIRE(dgeo_levels[l] && dcorr_levels[l] && geo_len[l] > 0 && corr_len[l] > 0, "geo_lookup_bwd: level %d missing", l);
         a.dgeo[l] = dgeo_levels[l]; a.dcorr[l] = dcorr_levels[l]; a.Dl[l] = geo_len[l]; a.Wl[l] = corr_len[l];

@@ -142,31 +142,43 @@ def test_freeze_bn_training_step_converted_equals_unconverted(which):
         m.load_state_dict(synth_state_dict(m, seed=0))
         L, R = synth_images(1, 64, 128, seed=1)
         L, R = L.to(DEV), R.to(DEV)
-    plain = _freeze_bn(copy.deepcopy(m).train()).to(DEV)
-    plain2 = _freeze_bn(copy.deepcopy(m).train()).to(DEV)          # a second unconverted instance: the spread between two model OBJECTS
-    conv = _sync(_freeze_bn(copy.deepcopy(m).train())).to(DEV)
-    assert all(not x.training for x in conv.modules() if isinstance(x, nn.SyncBatchNorm))      # convert keeps the frozen (eval) flag
-    losses, grads = [], []
-    for net in (plain, conv, plain2):          # the third run (another unconverted instance) measures the step's own instance-to-instance spread
-        net.zero_grad(set_to_none=True)
-        out = net({"left": L, "right": R})
-        loss = sum(p.float().abs().mean() for p in out["disp_preds"]) + (out["init_disp"].abs().mean() if "init_disp" in out else 0.0)
-        loss.backward()
-        losses.append(float(loss))
-        grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    # [MI355X] r5, tools/diag_syncbn_spread.py (profiles/round5/training_step_determinism.txt): PyTorch-ROCm's own convolutions (MIOpen: the
+    # strided / dilated 2-D layers the engine leaves to torch in training mode) are not run-to-run reproducible by default -- ulp-level
+    # differences in the forward pass, which flip the ReLU mask of single near-zero activations and move individual gradients by 1e-4 .. 1e-2
+    # of their tensor's maximum between two runs of the SAME model object.  With MIOpen's deterministic attribute every run of the step --
+    # any model object, converted or not -- is bit-identical, engine kernels (forward, data gradient, weight gradient) included.
+    det0 = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        plain = _freeze_bn(copy.deepcopy(m).train()).to(DEV)
+        plain2 = _freeze_bn(copy.deepcopy(m).train()).to(DEV)          # a second unconverted instance: the spread between two model OBJECTS
+        conv = _sync(_freeze_bn(copy.deepcopy(m).train())).to(DEV)
+        assert all(not x.training for x in conv.modules() if isinstance(x, nn.SyncBatchNorm))      # convert keeps the frozen (eval) flag
+        losses, grads = [], []
+        for net in (plain, conv, plain2):      # the third run (another unconverted instance) measures the step's own instance-to-instance spread
+            net.zero_grad(set_to_none=True)
+            out = net({"left": L, "right": R})
+            loss = sum(p.float().abs().mean() for p in out["disp_preds"]) + (out["init_disp"].abs().mean() if "init_disp" in out else 0.0)
+            loss.backward()
+            losses.append(float(loss.detach()))
+            grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        torch.backends.cudnn.deterministic = det0
     assert np.isfinite(losses[0]) and abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0]), losses
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 10, (len(grads[0]), len(grads[1]))
-    worst = 0.0
+    worst, worst_noise = 0.0, 0.0
     for k in grads[0]:
         a, b, a2 = grads[0][k], grads[1][k], grads[2][k]
         s = max(1e-6, float(a.abs().max()))
-        noise = float((a - a2).abs().max()) / s          # float atomics in torch's own backward kernels (BatchNorm / interpolate) are order dependent
+        noise = float((a - a2).abs().max()) / s          # what is left are float atomics in torch's own backward kernels (interpolate, index ops)
         err = float((a - b).abs().max()) / s
-        worst = max(worst, err)
-        # [MI355X] r5: the two unconverted instances agree to ~1e-6, the converted one to 3-5e-5 of max |grad| (PyTorch's SyncBatchNorm module
-        # in eval mode inside the training graph; the engine's convolutions are the same launches) -- a dropped or mis-folded norm is O(1)
-        assert err <= 2e-4 + 4.0 * noise, (k, err, noise)
-    print(f"[{which}] converted vs unconverted FREEZE_BN step: worst relative gradient difference {worst:.2e}")
+        worst, worst_noise = max(worst, err), max(worst_noise, noise)
+        assert err <= TOL_FREEZE[which] + 4.0 * noise, (k, err, noise)     # a dropped or mis-folded norm is O(1)
+    print(f"[{which}] converted vs unconverted FREEZE_BN step: worst relative gradient difference {worst:.2e} (two unconverted objects: {worst_noise:.2e})")
+
+
+# GwcNet: measured 0 (bit-identical) over 8 runs of 4 model objects; the bound leaves room for one ulp of the largest element only
+TOL_FREEZE = {"gwcnet": 2e-7, "stereobase": 2e-4}
 
 
 def test_unfoldable_norm_raises_instead_of_being_dropped():
