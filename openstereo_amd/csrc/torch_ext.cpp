@@ -401,6 +401,203 @@ void geo_lookup_bwd(at::TensorList dlevels, const at::Tensor& disp, const at::Te
     OSA_CALL(osa_geo_lookup_bwd_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), fp(dout), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
 }
 
+// ---- r5, second batch: the rest of the launch path (inference helpers of the GRU loop, LightStereo's depthwise layers, weight packing, the
+// fused redir branch, preprocessing), so that a process with the extension loaded issues NO launch through ctypes (tools/ctypes_census.py).
+// These are in-place engine launches on caller-allocated buffers (allocation policy and range-block bookkeeping stay with the Python layer
+// classes), hence the Tensor(a!) schemas and no Meta / Autograd registrations: inference-only, nothing to trace or differentiate.
+inline float* mfp(const c10::optional<at::Tensor>& t) { return (t.has_value() && t->defined() && t->numel()) ? t->data_ptr<float>() : nullptr; }
+inline const at::Tensor* opt(const c10::optional<at::Tensor>& t) { return (t.has_value() && t->defined()) ? &*t : nullptr; }
+
+// osa_build_volume_f32: group-wise correlation and / or concatenation volume into `out` (layout 0 NCDHW / 1 NDHWC with VC channel stride, c_off)
+void build_volume(const c10::optional<at::Tensor>& lg, const c10::optional<at::Tensor>& rg, int64_t G, const c10::optional<at::Tensor>& lc,
+                  const c10::optional<at::Tensor>& rc, at::Tensor out, int64_t layout, int64_t VC, int64_t c_off, int64_t maxdisp, bool mask_left,
+                  const c10::optional<at::Tensor>& meta) {
+    const at::Tensor* g0 = opt(lg); const at::Tensor* c0 = opt(lc);
+    TORCH_CHECK(g0 || c0, "build_volume: no features");
+    const at::Tensor& ref = g0 ? *g0 : *c0;
+    gpu_f32(ref, "features"); gpu_f32(out, "out");
+    TORCH_CHECK(ref.dim() == 4, "build_volume: features are [B,C,H,W]");
+    for (const auto* t : {opt(lg), opt(rg), opt(lc), opt(rc)})
+        if (t) TORCH_CHECK(gpu_f32(*t, "features").is_contiguous() && t->size(0) == ref.size(0) && t->size(2) == ref.size(2) && t->size(3) == ref.size(3),
+                           "build_volume: contiguous fp32 feature maps of one spatial shape");
+    TORCH_CHECK((g0 != nullptr) == (opt(rg) != nullptr) && (c0 != nullptr) == (opt(rc) != nullptr), "build_volume: left and right maps come in pairs");
+    OSA_CALL(osa_build_volume_f32(fpo(lg), fpo(rg), g0 ? (int)g0->size(1) : 0, (int)G, fpo(lc), fpo(rc), c0 ? (int)c0->size(1) : 0, out.data_ptr<float>(),
+                                  (int)layout, (int)VC, (int)c_off, (int)ref.size(0), (int)ref.size(2), (int)ref.size(3), (int)maxdisp, mask_left ? 1 : 0, mfp(meta),
+                                  cur_stream()));
+}
+
+// transposed conv + fused 1x1x1 redir branch (hourglass.py:52-56: relu(conv6(c5) + redir1(x))); dims = [B, D, H, W, Ci, xCs, Co, yCs],
+// geom = [k, pad, opad], rdims = [rxCs, rCi]; prec 0 f32 / 1 f16x3 (metas as in conv_ndhwc)
+void deconv_redir(const at::Tensor& x, int64_t x_off, const at::Tensor& packed, const c10::optional<at::Tensor>& scale, const c10::optional<at::Tensor>& shift,
+                  at::Tensor out, int64_t out_off, at::IntArrayRef dims, at::IntArrayRef geom, const at::Tensor& rx, at::IntArrayRef rdims, const at::Tensor& rpacked,
+                  const c10::optional<at::Tensor>& rscale, const c10::optional<at::Tensor>& rshift, double r_out_scale, int64_t prec, int64_t act, double slope,
+                  double out_scale, at::TensorList metas) {
+    gpu_f32(x, "x"); gpu_f32(out, "out"); gpu_f32(rx, "redir input"); gpu_f32(packed, "packed"); gpu_f32(rpacked, "redir packed");
+    TORCH_CHECK(dims.size() == 8 && geom.size() == 3 && rdims.size() == 2, "deconv_redir: dims = [B, D, H, W, Ci, xCs, Co, yCs], geom = [k, pad, opad], rdims = [rxCs, rCi]");
+    TORCH_CHECK(prec == 0 || prec == 1, "deconv_redir: f32 and f16x3 only (the f16 mode runs the 1x1x1 layer separately)");
+    const int d[8] = {(int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7]};
+    const float* xp = (const float*)vp(x, x_off);
+    float* yp = (float*)vp(out, out_off);
+    if (prec == 0) {
+        OSA_CALL(osa_deconv3d_redir_ndhwc_f32(xp, fp(packed), fpo(scale), fpo(shift), yp, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], (int)geom[0], (int)geom[1], (int)geom[2],
+                                              fp(rx), (int)rdims[0], (int)rdims[1], fp(rpacked), fpo(rscale), fpo(rshift), (int)act, (float)slope, cur_stream()));
+        return;
+    }
+    TORCH_CHECK(metas.size() == 7, "deconv_redir: the f16x3 mode takes the 7 range blocks of conv_ndhwc");
+    auto mp = [&](size_t i) -> float* { return metas[i].defined() && metas[i].numel() ? metas[i].data_ptr<float>() : nullptr; };
+    osa_f16x3_ranges rng{};
+    rng.x_meta = mp(0); rng.residual_meta = mp(1); rng.redir_meta = mp(2); rng.y_meta = mp(3); rng.bound_coef = mp(4); rng.redir_bound_coef = mp(5); rng.weight_scale = mp(6);
+    OSA_CALL(osa_deconv3d_redir_ndhwc_f16x3(xp, fp(packed), fpo(scale), fpo(shift), yp, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], (int)geom[0], (int)geom[1], (int)geom[2],
+                                            fp(rx), (int)rdims[0], (int)rdims[1], fp(rpacked), fpo(rscale), fpo(rshift), (float)r_out_scale, (int)act, (float)slope,
+                                            (float)out_scale, &rng, cur_stream()));
+}
+
+// classification conv with Co <= 4 (gwcnet_disp_processor.py:64-81 classif*: 32 -> 1): dims = [B, D, H, W, Ci, xCs, Co, yCs], geom = [kd, kh, kw, pd, ph, pw]
+void small_co_conv(const at::Tensor& x, const at::Tensor& packed, const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& residual, at::Tensor y,
+                   at::IntArrayRef dims, at::IntArrayRef geom) {
+    gpu_f32(x, "x"); gpu_f32(packed, "packed"); gpu_f32(y, "y");
+    TORCH_CHECK(dims.size() == 8 && geom.size() == 6, "small_co_conv: dims = [B, D, H, W, Ci, xCs, Co, yCs], geom = [kd, kh, kw, pd, ph, pw]");
+    OSA_CALL(osa_conv3d_small_co_packed_ndhwc_f32(fp(x), fp(packed), fpo(bias), fpo(residual), y.data_ptr<float>(), (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3],
+                                                  (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7], (int)geom[0], (int)geom[1], (int)geom[2], (int)geom[3], (int)geom[4],
+                                                  (int)geom[5], cur_stream()));
+}
+
+// depthwise 2-D conv + folded norm + activation (+ add) on NHWC maps (lightstereo aggregation.py:79-113): dims = [B, Hi, Wi, C, xCs, yCs, aCs],
+// geom = [kh, kw, stride, pad_h, pad_w, dil_h, dil_w]
+void dwconv2d(const at::Tensor& x, const at::Tensor& packed, const c10::optional<at::Tensor>& scale, const c10::optional<at::Tensor>& shift,
+              const c10::optional<at::Tensor>& add, at::Tensor y, at::IntArrayRef dims, at::IntArrayRef geom, int64_t act, const c10::optional<at::Tensor>& y_meta) {
+    gpu_f32(x, "x"); gpu_f32(packed, "packed"); gpu_f32(y, "y");
+    TORCH_CHECK(dims.size() == 7 && geom.size() == 7, "dwconv2d: dims = [B, Hi, Wi, C, xCs, yCs, aCs], geom = [kh, kw, stride, pad_h, pad_w, dil_h, dil_w]");
+    OSA_CALL(osa_dwconv2d_nhwc_f32(fp(x), fp(packed), fpo(scale), fpo(shift), fpo(add), y.data_ptr<float>(), (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4],
+                                   (int)dims[5], (int)dims[6], (int)geom[0], (int)geom[1], (int)geom[2], (int)geom[3], (int)geom[4], (int)geom[5], (int)geom[6], (int)act,
+                                   mfp(y_meta), cur_stream()));
+}
+
+// h' = (1 - z) h + z q of the inference GRU loop (igev/update.py:45) on channel slices of the level buffer: dims = [npix, C, zCs, qCs, hCs, oCs]
+void gru_combine(const at::Tensor& z, int64_t z_off, const at::Tensor& q, const at::Tensor& h, at::Tensor out, at::IntArrayRef dims, const c10::optional<at::Tensor>& out_meta) {
+    gpu_f32(z, "z"); gpu_f32(q, "q"); gpu_f32(h, "h"); gpu_f32(out, "out");
+    TORCH_CHECK(dims.size() == 6, "gru_combine: dims = [npix, C, zCs, qCs, hCs, oCs]");
+    OSA_CALL(osa_gru_combine_f32(fp(z) + z_off, fp(q), fp(h), out.data_ptr<float>(), (long long)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5],
+                                 mfp(out_meta), cur_stream()));
+}
+
+// pool2x (update.py:99-100; kind 0, dims = [B, H, W, C, xCs, yCs]) / bilinear align_corners resize (:107-109; kind 1, dims = [B, Hi, Wi, Ho, Wo, C, xCs, yCs])
+// of channels [0, C) of x into channels [y_off, y_off + C) of y
+void resample_nhwc(const at::Tensor& x, at::Tensor y, int64_t y_off, int64_t kind, at::IntArrayRef dims, const c10::optional<at::Tensor>& x_meta,
+                   const c10::optional<at::Tensor>& y_meta) {
+    gpu_f32(x, "x"); gpu_f32(y, "y");
+    float* yp = y.data_ptr<float>() + y_off;
+    if (kind == 0) {
+        TORCH_CHECK(dims.size() == 6, "resample_nhwc: pool dims = [B, H, W, C, xCs, yCs]");
+        OSA_CALL(osa_pool2x_nhwc_f32(fp(x), yp, (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5], fpo(x_meta), mfp(y_meta), cur_stream()));
+    } else {
+        TORCH_CHECK(dims.size() == 8, "resample_nhwc: resize dims = [B, Hi, Wi, Ho, Wo, C, xCs, yCs]");
+        OSA_CALL(osa_resize_bilinear_nhwc_f32(fp(x), yp, (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (int)dims[5], (int)dims[6], (int)dims[7],
+                                              fpo(x_meta), mfp(y_meta), cur_stream()));
+    }
+}
+
+// disp += delta and its two other homes (NHWC [disp,0,0,0] map, channel `slot_off` of the 1/4 level's x slot): igev_stereo.py:196-199
+void disp_update(at::Tensor disp, const c10::optional<at::Tensor>& delta, int64_t delta_cs, at::Tensor disp4, at::Tensor slot, int64_t slot_off, int64_t slot_cs,
+                 int64_t npix, const c10::optional<at::Tensor>& disp4_meta, const c10::optional<at::Tensor>& slot_meta) {
+    gpu_f32(disp, "disp"); gpu_f32(disp4, "disp4"); gpu_f32(slot, "slot");
+    OSA_CALL(osa_disp_update_f32(disp.data_ptr<float>(), fpo(delta), (int)delta_cs, disp4.data_ptr<float>(), slot.data_ptr<float>() + slot_off, (int)slot_cs, (long long)npix,
+                                 mfp(disp4_meta), mfp(slot_meta), cur_stream()));
+}
+
+// the lookup of the inference loop: NHWC output with channel stride out_cs (geometry.py lookup_cl); bhw = [B, H, W]
+void geo_lookup_nhwc(at::TensorList levels, const at::Tensor& disp, const at::Tensor& coords_x, at::Tensor out, int64_t out_cs, at::IntArrayRef bhw, int64_t C, int64_t radius) {
+    const size_t L = levels.size() / 2;
+    TORCH_CHECK(L >= 1 && L <= 4 && levels.size() == 2 * L && bhw.size() == 3, "geo_lookup_nhwc: levels = geo pyramid + corr pyramid (1..4 levels each), bhw = [B, H, W]");
+    gpu_f32(disp, "disp"); gpu_f32(coords_x, "coords_x"); gpu_f32(out, "out");
+    const float* gp[4]; const float* cp[4]; int gl[4], cl[4];
+    for (size_t l = 0; l < L; ++l) {
+        gp[l] = fp(gpu_f32(levels[l], "geo level")); cp[l] = fp(gpu_f32(levels[L + l], "corr level"));
+        gl[l] = (int)levels[l].size(-1); cl[l] = (int)levels[L + l].size(-1);
+    }
+    OSA_CALL(osa_geo_lookup_nhwc_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), out.data_ptr<float>(), (int)out_cs, (int)bhw[0], (int)bhw[1], (int)bhw[2], (int)C, (int)radius,
+                                     cur_stream()));
+}
+
+// pyramid construction (igev/geometry.py:8-31): all-pairs correlation, volume -> per-pixel rows, row-wise average pooling
+void allpairs_corr(const at::Tensor& f1, const at::Tensor& f2, at::Tensor corr) {
+    gpu_f32(f1, "fmap1"); gpu_f32(f2, "fmap2"); gpu_f32(corr, "corr");
+    TORCH_CHECK(f1.dim() == 4 && f2.dim() == 4 && f1.is_contiguous() && f2.is_contiguous(), "allpairs_corr: contiguous [B,C,H,W] feature maps");
+    OSA_CALL(osa_allpairs_corr_f32(fp(f1), fp(f2), corr.data_ptr<float>(), (int)f1.size(0), (int)f1.size(1), (int)f1.size(2), (int)f1.size(3), (int)f2.size(3), cur_stream()));
+}
+void geo_rows(const at::Tensor& vol, at::Tensor rows, int64_t C) {
+    gpu_f32(vol, "volume"); gpu_f32(rows, "rows");
+    TORCH_CHECK(vol.dim() == 5, "geo_rows: volume is logical [B,Cs,D,H,W] in NDHWC memory order");
+    OSA_CALL(osa_geo_rows_f32(fp(vol), rows.data_ptr<float>(), (int)vol.size(0), (int)vol.size(2), (int)vol.size(3), (int)vol.size(4), (int)C, (int)vol.size(1), cur_stream()));
+}
+void avgpool_rows(const at::Tensor& x, at::Tensor y) {
+    gpu_f32(x, "x"); gpu_f32(y, "y");
+    TORCH_CHECK(x.is_contiguous() && x.dim() >= 1 && x.size(-1) > 0, "avgpool_rows: contiguous rows");
+    OSA_CALL(osa_avgpool_rows_f32(fp(x), y.data_ptr<float>(), (long long)(x.numel() / x.size(-1)), (int)x.size(-1), cur_stream()));
+}
+
+// weight packing of the inference layer classes (host float weight scale).  family 0 conv3d geom = [Ci, Co, kd, kh, kw]; 1 deconv3d / 2 deconv2d
+// geom = [Ci, Co, k, pad]; 3 depthwise 2-D geom = [C, kh, kw]; 4 small-Co conv geom = [Ci, Co, kd, kh, kw].  prec 0 f32 / 1 f16x3 / 2 f16.
+void weight_pack(const at::Tensor& w, at::Tensor packed, int64_t family, int64_t prec, at::IntArrayRef geom, double wscale) {
+    gpu_f32(w, "w"); gpu_f32(packed, "packed");
+    TORCH_CHECK(w.is_contiguous(), "weight_pack: contiguous reference-layout weights");
+    const float* src = fp(w); float* dst = packed.data_ptr<float>(); void* st = cur_stream();
+    auto g = [&](size_t i) { return (int)geom[i]; };
+    if (family == 0) {
+        TORCH_CHECK(geom.size() == 5, "weight_pack: conv geometry = [Ci, Co, kd, kh, kw]");
+        if (prec == 1) OSA_CALL(osa_conv3d_pack_f16x3(src, dst, g(0), g(1), g(2), g(3), g(4), (float)wscale, st));
+        else if (prec == 2) OSA_CALL(osa_conv3d_pack_f16(src, dst, g(0), g(1), g(2), g(3), g(4), st));
+        else OSA_CALL(osa_conv3d_pack_f32(src, dst, g(0), g(1), g(2), g(3), g(4), st));
+    } else if (family == 1 || family == 2) {
+        TORCH_CHECK(geom.size() == 4, "weight_pack: transposed-conv geometry = [Ci, Co, k, pad]");
+        const bool flat = family == 2;
+        if (prec == 1) OSA_CALL((flat ? osa_deconv2d_pack_f16x3 : osa_deconv3d_pack_f16x3)(src, dst, g(0), g(1), g(2), g(3), (float)wscale, st));
+        else if (prec == 2) OSA_CALL((flat ? osa_deconv2d_pack_f16 : osa_deconv3d_pack_f16)(src, dst, g(0), g(1), g(2), g(3), st));
+        else OSA_CALL((flat ? osa_deconv2d_pack_f32 : osa_deconv3d_pack_f32)(src, dst, g(0), g(1), g(2), g(3), st));
+    } else if (family == 3) {
+        TORCH_CHECK(geom.size() == 3, "weight_pack: depthwise geometry = [C, kh, kw]");
+        OSA_CALL(osa_dwconv2d_pack_f32(src, dst, g(0), g(1), g(2), st));
+    } else {
+        TORCH_CHECK(family == 4 && geom.size() == 5, "weight_pack: small-Co geometry = [Ci, Co, kd, kh, kw]");
+        OSA_CALL(osa_conv3d_small_co_pack_f32(src, dst, g(0), g(1), g(2), g(3), g(4), st));
+    }
+}
+
+// remaining single-launch helpers: PSMNet's cat_fms volume, the pairwise volumes of the smaller model families, instance norm on NHWC maps, the
+// fused preprocessing of one stereo pair (mean / std: 3 host floats each), max |t| into a range block
+void cat_fms(const at::Tensor& ref, const at::Tensor& tgt, at::Tensor out, const at::Tensor& disp_index) {
+    gpu_f32(ref, "reference_fm"); gpu_f32(tgt, "target_fm"); gpu_f32(out, "out");
+    TORCH_CHECK(ref.dim() == 4 && ref.is_contiguous() && tgt.is_contiguous() && disp_index.is_cuda() && disp_index.scalar_type() == at::kInt, "cat_fms: contiguous [B,C,H,W] maps, int32 indices");
+    OSA_CALL(osa_cat_fms_f32(fp(ref), fp(tgt), out.data_ptr<float>(), disp_index.data_ptr<int>(), (int)ref.size(0), (int)ref.size(1), (int)ref.size(2), (int)ref.size(3),
+                             (int)disp_index.numel(), cur_stream()));
+}
+void pair_volume(const at::Tensor& l, const at::Tensor& r, at::Tensor out, int64_t groups, int64_t planes, int64_t mode) {
+    gpu_f32(l, "left"); gpu_f32(r, "right"); gpu_f32(out, "out");
+    TORCH_CHECK(l.dim() == 4 && l.is_contiguous() && r.is_contiguous() && l.sizes() == r.sizes(), "pair_volume: contiguous [B,C,H,W] maps of equal shape");
+    OSA_CALL(osa_pair_volume_f32(fp(l), fp(r), out.data_ptr<float>(), (int)l.size(0), (int)l.size(1), (int)groups, (int)l.size(2), (int)l.size(3), (int)planes, (int)mode, cur_stream()));
+}
+void instnorm_nhwc(const at::Tensor& x, at::Tensor out, int64_t out_off, at::IntArrayRef dims, double eps, int64_t act, double slope, at::Tensor workspace,
+                   const c10::optional<at::Tensor>& y_meta) {
+    gpu_f32(x, "x"); gpu_f32(out, "out"); gpu_f32(workspace, "workspace");
+    TORCH_CHECK(dims.size() == 5, "instnorm_nhwc: dims = [B, HW, C, xCs, yCs]");
+    OSA_CALL(osa_instnorm_nhwc_f32(fp(x), out.data_ptr<float>() + out_off, (int)dims[0], (long long)dims[1], (int)dims[2], (int)dims[3], (int)dims[4], (float)eps, (int)act,
+                                   (float)slope, workspace.data_ptr<float>(), mfp(y_meta), cur_stream()));
+}
+void preprocess_pair(const at::Tensor& l, const at::Tensor& r, at::Tensor out, at::IntArrayRef pad_size, at::ArrayRef<double> mean, at::ArrayRef<double> stdv, bool channels_last) {
+    TORCH_CHECK(l.is_cuda() && r.is_cuda() && l.dim() == 3 && l.size(2) == 3 && l.sizes() == r.sizes() && l.scalar_type() == r.scalar_type() && l.is_contiguous() && r.is_contiguous(),
+                "preprocess_pair: two contiguous [H,W,3] CUDA images of one dtype");
+    TORCH_CHECK(l.scalar_type() == at::kByte || l.scalar_type() == at::kFloat, "preprocess_pair: uint8 or float32 images");
+    TORCH_CHECK(pad_size.size() == 2 && mean.size() == 3 && stdv.size() == 3, "preprocess_pair: pad_size = [Hp, Wp], mean / std of 3 channels");
+    gpu_f32(out, "out");
+    const float m3[3] = {(float)mean[0], (float)mean[1], (float)mean[2]}, s3[3] = {(float)stdv[0], (float)stdv[1], (float)stdv[2]};
+    OSA_CALL(osa_preprocess_pair_f32(l.data_ptr(), r.data_ptr(), l.scalar_type() == at::kByte ? 1 : 0, (int)l.size(0), (int)l.size(1), (int)pad_size[0], (int)pad_size[1], m3, s3,
+                                     out.data_ptr<float>(), channels_last ? 1 : 0, cur_stream()));
+}
+void amax_into(const at::Tensor& t, at::Tensor meta) {
+    gpu_f32(t, "t"); gpu_f32(meta, "meta");
+    OSA_CALL(osa_amax_f32(fp(t), (long long)t.numel(), meta.data_ptr<float>(), cur_stream()));
+}
+
 // ---- Meta kernels (shape / dtype inference in C++: FakeTensor tracing, torch.export, torch.compile need no Python shim) --------------------
 at::Tensor gwc_volume_meta(const at::Tensor& l, const at::Tensor& r, int64_t maxdisp, int64_t groups) {
     TORCH_CHECK(l.dim() == 4 && l.sizes() == r.sizes() && groups > 0 && l.size(1) % groups == 0, "gwc_volume: [B,C,H,W] features of equal shape, C % groups == 0");
@@ -580,6 +777,26 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("gru_gates_q_bwd(Tensor z, Tensor qpre, Tensor? bias_q, Tensor cq, Tensor h, Tensor dout, Tensor(a!) dz, Tensor(b!) dqpre, Tensor(c!) dh) -> ()");
     m.def("geo_lookup(Tensor[] levels, Tensor disp, Tensor coords_x, Tensor(a!) out, int C, int radius) -> ()");
     m.def("geo_lookup_bwd(Tensor(a!)[] dlevels, Tensor disp, Tensor coords_x, Tensor dout, int C, int radius) -> ()");
+    m.def("build_volume(Tensor? left_gwc, Tensor? right_gwc, int groups, Tensor? left_cat, Tensor? right_cat, Tensor(a!) out, int layout, int vol_channels, int c_off, "
+          "int maxdisp, bool mask_left, Tensor(b!)? meta) -> ()");
+    m.def("deconv_redir(Tensor x, int x_off, Tensor packed, Tensor? scale, Tensor? shift, Tensor(a!) out, int out_off, int[] dims, int[] geom, Tensor rx, int[] rdims, "
+          "Tensor rpacked, Tensor? rscale, Tensor? rshift, float r_out_scale, int prec, int act, float slope, float out_scale, Tensor[] metas) -> ()");
+    m.def("small_co_conv(Tensor x, Tensor packed, Tensor? bias, Tensor? residual, Tensor(a!) y, int[] dims, int[] geom) -> ()");
+    m.def("dwconv2d(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, Tensor? add, Tensor(a!) y, int[] dims, int[] geom, int act, Tensor(b!)? y_meta) -> ()");
+    m.def("gru_combine(Tensor z, int z_off, Tensor q, Tensor h, Tensor(a!) out, int[] dims, Tensor(b!)? out_meta) -> ()");
+    m.def("resample_nhwc(Tensor x, Tensor(a!) y, int y_off, int kind, int[] dims, Tensor? x_meta, Tensor(b!)? y_meta) -> ()");
+    m.def("disp_update(Tensor(a!) disp, Tensor? delta, int delta_cs, Tensor(b!) disp4, Tensor(c!) slot, int slot_off, int slot_cs, int npix, Tensor(d!)? disp4_meta, "
+          "Tensor(e!)? slot_meta) -> ()");
+    m.def("geo_lookup_nhwc(Tensor[] levels, Tensor disp, Tensor coords_x, Tensor(a!) out, int out_cs, int[] bhw, int C, int radius) -> ()");
+    m.def("allpairs_corr(Tensor fmap1, Tensor fmap2, Tensor(a!) corr) -> ()");
+    m.def("geo_rows(Tensor volume, Tensor(a!) rows, int C) -> ()");
+    m.def("avgpool_rows(Tensor x, Tensor(a!) y) -> ()");
+    m.def("weight_pack(Tensor w, Tensor(a!) packed, int family, int prec, int[] geom, float wscale) -> ()");
+    m.def("cat_fms(Tensor reference_fm, Tensor target_fm, Tensor(a!) out, Tensor disp_index) -> ()");
+    m.def("pair_volume(Tensor left, Tensor right, Tensor(a!) out, int groups, int planes, int mode) -> ()");
+    m.def("instnorm_nhwc(Tensor x, Tensor(a!) out, int out_off, int[] dims, float eps, int act, float slope, Tensor(b!) workspace, Tensor(c!)? y_meta) -> ()");
+    m.def("preprocess_pair(Tensor left_hwc, Tensor right_hwc, Tensor(a!) out, int[] pad_size, float[] mean, float[] std, bool channels_last) -> ()");
+    m.def("amax_into(Tensor t, Tensor(a!) meta) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers under PyTorch's CUDA dispatch key)
@@ -607,6 +824,23 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("gru_gates_q_bwd", &gru_gates_q_bwd);
     m.impl("geo_lookup", &geo_lookup);
     m.impl("geo_lookup_bwd", &geo_lookup_bwd);
+    m.impl("build_volume", &build_volume);
+    m.impl("deconv_redir", &deconv_redir);
+    m.impl("small_co_conv", &small_co_conv);
+    m.impl("dwconv2d", &dwconv2d);
+    m.impl("gru_combine", &gru_combine);
+    m.impl("resample_nhwc", &resample_nhwc);
+    m.impl("disp_update", &disp_update);
+    m.impl("geo_lookup_nhwc", &geo_lookup_nhwc);
+    m.impl("allpairs_corr", &allpairs_corr);
+    m.impl("geo_rows", &geo_rows);
+    m.impl("avgpool_rows", &avgpool_rows);
+    m.impl("weight_pack", &weight_pack);
+    m.impl("cat_fms", &cat_fms);
+    m.impl("pair_volume", &pair_volume);
+    m.impl("instnorm_nhwc", &instnorm_nhwc);
+    m.impl("preprocess_pair", &preprocess_pair);
+    m.impl("amax_into", &amax_into);
 }
 
 TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference without a device: FakeTensor, torch.export, torch.compile

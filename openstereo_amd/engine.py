@@ -291,7 +291,10 @@ class PackedConv3d:
                 fam = "osa_deconv3d"
             n = getattr(_lib.load(), fam + "_packed_floats")(self.Ci, self.Co, self.k[1])
             self.packed = torch.zeros(n, device=w.device, dtype=torch.float32)
-            if f16:
+            ext = _ext.load()
+            if ext is not None:
+                ext.weight_pack(w, self.packed, 2 if self.flat_deconv else 1, PRECISIONS.index(self.precision), [self.Ci, self.Co, self.k[1], self.pad[1]], wscale)
+            elif f16:
                 _lib.call(fam + "_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co,
                           self.k[1], self.pad[1], wscale, st)
             elif h16:
@@ -306,7 +309,10 @@ class PackedConv3d:
             assert s[1] == s[2] and (s[0] == s[1] or (self.k[0] == 1)), f"anisotropic stride {s}"
             n = _lib.load().osa_conv3d_packed_floats(self.Ci, self.Co, *self.k)
             self.packed = torch.zeros(n, device=w.device, dtype=torch.float32)
-            if f16:
+            ext = _ext.load()
+            if ext is not None:
+                ext.weight_pack(w, self.packed, 0, PRECISIONS.index(self.precision), [self.Ci, self.Co, *self.k], wscale)
+            elif f16:
                 _lib.call("osa_conv3d_pack_f16x3", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, wscale, st)
             elif h16:
                 _lib.call("osa_conv3d_pack_f16", w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, st)
@@ -394,8 +400,9 @@ class PackedConv3d:
             # output's own running maximum
             need_res = residual is not None and (out_split or is_split(residual))    # its scale (split) / its share of the output bound
             mx, mr, mo = input_meta(x), (input_meta(residual) if need_res else None), attach_meta(out, st)
+            mrd = None if redir is None else input_meta(redir[1])
             rng = _lib.F16x3Ranges(mx.data_ptr(), None if mr is None else mr.data_ptr(),
-                                   None if redir is None else input_meta(redir[1]).data_ptr(), mo.data_ptr(),
+                                   None if mrd is None else mrd.data_ptr(), mo.data_ptr(),
                                    self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
         taps = self.k[0] * self.k[1] * self.k[2]
         macs = B * Do * Ho * Wo * self.Ci * self.Co * taps / ((4 if self.flat_deconv else 8) if self.transposed else 1)
@@ -404,8 +411,22 @@ class PackedConv3d:
                          flops=2 * macs, nbytes=nbytes):
             tail = (self.out_scale, rng, st) if self.precision == "f16x3" else (st,)
             sfx = self.precision
-            ext = _ext.load() if redir is None else None
-            if ext is not None:
+            ext = _ext.load()
+            if ext is not None and redir is not None:
+                assert not h16, "the f16 mode has no fused redir branch (run the 1x1x1 layer and pass it as residual)"
+                rl, rt = redir
+                assert self.transposed and not self.flat_deconv and residual is None and gate is None
+                assert rl.precision == self.precision and rl.k == (1, 1, 1) and rl.Co == self.Co and rl.act == ACT_NONE
+                assert is_cl(rt) and tuple(rt.shape[2:]) == (Do, Ho, Wo) and rt.shape[1] >= rl.Ci and rl.Ci <= 64
+                if self.precision == "f16x3":
+                    e = _empty(x.device)
+                    metas = [mx, e, mrd, mo, self.coef, rl.coef, e]
+                else:
+                    metas = []
+                ext.deconv_redir(x, x_off, self.packed, self.scale, self.shift, out, out_off, [B, D, H, W, Ci, Cs, self.Co, yCs],
+                                 [self.k[0], self.pad[0], self.opad[0]], rt, [rt.shape[1], (rl.Ci + 3) // 4 * 4], rl.packed, rl.scale, rl.shift,
+                                 rl.out_scale, PRECISIONS.index(self.precision), act, self.slope, self.out_scale, metas)
+            elif ext is not None:
                 # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp): one dispatcher call, tensors in, current HIP stream inside
                 if self.transposed:
                     fam, geom = (2 if self.flat_deconv else 1), [self.k[1], self.pad[1], self.opad[1]]
@@ -474,7 +495,11 @@ class DepthwiseConv2d:
             else:
                 self.shift = (self.shift + bias * self.scale).contiguous()
         self.packed = torch.empty(self.k[0] * self.k[1] * self.C, device=w.device, dtype=torch.float32)
-        _lib.call("osa_dwconv2d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.C, self.k[0], self.k[1], _stream())
+        ext = _ext.load()
+        if ext is not None:
+            ext.weight_pack(w, self.packed, 3, 0, [self.C, self.k[0], self.k[1]], 1.0)
+        else:
+            _lib.call("osa_dwconv2d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.C, self.k[0], self.k[1], _stream())
 
     def __call__(self, x, add=None):
         assert is_cl(x) and x.dtype == torch.float32 and x.shape[2] == 1
@@ -488,10 +513,15 @@ class DepthwiseConv2d:
             assert is_cl(add) and tuple(add.shape[2:]) == (1, Ho, Wo) and add.shape[1] >= self.C
             aCs = add.shape[1]
         with timing.span("dwconv2d", self.C, self.C, self.k[0] * self.k[1], self.stride[0], 1, H, W):
-            _lib.call("osa_dwconv2d_nhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
-                      _p(add), out.data_ptr(), B, H, W, self.C, Cs, self.C, aCs,
-                      self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1], self.dil[0], self.dil[1],
-                      self.act, attach_meta(out).data_ptr(), _stream())
+            ext = _ext.load()
+            if ext is not None:
+                ext.dwconv2d(x, self.packed, self.scale, self.shift, add, out, [B, H, W, self.C, Cs, self.C, aCs],
+                             [self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1], self.dil[0], self.dil[1]], self.act, attach_meta(out))
+            else:
+                _lib.call("osa_dwconv2d_nhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                          _p(add), out.data_ptr(), B, H, W, self.C, Cs, self.C, aCs,
+                          self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1], self.dil[0], self.dil[1],
+                          self.act, attach_meta(out).data_ptr(), _stream())
         return out
 
 
@@ -512,7 +542,11 @@ class SmallCoConv3d:
         self.packed = torch.empty(n + 16, device=self.w.device, dtype=torch.float32)     # scalar-cache friendly layout
         off = (-self.packed.data_ptr() // 4) % 16                                         # 64-byte alignment
         self.packed = self.packed[off:off + n]
-        _lib.call("osa_conv3d_small_co_pack_f32", self.w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, _stream())
+        ext = _ext.load()
+        if ext is not None:
+            ext.weight_pack(self.w, self.packed, 4, 0, [self.Ci, self.Co, *self.k], 1.0)
+        else:
+            _lib.call("osa_conv3d_small_co_pack_f32", self.w.data_ptr(), self.packed.data_ptr(), self.Ci, self.Co, *self.k, _stream())
 
     def __call__(self, x, residual=None):
         """x NDHWC logical [B,Cs,D,H,W] -> logical [B,Co,D,H,W] stored [B,D,H,W,Co] (for Co==1 this
@@ -523,6 +557,10 @@ class SmallCoConv3d:
         if residual is not None:
             assert tuple(residual.shape) == (B, self.Co, D, H, W) and is_cl(residual)
         with timing.span("conv3d_small_co", self.Ci, self.Co, self.k[0], 1, D, H, W):
-            _lib.call("osa_conv3d_small_co_packed_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.bias), _p(residual), y.data_ptr(),
-                      B, D, H, W, self.Ci, Cs, self.Co, self.Co, *self.k, *self.pad, _stream())
+            ext = _ext.load()
+            if ext is not None:
+                ext.small_co_conv(x, self.packed, self.bias, residual, y, [B, D, H, W, self.Ci, Cs, self.Co, self.Co], [*self.k, *self.pad])
+            else:
+                _lib.call("osa_conv3d_small_co_packed_ndhwc_f32", x.data_ptr(), self.packed.data_ptr(), _p(self.bias), _p(residual), y.data_ptr(),
+                          B, D, H, W, self.Ci, Cs, self.Co, self.Co, *self.k, *self.pad, _stream())
         return y.permute(0, 4, 1, 2, 3)

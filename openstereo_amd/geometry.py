@@ -99,21 +99,31 @@ class CombinedGeoEncodingVolume:
         W2 = f2.shape[3]
         dev = f1.device
         corr = torch.empty((B, H, W1, W2), device=dev, dtype=torch.float32)
-        _lib.call("osa_allpairs_corr_f32", f1.data_ptr(), f2.data_ptr(), corr.data_ptr(), B, Cf, H, W1, W2, _stream())
+        ext = _ext.load()
+        if ext is not None:
+            ext.allpairs_corr(f1, f2, corr)
+        else:
+            _lib.call("osa_allpairs_corr_f32", f1.data_ptr(), f2.data_ptr(), corr.data_ptr(), B, Cf, H, W1, W2, _stream())
         gv = geo_volume if is_cl(geo_volume) and geo_volume.dtype == torch.float32 else ops.to_cl(geo_volume.float(), pad_to=1)
         _, Cs, D, Hg, Wg = gv.shape
         C = geo_volume.shape[1] if not is_cl(geo_volume) else Cs
         self.C = C
         assert (Hg, Wg) == (H, W1)
         rows = torch.empty((B, H, W1, C, D), device=dev, dtype=torch.float32)
-        _lib.call("osa_geo_rows_f32", gv.data_ptr(), rows.data_ptr(), B, D, H, W1, C, Cs, _stream())
+        if ext is not None:
+            ext.geo_rows(gv, rows, C)
+        else:
+            _lib.call("osa_geo_rows_f32", gv.data_ptr(), rows.data_ptr(), B, D, H, W1, C, Cs, _stream())
         self.geo_volume_pyramid, self.init_corr_pyramid = [rows], [corr]
         for _ in range(num_levels - 1):
             g, c = self.geo_volume_pyramid[-1], self.init_corr_pyramid[-1]
             g2 = torch.empty(g.shape[:-1] + (g.shape[-1] // 2,), device=dev, dtype=torch.float32)
             c2 = torch.empty(c.shape[:-1] + (c.shape[-1] // 2,), device=dev, dtype=torch.float32)
-            _lib.call("osa_avgpool_rows_f32", g.data_ptr(), g2.data_ptr(), g.numel() // g.shape[-1], g.shape[-1], _stream())
-            _lib.call("osa_avgpool_rows_f32", c.data_ptr(), c2.data_ptr(), c.numel() // c.shape[-1], c.shape[-1], _stream())
+            if ext is not None:
+                ext.avgpool_rows(g, g2); ext.avgpool_rows(c, c2)
+            else:
+                _lib.call("osa_avgpool_rows_f32", g.data_ptr(), g2.data_ptr(), g.numel() // g.shape[-1], g.shape[-1], _stream())
+                _lib.call("osa_avgpool_rows_f32", c.data_ptr(), c2.data_ptr(), c.numel() // c.shape[-1], c.shape[-1], _stream())
             self.geo_volume_pyramid.append(g2); self.init_corr_pyramid.append(c2)
         L = num_levels
         self._gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in self.geo_volume_pyramid])
@@ -151,8 +161,12 @@ class CombinedGeoEncodingVolume:
         d, cx = _f32c(disp), _f32c(coords)
         assert d.numel() == B * H * W and cx.numel() == B * H * W
         with timing.span("geo_lookup", self.C, self.num_levels, self.radius, H, W):
-            _lib.call("osa_geo_lookup_nhwc_f32", self._gp, self._cp, self._gl, self._cl, self.num_levels,
-                      d.data_ptr(), cx.data_ptr(), out.data_ptr(), out.shape[1], B, H, W, self.C, self.radius, _stream())
+            ext = _ext.load()
+            if ext is not None:
+                ext.geo_lookup_nhwc(self.geo_volume_pyramid + self.init_corr_pyramid, d, cx, out, out.shape[1], [B, H, W], self.C, self.radius)
+            else:
+                _lib.call("osa_geo_lookup_nhwc_f32", self._gp, self._cp, self._gl, self._cl, self.num_levels,
+                          d.data_ptr(), cx.data_ptr(), out.data_ptr(), out.shape[1], B, H, W, self.C, self.radius, _stream())
         out._osa_meta = self.meta                  # taps interpolate / zero-pad the volumes: bounded by their max |.|
         return out
 
@@ -163,7 +177,11 @@ class CombinedGeoEncodingVolume:
         B, Cf, H, W1 = f1.shape
         W2 = f2.shape[3]
         out = torch.empty((B, H, W1, 1, W2), device=f1.device, dtype=torch.float32)
-        _lib.call("osa_allpairs_corr_f32", f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cf, H, W1, W2, _stream())
+        ext = _ext.load()
+        if ext is not None:
+            ext.allpairs_corr(f1, f2, out)
+        else:
+            _lib.call("osa_allpairs_corr_f32", f1.data_ptr(), f2.data_ptr(), out.data_ptr(), B, Cf, H, W1, W2, _stream())
         return out
 
 

@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib, amp
+from .. import _ext, _lib, amp
 from ..engine import (ACT_LEAKY, ACT_NONE, ACT_RELU6, DepthwiseConv2d, PackedConv3d, cached_pack, norm_kind)
 from ..ops import _stream, empty_cl, is_cl, on_engine
 from ..ranges import attach_meta, combine_meta, input_meta, meta_of
@@ -125,8 +125,12 @@ def instance_norm_act_cl(x, C, act=ACT_LEAKY, slope=0.01, out=None, out_off=0, e
     m = meta_of(out)
     if m is None and meta_of(x) is not None:
         m = attach_meta(out)
-    _lib.call("osa_instnorm_nhwc_f32", x.data_ptr(), out.data_ptr() + 4 * out_off, B, H * W, C, Cs, out.shape[1], float(eps), act, float(slope),
-              ws.data_ptr(), None if m is None else m.data_ptr(), _stream())
+    ext = _ext.load()
+    if ext is not None:
+        ext.instnorm_nhwc(x, out, out_off, [B, H * W, C, Cs, out.shape[1]], float(eps), act, float(slope), ws, m)
+    else:
+        _lib.call("osa_instnorm_nhwc_f32", x.data_ptr(), out.data_ptr() + 4 * out_off, B, H * W, C, Cs, out.shape[1], float(eps), act, float(slope),
+                  ws.data_ptr(), None if m is None else m.data_ptr(), _stream())
     return out
 
 

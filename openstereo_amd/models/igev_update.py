@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import _lib, amp
+from .. import _ext, _lib, amp
 from .. import autograd as AG
 from ..engine import cached_pack, PackedConv3d, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from ..ops import empty_cl, is_cl, on_engine, _stream
@@ -90,10 +90,16 @@ def _resample_into(kind, src, C, dst, off):
     B, sCs, _, H, W = src.shape
     _, dCs, _, Hd, Wd = dst.shape
     sm, dm = meta_of(src), meta_of(dst)
-    xm = None if (sm is None or dm is None) else sm.data_ptr()
-    ym = None if xm is None else dm.data_ptr()
+    if sm is None or dm is None:
+        sm = dm = None
     if kind == "pool":
         assert (Hd, Wd) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1), ((H, W), (Hd, Wd))
+    ext = _ext.load()
+    if ext is not None:
+        ext.resample_nhwc(src, dst, off, 0 if kind == "pool" else 1, [B, H, W, C, sCs, dCs] if kind == "pool" else [B, H, W, Hd, Wd, C, sCs, dCs], sm, dm)
+        return
+    xm, ym = (None, None) if sm is None else (sm.data_ptr(), dm.data_ptr())
+    if kind == "pool":
         _lib.call("osa_pool2x_nhwc_f32", src.data_ptr(), dst.data_ptr() + 4 * off, B, H, W, C, sCs, dCs, xm, ym, _stream())
     else:
         _lib.call("osa_resize_bilinear_nhwc_f32", src.data_ptr(), dst.data_ptr() + 4 * off, B, H, W, Hd, Wd, C, sCs, dCs, xm, ym, _stream())
@@ -194,6 +200,10 @@ class ConvGRU(nn.Module):
         assert prz.Ci == hd + cx, (prz.Ci, hd, cx)
         prz(T, residual=lv.crz, gate=_nhwc(T), gate_raw=True, gate_channels=hd, out=T, out_off=hd + cx)    # [sigmoid(convr+cr)*h | sigmoid(convz+cz)]
         pq(T, x_off=hd, residual=lv.cq, out=lv.q)                                                           # tanh(convq([r*h, x]) + cq)
+        ext = _ext.load()
+        if ext is not None:
+            ext.gru_combine(T, 2 * hd + cx, lv.q, T, T, [lv.B * lv.H * lv.W, hd, T.shape[1], lv.q.shape[1], T.shape[1], T.shape[1]], meta_of(T))
+            return
         zoff = 4 * (2 * hd + cx)
         _lib.call("osa_gru_combine_f32", T.data_ptr() + zoff, lv.q.data_ptr(), T.data_ptr(), T.data_ptr(), lv.B * lv.H * lv.W, hd,
                   T.shape[1], lv.q.shape[1], T.shape[1], T.shape[1], None if meta_of(T) is None else meta_of(T).data_ptr(), _stream())
@@ -481,11 +491,16 @@ def run_refinement(update_block, a, match_left, match_right, geo_encoding_volume
     lvs = update_block._levels(net, inp, n_gru)
     lv4 = lvs[0]
     net = [l.T for l in lvs if l is not None] + net[n_gru:]
-    m4 = attach_meta(disp4).data_ptr() if meta_of(lv4.T) is not None else None
-    ms = None if meta_of(lv4.T) is None else meta_of(lv4.T).data_ptr()
+    m4t = attach_meta(disp4) if meta_of(lv4.T) is not None else None
+    mst = meta_of(lv4.T)
+    m4, ms = (None if m4t is None else m4t.data_ptr()), (None if mst is None else mst.data_ptr())
     slot = lv4.T.data_ptr() + 4 * (lv4.hd + 127)
+    ext = _ext.load()
 
     def advance(delta):
+        if ext is not None:
+            ext.disp_update(disp, delta, 0 if delta is None else delta.shape[1], disp4, lv4.T, lv4.hd + 127, lv4.T.shape[1], b * h * w, m4t, mst)
+            return
         _lib.call("osa_disp_update_f32", disp.data_ptr(), None if delta is None else delta.data_ptr(), 0 if delta is None else delta.shape[1],
                   disp4.data_ptr(), slot, lv4.T.shape[1], b * h * w, m4, ms, _stream())
     advance(None)

@@ -132,10 +132,14 @@ def _build(lg, rg, G, lc, rc, maxdisp, layout, mask_left=True, out=None, vol_cha
                 out.zero_()
         else:
             out = torch.empty((B, VC, maxdisp, H, W), device=ref.device, dtype=torch.float32)
-    meta = attach_meta(out).data_ptr() if layout == NDHWC else None     # range block for f16x3 consumers
+    meta = attach_meta(out) if layout == NDHWC else None     # range block for f16x3 consumers
     with timing.span("build_volume", Cg, G, Cc, layout, maxdisp, H, W):
-        _lib.call("osa_build_volume_f32", _p(lg), _p(rg), Cg, G, _p(lc), _p(rc), Cc,
-                  out.data_ptr(), layout, VC, c_off, B, H, W, maxdisp, 1 if mask_left else 0, meta, _stream())
+        ext = _ext.load()
+        if ext is not None:
+            ext.build_volume(lg, rg, G, lc, rc, out, layout, VC, c_off, maxdisp, bool(mask_left), meta)
+        else:
+            _lib.call("osa_build_volume_f32", _p(lg), _p(rg), Cg, G, _p(lc), _p(rc), Cc,
+                      out.data_ptr(), layout, VC, c_off, B, H, W, maxdisp, 1 if mask_left else 0, _p(meta), _stream())
     return out
 
 
@@ -190,7 +194,11 @@ def cat_fms(reference_fm, target_fm, max_disp=192, start_disp=0, dilation=1):
     n = (max_disp + dilation - 1) // dilation                                          # psmnet_cost_processor.py:31-33
     idx = torch.tensor([int(i) for i in torch.linspace(start_disp, start_disp + max_disp - 1, n)], dtype=torch.int32, device=ref.device)
     out = torch.empty((B, 2 * C, n, H, W), device=ref.device, dtype=torch.float32)
-    _lib.call("osa_cat_fms_f32", ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), idx.data_ptr(), B, C, H, W, n, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        ext.cat_fms(ref, tgt, out, idx)
+    else:
+        _lib.call("osa_cat_fms_f32", ref.data_ptr(), tgt.data_ptr(), out.data_ptr(), idx.data_ptr(), B, C, H, W, n, _stream())
     return out
 
 
@@ -200,7 +208,11 @@ def _pair_volume(left, right, planes, mode, groups=1):
     B, C, H, W = l.shape
     shape = (B, groups, planes, H, W) if mode == 0 else ((B, planes, H, W) if mode == 3 else (B, C, planes, H, W))
     out = torch.empty(shape, device=l.device, dtype=torch.float32)
-    _lib.call("osa_pair_volume_f32", l.data_ptr(), r.data_ptr(), out.data_ptr(), B, C, groups, H, W, planes, mode, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        ext.pair_volume(l, r, out, groups, planes, mode)
+    else:
+        _lib.call("osa_pair_volume_f32", l.data_ptr(), r.data_ptr(), out.data_ptr(), B, C, groups, H, W, planes, mode, _stream())
     return out if left.dtype == torch.float32 else out.to(left.dtype)
 
 
@@ -395,8 +407,12 @@ def preprocess_pair(left_hwc, right_hwc, pad_size, mean=IMAGENET_MEAN, std=IMAGE
         out = torch.empty((2, 1, Hp, Wp, 4), device=l.device, dtype=torch.float32)
     else:
         out = torch.empty((2, 3, Hp, Wp), device=l.device, dtype=torch.float32)
-    _lib.call("osa_preprocess_pair_f32", l.data_ptr(), r.data_ptr(), 1 if l.dtype == torch.uint8 else 0, H, W, Hp, Wp,
-              m3, s3, out.data_ptr(), 1 if channels_last else 0, _stream())
+    ext = _ext.load()
+    if ext is not None:
+        ext.preprocess_pair(l, r, out, [Hp, Wp], [float(v) for v in mean], [float(v) for v in std], bool(channels_last))
+    else:
+        _lib.call("osa_preprocess_pair_f32", l.data_ptr(), r.data_ptr(), 1 if l.dtype == torch.uint8 else 0, H, W, Hp, Wp,
+                  m3, s3, out.data_ptr(), 1 if channels_last else 0, _stream())
     if channels_last:
         return out.permute(0, 4, 1, 2, 3)
     return out[0:1], out[1:2]

