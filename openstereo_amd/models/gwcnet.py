@@ -46,6 +46,7 @@ def _cb2(cin, cout, k, stride, pad, dil):
         nn.BatchNorm2d(cout))
 
 
+TRAIN_BACKBONE_ENGINE = os.environ.get("OSA_GWC_TRAIN_BACKBONE_ENGINE", "0") == "1"     # A/B switch (r5): the 2-D extractor's training path through autograd.engine_convs()
 _FUSE_REDIR = os.environ.get("OSA_FUSE_REDIR", "1") != "0"
 _SPLIT_ACT = os.environ.get("OSA_SPLIT_ACT", "1") != "0"     # f16x3: 3-D activations stored pre-split between engine layers
 _VOL_SPLIT = os.environ.get("OSA_VOL_SPLIT", "1") != "0"     # f16x3: the cost volume itself is written in the split format (r4; A/B switch)
@@ -174,6 +175,9 @@ class GwcBackbone(nn.Module):
             # gwcnet_backbone.py:108-109: two separate calls -- with FREEZE_BN off (the GwcNet / PSMNet default) each call has
             # its own batch statistics and its own momentum update of the running statistics
             with timing.span("backbone2d", left.shape[2], left.shape[3]):
+                if TRAIN_BACKBONE_ENGINE and ops.on_engine(left):       # stride-1 convolutions forward + backward on the engine; BN / ReLU / strided convs torch
+                    with AG.engine_convs():
+                        return {"ref_feature": self.feature_extraction(left), "tgt_feature": self.feature_extraction(right)}
                 return {"ref_feature": self.feature_extraction(left), "tgt_feature": self.feature_extraction(right)}
         else:
             with timing.span("backbone2d", left.shape[2], left.shape[3]):

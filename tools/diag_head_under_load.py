@@ -28,6 +28,8 @@ cost = (torch.randn(B, D, H, W, generator=g) * 3.0).to(dev)
 x32 = ops.to_cl((torch.randn(B, 32, D, H, W, generator=g)).to(dev))
 conv = nn.Conv3d(32, 32, 3, padding=1, bias=False).to(dev)
 small = nn.Conv3d(32, 1, 3, padding=1, bias=False).to(dev)
+fl, fr = torch.randn(B, 320, H, W, generator=g).to(dev), torch.randn(B, 320, H, W, generator=g).to(dev)
+cl_, cr_ = torch.randn(B, 12, H, W, generator=g).to(dev), torch.randn(B, 12, H, W, generator=g).to(dev)
 
 
 def launch():
@@ -37,6 +39,14 @@ def launch():
         return cost.clone()
     if a.kernel == "classifier":
         return clf(x32)
+    if a.kernel == "softmax":                       # softmax_softargmin_kernel (StereoBase / IGEV / LightStereo heads): 18 packed-fp32 instructions as shipped in r5
+        return ops.softmax_disparity_regression(cost, D)
+    if a.kernel == "upgeneric":                     # the any-size upsample + soft-argmin kernel (71 packed-fp32 instructions as shipped in r5)
+        return ops.upsample_softargmin(cost, 96, 2 * H, 2 * W)
+    if a.kernel == "gwcvol":                        # NCDHW volume builder
+        return ops.build_gwc_volume(fl, fr, 48, 40)
+    if a.kernel == "clvol":                         # the fused gwc + concat builder writing NDHWC (osa_build_volume_f32, layout 1)
+        return ops.build_cost_volume_cl(fl, fr, 40, cl_, cr_, maxdisp=48)
     raise SystemExit("unknown kernel")
 
 
