@@ -270,6 +270,66 @@ __global__ __launch_bounds__(256) void geo_lookup_bwd_gather_kernel(const Lookup
     dst[e] = v;
 }
 
+// Gather form, one WAVE per (pixel, level) (r5, second version): the 2r + 1 tap positions of the level's geometry rows and of its correlation row
+// are evaluated once per wave (they depend on the pixel only), a lane owns output positions j = lane, lane + 64, ... of every row, the
+// upstream gradients of a row's taps are wave-uniform loads, and the lanes of a wave store consecutive floats.  The thread-per-element form
+// above evaluates the same 9 taps for each of the C * D + W elements of the pixel.  Same taps, same order of additions: bit-identical.
+template <int MAXT>
+__global__ __launch_bounds__(256) void geo_lookup_bwd_rows_kernel(const LookupBwdGatherArgs p) {
+    const long long HW = (long long)p.H * p.W;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long i = (long long)blockIdx.x * 4 + wv;                // pixel (wave-uniform)
+    const int l = blockIdx.y;
+    if (i >= (long long)p.B * HW) return;
+    const int lane = threadIdx.x & 63;
+    const long long b = i / HW, hw = i - b * HW;
+    const int taps = 2 * p.radius + 1;                                  // <= MAXT (host)
+    const int per_level = (p.C + 1) * taps;
+    float scale = 1.f;
+    for (int q = 0; q < l; ++q) scale *= 0.5f;
+    const float d = p.disp[i], cx = p.coords[i];
+    const float xg = d * scale, xc = cx * scale - d * scale;
+    const int Dl = p.Dl[l], Wl = p.Wl[l];
+    int gx0[MAXT], cx0[MAXT]; float gw0[MAXT], gw1[MAXT], cw0[MAXT], cw1[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+        const float dx = (float)(k - p.radius);
+        const Tap tg = tap_of(dx + xg, Dl), tc = tap_of(xc + dx, Wl);
+        const bool on = k < taps;
+        gx0[k] = on ? tg.x0 : -4; gw0[k] = tg.w0; gw1[k] = tg.w1;       // (-4: matches no position j >= 0, nor j - 1)
+        cx0[k] = on ? tc.x0 : -4; cw0[k] = tc.w0; cw1[k] = tc.w1;
+    }
+    const float* o = p.dout + (size_t)b * per_level * p.levels * HW + hw + (size_t)l * per_level * HW;
+    float* g = p.dgeo[l] + (size_t)i * p.C * Dl;
+    for (int c = 0; c < p.C; ++c) {
+        float ov[MAXT];
+#pragma unroll
+        for (int k = 0; k < MAXT; ++k) ov[k] = k < taps ? o[((size_t)c * taps + k) * HW] : 0.f;
+        for (int j = lane; j < Dl; j += 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXT; ++k) {
+                if (gx0[k] == j) v += ov[k] * gw0[k];
+                if (gx0[k] + 1 == j) v += ov[k] * gw1[k];
+            }
+            g[(size_t)c * Dl + j] = v;
+        }
+    }
+    float ov[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) ov[k] = k < taps ? o[((size_t)p.C * taps + k) * HW] : 0.f;
+    float* crow = p.dcorr[l] + (size_t)i * Wl;
+    for (int j = lane; j < Wl; j += 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXT; ++k) {
+            if (cx0[k] == j) v += ov[k] * cw0[k];
+            if (cx0[k] + 1 == j) v += ov[k] * cw1[k];
+        }
+        crow[j] = v;
+    }
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -294,6 +354,11 @@ extern "C" int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* d
         g.disp = disp; g.coords = coords_x; g.dout = dout;
         g.B = B; g.H = H; g.W = W; g.C = C; g.levels = levels; g.radius = radius;
         OSA_REQUIRE((end + 255) / 256 < (1ll << 31), "geo_lookup_bwd: grid too large");
+        if (2 * radius + 1 <= 9 && exp_int("OSA_GEO_BWD_FORM", 2) == 2) {     // one wave per (pixel, level): every shipped config has radius 4
+            hipLaunchKernelGGL(geo_lookup_bwd_rows_kernel<9>, dim3((unsigned)((total + 3) / 4), levels), dim3(256), 0, (hipStream_t)stream, g);
+            OSA_LAUNCH_CHECK("geo_lookup_bwd (rows)");
+            return 0;
+        }
         hipLaunchKernelGGL(geo_lookup_bwd_gather_kernel, dim3((unsigned)((end + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
         OSA_LAUNCH_CHECK("geo_lookup_bwd (gather)");
         return 0;
