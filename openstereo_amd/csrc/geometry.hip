@@ -135,6 +135,35 @@ __global__ __launch_bounds__(256) void geo_lookup_kernel(const LookupArgs p) {
     }
 }
 
+// The same NCHW lookup with one thread per (row, pixel) (r5): the per-pixel kernel above has B*H*W threads -- 14720 at the StereoBase training
+// map (80 x 184), under one wave per SIMD of the chip, each walking 324 scattered loads.  Here a thread produces the 2r + 1 taps of ONE row
+// (geometry row c of level l, or that level's correlation row) of one pixel; consecutive threads are consecutive pixels of the same row, so
+// every store instruction of a wave writes consecutive floats of one output plane.  Same tap_of / sample_row: same values.
+__global__ __launch_bounds__(256) void geo_lookup_rows_kernel(const LookupArgs p) {
+    const long long HW = (long long)p.H * p.W, npix = (long long)p.B * HW;
+    const int rows_per_px = p.levels * (p.C + 1);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= npix * rows_per_px) return;
+    const int j = (int)(t / npix);                                  // row (uniform over a workgroup unless it straddles a row boundary)
+    const long long i = t - (long long)j * npix;                    // pixel
+    const long long b = i / HW, hw = i - b * HW;
+    const int l = j / (p.C + 1), c = j - l * (p.C + 1);
+    const int taps = 2 * p.radius + 1;
+    const int per_level = (p.C + 1) * taps;
+    float scale = 1.f;
+    for (int q = 0; q < l; ++q) scale *= 0.5f;
+    const float d = p.disp[i], cx = p.coords[i];
+    const bool is_corr = (c == p.C);
+    const int n = is_corr ? p.Wl[l] : p.Dl[l];
+    const float* row = is_corr ? p.corr[l] + (size_t)i * p.Wl[l] : p.geo[l] + ((size_t)i * p.C + c) * p.Dl[l];
+    const float xg = d * scale, xc = cx * scale - d * scale;
+    float* o = p.out + (size_t)b * per_level * p.levels * HW + hw + ((size_t)l * per_level + (size_t)c * taps) * HW;
+    for (int k = 0; k < taps; ++k) {
+        const float dx = (float)(k - p.radius);
+        o[(size_t)k * HW] = sample_row(row, n, is_corr ? tap_of(xc + dx, n) : tap_of(dx + xg, n));      // operand order of geometry.py:36 / :44
+    }
+}
+
 // Channels-last form for the engine's GRU loop: out [B,H,W,Cs] (Cs >= channels, the padding zero-filled), i.e. what the update
 // block's 1x1 convc1 reads -- the NCHW result of the kernel above had to be transposed every iteration (85 MB at 4 pairs).  One thread =
 // one (pixel, row): row j < levels * (C + 1) is geometry row c of level l or that level's correlation row, and produces the 2r + 1 taps of
@@ -446,7 +475,13 @@ extern "C" int osa_geo_lookup_f32(const float* const* geo_levels, const float* c
     a.disp = disp; a.coords = coords_x; a.out = out;
     a.B = B; a.H = H; a.W = W; a.C = C; a.levels = levels; a.radius = radius;
     const long long total = (long long)B * H * W;
-    hipLaunchKernelGGL(geo_lookup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (exp_int("OSA_GEO_FWD_PIXEL", 0)) {                           // the r2 form: one thread per pixel (experiments build only)
+        hipLaunchKernelGGL(geo_lookup_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        const long long nthr = total * levels * (C + 1);
+        OSA_REQUIRE(cdiv(nthr, 256) > 0, "geo_lookup: grid too large");
+        hipLaunchKernelGGL(geo_lookup_rows_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    }
     OSA_LAUNCH_CHECK("geo_lookup");
     return 0;
 }

@@ -1,8 +1,9 @@
-"""Gradient of the geometry-encoding lookup w.r.t. the pyramid levels (osa_geo_lookup_bwd_f32) at the StereoBase training map (320x736 crop:
-80 x 184 at 1/4, C = 8, D = 48, two levels, radius 4): the three forms of the kernel timed and compared bit for bit.
+"""The training path's geometry-encoding lookup (osa_geo_lookup_f32, NCHW output) and its gradient w.r.t. the pyramid levels
+(osa_geo_lookup_bwd_f32) at the StereoBase training map (320x736 crop: 80 x 184 at 1/4, C = 8, D = 48, two levels, radius 4): the forms of
+both kernels timed and compared bit for bit.
     bash tools/build_one_variant.sh exp_geo geometry -DOSA_EXPERIMENTS
-    OSA_LIB_PATH=openstereo_amd/lib/variants/exp_geo.so python tools/bench_lookup_bwd.py
-(the form switch is an experiments-build switch: the shipped library always runs the rows form for radius <= 4)"""
+    OSA_LIB_PATH=openstereo_amd/lib/variants/exp_geo.so python tools/bench_lookup.py
+(the form switches exist in the experiments build only: the shipped library always runs the rows forms)"""
 import ctypes
 import os
 import sys
@@ -53,3 +54,27 @@ for form in ("scatter", "gather", "rows"):
     ref = ref or grads
     nbytes = sum(t.numel() for t in grads) * 4 + dout.numel() * 4
     print(f"[lookup bwd, {form:7s}] {us:7.1f} us per call ({nbytes / us / 1e6:.2f} TB/s of written + read bytes){same}")
+
+
+levels = [torch.randn(s_, generator=g).to(dev) for s_ in shapes]
+gpl = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels[:L]])
+cpl = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels[L:]])
+gl_ = (ctypes.c_int * L)(*[s_[-1] for s_ in shapes[:L]])
+cl_ = (ctypes.c_int * L)(*[s_[-1] for s_ in shapes[L:]])
+ref = None
+for form in ("pixel", "rows"):
+    os.environ["OSA_GEO_FWD_PIXEL"] = "1" if form == "pixel" else "0"
+    out = torch.full_like(dout, float("nan"))
+    call = lambda: _lib.call("osa_geo_lookup_f32", gpl, cpl, gl_, cl_, L, disp.data_ptr(), cx.data_ptr(), out.data_ptr(), B, H, W, C, r, st)
+    for _ in range(5):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1000
+    same = "" if ref is None else f"; bit-identical to the pixel form: {torch.equal(out, ref)}"
+    ref = out if ref is None else ref
+    print(f"[lookup fwd, {form:7s}] {us:7.1f} us per call{same}")
