@@ -9,7 +9,9 @@ O=gpurun_out/r5_final; mkdir -p $O
 python -m pytest tests -m gpu -q 2>&1 | grep -v GridwiseOp > $O/suite.log; tail -4 $O/suite.log
 bash tools/profile_round4.sh r5 > $O/profile.log 2>&1; tail -3 $O/profile.log
 cd $GRAFT_REPO_ROOT
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; head -c 700 $O/bench_default.json; echo
+T0=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; T1=$(date +%s)
+echo "python bench.py --gpus 1 --steps 20 --warmup 5: $((T1 - T0)) s wall, $(grep -c . $O/bench_default.json) line(s) on stdout" > $O/bench_time.txt; head -c 700 $O/bench_default.json; echo; cat $O/bench_time.txt
+python tools/ctypes_census.py 2>&1 | grep "^\[\|extension" > $O/census.txt
 for i in 1 2 3; do python tools/diag_timed_config.py --tag final_$i 2>&1 | grep "^\[" ; done > $O/determinism.txt
 python tools/diag_head_under_load.py --load f16x3 --iters 60 --tag "shipped head next to the marching kernel" 2>&1 | grep "^\[" >> $O/determinism.txt
 cat $O/determinism.txt
