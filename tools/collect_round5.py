@@ -45,6 +45,7 @@ if os.path.exists(b):
     for k, v in (d.get("workloads") or {}).items():
         print(f"   {k}: {v.get('value')} {v.get('unit')} ({v.get('ms_per_step')} ms)")
 cp("r5_final/bench_time.txt", "final_bench_wall_time.txt")
+cp("r5_final/power_summary.txt", "final_power_and_clock_timed_config.txt")
 # traffic
 t = os.path.join(G, "prof_r5", "traffic.json")
 if os.path.exists(t):

@@ -15,3 +15,11 @@ python tools/ctypes_census.py 2>&1 | grep "^\[\|extension" > $O/census.txt
 for i in 1 2 3; do python tools/diag_timed_config.py --tag final_$i 2>&1 | grep "^\[" ; done > $O/determinism.txt
 python tools/diag_head_under_load.py --load f16x3 --iters 60 --tag "shipped head next to the marching kernel" 2>&1 | grep "^\[" >> $O/determinism.txt
 cat $O/determinism.txt
+# 5. socket power / shader clock while the timed configuration runs (what power the headline assumes); parse_smi.py reads
+#    smi_f16x3.jsonl + bench_f16x3.json of a directory
+P=$O/power; mkdir -p $P
+( while true; do rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n'; echo; sleep 0.2; done ) > $P/smi_f16x3.jsonl & SMI=$!
+timeout 200 python bench.py --timed-only --steps 400 --warmup 5 > $P/bench_f16x3.json 2>/dev/null
+kill $SMI; wait $SMI 2>/dev/null
+python tools/parse_smi.py $P > $O/power_summary.txt 2>&1; cat $O/power_summary.txt; rm -f $P/smi_f16x3.jsonl
+
