@@ -218,3 +218,55 @@ def test_cpp_autograd_matches_the_python_custom_ops_bit_for_bit():
                      (ns.upsample_softargmin.default, (c.clone().requires_grad_(), 32, 24, 80, False)),
                      (ns.softmax_softargmin.default, (c.clone().requires_grad_(), False))):
         opcheck(op, args, test_utils=("test_schema", "test_autograd_registration", "test_faketensor"))
+
+
+@pytest.mark.gpu
+def test_inplace_launch_ops_mutate_only_what_their_schemas_declare():
+    """r5 second batch (the ops that took the rest of the launch path off ctypes): torch.library.opcheck's schema check -- every launch runs on
+    small operands and writes only the arguments its `Tensor(a!)` annotations declare.  (Their values are pinned where they are used: the
+    model-level parity tests run through them, test_extension_and_ctypes_paths_agree_bit_for_bit compares them with the ctypes launches.)"""
+    from torch.library import opcheck
+    from openstereo_amd import _ext, _lib, ops
+    ns, lib = _ext.load(), _lib.load()
+    assert ns is not None
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    meta = lambda: z(128)
+    a, b = r(1, 16, 6, 20), r(1, 16, 6, 20)
+    w3 = r(32, 32, 3, 3, 3) * 0.1
+    wdw = r(8, 1, 3, 3)
+    dwp = z(3 * 3 * 8)
+    ns.weight_pack(wdw, dwp, 3, 0, [8, 3, 3], 1.0)
+    wsm = r(1, 32, 3, 3, 3) * 0.1
+    nsm = lib.osa_conv3d_small_co_packed_floats(32, 1, 3, 3, 3)
+    smp = z(nsm + 16)
+    off = (-smp.data_ptr() // 4) % 16
+    smp = smp[off:off + nsm]
+    ns.weight_pack(wsm, smp, 4, 0, [32, 1, 3, 3, 3], 1.0)
+    vol = ops.to_cl(r(1, 8, 12, 6, 20))                                       # logical [B,C,D,H,W], NDHWC in memory
+    lv = [r(1, 6, 10, 2, 8), r(1, 6, 10, 2, 4), r(1, 6, 10, 10), r(1, 6, 10, 5)]
+    img = (torch.rand(10, 12, 3, generator=g) * 255).to(torch.uint8).cuda()
+    cases = [
+        (ns.build_volume, (a, b, 4, None, None, z(1, 4, 8, 6, 20), ops.NCDHW, 4, 0, 8, True, None)),
+        (ns.allpairs_corr, (a, b, z(1, 6, 20, 20))),
+        (ns.avgpool_rows, (r(4, 6, 20), z(4, 6, 10))),
+        (ns.geo_rows, (vol, z(1, 6, 20, 8, 12), 8)),
+        (ns.pair_volume, (a, b, z(1, 4, 6, 6, 20), 4, 6, 0)),
+        (ns.cat_fms, (a, b, z(1, 32, 3, 6, 20), torch.tensor([0, 2, 5], dtype=torch.int32, device="cuda"))),
+        (ns.gru_combine, (r(1, 6, 20, 8), 0, r(1, 6, 20, 8), r(1, 6, 20, 8), z(1, 6, 20, 8), [120, 8, 8, 8, 8, 8], meta())),
+        (ns.resample_nhwc, (r(1, 6, 20, 8), z(1, 3, 10, 8), 0, 0, [1, 6, 20, 8, 8, 8], meta(), meta())),
+        (ns.resample_nhwc, (r(1, 3, 10, 8), z(1, 6, 20, 16), 8, 1, [1, 3, 10, 6, 20, 8, 8, 16], None, None)),
+        (ns.weight_pack, (w3, z(lib.osa_conv3d_packed_floats(32, 32, 3, 3, 3)), 0, 0, [32, 32, 3, 3, 3], 1.0)),
+        (ns.weight_pack, (w3, z(lib.osa_conv3d_packed_floats(32, 32, 3, 3, 3)), 0, 1, [32, 32, 3, 3, 3], 4096.0)),
+        (ns.dwconv2d, (r(1, 6, 20, 8), dwp, None, None, None, z(1, 6, 20, 8), [1, 6, 20, 8, 8, 8, 0], [3, 3, 1, 1, 1, 1, 1], 0, meta())),
+        (ns.small_co_conv, (ops.to_cl(r(1, 32, 4, 6, 20)), smp, None, None, z(1, 4, 6, 20, 1), [1, 4, 6, 20, 32, 32, 1, 1], [3, 3, 3, 1, 1, 1])),
+        (ns.disp_update, (r(1, 6, 20), None, 0, z(1, 6, 20, 4), z(1, 6, 20, 8), 3, 8, 120, meta(), meta())),
+        (ns.amax_into, (r(1024), meta())),
+        (ns.instnorm_nhwc, (r(1, 6, 20, 8), z(1, 6, 20, 8), 0, [1, 120, 8, 8, 8], 1e-5, 0, 0.0, z(lib.osa_instnorm_workspace_floats(1, 120, 8)), meta())),
+        (ns.preprocess_pair, (img, img.flip(1).contiguous(), z(2, 3, 16, 16), [16, 16], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], False)),
+        (ns.geo_lookup_nhwc, (lv, (torch.rand(1, 6, 10, generator=g) * 5).cuda(), torch.arange(10).float().view(1, 1, 10).repeat(1, 6, 1).cuda(),
+                              z(1, 6, 10, 56), 56, [1, 6, 10], 2, 4)),
+    ]
+    for op, args in cases:
+        opcheck(op.default, args, test_utils=("test_schema",))
