@@ -328,12 +328,25 @@ __global__ __launch_bounds__(256) void geo_lookup_bwd_rows_kernel(const LookupBw
         gx0[k] = on ? tg.x0 : -4; gw0[k] = tg.w0; gw1[k] = tg.w1;       // (-4: matches no position j >= 0, nor j - 1)
         cx0[k] = on ? tc.x0 : -4; cw0[k] = tc.w0; cw1[k] = tc.w1;
     }
+    // every upstream gradient of this (pixel, level) -- (C + 1) rows x taps, 81 in the shipped configs, each in its own output plane -- with ONE
+    // round of loads (each lane holds up to four of them; host: (C + 1) * taps <= 256); the rows then take theirs by readlane.  (The first
+    // version loaded a row's taps as wave-uniform values inside the row loop: C + 1 dependent memory round trips per wave, 237 us inside the
+    // training step although the kernel moves 60 MB.)
     const float* o = p.dout + (size_t)b * per_level * p.levels * HW + hw + (size_t)l * per_level * HW;
+    float gq[4];                                                         // lane t holds elements t, t + 64, t + 128, t + 192 (host: per_level <= 256)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) gq[v] = lane + 64 * v < per_level ? o[(size_t)(lane + 64 * v) * HW] : 0.f;
+    auto take = [&](int idx) -> float {                                  // idx wave-uniform
+        const int s_ = __builtin_amdgcn_readfirstlane(idx);
+        const int q = s_ >> 6;
+        const float src = q == 0 ? gq[0] : (q == 1 ? gq[1] : (q == 2 ? gq[2] : gq[3]));
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), s_ & 63));
+    };
     float* g = p.dgeo[l] + (size_t)i * p.C * Dl;
     for (int c = 0; c < p.C; ++c) {
         float ov[MAXT];
 #pragma unroll
-        for (int k = 0; k < MAXT; ++k) ov[k] = k < taps ? o[((size_t)c * taps + k) * HW] : 0.f;
+        for (int k = 0; k < MAXT; ++k) ov[k] = k < taps ? take(c * taps + k) : 0.f;
         for (int j = lane; j < Dl; j += 64) {
             float v = 0.f;
 #pragma unroll
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void geo_lookup_bwd_rows_kernel(const LookupBw
     }
     float ov[MAXT];
 #pragma unroll
-    for (int k = 0; k < MAXT; ++k) ov[k] = k < taps ? o[((size_t)p.C * taps + k) * HW] : 0.f;
+    for (int k = 0; k < MAXT; ++k) ov[k] = k < taps ? take(p.C * taps + k) : 0.f;
     float* crow = p.dcorr[l] + (size_t)i * Wl;
     for (int j = lane; j < Wl; j += 64) {
         float v = 0.f;
@@ -383,7 +396,7 @@ extern "C" int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* d
         g.disp = disp; g.coords = coords_x; g.dout = dout;
         g.B = B; g.H = H; g.W = W; g.C = C; g.levels = levels; g.radius = radius;
         OSA_REQUIRE((end + 255) / 256 < (1ll << 31), "geo_lookup_bwd: grid too large");
-        if (2 * radius + 1 <= 9 && exp_int("OSA_GEO_BWD_FORM", 2) == 2) {     // one wave per (pixel, level): every shipped config has radius 4
+        if (2 * radius + 1 <= 9 && (C + 1) * (2 * radius + 1) <= 256 && exp_int("OSA_GEO_BWD_FORM", 2) == 2) {     // one wave per (pixel, level): every shipped config has radius 4
             hipLaunchKernelGGL(geo_lookup_bwd_rows_kernel<9>, dim3((unsigned)((total + 3) / 4), levels), dim3(256), 0, (hipStream_t)stream, g);
             OSA_LAUNCH_CHECK("geo_lookup_bwd (rows)");
             return 0;

@@ -14,7 +14,7 @@ sys.path.insert(0, ".")
 from openstereo_amd import _lib     # noqa: E402
 
 dev = "cuda"
-B, H, W, C, D, r, L = 1, 80, 184, 8, 48, 4, 2
+B, H, W, C, D, r, L = 1, 80, 184, int(os.environ.get("LOOKUP_C", "8")), 48, 4, 2      # LOOKUP_C: geometry channels (IGEV 8)
 g = torch.Generator().manual_seed(0)
 disp = (torch.rand(B, H, W, generator=g) * 40).to(dev)
 cx = torch.arange(W).float().view(1, 1, W).repeat(B, H, 1).to(dev)

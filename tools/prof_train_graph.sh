@@ -1,12 +1,13 @@
 #!/bin/bash
+# kernel table + idle gaps of a training workload as it is TIMED (hipGraph replay): bash tools/prof_train_graph.sh <workload> <tag> <window_ms> <steps_in_window> [extra bench.py flags, e.g. --amp]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-W=$1; TAG=$2; WIN=$3; NS=$4
+W=$1; TAG=$2; WIN=$3; NS=$4; EXTRA="${@:5}"
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python $R/bench.py --workload $W --timed-only --steps 12 --warmup 4 > $OUT/stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python $R/bench.py --workload $W --timed-only --steps 12 --warmup 4 $EXTRA > $OUT/stdout.log 2>&1
 F=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
-python $R/tools/steady_state.py $F $WIN $NS 12 > $OUT/steady_state.txt 2>&1
+python $R/tools/steady_state.py $F $WIN $NS 45 > $OUT/steady_state.txt 2>&1
 python - "$F" > $OUT/gaps.txt <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
