@@ -18,6 +18,17 @@ def test_extension_builds_loads_and_has_no_cpu_backend(lib):
     assert ns is not None and int(ns.abi_version()) == lib.osa_abi_version() == _lib.abi_version()
     for name in ("gwc_volume", "concat_volume", "corr_volume", "softargmin", "softmax_softargmin", "upsample_softargmin", "context_upsample", "conv_ndhwc"):
         assert hasattr(ns, name), name
+    # r5: the rest of the launch path (every `_lib.call` site of the package has an extension branch in front of it).  In-place launches:
+    # their schemas name what they write
+    inplace = ("build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update", "geo_lookup_nhwc", "allpairs_corr",
+               "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair", "amax_into", "to_cl", "to_ncdhw",
+               "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd", "geo_lookup", "geo_lookup_bwd")
+    for name in inplace:
+        sch = getattr(ns, name).default._schema
+        assert str(sch.returns) in ("[]", "()") or len(sch.returns) == 0, name
+        assert any(a.alias_info is not None and a.alias_info.is_write for a in sch.arguments), name
+    # (that every ctypes launch site sits behind an extension branch is counted at run time on the GPU:
+    # test_extension_and_ctypes_paths_agree_bit_for_bit asserts 0 ctypes launches)
     x = torch.zeros(1, 8, 4, 8)
     with pytest.raises((NotImplementedError, RuntimeError)):        # no CPU kernel is registered: the dispatcher refuses
         ns.gwc_volume(x, x, 4, 2)
