@@ -2,10 +2,9 @@
 timing, whole-job throughput) with the GPU forward replaced by a stub.  Inference has no data-path
 collective, so this is the whole N>1 logic."""
 import os
-
-import pytest
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
