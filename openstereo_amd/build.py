@@ -23,15 +23,20 @@ SOURCES = ["api.hip", "volume.hip", "conv3d.hip", "conv_inst_f32.hip", "conv_ins
 ARCH = "gfx950"
 HIPCC_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
-# Per-file flags.  softargmin.hip is built WITHOUT the SLP vectoriser, i.e. without packed-fp32 VALU instructions (v_pk_mul / add / fma_f32):
-# r5 found the fused head returning wrong disparities in isolated quarter waves (16 pixels of one row, errors up to tens of pixels)
-# whenever the d-marching conv kernel (250-256 VGPRs, 16-pass f16 MFMAs) runs on another stream of the same GPU -- the timed
-# configuration's sub-batch streams.  Its loads are right (checksum of everything it loads: clean), its arithmetic is not (checksum of its
-# exponentials: dirty; polynomial exp2 instead of v_exp_f32: still dirty), and the same source compiled without packed math is clean:
-# 0 differing elements in 40 launches under that load against 40 of 40 launches with ~600 wrong pixels each
-# (profiles/round5/head_packed_math_under_march_load.txt, tools/diag_head_under_load.py).  Same arithmetic, same
-# order (-ffp-contract=off): results are bit-identical to the packed build on an otherwise idle GPU.
-EXTRA_FLAGS = {"softargmin.hip": ["-fno-slp-vectorize"]}
+# NO packed-fp32 VALU instructions (v_pk_mul / add / fma_f32) in ANY kernel of the library: the backend feature is switched off for every
+# translation unit, and tests/test_isa_lint_cpu.py disassembles the shipped objects and fails on the first one it finds.
+# Why: r5 found the x4 fused head returning wrong values in isolated 16-lane passes whenever another stream's d-marching convolution was
+# resident on the same SIMD -- its loads right, its arithmetic wrong, only in the build whose loop carried packed-fp32 instructions (DESIGN.md
+# 3.3; profiles/round5/head_packed_math_under_march_load.txt; r6 narrowed the trigger with single-instruction probes: tools/diag_pk_probe.py,
+# profiles/round6/pk_probe_matrix.txt).  r5 fixed that one file with -fno-slp-vectorize, which leaves the packed forms the backend selects
+# from explicit vector arithmetic (89 in softargmin.hip alone, 17.5 k in the f16x3 conv instantiations).  Every kernel of a forward can be
+# co-resident with another sub-batch stream's marching kernel, so the property has to hold for all of them; it costs nothing measurable
+# (packed fp32 beside MFMAs is an anti-lever on gfx950: MI355X_MICROARCH.md, per-instruction constants) and takes the marching kernels'
+# spills down (conv_march_kernel<4,16,0,0> 76 -> 56 bytes of scratch, <4,16,1,0> 8 -> 0).  Same operations in the same order
+# (-ffp-contract=off): results are bit-identical to the packed build on an idle GPU.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+HIPCC_FLAGS += NO_PACKED_F32
+EXTRA_FLAGS: dict = {}
 
 
 def _hipcc() -> str:
