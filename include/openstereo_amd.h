@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OSA_ABI_VERSION 5
+#define OSA_ABI_VERSION 6
 #define OSA_META_FLOATS 128   /* floats per range block (osa_f16x3_ranges) */
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
@@ -581,6 +581,14 @@ int osa_instnorm_nhwc_f32(const float* x, float* y, int B, long long HW, int C, 
  * feeding three output planes.  Same arguments, same semantics; results agree with the brick form to fp32 rounding (different summation
  * order).  This counter tells how many calls of this process took that form (tests assert that the intended layers do). */
 long long osa_conv3d_march_launches(void);
+
+/* ---- d-marching form of the 3x3x3 STRIDE-2 convolutions with 64 output channels (r6, csrc/conv_march_s2.h) ----
+ * osa_conv3d_ndhwc_f16x3 runs eligible layers (3x3x3, stride 2, padding 1, Ci % 16 == 0, Co == 64, split input and output, no residual /
+ * gate: conv1 of the GwcNet / PSMNet hourglasses -- models/gwcnet/hourglass.py:19-24) as workgroups that own a 4 x 32 output pixel column
+ * and walk along d: even input planes feed one output plane, odd ones two; every input plane is staged once, by LDS-DMA into a
+ * parity-planar LDS image.  Same arguments, same semantics; results agree with the brick form to fp32 rounding.  Bit 29 of
+ * osa_conv_b_ring_mask switches the form (A/B runs, parity tests); this counter tells how many calls took it. */
+long long osa_conv3d_march_s2_launches(void);
 
 /* ---- B (weight) operands through an LDS ring (r4, csrc/conv_kernel.h BL = 1; f16x3 and f16 modes) ----
  * Every convolution / transposed convolution entry point above (the MFMA tiles behind nn.Conv3d / nn.Conv2d / nn.ConvTranspose3d of

@@ -229,6 +229,9 @@ static void set_stagger(ConvArgs& a, const KernelCfg& k, void (*fn)(const ConvAr
 
 // d-marching form of the 3x3x3 stride-1 32-output-channel layers (f16x3): conv_march.hip.  1 = launched, 0 = not eligible, -1 = error
 int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
+// d-marching form of the 3x3x3 stride-2 64-output-channel layers (f16x3, split tensors): conv_march.hip / conv_march_s2.h.  Switch: bit 29 of
+// osa_conv_b_ring_mask (A/B runs and the parity test against the brick form)
+int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what);
 
 // Which tile configurations take their B operands through the LDS ring (osa_conv_b_ring_mask; bit i = conv_cfgs.def entry i, bit 30 = the
 // fused transposed convs).  Default = the tiles where the ring measured ahead at 8 AND at 4 pairs per launch (profiles/round4/
@@ -238,7 +241,7 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
 // 14 / 15 (3-6 MFMAs per step: one barrier + one transfer per 96-192 matrix cycles costs more than the stream, conv3 -36 %), the 32-channel
 // tiles 0 / 7 / 12 (first 32 -> 32: -11 %), 9 (2 x 2 waves share a fragment only pairwise: 128 -> 128 @1/4 -3 ... +1 %), 11 (no sharing at
 // all), the fused transposed convs (+-1 %).
-static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13);
+static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13) | (1 << 29);
 // (measured and not kept: tile 9 on the ring for long K loops only, >= 16 input chunks -- the GRU gate convs 384 -> 128 / 256 @1/4 gain 0 ... +5 % as
 // single layers, and the IGEV x 32 loop LOSES 1.3 % with it, StereoBase 0.4 %: profiles/round4/b_ring_tile9_long_k.txt)
 static long long g_b_ring_launches = 0;
@@ -910,6 +913,11 @@ static int conv3d_impl(const float* x, const float* w_packed,
     if (prec == PREC_F16X3 && kd == 3 && kh == 3 && kw == 3 && stride == 1 && a.isd == 1 && pad_d == 1 && pad_h == 1 && pad_w == 1 &&
         dil_d == 1 && dil_h == 1 && dil_w == 1) {
         const int r = launch_conv_march(a, (hipStream_t)stream, "conv3d (march)");
+        if (r != 0) return r < 0 ? r : 0;
+    }
+    if (prec == PREC_F16X3 && kd == 3 && kh == 3 && kw == 3 && stride == 2 && a.isd == 2 && pad_d == 1 && pad_h == 1 && pad_w == 1 &&
+        dil_d == 1 && dil_h == 1 && dil_w == 1 && ((g_b_ring_mask_value() >> 29) & 1)) {
+        const int r = launch_conv_march_s2(a, (hipStream_t)stream, "conv3d (march, stride 2)");
         if (r != 0) return r < 0 ? r : 0;
     }
     return launch_conv(a, stride, prec, (hipStream_t)stream, "conv3d");

@@ -1,6 +1,7 @@
 // d-marching 3x3x3 convolutions (conv_march.h): instantiations and host-side launch.  A translation unit of its own so that the
 // brick kernel's ~200 instantiations (conv3d.hip) are not recompiled with it.
 #include "conv_march.h"
+#include "conv_march_s2.h"
 
 namespace osa {
 
@@ -90,6 +91,51 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
     return 1;
 }
 
+// ------------------------------------------------------------------ stride-2 d-marching form (conv_march_s2.h) --
+// 3x3x3 stride-2 pad-1 convolutions with 64 output channels, f16x3 mode, split input AND split output, no residual (conv1 of the GwcNet /
+// PSMNet hourglasses).  Returns 1 when launched, 0 when the layer is not eligible (the brick kernel then runs it), -1 on error.
+static long long g_march_s2_launches = 0;
+long long march_s2_launches() { return g_march_s2_launches; }
+
+int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what) {
+    using G = MarchS2Geo;
+    if (a.T != 27 || a.Co != 64 || a.CoP != 64 || a.Di < 2 || a.gate || a.rx || a.res) return 0;
+    if (a.Ci % 16 != 0 || a.xCs % 16 != 0) return 0;
+    if (!(a.act & OSA_IN_SPLIT) || !(a.act & OSA_OUT_SPLIT)) return 0;
+    const int actk = a.act & 15;
+    if (actk > OSA_ACT_LEAKY || (a.act & (OSA_GATE_RAW | OSA_RES_AFTER_ACT)) || ((unsigned)a.act >> 16)) return 0;
+    if ((a.yCs % 16) || ((size_t)a.y & 15) || ((size_t)a.x & 15)) return 0;
+    if ((long long)a.Do * a.Ho * a.Wo * a.yCs >= (1ll << 31)) return 0;
+    if ((long long)a.Hi * a.Wi * a.xCs >= (1ll << 29)) return 0;        // per-plane byte offsets are 32-bit
+    a.tilesD = 1; a.tilesH = cdiv(a.Ho, G::TH); a.tilesW = cdiv(a.Wo, G::TW);
+    a.dbg = 0;
+    // D segments of `oseg` output planes: a segment stages 2 oseg + 1 input planes (the first one for a third of its taps).  Cost model in
+    // plane-steps per round of resident workgroups (one per CU); the fewest segments win a tie.
+    const long long cols = (long long)a.B * a.tilesH * a.tilesW;
+    int nseg = 1;
+    {
+        double best = 1e30;
+        for (int n = 1; n <= a.Do; ++n) {
+            const int os = cdiv(a.Do, n), ns = cdiv(a.Do, os);
+            if (ns != n) continue;
+            const double cost = (double)((cols * ns + 255) / 256) * (2.0 * os + (ns > 1 ? 1.0 : 0.0) + 0.5);     // (+ 0.5: prologue / drain of a workgroup)
+            if (cost < best - 1e-9) { best = cost; nseg = ns; }
+        }
+        const int o = exp_int("OSA_MARCH_NSEG", 0);
+        if (o > 0 && o <= a.Do) nseg = o;
+    }
+    const int oseg = cdiv(a.Do, nseg);
+    nseg = cdiv(a.Do, oseg);
+    OSA_REQUIRE(cols * nseg < (1ll << 31), "%s: grid too large", what);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_march_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes()); attr_set = true; }
+    hipLaunchKernelGGL(conv_march_s2_kernel, dim3((unsigned)(cols * nseg)), dim3(G::NWV * 64), G::lds_bytes(), st, a, oseg, nseg);
+    OSA_LAUNCH_CHECK(what);
+    ++g_march_s2_launches;
+    return 1;
+}
+
 }  // namespace osa
 
 extern "C" long long osa_conv3d_march_launches(void) { return osa::march_launches(); }
+extern "C" long long osa_conv3d_march_s2_launches(void) { return osa::march_s2_launches(); }

@@ -33,6 +33,7 @@ _lib.load()
 probe = C.CDLL(os.path.join(ROOT, "tools", "experiments", "libpk_probe.so"))
 probe.pk_probe_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 probe.burner_launch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+probe.pk_micro_launch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 hp_path = os.path.join(ROOT, "openstereo_amd", "lib", "variants", "head_packed.so")
 headp = C.CDLL(hp_path) if os.path.exists(hp_path) else None
 if headp is not None:
@@ -51,6 +52,7 @@ B, D, H, W = 3, 48, 136, 240
 N = B * 4 * H * 4 * W
 cost = (torch.randn(B, D, H, W, generator=g) * 3.0).to(dev)
 pin = torch.randn(N, generator=g).to(dev)
+micro_in = (torch.randn(D * H * W, generator=g) * 3.0).to(dev)
 bsrc = torch.randn(1 << 16, generator=g).to(dev)
 bsink = torch.zeros(256, device=dev)
 side = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -73,6 +75,15 @@ def make_victim(name):
             assert rc == 0
             return out
         return run
+    if name[0] == "m":                                    # micro probes (third round): four tap loads, two products, ONE packed add per step
+        mode = int(name[1:])
+
+        def run_m():
+            out = torch.empty(N, device=dev)
+            rc = probe.pk_micro_launch(mode, micro_in.data_ptr(), out.data_ptr(), N, D, H * W, cur())
+            assert rc == 0, rc
+            return out
+        return run_m
     assert name[0] == "p"
     mode, _, regs = name[1:].partition("r")
     mode, regs = int(mode), int(regs or 0)

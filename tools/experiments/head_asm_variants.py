@@ -93,7 +93,8 @@ def rewrite(asm_lines, pick, pre=None, nop_scale=None):
                 in_loop = False
             m = PK.match(ln)
             if m:
-                if pick(m.group(1), ln, in_loop):
+                ordinal = n_exp + n_keep
+                if (pick(m.group(1), ln, in_loop, ordinal) if pick.__code__.co_argcount == 4 else pick(m.group(1), ln, in_loop)):
                     out.extend(expand(ln.rstrip("\n")))
                     n_exp += 1
                     continue
@@ -147,6 +148,19 @@ def main():
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-S",
                            "--cuda-device-only", "-o", base, src], stderr=subprocess.DEVNULL)
     lines = open(base).read().split("\n")
+    # third round: exactly ONE of the pre-loop cross-half v_pk_add_f32 instructions stays packed (k_one<ordinal>), everything else scalar
+    ordinal = 0
+    inside = False
+    for ln in lines:
+        if ln.startswith(KERNEL + ":"):
+            inside = True
+        elif inside and ln.startswith(".LBB3_12:"):
+            break
+        if inside and PK.match(ln):
+            if PK.match(ln).group(1) == "add" and xhalf(ln):
+                VARIANTS[f"k_one{ordinal:02d}"] = (lambda o: (lambda k, t, l, i: i != o))(ordinal)
+                print(f"k_one{ordinal:02d}: {ln.strip()}")
+            ordinal += 1
     jobs = [(n, dict(pick=p)) for n, p in VARIANTS.items()] + [(n, dict(pick=lambda k, t, l: False, **kw)) for n, kw in PADDED.items()]
     for name, kw in jobs:
         txt, n_exp, n_keep = rewrite(lines, **kw)

@@ -153,6 +153,83 @@ extern "C" int pk_probe_launch(int mode, int regs, const float* in, float* out, 
     return -1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ micro probes (third round)
+// The delta-debugged head (tools/diag_head_variants.py) fails with ONLY its v_pk_add_f32 instructions packed, only those that read a VGPR pair
+// across halves, only the ones BEFORE its loop: the horizontal sums of the first plane's four bilinear taps, right behind the global loads.
+// These kernels are that context in ten lines: four dword loads per step (the head's tap pattern), two products, ONE packed add.
+// MODE 20: v_pk_add_f32 D, D, D op_sel:[0,1] op_sel_hi:[1,0] (both halves = lo + hi)     21: D, D, S with the same modifiers     22: scalar control
+//      23: mode 20 on register data (no loads in the loop)     24: D, D, D op_sel_hi:[0,1]     25: D, D, S op_sel_hi:[1,0] neg:[0,1] (the in-loop form)
+//      26: mode 20 once per thread (no loop)
+// fourth round (m21 fails, the others do not): what about the failing form matters?
+//      30: T = D + swap(S) into a FRESH destination      31: v_pk_mul_f32 with the same operands / modifiers      32: v_pk_fma_f32 D, D, swap(S), D
+//      33: op_sel:[0,1] only (both results read S.hi)    34: the swap on src0: v_pk_add_f32 D, S, D op_sel:[1,0] op_sel_hi:[0,1]
+//      35: m21 behind 16 wait states                      36: m21 on register data (no loads in the loop)     37: the scalar pair m21 stands for
+//      38: v_pk_add_f32 D, D, S without modifiers         39: op_sel_hi:[1,0] only (both results read S.lo)
+template <int MODE>
+__global__ __launch_bounds__(256) void pk_micro_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int iters, int plane) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int o = (i >> 2) % (plane - 300);
+    const float wx = 0.25f + (float)(i & 3) * 0.125f, wy = 0.75f - (float)(i & 3) * 0.125f;
+    float acc = 0.f;
+    const int reps = (MODE == 26) ? 1 : iters;
+    for (int k = 0; k < reps; ++k) {
+        float t0, t1, t2, t3;
+        if constexpr (MODE == 23 || MODE == 36) {
+            t0 = acc * 0.5f + wx; t1 = acc * 0.25f + wy; t2 = wx - acc * 0.125f; t3 = wy + (float)k;
+        } else {
+            const float* cp = in + (size_t)k * plane + o;
+            t0 = cp[0]; t1 = cp[1]; t2 = cp[240]; t3 = cp[241];
+        }
+        f32x2 d = {wx * t0, wy * t1}, e = {wy * t2, wx * t3};
+        if constexpr (MODE == 20 || MODE == 23 || MODE == 26) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(d));
+        else if constexpr (MODE == 21) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 22) { float lo, hi; asm volatile("s_nop 0\n\tv_add_f32 %0, %2, %3\n\tv_add_f32 %1, %3, %2" : "=&v"(lo), "=&v"(hi) : "v"(d.x), "v"(d.y)); d.x = lo; d.y = hi; }
+        else if constexpr (MODE == 24) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %0 op_sel_hi:[0,1]" : "+v"(d));
+        else if constexpr (MODE == 25) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 30) { f32x2 t; asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(t) : "v"(d), "v"(e)); d = t; }
+        else if constexpr (MODE == 31) asm volatile("s_nop 0\n\tv_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 32) asm volatile("s_nop 0\n\tv_pk_fma_f32 %0, %0, %1, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 33) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 34) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[0,1]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 35) asm volatile("s_nop 7\n\ts_nop 7\n\tv_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 36) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 37) { float lo, hi; asm volatile("s_nop 0\n\tv_add_f32 %0, %2, %5\n\tv_add_f32 %1, %3, %4" : "=&v"(lo), "=&v"(hi) : "v"(d.x), "v"(d.y), "v"(e.x), "v"(e.y)); d.x = lo; d.y = hi; }
+        else if constexpr (MODE == 38) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1" : "+v"(d) : "v"(e));
+        else if constexpr (MODE == 39) asm volatile("s_nop 0\n\tv_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d) : "v"(e));
+        float r0, r1;
+        asm volatile("s_nop 0\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(r0), "=v"(r1) : "v"(d.x), "v"(d.y));     // (halves read back by scalar code)
+        acc = acc * 0.5f + r0 + 0.25f * r1 + 0.125f * (e.x + e.y);
+    }
+    out[i] = acc;
+}
+
+extern "C" int pk_micro_launch(int mode, const float* in, float* out, int n, int iters, int plane, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((n + 255) / 256), b(256);
+    switch (mode) {
+        case 20: hipLaunchKernelGGL(pk_micro_kernel<20>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 21: hipLaunchKernelGGL(pk_micro_kernel<21>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 22: hipLaunchKernelGGL(pk_micro_kernel<22>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 23: hipLaunchKernelGGL(pk_micro_kernel<23>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 24: hipLaunchKernelGGL(pk_micro_kernel<24>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 25: hipLaunchKernelGGL(pk_micro_kernel<25>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 26: hipLaunchKernelGGL(pk_micro_kernel<26>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 30: hipLaunchKernelGGL(pk_micro_kernel<30>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 31: hipLaunchKernelGGL(pk_micro_kernel<31>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 32: hipLaunchKernelGGL(pk_micro_kernel<32>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 33: hipLaunchKernelGGL(pk_micro_kernel<33>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 34: hipLaunchKernelGGL(pk_micro_kernel<34>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 35: hipLaunchKernelGGL(pk_micro_kernel<35>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 36: hipLaunchKernelGGL(pk_micro_kernel<36>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 37: hipLaunchKernelGGL(pk_micro_kernel<37>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 38: hipLaunchKernelGGL(pk_micro_kernel<38>, g, b, 0, st, in, out, n, iters, plane); break;
+        case 39: hipLaunchKernelGGL(pk_micro_kernel<39>, g, b, 0, st, in, out, n, iters, plane); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------------ burners
 // KIND 0: 32x32x16 f16 MFMAs back to back on 6 accumulator sets (the marching kernel's 3 planes x 2 M-tiles), operands in registers,
 //         whatever registers the compiler needs (~110)                 1: the same with 256 VGPRs claimed (2 waves per SIMD, like the marching kernel)

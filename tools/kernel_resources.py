@@ -8,7 +8,7 @@ import re
 import subprocess
 import sys
 
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]   # openstereo_amd/build.py HIPCC_FLAGS
 
 
 def table(src, extra=()):
