@@ -108,7 +108,7 @@ int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what) {
     if ((long long)a.Do * a.Ho * a.Wo * a.yCs >= (1ll << 31)) return 0;
     if ((long long)a.Hi * a.Wi * a.xCs >= (1ll << 29)) return 0;        // per-plane byte offsets are 32-bit
     a.tilesD = 1; a.tilesH = cdiv(a.Ho, G::TH); a.tilesW = cdiv(a.Wo, G::TW);
-    a.dbg = 0;
+    a.dbg = exp_int("OSA_DBG", 0);                          // (experiments build only: timing ablations of conv_march_s2.h)
     // D segments of `oseg` output planes: a segment stages 2 oseg + 1 input planes (the first one for a third of its taps).  Cost model in
     // plane-steps per round of resident workgroups (one per CU); the fewest segments win a tie.
     const long long cols = (long long)a.B * a.tilesH * a.tilesW;

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p openstereo_amd/lib/variants
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Iopenstereo_amd/csrc"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops -Iopenstereo_amd/csrc"
 for f in openstereo_amd/csrc/conv3d openstereo_amd/csrc/conv_inst_f32 openstereo_amd/csrc/conv_inst_f16x3 openstereo_amd/csrc/conv_inst_f16 openstereo_amd/csrc/conv_march openstereo_amd/csrc/volume openstereo_amd/csrc/wgrad tools/experiments/conv_pipe; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o openstereo_amd/lib/variants/$NAME.$(basename $f).o &
 done
