@@ -14,15 +14,15 @@
 //     16 consecutive voxels conflict-free for ds_read_b128 (4 v + (q ^ (v >> 2 & 3)) mod 16 is a bijection of v mod 16);
 //   * 8 waves = 4 M-tiles (output rows) x 2 N-tiles (32 output channels each), ONE workgroup per CU: the weights of a step are fetched once
 //     per CU into a 3-slot LDS ring (a step = one (chunk, kh, kd): 3 kw taps x [hi | lo] x 2 N-tiles = 12 KB, 9 MFMAs per wave, 18 per
-//     SIMD between barriers), three steps = one BLOCK ahead of their use; the plane of pass q + 1 lands in the second plane buffer while
-//     pass q computes;
-//   * the unit of control is a block of three steps (kh = 0, 1, 2 of one (plane, chunk, kd)), fully unrolled: ring slot = kh, every LDS
-//     address is a register computed once per pass plus an immediate, the weight transfers take their base from an SGPR pair.  The first
-//     version walked a generic step loop: ~290 instructions per 9 MFMAs, and its timing-only ablation ran 0.62 ms of its 1.0 ms with
-//     neither transfers nor MFMAs (profiles/round6/march_s2_ablation.txt) -- the layer was bound by instruction issue, not by bytes;
-//   * fragment reads are software-pipelined: while the 9 MFMAs of step t run from one register set, the 12 ds_read_b128 of step t + 1
-//     fill the next (every wave of the workgroup sits at the same barrier: without this the LDS -- 96 KB per step, 384 cycles -- and the
-//     matrix pipes -- 576 cycles per SIMD and step -- take turns instead of overlapping).
+//     SIMD between barriers); the plane of pass q + 1 lands in the second plane buffer while pass q computes.
+// r6 measured [MI355X], 9 pairs per launch: HBM traffic 2.37 GB = 1.05x the algorithmic bytes (brick form: 4.89 GB = 2.16x), 1.02 ms against
+// the brick form's 1.10 ms on the same box; the default bench line (three sub-batch streams) gains 0.9 %.  Four restructured versions
+// (static 3-step blocks with software-pipelined fragment reads, triple-buffered planes with role-split loader waves, weights by ordinary
+// loads instead of LDS-DMA: tools/experiments/conv_march_s2_v5.h) cut the instructions per step from ~290 to ~65 and did NOT run faster
+// (1.13-1.16 ms): with ONE 8-wave workgroup per CU in barrier lockstep and 9 MFMAs per wave and step, a step takes ~2100 cycles whatever
+// moves the bytes -- 43 % of the wave cycles issue instructions (25 non-MFMA instructions per MFMA by the SQ counters), 31 % wait at
+// barriers / counters, LDS bank conflicts 1.7 %.  What would change it is more MFMAs per barrier (a second M-tile per wave needs plane
+// buffers this LDS cannot hold twice) or two independent workgroups per CU.  profiles/round6/march_s2_versions.txt has every line.
 // Same split arithmetic (Ahi.Blo + Alo.Bhi + Ahi.Bhi, fp32 accumulate), operand ranges and epilogue semantics as conv_mfma_kernel; the
 // summation order differs (plane-major), so results agree with the brick form to fp32 rounding, not bitwise.
 #pragma once
@@ -66,11 +66,6 @@ __global__ __launch_bounds__(512, 2) void conv_march_s2_kernel(const ConvArgs p,
     constexpr int PLANEQ = G::PLANEQ, NP = G::NP, NPI = G::NPI, NWV = G::NWV, NIB = G::NIB, TH = G::TH, TW = G::TW, LW = G::LW, NEV = G::NEV;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* const bring = smem + 2 * PLANEQ;
-#ifdef OSA_EXPERIMENTS
-    const int dbg = p.dbg;                                    // timing-only ablations (tools/bench_layers.py --dbgs): 1 no weight transfers, 2 no plane transfers, 4 no MFMAs, 8 no epilogue
-#else
-    constexpr int dbg = 0;
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,28 +116,20 @@ __global__ __launch_bounds__(512, 2) void conv_march_s2_kernel(const ConvArgs p,
 
     // B: a step's 12 fragments f = (kw * 2 + hl) * 2 + n, 64 lanes x 16 B each.  Wave w fetches fragment w and fragment 8 + (w & 3)
     // (waves 4..7 repeat 8..11: the same bytes to the same slots, so that every wave issues exactly NIB instructions per step).
-    // packed weights: 16-byte unit ((ch * 27 + t) * 4 + hl * 2 + kg) * CoP + co, t = kd * 9 + kh * 3 + kw  (conv3d.hip pack_weights_f16x3).
-    // The step's base (ch, kd, kh) is wave-uniform: an SGPR pair; the lane's share is a 32-bit offset (saddr form of the transfer).
+    // packed weights: 16-byte unit ((ch * 27 + t) * 4 + hl * 2 + kg) * CoP + co, t = kd * 9 + kh * 3 + kw  (conv3d.hip pack_weights_f16x3)
     unsigned boff[NIB], bdst[NIB];
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
         const int f = i == 0 ? wv : 8 + (wv & 3);
         const int kw = f >> 2, hl = (f >> 1) & 1, n = f & 1;
         boff[i] = (unsigned)((kw * 4 * CoP + hl * 2 * CoP + hh * CoP + n * 32 + col) * 16);
-        bdst[i] = bring_lds + (unsigned)(f * 64 * 16);
+        bdst[i] = (unsigned)(f * 64 * 16);
     }
-    auto dma_b = [&](const int slot, const char* stepbase) {       // stepbase: wave-uniform
-        if (dbg & 1) return;                                 // (timing-only ablation, experiments build: no weight transfers)
+    auto dma_b = [&](const int slot, const int ch, const int kh, const int kd) {
+        const char* base = reinterpret_cast<const char*>(p.w) + (size_t)((ch * 27 + kd * 9 + kh * 3) * 4 * CoP) * 16;
 #pragma unroll
-        for (int i = 0; i < NIB; ++i) {
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(bdst[i] + (unsigned)(slot * G::BSTEPQ * 16));
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(boff[i]), "s"(stepbase), "s"(m0v) : "memory");
-        }
+        for (int i = 0; i < NIB; ++i) dma(base + boff[i], bring_lds + (unsigned)(slot * G::BSTEPQ * 16) + bdst[i]);
     };
-    const size_t kh_bytes = (size_t)3 * 4 * CoP * 16;           // bytes between the kh rows of a (chunk, kd): 3 taps
-    auto block_base = [&](const int ch, const int kd) { return reinterpret_cast<const char*>(p.w) + (size_t)((ch * 27 + kd * 9) * 4 * CoP) * 16; };
 
     // planes: piece i of this wave is DMA instruction n = i * NWV + wave (beyond NPI - 1: instruction NPI - 1 again).  LDS slot j = 64 n + lane
     // -> swizzled quad of voxel v = j >> 2 of the parity-planar image: row lh = v / 65, r = v % 65, column lw = 2 r (r < 33) or 2 (r - 33) + 1
@@ -165,7 +152,6 @@ __global__ __launch_bounds__(512, 2) void conv_march_s2_kernel(const ConvArgs p,
     const char* const xb = reinterpret_cast<const char*>(p.x) + (size_t)b * p.Di * plane_bytes;
     auto dma_plane = [&](const int buf, const int pd, const int c) {          // pd < 0: nothing to fetch (zeros: the instruction count stays the same)
         const char* base = xb + (size_t)(pd < 0 ? 0 : pd) * plane_bytes + (size_t)c * (CC * 4);
-        if (dbg & 2) return;                                 // (ablation: no plane transfers)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             int n = i * NWV + wv;
@@ -214,129 +200,85 @@ __global__ __launch_bounds__(512, 2) void conv_march_s2_kernel(const ConvArgs p,
         }
     };
 
-    // ---- per-lane LDS byte addresses of the A fragments in plane buffer 0: row kh, tap kw -> hi quad; the lo quad is the address ^ 32
-    // (quad index q ^ 2); + PLANEQ * 16 for buffer 1.  B fragments: one base per lane + immediates.
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) const v4f lds_f4;
-    unsigned aaddr[3][3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    // ---- one step: the 3 kw taps of (kh, kd) from plane buffer `cur`, B fragments from ring slot `slot`, 9 MFMAs
+    auto taps = [&](f32x16& acc, const int cur, const int slot, const int kh) {
+        const int vrow = (2 * wm + kh) * LW + col;
+        float4 A[3][2], Bf[3][2];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int v = (2 * wm + kh) * LW + col + (kw == 1 ? NEV : (kw >> 1));
-            aaddr[kh][kw] = smem_lds + (unsigned)((4 * v + (hh ^ ((v >> 2) & 3))) * 16);
-        }
-    const unsigned baddr = bring_lds + (unsigned)((wn * 64 + lane) * 16);
-    auto lds16 = [](const unsigned a) -> v4f { return *reinterpret_cast<lds_f4*>((size_t)a); };
-    struct Frags { v4f A[3][2], B[3][2]; };
-    auto read_frags = [&](Frags& F, const unsigned a0, const unsigned a1, const unsigned a2, const int slot) {   // slot: constant after unrolling
-        const unsigned a[3] = {a0, a1, a2};
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            F.A[kw][0] = lds16(a[kw]);
-            F.A[kw][1] = lds16(a[kw] ^ 32u);
-            F.B[kw][0] = lds16(baddr + (unsigned)((slot * 12 + (kw * 2 + 0) * 2) * 64 * 16));
-            F.B[kw][1] = lds16(baddr + (unsigned)((slot * 12 + (kw * 2 + 1) * 2) * 64 * 16));
-        }
-    };
-    auto mfmas = [&](f32x16& acc, const Frags& F) {
-        if (dbg & 4) {                                       // (timing-only ablation, experiments build: LDS reads without the MFMAs)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) acc[kw] += F.A[kw][0].x + F.A[kw][1].x + F.B[kw][0].x + F.B[kw][1].x;
-            return;
+            const int v = vrow + (kw == 1 ? NEV : (kw >> 1));
+            const int qs = hh ^ ((v >> 2) & 3);
+            A[kw][0] = smem[cur * PLANEQ + 4 * v + qs];
+            A[kw][1] = smem[cur * PLANEQ + 4 * v + (qs ^ 2)];
+            Bf[kw][0] = bring[slot * G::BSTEPQ + ((kw * 2 + 0) * 2 + wn) * 64 + lane];
+            Bf[kw][1] = bring[slot * G::BSTEPQ + ((kw * 2 + 1) * 2 + wn) * 64 + lane];
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int term = 0; term < 3; ++term) {                      // small cross terms first (as the other forms)
-                const f16x8 a = __builtin_bit_cast(f16x8, F.A[kw][term == 1 ? 1 : 0]);
-                const f16x8 w = __builtin_bit_cast(f16x8, F.B[kw][term == 0 ? 1 : 0]);
+                const f16x8 a = __builtin_bit_cast(f16x8, A[kw][term == 1 ? 1 : 0]);
+                const f16x8 w = __builtin_bit_cast(f16x8, Bf[kw][term == 0 ? 1 : 0]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, w, acc, 0, 0, 0);
             }
     };
 
-    // ---- pass / block sequence.  Planes pf .. pl are walked; pass q = (plane pd, chunk c) reads plane buffer q & 1.  A BLOCK is the three
-    // steps kh = 0, 1, 2 of one (pass, kd); step kh uses ring slot kh.  An even plane has one block (kd = 1 into accumulator set 0), an odd
-    // plane the block kd = 2 into set 0 -- the output plane od = pd >> 1 it completes, if that plane belongs to this segment -- and the
-    // block kd = 0 into set 1 (od + 1, if that one does).
+    // ---- pass / step sequence.  Planes pf .. pl are walked; pass = (plane pd, chunk c); an even plane has 3 steps (kh, kd = 1), an odd plane
+    // 3 steps (kh, kd = 2) into the plane od = pd >> 1 it completes (if that plane belongs to this segment) + 3 steps (kh, kd = 0) into od + 1
+    // (if that one does).  Global step t uses ring slot t % 3.
     const int pf = (2 * o0 - 1 > 0) ? 2 * o0 - 1 : 0;
     const int pl = (2 * o1 - 1 < p.Di - 1) ? 2 * o1 - 1 : p.Di - 1;
-    auto has0 = [&](const int pd) { return !(pd & 1) || (pd >> 1) >= o0; };              // does plane pd have a block into set 0 / set 1?
-    auto has1 = [&](const int pd) { return (pd & 1) && (pd >> 1) + 1 < o1; };
-    auto first_kd = [&](const int pd) { return (pd & 1) ? (has0(pd) ? 2 : 0) : 1; };
-
-    Frags F0, F1, F2;
-    // One block.  `wcur`: weight base of THIS block (re-fetched when there is no next block: the instruction counts of the waits stay what they
-    // are), `wnext` / `nvalid`: the next block; `anext`: A addresses (row kh = 0) of the next block's first step; `first` / `lng`: first
-    // block of its pass (the plane transfer of pass q + 1 goes out in step 0) / the pass has two blocks; pieces: (buffer, plane, chunk).
-    auto block = [&](auto SEL1, const unsigned (&ac)[3][3], const unsigned (&anext)[3], const char* wnext, const bool first, const bool lng,
-                     const int fbuf, const int fpd, const int fc) {
-        auto step = [&](auto KH, const Frags& Fc, Frags& Fn) {
-            constexpr int kh = decltype(KH)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's fragments (read a step ago from ring slot kh) are in registers BEFORE the
-                                                              // barrier behind which the other waves overwrite that slot
-            __syncthreads();                                  // every wave's share of the next step's B (and, before a pass's last step, of the next pass's
-                                                              // plane) has landed: each wave waited for its own before it arrived; the fragments of THIS
-                                                              // step are in registers, so ring slot kh and -- in a last step -- this pass's buffer are free
-            dma_b(kh, wnext + (size_t)kh * kh_bytes);         // the same step of the next block -> slot kh
-            if (first && kh == 0) dma_plane(fbuf, fpd, fc);
-            if constexpr (kh < 2) read_frags(Fn, ac[kh + 1][0], ac[kh + 1][1], ac[kh + 1][2], kh + 1);
-            else read_frags(Fn, anext[0], anext[1], anext[2], 0);          // (past the end: the addresses of this block again -- read and dropped)
-            if constexpr (decltype(SEL1)::value) mfmas(acc1, Fc); else mfmas(acc0, Fc);
-            // own share of the B transfer issued a step ago is home; younger than it: this step's transfer and the plane pieces of a pass's step 0,
-            // which must be home one step before the pass ends (the next pass's first fragments are read in its last step)
-            if (first && (kh == 0 || (kh == 1 && lng))) wait_vmcnt_c<NIB + NP>(); else wait_vmcnt_c<NIB>();
-        };
-        step(std::integral_constant<int, 0>{}, F0, F1);
-        step(std::integral_constant<int, 1>{}, F1, F2);
-        step(std::integral_constant<int, 2>{}, F2, F0);
+    auto steps_of = [&](const int pd) { const int od = pd >> 1; return (pd & 1) ? ((od >= o0 ? 3 : 0) + (od + 1 < o1 ? 3 : 0)) : 3; };
+    auto kd_of = [&](const int pd, const int k) { return (pd & 1) ? ((k < 3 && (pd >> 1) >= o0) ? 2 : 0) : 1; };
+    // look-ahead iterator of the B transfers (two steps ahead of the step being computed); past the end it stays on the last step
+    int lpd = pf, lc = 0, lk = 0;
+    bool ldone = false;
+    auto issue_b = [&](const int slot) {
+        dma_b(slot, lc, lk >= 3 ? lk - 3 : lk, kd_of(lpd, lk));
+        if (!ldone) {
+            if (++lk == steps_of(lpd)) {
+                lk = 0;
+                if (++lc == nch) { lc = 0; ++lpd; }
+                if (lpd > pl) { ldone = true; lpd = pl; lc = nch - 1; lk = steps_of(pl) - 1; }
+            }
+        }
     };
 
     dma_plane(0, pf, 0);
-    {
-        const char* w0 = block_base(0, first_kd(pf));
-        dma_b(0, w0); dma_b(1, w0 + kh_bytes); dma_b(2, w0 + 2 * kh_bytes);
-    }
+    issue_b(0); issue_b(1);
     wait_vmcnt_c<0>();
-    __syncthreads();
-    read_frags(F0, aaddr[0][0], aaddr[0][1], aaddr[0][2], 0);
 
+    int slot = 0;                                             // ring slot of the step being computed
     int q = 0;
     for (int pd = pf; pd <= pl; ++pd) {
         const bool odd = pd & 1;
         const int od = pd >> 1;
-        const bool b0 = has0(pd), b1 = has1(pd);
+        const bool do0 = !odd || od >= o0;
+        const int ns = steps_of(pd);
         for (int c = 0; c < nch; ++c, ++q) {
-            const unsigned boffs = (q & 1) ? (unsigned)(PLANEQ * 16) : 0u;
-            unsigned ac[3][3], an_same[3], an_next[3];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) ac[kh][kw] = aaddr[kh][kw] + boffs;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) { an_same[kw] = ac[0][kw]; an_next[kw] = aaddr[0][kw] + ((q & 1) ? 0u : (unsigned)(PLANEQ * 16)); }
-            // the pass after this one
+            const int cur = q & 1;
+            // plane-chunk of pass q + 1
             int npd = pd, nc = c + 1;
             if (nc == nch) { nc = 0; ++npd; }
-            const bool more = npd <= pl;
-            const char* wfirst_next = more ? block_base(nc, first_kd(npd)) : nullptr;
-            const int fpd = more ? npd : -1;
-            // blocks of this pass: even plane: (kd = 1 -> set 0); odd plane: (kd = 2 -> set 0) if b0, then (kd = 0 -> set 1) if b1
-            const int nblk = odd ? (int)b0 + (int)b1 : 1;
-            for (int bi = 0; bi < nblk; ++bi) {
-                const bool last = bi + 1 == nblk;                  // the next block is the first block of the next pass (or there is none)
-                const bool sel1 = odd && (bi == 1 || !b0);
-                const int kd_here = odd ? (sel1 ? 0 : 2) : 1;
-                const char* wn = last ? (more ? wfirst_next : block_base(c, kd_here)) : block_base(c, 0);
-                if (sel1) block(std::true_type{}, ac, last ? an_next : an_same, wn, bi == 0, nblk == 2, (q & 1) ^ 1, fpd, nc);
-                else block(std::false_type{}, ac, last ? an_next : an_same, wn, bi == 0, nblk == 2, (q & 1) ^ 1, fpd, nc);
+            if (npd > pl) npd = -1;
+            for (int k = 0; k < ns; ++k) {
+                __syncthreads();                                  // every wave's share of this step's B (and, at k = 0, of this pass's plane) has landed;
+                                                                  // the previous step's readers of ring slot (slot + 2) % 3 are done
+                issue_b(slot >= 1 ? slot - 1 : 2);                // step t + 2 -> slot (t + 2) % 3
+                if (k == 0) dma_plane(cur ^ 1, npd, nc);
+                const int kh = k >= 3 ? k - 3 : k;
+                if (odd && !(k < 3 && do0)) taps(acc1, cur, slot, kh);
+                else taps(acc0, cur, slot, kh);
+                // B of step t + 1 is home (issued a step ago); younger: this step's B transfer and -- during steps 0 and 1 -- the plane pieces
+                if (k <= 1) wait_vmcnt_c<NIB + NP>(); else wait_vmcnt_c<NIB>();
+                slot = slot == 2 ? 0 : slot + 1;
             }
             if (c + 1 == nch) {                                   // plane pd complete: does an output plane complete with it?
                 const bool fin = odd || pd == p.Di - 1;           // (an even LAST plane: plane pd + 1 lies outside the tensor)
-                // buffer q & 1 becomes the wave-private transpose tiles: its last readers (the last step's fragments, read a step earlier) had their
-                // data before that step's barrier, the prefetch of the next step reads the other buffer, and the transfer that refills this buffer is
-                // issued behind the next barrier
-                if (fin && od >= o0 && od < o1 && !(dbg & 8)) epilogue(od, reinterpret_cast<float*>(smem + (q & 1) * PLANEQ) + wv * (32 * 36));
+                if (fin && od >= o0 && od < o1) {
+                    __syncthreads();                              // every wave is past its taps: buffer `cur` becomes the transpose tiles
+                    epilogue(od, reinterpret_cast<float*>(smem + cur * PLANEQ) + wv * (32 * 36));
+                }
                 if (odd) {
                     acc0 = acc1;
 #pragma unroll
