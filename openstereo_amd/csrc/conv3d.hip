@@ -232,6 +232,7 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
 // d-marching form of the 3x3x3 stride-2 64-output-channel layers (f16x3, split tensors): conv_march.hip / conv_march_s2.h.  Switch: bit 29 of
 // osa_conv_b_ring_mask (A/B runs and the parity test against the brick form)
 int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what);
+void march_s2_set_waves(int w);     // bit 28 of the mask: the 4-wave 2 x 32 column (two workgroups per CU) instead of the 8-wave 4 x 32 column (one per CU)
 
 // Which tile configurations take their B operands through the LDS ring (osa_conv_b_ring_mask; bit i = conv_cfgs.def entry i, bit 30 = the
 // fused transposed convs).  Default = the tiles where the ring measured ahead at 8 AND at 4 pairs per launch (profiles/round4/
@@ -1194,5 +1195,5 @@ extern "C" int osa_debug_trace_read(unsigned long long* dst, size_t n_words) {
 }
 #endif
 
-extern "C" int osa_conv_b_ring_mask(int mask) { const int prev = osa::g_b_ring_mask; osa::g_b_ring_mask = mask; return prev; }
+extern "C" int osa_conv_b_ring_mask(int mask) { const int prev = osa::g_b_ring_mask; osa::g_b_ring_mask = mask; osa::march_s2_set_waves(((mask >> 28) & 1) ? 4 : 8); return prev; }
 extern "C" long long osa_conv_b_ring_launches(void) { return osa::g_b_ring_launches; }

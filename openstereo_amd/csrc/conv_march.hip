@@ -97,28 +97,23 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what) {
 static long long g_march_s2_launches = 0;
 long long march_s2_launches() { return g_march_s2_launches; }
 
-int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what) {
-    using G = MarchS2Geo;
-    if (a.T != 27 || a.Co != 64 || a.CoP != 64 || a.Di < 2 || a.gate || a.rx || a.res) return 0;
-    if (a.Ci % 16 != 0 || a.xCs % 16 != 0) return 0;
-    if (!(a.act & OSA_IN_SPLIT) || !(a.act & OSA_OUT_SPLIT)) return 0;
-    const int actk = a.act & 15;
-    if (actk > OSA_ACT_LEAKY || (a.act & (OSA_GATE_RAW | OSA_RES_AFTER_ACT)) || ((unsigned)a.act >> 16)) return 0;
-    if ((a.yCs % 16) || ((size_t)a.y & 15) || ((size_t)a.x & 15)) return 0;
-    if ((long long)a.Do * a.Ho * a.Wo * a.yCs >= (1ll << 31)) return 0;
-    if ((long long)a.Hi * a.Wi * a.xCs >= (1ll << 29)) return 0;        // per-plane byte offsets are 32-bit
+static int g_march_s2_waves = 8;                            // 8: 4 x 32 columns, one workgroup per CU (measured ahead: profiles/round6/march_s2_versions.txt); 4: 2 x 32 columns, two per CU (osa_conv_b_ring_mask bit 28)
+template <int NWV>
+static int launch_conv_march_s2_t(ConvArgs& a, hipStream_t st, const char* what) {
+    using G = MarchS2Geo<NWV>;
     a.tilesD = 1; a.tilesH = cdiv(a.Ho, G::TH); a.tilesW = cdiv(a.Wo, G::TW);
-    a.dbg = exp_int("OSA_DBG", 0);                          // (experiments build only: timing ablations of conv_march_s2.h)
+    a.dbg = exp_int("OSA_DBG", 0);
     // D segments of `oseg` output planes: a segment stages 2 oseg + 1 input planes (the first one for a third of its taps).  Cost model in
-    // plane-steps per round of resident workgroups (one per CU); the fewest segments win a tie.
+    // plane-steps per round of resident workgroups; the fewest segments win a tie.
     const long long cols = (long long)a.B * a.tilesH * a.tilesW;
+    const long long slots = 256 * (NWV == 8 ? 1 : 2);
     int nseg = 1;
     {
         double best = 1e30;
         for (int n = 1; n <= a.Do; ++n) {
             const int os = cdiv(a.Do, n), ns = cdiv(a.Do, os);
             if (ns != n) continue;
-            const double cost = (double)((cols * ns + 255) / 256) * (2.0 * os + (ns > 1 ? 1.0 : 0.0) + 0.5);     // (+ 0.5: prologue / drain of a workgroup)
+            const double cost = (double)((cols * ns + slots - 1) / slots) * (2.0 * os + (ns > 1 ? 1.0 : 0.0) + 0.5);     // (+ 0.5: prologue / drain of a workgroup)
             if (cost < best - 1e-9) { best = cost; nseg = ns; }
         }
         const int o = exp_int("OSA_MARCH_NSEG", 0);
@@ -128,11 +123,26 @@ int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what) {
     nseg = cdiv(a.Do, oseg);
     OSA_REQUIRE(cols * nseg < (1ll << 31), "%s: grid too large", what);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_march_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes()); attr_set = true; }
-    hipLaunchKernelGGL(conv_march_s2_kernel, dim3((unsigned)(cols * nseg)), dim3(G::NWV * 64), G::lds_bytes(), st, a, oseg, nseg);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_march_s2_kernel<NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes()); attr_set = true; }
+    hipLaunchKernelGGL(conv_march_s2_kernel<NWV>, dim3((unsigned)(cols * nseg)), dim3(NWV * 64), G::lds_bytes(), st, a, oseg, nseg);
     OSA_LAUNCH_CHECK(what);
-    ++g_march_s2_launches;
     return 1;
+}
+
+void march_s2_set_waves(int w) { g_march_s2_waves = (w == 4) ? 4 : 8; }
+
+int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what) {
+    if (a.T != 27 || a.Co != 64 || a.CoP != 64 || a.Di < 2 || a.gate || a.rx || a.res) return 0;
+    if (a.Ci % 16 != 0 || a.xCs % 16 != 0) return 0;
+    if (!(a.act & OSA_IN_SPLIT) || !(a.act & OSA_OUT_SPLIT)) return 0;
+    const int actk = a.act & 15;
+    if (actk > OSA_ACT_LEAKY || (a.act & (OSA_GATE_RAW | OSA_RES_AFTER_ACT)) || ((unsigned)a.act >> 16)) return 0;
+    if ((a.yCs % 16) || ((size_t)a.y & 15) || ((size_t)a.x & 15)) return 0;
+    if ((long long)a.Do * a.Ho * a.Wo * a.yCs >= (1ll << 31)) return 0;
+    if ((long long)a.Hi * a.Wi * a.xCs >= (1ll << 29)) return 0;        // per-plane byte offsets are 32-bit
+    const int r = g_march_s2_waves == 8 ? launch_conv_march_s2_t<8>(a, st, what) : launch_conv_march_s2_t<4>(a, st, what);
+    if (r == 1) ++g_march_s2_launches;
+    return r;
 }
 
 }  // namespace osa

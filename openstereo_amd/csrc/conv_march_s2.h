@@ -30,15 +30,18 @@
 
 namespace osa {
 
+// NWV = 8: a 4 x 32 output column, ONE workgroup per CU (112 KB of LDS); NWV = 4: a 2 x 32 column, TWO independent workgroups per CU (2 x 80 KB:
+// while one sits at its step barrier the other multiplies) at the price of a taller halo (1.27x instead of 1.14x) and the weights fetched twice per CU.
+template <int NWV_>
 struct MarchS2Geo {
-    static constexpr int NWV = 8, TW = 32, TH = 4;
+    static constexpr int NWV = NWV_, TW = 32, TH = NWV_ / 2;
     static constexpr int LH = 2 * TH + 1, LW = 2 * TW + 1, NEV = TW + 1;       // footprint rows / columns, even columns per row
     static constexpr int NVOX = LH * LW;                                       // 585 voxels, 4 quads each
     static constexpr int NPI = (NVOX * 4 + 63) / 64;                           // LDS-DMA instructions per chunk-plane (37)
     static constexpr int PLANEQ = NPI * 64;                                    // float4 slots per plane buffer
     static constexpr int NP = (NPI + NWV - 1) / NWV;                           // pieces per wave and pass (5)
     static constexpr int BRING = 3, BSTEPQ = 12 * 64;                          // ring slots, float4 slots per step (12 fragments of 1 KB)
-    static constexpr int NIB = 2;                                              // B transfers per wave and step (16 issued for 12 fragments: 4 duplicates)
+    static constexpr int NIB = NWV == 8 ? 2 : 3;                               // B transfers per wave and step (8 waves: 16 issued for 12 fragments, 4 duplicates)
     static constexpr size_t lds_bytes() { return (size_t)2 * PLANEQ * 16 + (size_t)BRING * BSTEPQ * 16; }
     static_assert((size_t)NWV * 32 * 36 * 4 <= (size_t)PLANEQ * 16, "epilogue tiles must fit into one plane buffer");
 };
@@ -61,15 +64,16 @@ __device__ __forceinline__ void wait_vmcnt_c() {
 }
 
 // split input, split output, no residual (conv1 of the hourglasses); oseg output planes per segment
-__global__ __launch_bounds__(512, 2) void conv_march_s2_kernel(const ConvArgs p, const int oseg, const int nseg) {
-    using G = MarchS2Geo;
+template <int NWV_>
+__global__ __launch_bounds__(NWV_ * 64, 2) void conv_march_s2_kernel(const ConvArgs p, const int oseg, const int nseg) {
+    using G = MarchS2Geo<NWV_>;
     constexpr int PLANEQ = G::PLANEQ, NP = G::NP, NPI = G::NPI, NWV = G::NWV, NIB = G::NIB, TH = G::TH, TW = G::TW, LW = G::LW, NEV = G::NEV;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* const bring = smem + 2 * PLANEQ;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv & 3, wn = wv >> 2;                      // M-tile (output row of the column), N-tile (32 output channels)
+    const int wm = wv & (TH - 1), wn = wv / TH;               // M-tile (output row of the column), N-tile (32 output channels)
     const int col = lane & 31, hh = lane >> 5;
 
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void conv_march_s2_kernel(const ConvArgs p,
     unsigned boff[NIB], bdst[NIB];
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
-        const int f = i == 0 ? wv : 8 + (wv & 3);
+        const int f = NWV == 8 ? (i == 0 ? wv : 8 + (wv & 3)) : wv * 3 + i;
         const int kw = f >> 2, hl = (f >> 1) & 1, n = f & 1;
         boff[i] = (unsigned)((kw * 4 * CoP + hl * 2 * CoP + hh * CoP + n * 32 + col) * 16);
         bdst[i] = (unsigned)(f * 64 * 16);
