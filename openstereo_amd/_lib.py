@@ -228,8 +228,8 @@ def load():
                 raise
             fn.restype = res
             fn.argtypes = args
-        if lib.osa_abi_version() != abi_version():
-            raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}, include/openstereo_amd.h declares {abi_version()}")
+        if lib.osa_abi_version() != abi_version(lib):
+            raise EngineError(f"ABI version mismatch: library reports {lib.osa_abi_version()}, include/openstereo_amd.h declares {abi_version(lib)}")
         if os.environ.get("OSA_B_RING_MASK") and hasattr(lib, "osa_conv_b_ring_mask"):
             lib.osa_conv_b_ring_mask(int(os.environ["OSA_B_RING_MASK"], 0))     # A/B runs: which tiles take their weights through the LDS ring
         if os.environ.get("OSA_VOL_WALK") and hasattr(lib, "osa_volume_walk_step"):
@@ -241,14 +241,22 @@ def load():
 _abi = None
 
 
-def abi_version() -> int:
+def abi_version(lib=None) -> int:
     """OSA_ABI_VERSION of include/openstereo_amd.h -- the ONE place the number lives (the loaders and the tests read it from here)."""
     global _abi
     if _abi is None:
         import re
         hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "openstereo_amd.h")
-        with open(hdr) as f:
-            _abi = int(re.search(r"#define\s+OSA_ABI_VERSION\s+(\d+)", f.read()).group(1))
+        try:
+            with open(hdr) as f:
+                _abi = int(re.search(r"#define\s+OSA_ABI_VERSION\s+(\d+)", f.read()).group(1))
+        except (OSError, AttributeError):
+            # a copy of the package without the repository's include/ directory (wheel / site-packages): the library was compiled against the
+            # header, so what it reports IS the version (ADVICE r5)
+            h = lib if lib is not None else _lib
+            if h is None:
+                return -1
+            _abi = int(h.osa_abi_version())
     return _abi
 
 

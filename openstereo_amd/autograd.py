@@ -248,7 +248,10 @@ def _wcache2(w, w2):
     a, b = _wcache(w), _wcache(w2)
     if a is None or b is None:
         return None
-    return _Memo(a.memo, (a.stamp, b.stamp))
+    pair = a.memo.get(("pair", id(w2)))                 # a dict of its own: the pair's stamp must not overwrite the stamp of w used alone
+    if pair is None:
+        pair = a.memo[("pair", id(w2))] = {}
+    return _Memo(pair, (a.stamp, b.stamp))
 
 
 def _pack_now(w, Ci, Co, k, mode, precision):
@@ -412,12 +415,13 @@ WGRAD_F16_CLASS = os.environ.get("OSA_WGRAD_F16_CLASS", "1") != "0"
 
 
 def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, transposed, precision="f32", xmeta=None, dymeta=None, xcs=None, dycs=None):
-    assert precision == "f16" or (xc.dtype == torch.float32 and dyc.dtype == torch.float32), "fp16 tensors exist in the native f16 form only"
-    xcs, dycs = (xc.shape[1] if xcs is None else xcs), (dyc.shape[1] if dycs is None else dycs)        # channel strides (rows may be wider than the tensors' logical channels)
     """Weight gradient, two-stage form: partial tiles in a scratch tensor from the caching allocator, summed in a fixed order --
     deterministic, and free of the contended float atomics of the one-stage form.  precision "f16x3": the split-precision kernel where it
     applies (unit stride / dilation, 3x3 planes: osa_conv3d_wgrad_ws_f16x3, operand ranges from the tensors' range blocks), the exact
-    fp32 kernel (osa_conv3d_wgrad_ws_f32) everywhere else."""
+    fp32 kernel (osa_conv3d_wgrad_ws_f32) everywhere else.  fp16 tensors (the native f16 form) that the fp16 kernel declines are widened
+    and take the exact kernel (never raise inside backward() for a layer the forward accepted)."""
+    assert precision == "f16" or (xc.dtype == torch.float32 and dyc.dtype == torch.float32), "fp16 tensors exist in the native f16 form only"
+    xcs, dycs = (xc.shape[1] if xcs is None else xcs), (dyc.shape[1] if dycs is None else dycs)        # channel strides (rows may be wider than the tensors' logical channels)
     dims = (B, D, H, W, Ci, Do, Ho, Wo, Co, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed)
     lib = _lib.load()
     vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
@@ -435,7 +439,7 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
                 if ext.conv_wgrad(xc, dyc, dw, ed, 1, xmeta if xmeta is not None else input_meta(xc), dymeta if dymeta is not None else input_meta(dyc)):
                     return
         if xc.dtype != torch.float32 or dyc.dtype != torch.float32:
-            raise _lib.EngineError("the native f16 weight gradient does not cover this layer and its tensors are fp16: " + str(dims))
+            xc, dyc = xc.float(), dyc.float()                     # (dense tensors: .float() keeps the strides the channel strides refer to)
         with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
             ext.conv_wgrad(xc, dyc, dw, ed, 0, None, None)
         return
@@ -462,6 +466,8 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     need = lib.osa_conv3d_wgrad_workspace_bytes(*dims)
     if need == 0:
         raise _lib.EngineError("osa_conv3d_wgrad_workspace_bytes: unsupported layer " + str(dims))
+    if xc.dtype != torch.float32 or dyc.dtype != torch.float32:
+        xc, dyc = xc.float(), dyc.float()
     ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
     with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
         _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
@@ -679,7 +685,7 @@ class _ConvTranspose3d(torch.autograd.Function):
         y = _run_deconv(xc, packed, osc, Ci, Co, k, pad, opad, precision)
         ctx.save_for_backward(xc, wf)
         ctx.meta = (pad, opad, precision, x.dtype)
-        return y[:, :Co]
+        return _alias(y[:, :Co])
 
     @staticmethod
     @_bwd
@@ -725,13 +731,13 @@ class _ConvTranspose2d(torch.autograd.Function):
         if _ext_conv(2, xc, packed, y, [B, 1, H, W, Ci4, Cs, Co, CoS, 0, 0], [k, pad, opad], precision, osc):
             ctx.save_for_backward(xc, wf)
             ctx.meta = (pad, opad, precision, x.dtype)
-            return y[:, :Co, 0]
+            return _alias(y[:, :Co, 0])
         sfx, tail = _sfx_tail(precision, xc, y, osc)
         _lib.call("osa_deconv2d_nhwc_" + sfx, xc.data_ptr(), packed.data_ptr(), None, None, None, y.data_ptr(),
                   B, H, W, Ci4, Cs, Co, CoS, 0, k, pad, opad, None, 0, 0, 0.0, *tail)
         ctx.save_for_backward(xc, wf)
         ctx.meta = (pad, opad, precision, x.dtype)
-        return y[:, :Co, 0]
+        return _alias(y[:, :Co, 0])
 
     @staticmethod
     @_bwd

@@ -93,7 +93,9 @@ def train_precision(requested=None) -> str:
     p = requested or _precision
     if p == "f16":
         return "f16" if AMP_TRAIN_NATIVE else "f16x3"
-    if AMP_TRAIN_NATIVE and AUTOCAST_NATIVE and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
+    # the autocast override applies to the GLOBAL mode only: an explicit per-call precision (an exact-f32 layer or test inside an autocast
+    # region) is honoured
+    if requested is None and AMP_TRAIN_NATIVE and AUTOCAST_NATIVE and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
         return "f16"
     return p
 

@@ -742,3 +742,33 @@ def test_training_step_captured_as_hipgraph_under_ddp():
     line = json.loads(lines[-1])
     assert line["config"]["launch"].startswith("hipGraph replay of the whole training step"), (line["config"]["launch"], r.stderr[-1500:])
     assert line["value"] > 0
+
+
+@pytest.mark.parametrize("kind", ["conv3d", "conv2d", "conv_transpose3d", "conv_transpose2d"])
+def test_inplace_activation_after_every_differentiable_conv(kind):
+    """nn.ReLU(inplace=True) directly on the output of each engine convolution Function (hourglass.py:53-54 uses in-place ReLU on intermediates):
+    the outputs are alias tensors over the NDHWC storage, not autograd views (the transposed forms returned views and raised),
+    and the gradients equal those of the out-of-place composition."""
+    from openstereo_amd import autograd as AG
+    g = torch.Generator().manual_seed(3)
+    if kind == "conv3d":
+        x, w = torch.randn(1, 16, 4, 6, 8, generator=g), torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
+        f, ref = (lambda a, b: AG.conv3d(a, b, padding=1)), (lambda a, b: F.conv3d(a, b, padding=1))
+    elif kind == "conv2d":
+        x, w = torch.randn(2, 16, 6, 8, generator=g), torch.randn(32, 16, 3, 3, generator=g) * 0.1
+        f, ref = (lambda a, b: AG.conv2d(a, b, padding=1)), (lambda a, b: F.conv2d(a, b, padding=1))
+    elif kind == "conv_transpose3d":
+        x, w = torch.randn(1, 16, 2, 3, 4, generator=g), torch.randn(16, 16, 3, 3, 3, generator=g) * 0.1
+        f = lambda a, b: AG.conv_transpose3d(a, b, stride=2, padding=1, output_padding=1)
+        ref = lambda a, b: F.conv_transpose3d(a, b, stride=2, padding=1, output_padding=1)
+    else:
+        x, w = torch.randn(2, 16, 3, 4, generator=g), torch.randn(16, 16, 3, 3, generator=g) * 0.1
+        f = lambda a, b: AG.conv_transpose2d(a, b, stride=2, padding=1, output_padding=1)
+        ref = lambda a, b: F.conv_transpose2d(a, b, stride=2, padding=1, output_padding=1)
+    xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = torch.relu_(f(xg, wg))                                   # must not raise "a view of ... is being modified inplace"
+    y.square().sum().backward()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.relu(ref(xr, wr)).square().sum().backward()
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(wg.grad.cpu(), wr.grad, atol=2e-4, rtol=2e-4)
