@@ -1012,6 +1012,11 @@ def main():
         roofs, alt, latency_1, cpu = [], None, None, None
         if not args.timed_only and world == 1:
             cfg["timed_config_parity"] = gwcnet_timed_config_parity(wl, step)      # every pair of the timed step vs single-pair single-stream runs
+            # the same maxima as scalar keys: the driver's parsed copy of `config` keeps scalars only
+            tp = cfg["timed_config_parity"]
+            cfg.update({"parity_replay_vs_replay_max_px": tp["replay_vs_replay_max_px"], "parity_vs_one_stream_max_px": tp["vs_same_sub_batches_on_one_stream_max_px"],
+                        "parity_vs_single_pair_runs_max_px": tp["vs_single_pair_runs_max_px"], "parity_worst_pair_epe_px": tp["vs_single_pair_runs_worst_pair_epe_px"],
+                        "parity_all_finite": tp["all_finite"]})
         if not args.timed_only:
             nrep = max(2, min(args.steps, 5))
             if graph is not None and world == 1:
@@ -1023,6 +1028,7 @@ def main():
                 roofs[0]["note"] = (f"kernel timed in a single-stream replay of the same forward ({B} pairs per launch, nothing else on the GPU); the timed region "
                                     f"issues every launch as {wl.nstreams} concurrent launches of {B // wl.nstreams} pairs on separate streams (config.sub_batch_streams)")
             cfg["stage_ms_per_step"] = dict(list(per_step.items())[:14])
+            cfg["stage_top6_ms_per_step"] = "; ".join(f"{k}={v}" for k, v in list(per_step.items())[:6])       # (scalar copy for the driver's parsed config)
             if args.stages:
                 json.dump(per_step, open(args.stages, "w"), indent=1)
             if world == 1:
