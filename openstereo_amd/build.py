@@ -25,15 +25,13 @@ HIPCC_FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-ffp-con
                "-Wall", "-Wno-unused-function"]
 # NO packed-fp32 VALU instructions (v_pk_mul / add / fma_f32) in ANY kernel of the library: the backend feature is switched off for every
 # translation unit, and tests/test_isa_lint_cpu.py disassembles the shipped objects and fails on the first one it finds.
-# Why: r5 found the x4 fused head returning wrong values in isolated 16-lane passes whenever another stream's d-marching convolution was
-# resident on the same SIMD -- its loads right, its arithmetic wrong, only in the build whose loop carried packed-fp32 instructions (DESIGN.md
-# 3.3; profiles/round5/head_packed_math_under_march_load.txt; r6 narrowed the trigger with single-instruction probes: tools/diag_pk_probe.py,
-# profiles/round6/pk_probe_matrix.txt).  r5 fixed that one file with -fno-slp-vectorize, which leaves the packed forms the backend selects
-# from explicit vector arithmetic (89 in softargmin.hip alone, 17.5 k in the f16x3 conv instantiations).  Every kernel of a forward can be
-# co-resident with another sub-batch stream's marching kernel, so the property has to hold for all of them; it costs nothing measurable
-# (packed fp32 beside MFMAs is an anti-lever on gfx950: MI355X_MICROARCH.md, per-instruction constants) and takes the marching kernels'
-# spills down (conv_march_kernel<4,16,0,0> 76 -> 56 bytes of scratch, <4,16,1,0> 8 -> 0).  Same operations in the same order
-# (-ffp-contract=off): results are bit-identical to the packed build on an idle GPU.
+# Why: on gfx950 a VOP3P fp32 instruction whose LO result reads the HI half of its src1 pair (op_sel:[0,1] -- hipcc's SLP
+# vectoriser emits it for horizontal sums) returns wrong values in isolated 16-lane passes while an MFMA-dense kernel of another stream is
+# resident on the same SIMD: r5 found the x4 fused head wrong next to the d-marching convolution, r6 reduced it to one instruction in a
+# ten-line kernel on three GPUs (profiles/round6/pk_micro_matrix2.txt, head_variants_single.txt).  Every kernel of a forward can be
+# co-resident with another sub-batch stream's marching kernel, so the property has to hold for all of them; it costs nothing (packed fp32
+# beside MFMAs is an anti-lever on gfx950: +1 % on the headline without it, profiles/round6/build_flags_ab.txt) and takes the marching
+# kernels' spills down.  Same operations in the same order (-ffp-contract=off): bit-identical to the packed build on an idle GPU.
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 HIPCC_FLAGS += NO_PACKED_F32
 EXTRA_FLAGS: dict = {}

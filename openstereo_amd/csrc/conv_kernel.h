@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {         // executed by all 64 lanes (no lane-dependent branch around it)
                     // (__float_as_uint of a scalar copy: __builtin_bit_cast applied to the vector element itself makes this clang fold every
-                    // swap of the tile onto accumulator 0 -- tools/experiments note in DESIGN.md 3.2 r3)
+                    // swap of the tile onto accumulator 0 -- tools/experiments note in profiles/DESIGN_rounds1-5.md 3.2 r3)
                     const float xf = acc[0][m][n][8 * P + e], yf = acc[0][m][n][8 * P + 4 + e];
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf), __float_as_uint(yf), false, false);
                     a8[0][e] = __uint_as_float(sw[0]); a8[1][e] = __uint_as_float(sw[1]);

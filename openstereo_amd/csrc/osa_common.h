@@ -77,7 +77,7 @@ __device__ __forceinline__ void publish_amax(float* meta, float am, unsigned see
 
 // 16-byte activation stores of the big producers (conv epilogues, volume builder).  -DOSA_NT_STORE=1 issues them with the non-temporal
 // hint (streaming outputs of 0.2-3.2 GB per launch that the next launch reads long after L2 / Infinity Cache have turned over): an r3
-// A/B experiment (tools/build_variant.sh ntstore -DOSA_NT_STORE=1), see DESIGN.md 3.2.
+// A/B experiment (tools/build_variant.sh ntstore -DOSA_NT_STORE=1), see profiles/DESIGN_rounds1-5.md 3.2.
 #ifndef OSA_NT_STORE
 #define OSA_NT_STORE 0
 #endif

@@ -31,7 +31,7 @@ class SubBatchStreams:
     backbone layer at 4 pairs is only ~5 rounds of resident workgroups); with two sub-batches in flight the tail of one launch overlaps
     the head of the other stream's.  Measured on GwcNet 544x960, 8 pairs per step: 1 stream 176.2-177.3, 2 streams 180.2-180.6, 4
     streams ~177 pairs/s (profiles/round3/ab_substreams_*.txt); starting sub-batch i + 1 when sub-batch i leaves its 2-D backbone, so that
-    an HBM-leaning stage always runs beside an MFMA-bound one, gains nothing (the step is energy-bound)."""
+    an HBM-leaning stage always runs beside an MFMA-bound one, gains nothing (the step is energy-bound, profiles/DESIGN_rounds1-5.md 3.2c)."""
 
     def __init__(self, n: int):
         self.n = max(1, int(n))

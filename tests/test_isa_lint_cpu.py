@@ -1,7 +1,7 @@
 """CPU: no kernel of the shipped gfx950 library carries a packed-fp32 VALU instruction (v_pk_mul / add / fma_f32).
 
 r5 found the x4 fused head returning wrong 16-lane passes next to another stream's d-marching convolution only when its loop carried
-these instructions (DESIGN.md 3.3).  Every kernel of a forward can be co-resident with a marching kernel in the timed configuration
+these instructions (DESIGN.md 3.9).  Every kernel of a forward can be co-resident with a marching kernel in the timed configuration
 (three sub-batch streams), so the property is enforced for the whole library at build time (openstereo_amd/build.py NO_PACKED_F32) and
 checked here on the object code that ships -- a compiler bump, a new translation unit built with other flags or a hand-written
 `v_pk_*_f32` fails this test instead of a user's disparity map.  The GPU side of the same contract is tests/test_gpu_concurrency.py."""

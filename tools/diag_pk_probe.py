@@ -1,4 +1,4 @@
-"""r6: narrowest trigger of the r5 co-residency finding (DESIGN.md 3.3) -- a matrix of VICTIMS x LOADS, every victim launched repeatedly on
+"""r6: narrowest trigger of the r5 co-residency finding (DESIGN.md 3.9) -- a matrix of VICTIMS x LOADS, every victim launched repeatedly on
 one stream while two other streams loop the load, every output compared bit for bit with the victim's idle-GPU result.
 
     python tools/diag_pk_probe.py [--iters 30] [--victims ...] [--loads ...]

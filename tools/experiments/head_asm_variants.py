@@ -1,4 +1,4 @@
-"""r6: delta-debugging the VICTIM side of the co-residency finding (DESIGN.md 3.3) on the real x4 head kernel.
+"""r6: delta-debugging the VICTIM side of the co-residency finding (DESIGN.md 3.9) on the real x4 head kernel.
 
 The fused head built WITH packed-fp32 math returns wrong 16-lane passes next to the d-marching convolution; none of the single-instruction
 probes of tools/experiments/pk_probe.hip does.  So the real kernel's ISA is edited instead: csrc/softargmin.hip is compiled to assembly

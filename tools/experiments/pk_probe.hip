@@ -1,4 +1,4 @@
-// r6 probe: the narrowest trigger of the r5 co-residency finding (DESIGN.md 3.3: the x4 fused head built with packed-fp32 math returns wrong
+// r6 probe: the narrowest trigger of the r5 co-residency finding (DESIGN.md 3.9: the x4 fused head built with packed-fp32 math returns wrong
 // 16-lane passes while another stream's d-marching convolution is resident).  Stand-alone library (hipcc --offload-arch=gfx950 -shared -fPIC),
 // driven by tools/diag_pk_probe.py through ctypes.
 //   * PROBES: register-only loops of ONE instruction form each (inline asm: the assembler, not the compiler, picks the encoding), pure

@@ -2,7 +2,7 @@
 
     python tools/isa_lint.py [path/to/lib.so]        # default: the shipped openstereo_amd/lib/libopenstereo_amd.so
 
-The library is built with the backend's packed-fp32 feature switched off (openstereo_amd/build.py NO_PACKED_F32; DESIGN.md 3.3: a kernel
+The library is built with the backend's packed-fp32 feature switched off (openstereo_amd/build.py NO_PACKED_F32; DESIGN.md 3.9: a kernel
 whose loop carries these instructions returned wrong 16-lane passes next to the d-marching convolution of another stream), and
 tests/test_isa_lint_cpu.py fails when any kernel of any shipped code object carries one.  Works without a GPU: the .hip_fatbin section of
 the .so is split into its offload bundles, every gfx950 code object is disassembled with llvm-objdump."""

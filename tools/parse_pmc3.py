@@ -19,7 +19,8 @@ KERNELS = {
     "classifier": "classifier_march_kernel",
     "deconv_64_32_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 1, 1, 0, 1, 0>",
     "deconv_128_64_redir": "conv_mfma_kernel<1, 8, 1, 1, 1, 4, 1, 4, 8, 2, 1, 0, 1, 0>",
-    "conv_s2_32_64": "conv_mfma_kernel<1, 1, 3, 1, 1, 2, 2, 4, 8, 0, 1, 0, 1, 0>",
+    "conv_s2_32_64": os.environ.get("OSA_PMC_S2", "conv_march_s2_kernel<8>"),          # r6: the stride-2 d-marching form (before: conv_mfma_kernel<1, 1, 3, 1, 1, 2, 2, 4, 8, 0, 1, 0, 1, 0>)
+    "conv_s2_64_128": "conv_mfma_kernel<1, 1, 3, 1, 1, 2, 2, 4, 8, 0, 1, 0, 1, 0>",
     "backbone_64ch_quarter": "conv_mfma_kernel<1, 1, 1, 1, 2, 4, 1, 8, 16, 0, 1, 0, 1, 1>",
     "backbone_128ch_quarter": "conv_mfma_kernel<1, 1, 3, 2, 2, 2, 2, 8, 16, 0, 1, 0, 1, 0>",
 }
