@@ -746,6 +746,48 @@ at::Tensor upsample_softargmin_autograd(const at::Tensor& c, int64_t maxdisp, in
 
 int64_t abi_version() { return osa_abi_version(); }
 
+// ---- Meta (FakeTensor / torch.export / torch.compile) kernels of the launch ops (r6) ------------------------------------------------------
+// The in-place launch ops (`Tensor(a!) ... -> ()`) compute nothing a shape pass needs: their outputs are allocated by the caller.  One boxed
+// kernel serves all of them: pop the arguments, push nothing.
+void noop_boxed(const c10::OperatorHandle& op, torch::jit::Stack* stack) {
+    TORCH_INTERNAL_ASSERT(op.schema().returns().empty(), "noop_boxed serves ops without results only: ", op.schema().name());
+    torch::jit::drop(*stack, op.schema().arguments().size());
+}
+// cost_volume_cl: the volume's shape and the split decision (the eligibility test is host arithmetic on sizes and alignments: device
+// allocations are at least 256-byte aligned, so aligned stand-in addresses give the answer the CUDA kernel gives)
+std::tuple<at::Tensor, bool> cost_volume_cl_meta(const at::Tensor& gwc_feat, const c10::optional<at::Tensor>& cat_feat, int64_t B, int64_t num_groups, int64_t maxdisp,
+                                                 int64_t gwc_channels, int64_t cat_channels, int64_t gwc_off, bool mask_left, bool out_split,
+                                                 const c10::optional<at::Tensor>& gwc_meta, const c10::optional<at::Tensor>& cat_meta, const at::Tensor& out_meta) {
+    TORCH_CHECK(gwc_feat.dim() == 5 && gwc_feat.size(0) == 2 * B && gwc_feat.size(2) == 1, "cost_volume_cl: gwc_feat must be NHWC [2B, Cs, 1, H, W]");
+    const int64_t Gs = gwc_feat.size(1), H = gwc_feat.size(3), W = gwc_feat.size(4);
+    const int64_t C = gwc_channels >= 0 ? gwc_channels : Gs - gwc_off;
+    int64_t Cc = 0, cs = 0;
+    const bool has_cat = cat_feat.has_value() && cat_feat->defined();
+    if (has_cat) { cs = cat_feat->size(1); Cc = cat_channels >= 0 ? cat_channels : cs; }
+    const int64_t nch = num_groups + 2 * Cc, VC = (nch + 3) / 4 * 4;
+    auto out = at::empty({B, maxdisp, H, W, VC}, gwc_feat.options()).permute({0, 4, 1, 2, 3});
+    const float* al = reinterpret_cast<const float*>(static_cast<uintptr_t>(4096));
+    float* ao = reinterpret_cast<float*>(static_cast<uintptr_t>(8192));
+    const bool gm = gwc_meta.has_value() && gwc_meta->defined(), cm = cat_meta.has_value() && cat_meta->defined();
+    const bool split = out_split && VC == nch && (C == 0 || gm) && (Cc == 0 || cm) &&
+        osa_build_volume_nhwc_split_eligible(has_cat ? al : nullptr, has_cat ? al : nullptr, ao, (int)C, (int)num_groups, (int)Gs, (int)Cc, (int)cs, (int)VC, 0, (int)W, (int)maxdisp) == 1;
+    (void)mask_left; (void)out_meta;
+    return {out, split};
+}
+// conv_wgrad: whether the requested form covers the layer is the workspace query's answer (host arithmetic on dims)
+bool conv_wgrad_meta(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, at::IntArrayRef dims, int64_t prec, const c10::optional<at::Tensor>& x_meta,
+                     const c10::optional<at::Tensor>& dy_meta) {
+    TORCH_CHECK(dims.size() == 22, "conv_wgrad: dims = [B, D, H, W, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad x3, dil x3, transposed]");
+    int d[22];
+    for (int i = 0; i < 22; ++i) d[i] = (int)dims[i];
+    const size_t need = prec == 0
+        ? osa_conv3d_wgrad_workspace_bytes(d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21])
+        : osa_conv3d_wgrad_f16x3_workspace_bytes(d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21]);
+    TORCH_CHECK(need != 0 || prec != 0, "conv_wgrad: unsupported layer");
+    (void)x; (void)dy; (void)dw; (void)x_meta; (void)dy_meta;
+    return need != 0;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(osa_native, m) {
@@ -855,6 +897,14 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     m.impl("softargmin_bwd", &softargmin_bwd_meta);
     m.impl("softmax_softargmin_bwd", &softmax_softargmin_bwd_meta);
     m.impl("upsample_softargmin_bwd", &upsample_softargmin_bwd_meta);
+    // r6: every launch op -- an engine model traces under FakeTensorMode / make_fx without a kernel running (tests/test_gpu_fake_trace.py)
+    m.impl("cost_volume_cl", &cost_volume_cl_meta);
+    m.impl("conv_wgrad", &conv_wgrad_meta);
+    for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",
+                             "geo_lookup", "geo_lookup_bwd", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
+                             "geo_lookup_nhwc", "allpairs_corr", "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair",
+                             "amax_into"})
+        m.impl(name, torch::CppFunction::makeFromBoxedFunction<&noop_boxed>());
 }
 
 TORCH_LIBRARY_IMPL(osa_native, Autograd, m) {    // differentiable in C++: backward = the engine's *_bwd kernels (no Python autograd.Function involved)

@@ -373,8 +373,11 @@ class PackedConv3d:
             assert gate.is_contiguous() and tuple(gate.shape[:3]) == (B, Ho, Wo) and gate.shape[3] >= self.Co
             assert h16 or gate.dtype == torch.float32
             gCs = gate.shape[3]
-        xp, yp = x.data_ptr() + x.element_size() * x_off, out.data_ptr() + out.element_size() * out_off
-        rp = None if residual is None else residual.data_ptr() + residual.element_size() * res_off
+        ext = _ext.load()
+        xp = yp = rp = None                                  # raw addresses: the ctypes path only (FakeTensors have none: tests/test_gpu_fake_trace.py)
+        if ext is None:
+            xp, yp = x.data_ptr() + x.element_size() * x_off, out.data_ptr() + out.element_size() * out_off
+            rp = None if residual is None else residual.data_ptr() + residual.element_size() * res_off
         act = self.act | (GATE_RAW if (gate is not None and gate_raw) else 0)
         if gate_channels:
             assert gate is not None and gate_channels % 4 == 0 and 0 < gate_channels <= self.Co
@@ -403,9 +406,10 @@ class PackedConv3d:
             need_res = residual is not None and (out_split or is_split(residual))    # its scale (split) / its share of the output bound
             mx, mr, mo = input_meta(x), (input_meta(residual) if need_res else None), attach_meta(out, st)
             mrd = None if redir is None else input_meta(redir[1])
-            rng = _lib.F16x3Ranges(mx.data_ptr(), None if mr is None else mr.data_ptr(),
-                                   None if mrd is None else mrd.data_ptr(), mo.data_ptr(),
-                                   self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
+            if ext is None:
+                rng = _lib.F16x3Ranges(mx.data_ptr(), None if mr is None else mr.data_ptr(),
+                                       None if mrd is None else mrd.data_ptr(), mo.data_ptr(),
+                                       self.coef.data_ptr(), None if redir is None else redir[0].coef.data_ptr())
         taps = self.k[0] * self.k[1] * self.k[2]
         macs = B * Do * Ho * Wo * self.Ci * self.Co * taps / ((4 if self.flat_deconv else 8) if self.transposed else 1)
         nbytes = 4 * B * (D * H * W * self.Ci + Do * Ho * Wo * self.Co * (1 + (residual is not None) + (redir is not None)))
@@ -413,7 +417,6 @@ class PackedConv3d:
                          flops=2 * macs, nbytes=nbytes):
             tail = (self.out_scale, rng, st) if self.precision == "f16x3" else (st,)
             sfx = self.precision
-            ext = _ext.load()
             if ext is not None and redir is not None:
                 assert not h16, "the f16 mode has no fused redir branch (run the 1x1x1 layer and pass it as residual)"
                 rl, rt = redir

@@ -270,14 +270,11 @@ def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_ch
     _, Gs, _, H, W = gwc_feat.shape
     C = Gs - gwc_off if gwc_channels is None else gwc_channels
     img = H * W * Gs * 4
-    lg, rg = gwc_feat.data_ptr() + 4 * gwc_off, gwc_feat.data_ptr() + 4 * gwc_off + B * img
-    lc = rc = None
     Cc = cs = 0
     if cat_feat is not None:
         assert is_cl(cat_feat) and cat_feat.shape[0] == 2 * B and tuple(cat_feat.shape[3:]) == (H, W)
         cs = cat_feat.shape[1]
         Cc = cs if cat_channels is None else cat_channels
-        lc, rc = cat_feat.data_ptr(), cat_feat.data_ptr() + B * H * W * cs * 4
     nch = num_groups + 2 * Cc
     VC = (nch + 3) // 4 * 4
     gm = getattr(gwc_feat, "_osa_meta", None) if C > 0 else None
@@ -293,6 +290,11 @@ def build_cost_volume_from_cl(gwc_feat, num_groups, cat_feat, B, maxdisp, gwc_ch
         if split:
             out._osa_split = True
         return out
+    # ctypes path: raw addresses
+    lg, rg = gwc_feat.data_ptr() + 4 * gwc_off, gwc_feat.data_ptr() + 4 * gwc_off + B * img
+    lc = rc = None
+    if cat_feat is not None:
+        lc, rc = cat_feat.data_ptr(), cat_feat.data_ptr() + B * H * W * cs * 4
     out = empty_cl(B, VC, maxdisp, H, W, gwc_feat.device)
     if VC != nch:
         out.zero_()
