@@ -475,6 +475,92 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
                   ws.data_ptr(), need, _stream())
 
 
+
+# ----------------------------------------------------------------------------- deferred, batched weight gradients (r6)
+# A weight that is applied several times in one step -- the update block's convolutions: 22 GRU iterations -- used to get 22 weight-gradient
+# launches of one small map each (14720 pixels at 320x736: ~100 workgroups, most of the launch is staging latency) plus 21 accumulation adds.
+# Now every differentiable use is counted in forward; the backward calls queue their (x, dy) pairs and return no weight gradient until the
+# LAST pending use arrives, which runs ONE weight-gradient launch over the batch of all queued pairs and returns the total -- the same
+# sum, delivered through autograd as before (one AccumulateGrad, so DistributedDataParallel sees the parameter ready once).  The state lives
+# in the weight's pack memo (it dies with the content stamp: an optimizer step starts from zero).  Safety net: a use whose backward never
+# runs (a differentiable forward that is not back-propagated) would leave the count short; an engine callback at the end of every backward
+# pass therefore delivers whatever is still queued straight into `.grad`.
+DEFER_WGRAD = os.environ.get("OSA_DEFER_WGRAD", "1") != "0"
+_defer_live = []           # states with queued pairs in the running backward pass
+_defer_cb = threading.local()
+
+
+def _defer_note_use(cache, need, w, w2, flat, co1):
+    if cache is None or not DEFER_WGRAD or not need:
+        return
+    st = cache.memo.get("defer")
+    if st is None:
+        import weakref
+        st = cache.memo["defer"] = {"uses": 0, "done": 0, "pend": {}, "w": weakref.ref(w), "w2": None if w2 is None else weakref.ref(w2), "flat": flat, "co1": co1}
+    st["uses"] += 1
+
+
+def _defer_run(pend):
+    """pend: {key: (run, [items])} -- one launch per group of equally shaped uses (a weight applied at two resolutions, or through two
+    Functions, has one group per form); the groups' results are summed in insertion order."""
+    dw = None
+    for run, items in pend.values():
+        g = run(items)
+        dw = g if dw is None else dw + g
+    return dw
+
+
+def _defer_final_flush():
+    _defer_cb.armed = False
+    for st in list(_defer_live):
+        pend = st["pend"]
+        st.update(uses=0, done=0, pend={})
+        if not pend:
+            continue
+        dw = _defer_run(pend)                                  # uses of this weight that were not part of the finished backward pass stay uncounted
+        if st["flat"]:
+            dw = dw[:, :, 0]
+        parts = [(st["w"](), dw if st["co1"] is None else dw[:st["co1"]])]
+        if st["w2"] is not None:
+            parts.append((st["w2"](), dw[st["co1"]:]))
+        for prm, g in parts:
+            if prm is not None and prm.requires_grad:
+                g = g.to(prm.dtype)
+                prm.grad = g.clone() if prm.grad is None else prm.grad + g
+    _defer_live.clear()
+
+
+def _defer_wgrad(cache, key, item, run):
+    """item: one (x, dy, ...) pair of a backward call; key: everything run() takes from its closure (shapes, arithmetic mode, strides);
+    run(items) -> dw over all items of one key.  Returns the weight gradient of every queued use when this is the last one the forward
+    counted, None before that (autograd reads None as zero)."""
+    st = None if cache is None else cache.memo.get("defer")
+    if st is None or st["uses"] <= 1:
+        if st is not None:
+            st.update(uses=0, done=0, pend={})
+        return run([item])
+    st["pend"].setdefault(key, (run, []))[1].append(item)
+    st["done"] += 1
+    if st["done"] < st["uses"]:
+        if st not in _defer_live:
+            _defer_live.append(st)
+        if not getattr(_defer_cb, "armed", False):
+            _defer_cb.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(_defer_final_flush)
+        return None
+    pend = st["pend"]
+    st.update(uses=0, done=0, pend={})
+    if st in _defer_live:
+        _defer_live.remove(st)
+    return _defer_run(pend)
+
+
+def _cat_batch(ts, C=None):
+    """the batch concatenation of equally shaped NDHWC tensors (logical channels [0, C) only when their rows are wider): one copy"""
+    if len(ts) == 1 and C is None:
+        return ts[0]
+    return torch.cat([t.permute(0, 2, 3, 4, 1) if C is None else t.permute(0, 2, 3, 4, 1)[..., :C] for t in ts], 0).permute(0, 4, 1, 2, 3)
+
 class _Conv3d(torch.autograd.Function):
     """y = conv3d(x, w) (no bias).  x: logical [B,Ci,D,H,W] (any strides); y: NDHWC-strided [B,Co,...]."""
 
@@ -506,6 +592,7 @@ class _Conv3d(torch.autograd.Function):
         ctx.xmeta = xmeta
         ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
         ctx.cache = cache
+        _defer_note_use(cache, ctx.needs_input_grad[1] or (w2 is not None and ctx.needs_input_grad[7]), w, w2, flat, ctx.co1)
         # The result is a channel slice (and, flat, a squeeze) of the internal NDHWC allocation.  Returned as a view, autograd refuses
         # in-place operations on it ("view created inside a custom Function") -- and the reference's modules put nn.ReLU(inplace=True)
         # right behind biased convolutions (update.py:19-26); the bias add used to give them a fresh tensor.  So: a tensor object over the
@@ -537,9 +624,19 @@ class _Conv3d(torch.autograd.Function):
                 dxc = _run_deconv(dyc, packed, osc, Co, Ci, 3, 1, 1, precision)
             dx = (dxc[:, :Ci, 0] if ctx.flat else dxc[:, :Ci]).to(xdt)
         if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[7]):
-            dw = torch.empty_like(wf)
             Do, Ho, Wo = dyc.shape[2:]
-            _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, ctx.xmeta, dymeta)
+
+            def run(items):                                        # one weight-gradient launch over every queued (x, dy) pair of this weight
+                from .ranges import combine_meta
+                xs, dys = _cat_batch([it[0] for it in items]), _cat_batch([it[1] for it in items])
+                xm = dm = None
+                if precision == "f16x3":
+                    xm = combine_meta(*[it[2] if it[2] is not None else input_meta(it[0]) for it in items])
+                    dm = combine_meta(*[it[3] for it in items])
+                g = torch.empty_like(wf)
+                _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, xm, dm)
+                return g
+            dw = _defer_wgrad(ctx.cache, ("f32io", precision, tuple(xc.shape[1:]), tuple(dyc.shape[1:]), stride, pad, dil), (xc, dyc, ctx.xmeta, dymeta), run)
         db = None
         if ctx.bias_dt is not None and ctx.needs_input_grad[8]:
             db = dyc[:, :Co].sum((0, 2, 3, 4)).to(ctx.bias_dt)
@@ -607,6 +704,7 @@ class _Conv3dF16IO(torch.autograd.Function):
             ctx.save_for_backward(xc, wf)
             ctx.meta = (pad, dil, xcs, x.dtype)
             ctx.cache = cache
+            _defer_note_use(cache, ctx.needs_input_grad[1] or (w2 is not None and ctx.needs_input_grad[5]), w, w2, flat, ctx.co1)
             return _alias(y[:, :Co, 0] if flat else y[:, :Co])
 
     @staticmethod
@@ -634,10 +732,19 @@ class _Conv3dF16IO(torch.autograd.Function):
                 _launch_f16(dyc, dycs, packed, dxc, Ci, [B, *dyc.shape[2:], cin], Ci, k, p2, dil, fin | OUT_F16, None)
                 dx = (dxc[:, :, 0] if ctx.flat else dxc).to(xdt)
             if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[5]):
-                dw = torch.empty_like(wf)
                 Do, Ho, Wo = dyc.shape[2:]
-                _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xcs, dycs=dycs)
-                if ctx.flat:
+
+                def run(items):                                    # one weight-gradient launch over every queued (x, dy) pair of this weight
+                    if len(items) == 1:
+                        xs, dys, xs_cs, dys_cs = items[0][0], items[0][1], xcs, dycs
+                    else:                                          # (rows wider than the logical channels are dropped by the concatenation)
+                        xs, dys = _cat_batch([it[0] for it in items], Ci), _cat_batch([it[1] for it in items], Co if fin else None)
+                        xs_cs, dys_cs = xs.shape[1], dys.shape[1]
+                    g = torch.empty_like(wf)
+                    _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xs_cs, dycs=dys_cs)
+                    return g
+                dw = _defer_wgrad(ctx.cache, ("f16io", tuple(xc.shape[1:]), tuple(dyc.shape[1:]), xcs, dycs, pad, dil, fin), (xc, dyc), run)
+                if dw is not None and ctx.flat:
                     dw = dw[:, :, 0]
             db = None
             if ctx.bias_dt is not None and ctx.needs_input_grad[6]:
