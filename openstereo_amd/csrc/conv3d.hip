@@ -232,6 +232,7 @@ int launch_conv_march(ConvArgs& a, hipStream_t st, const char* what);
 // d-marching form of the 3x3x3 stride-2 64-output-channel layers (f16x3, split tensors): conv_march.hip / conv_march_s2.h.  Switch: bit 29 of
 // osa_conv_b_ring_mask (A/B runs and the parity test against the brick form)
 int launch_conv_march_s2(ConvArgs& a, hipStream_t st, const char* what);
+void wgrad_set_multi_tile(int on);   // bit 27 of the mask: the multi-tile form of the f16x3 / f16 weight gradient (csrc/wgrad.hip wgrad_mt_kernel); 0 = single-tile kernel
 void march_s2_set_waves(int w);     // bit 28 of the mask: the 4-wave 2 x 32 column (two workgroups per CU) instead of the 8-wave 4 x 32 column (one per CU)
 
 // Which tile configurations take their B operands through the LDS ring (osa_conv_b_ring_mask; bit i = conv_cfgs.def entry i, bit 30 = the
@@ -242,7 +243,7 @@ void march_s2_set_waves(int w);     // bit 28 of the mask: the 4-wave 2 x 32 col
 // 14 / 15 (3-6 MFMAs per step: one barrier + one transfer per 96-192 matrix cycles costs more than the stream, conv3 -36 %), the 32-channel
 // tiles 0 / 7 / 12 (first 32 -> 32: -11 %), 9 (2 x 2 waves share a fragment only pairwise: 128 -> 128 @1/4 -3 ... +1 %), 11 (no sharing at
 // all), the fused transposed convs (+-1 %).
-static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13) | (1 << 29);
+static int g_b_ring_mask = (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 13) | (1 << 29) | (1 << 27);
 // (measured and not kept: tile 9 on the ring for long K loops only, >= 16 input chunks -- the GRU gate convs 384 -> 128 / 256 @1/4 gain 0 ... +5 % as
 // single layers, and the IGEV x 32 loop LOSES 1.3 % with it, StereoBase 0.4 %: profiles/round4/b_ring_tile9_long_k.txt)
 static long long g_b_ring_launches = 0;
@@ -1195,5 +1196,5 @@ extern "C" int osa_debug_trace_read(unsigned long long* dst, size_t n_words) {
 }
 #endif
 
-extern "C" int osa_conv_b_ring_mask(int mask) { const int prev = osa::g_b_ring_mask; osa::g_b_ring_mask = mask; osa::march_s2_set_waves(((mask >> 28) & 1) ? 4 : 8); return prev; }
+extern "C" int osa_conv_b_ring_mask(int mask) { const int prev = osa::g_b_ring_mask; osa::g_b_ring_mask = mask; osa::march_s2_set_waves(((mask >> 28) & 1) ? 4 : 8); osa::wgrad_set_multi_tile((mask >> 27) & 1); return prev; }
 extern "C" long long osa_conv_b_ring_launches(void) { return osa::g_b_ring_launches; }

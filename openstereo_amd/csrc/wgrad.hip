@@ -470,6 +470,236 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         }
 }
 
+// ---- multi-tile form of the f16x3 / f16 kernel (r6) ----------------------------------------------------------------------------------
+// The kernel above gives a workgroup ONE 32x32 (a, b) tile and splits the brick's positions over its four waves: a 384 -> 256 layer
+// runs 96 tile columns, each of which re-reads all positions of dy and x (4 GB through L2 for the batched 22-iteration gradient of the
+// update block, against 0.25 GB of tensors), and every workgroup hands over after one row of bricks (a 36 KB record per ~12 bricks).
+// Here a workgroup owns NA x NB tiles (128 x 64 channels at 4 x 2), one WAVE per tile, every wave multiplying all 128 positions of the
+// brick (8 K blocks x 9 taps = 72 MFMAs per wave and brick), the P tile [128 pos][NA * 32] and the Q brick [.][NB * 32] staged once for
+// all of them: 2.7x fewer bytes per MAC at 4 x 2, no cross-wave reduction (a wave stores its own record), and a workgroup walks a
+// contiguous range of bricks over (batch, d, h, w) -- `strip` bricks, chosen so that the launch is ~2 workgroups per CU -- before it
+// hands over.  Same LDS images, operand reads, records and reduce kernel as above.  Unit-stride layers only (class mode keeps the
+// single-tile kernel).
+template <int TD, int TH, int TW, int SPLIT, int PF16, int QF16, int NA, int NB>
+__global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs p) {
+    static_assert(!SPLIT || (!PF16 && !QF16), "fp16 tensors exist in the native f16 form only");
+    static_assert(TD * TH * TW == 128 && (TW == 8 || TW == 16), "128-position bricks");
+    static_assert(8 % NB == 0, "P items per thread");
+    constexpr int NT = 64 * NA * NB;
+    constexpr int ROWH = (TW == 8) ? 16 : 24;
+    constexpr int LHM = TH + 2;
+    constexpr int CHS_P = 136;
+    constexpr int CHS_Q = TD * LHM * ROWH + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* const Ph = smem_h;                              // [NA * 32][CHS_P]
+    unsigned short* const Pl = Ph + NA * 32 * CHS_P;
+    unsigned short* const Qh = SPLIT ? Pl + NA * 32 * CHS_P : Pl;   // [NB * 32][CHS_Q]
+    unsigned short* const Ql = Qh + NB * 32 * CHS_Q;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave % NA, wb = wave / NA;
+    const int col = lane & 31, hh = lane >> 5;
+    const unsigned bx = blockIdx.x;
+    const int tg = bx % p.tgroups;
+    const int sidx = bx / p.tgroups;
+    const int atiles = (p.A + 31) / 32, btiles = (p.Bc + 31) / 32;
+    const int nablk = (atiles + NA - 1) / NA;
+    const int ablk = blockIdx.y % nablk, bblk = blockIdx.y / nablk;
+    const int a0 = ablk * NA * 32, b0 = bblk * NB * 32;
+    const int od = p.g_od[tg];
+    const float sP = p.Pmeta ? wg_pow2_scale(amax_read(p.Pmeta)) : 1.f, sQ = p.Qmeta ? wg_pow2_scale(amax_read(p.Qmeta)) : 1.f;
+    const float inv = (1.0f / sP) * (1.0f / sQ);
+    const int nbricks = p.B * p.tilesD * p.tilesH * p.tilesW;
+    const int bi0 = sidx * p.strip, bi1 = (bi0 + p.strip < nbricks) ? bi0 + p.strip : nbricks;
+
+    f32x16 acc[WG_TAPS];
+#pragma unroll
+    for (int t = 0; t < WG_TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int npq = (p.LW + 1) >> 1;                 // voxel pairs per Q row
+    const int nRP = TD * p.LH * npq;                 // (row, pair) items of the Q brick per channel quad
+    // staging items: a wave's 64 consecutive items are 8 (position pairs | row pairs) x 8 channel quads of ONE 32-channel group, as in the
+    // single-tile kernel (its LDS write pattern: 32-bit writes of 8 consecutive pairs, channel rows on distinct 16-byte slots)
+    constexpr int PIT = 8 / NB, QIT = (NB * TD * LHM * ((TW + 3) / 2) * 8 + NT - 1) / NT;
+    int p_src[PIT], p_dst[PIT], q_src[QIT], q_dst[QIT];
+    unsigned q_ok[QIT];
+    int p_d[PIT], p_h[PIT], p_w[PIT], q_d[QIT], q_h[QIT], q_w[QIT];
+#pragma unroll
+    for (int k = 0; k < PIT; ++k) {
+        const int it = tid + NT * k;
+        const int c4 = it & 7, pair = (it >> 3) & 63, cg = it >> 9;
+        const int q0 = pair * 2, ch = cg * 32 + c4 * 4;
+        p_w[k] = q0 % TW; p_h[k] = (q0 / TW) % TH; p_d[k] = q0 / (TW * TH);
+        p_src[k] = ch; p_dst[k] = ch * CHS_P + q0;
+    }
+#pragma unroll
+    for (int k = 0; k < QIT; ++k) {
+        const int it = tid + NT * k;
+        const int c4 = it & 7; int r = it >> 3;
+        const int rp = r % nRP, cg = r / nRP;
+        const int pr = rp % npq; r = rp / npq;
+        const int ch = cg * 32 + c4 * 4;
+        q_h[k] = r % p.LH; q_d[k] = r / p.LH; q_w[k] = pr * 2;
+        q_src[k] = ch; q_dst[k] = ch * CHS_Q + (q_d[k] * LHM + q_h[k]) * ROWH + q_w[k];
+        q_ok[k] = (cg < NB) ? 1u : 0u;
+    }
+    float4 pv[PIT][2], qv[QIT][2];
+    auto load4f = [&](const float* src, int nc, bool ok) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
+            else { if (nc > 0) v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
+        }
+        return v;
+    };
+    auto load4h = [&](const _Float16* src, int nc, bool ok) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            if (nc >= 4) {
+                const uint2 u = *reinterpret_cast<const uint2*>(src);
+                const wf16x2 a = __builtin_bit_cast(wf16x2, u.x), c = __builtin_bit_cast(wf16x2, u.y);
+                v = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);
+            } else { if (nc > 0) v.x = (float)src[0]; if (nc > 1) v.y = (float)src[1]; if (nc > 2) v.z = (float)src[2]; }
+        }
+        return v;
+    };
+    auto issue_loads = [&](int bi) {
+        const int twi = bi % p.tilesW; int t = bi / p.tilesW;
+        const int thi = t % p.tilesH; t /= p.tilesH;
+        const int tdi = t % p.tilesD; const int b = t / p.tilesD;
+        const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int gd = p0d + p_d[k], gh = p0h + p_h[k], gw = p0w + p_w[k];
+            const bool row = gd < p.Pd && gh < p.Ph;
+            const size_t off = ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
+            const int nc = p.PC - (a0 + p_src[k]);
+            if constexpr (PF16) {
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.P) + off;
+                pv[k][0] = load4h(src, nc, row && gw < p.Pw);
+                pv[k][1] = load4h(src + p.PCs, nc, row && gw + 1 < p.Pw);
+            } else {
+                const float* src = p.P + off;
+                pv[k][0] = load4f(src, nc, row && gw < p.Pw);
+                pv[k][1] = load4f(src + p.PCs, nc, row && gw + 1 < p.Pw);
+            }
+        }
+        const int q0d = p0d + od, q0h = p0h + p.hmin, q0w = p0w + p.wmin;
+#pragma unroll
+        for (int k = 0; k < QIT; ++k) {
+            const int gd = q0d + q_d[k], gh = q0h + q_h[k], gw = q0w + q_w[k];
+            const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
+            const size_t off = ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
+            const int nc = p.QC - (b0 + q_src[k]);
+            if constexpr (QF16) {
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.Q) + off;
+                qv[k][0] = load4h(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
+                qv[k][1] = load4h(src + p.QCs, nc, row && (unsigned)(gw + 1) < (unsigned)p.Qw);
+            } else {
+                const float* src = p.Q + off;
+                qv[k][0] = load4f(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
+                qv[k][1] = load4f(src + p.QCs, nc, row && (unsigned)(gw + 1) < (unsigned)p.Qw);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const float x0[4] = {pv[k][0].x, pv[k][0].y, pv[k][0].z, pv[k][0].w}, x1[4] = {pv[k][1].x, pv[k][1].y, pv[k][1].z, pv[k][1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (SPLIT) {
+                    unsigned h, l;
+                    wg_split2(x0[j] * sP, x1[j] * sP, h, l);
+                    *reinterpret_cast<unsigned*>(Ph + p_dst[k] + j * CHS_P) = h;
+                    *reinterpret_cast<unsigned*>(Pl + p_dst[k] + j * CHS_P) = l;
+                } else *reinterpret_cast<unsigned*>(Ph + p_dst[k] + j * CHS_P) = wg_round2(x0[j] * sP, x1[j] * sP);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QIT; ++k) {
+            if (q_ok[k]) {
+                const float x0[4] = {qv[k][0].x, qv[k][0].y, qv[k][0].z, qv[k][0].w}, x1[4] = {qv[k][1].x, qv[k][1].y, qv[k][1].z, qv[k][1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SPLIT) {
+                        unsigned h, l;
+                        wg_split2(x0[j] * sQ, x1[j] * sQ, h, l);
+                        *reinterpret_cast<unsigned*>(Qh + q_dst[k] + j * CHS_Q) = h;
+                        *reinterpret_cast<unsigned*>(Ql + q_dst[k] + j * CHS_Q) = l;
+                    } else *reinterpret_cast<unsigned*>(Qh + q_dst[k] + j * CHS_Q) = wg_round2(x0[j] * sQ, x1[j] * sQ);
+                }
+            }
+        }
+    };
+    if (bi0 < bi1) issue_loads(bi0);
+    const unsigned short* const Pa_h = Ph + (wa * 32 + col) * CHS_P;
+    const unsigned short* const Pa_l = Pl + (wa * 32 + col) * CHS_P;
+    const int qcol = (wb * 32 + col) * CHS_Q;
+    for (int bi = bi0; bi < bi1; ++bi) {
+        __syncthreads();                             // the previous brick's fragment reads are done
+        commit();
+        __syncthreads();
+        if (bi + 1 < bi1) issue_loads(bi + 1);       // in flight during the MFMA phase below
+#pragma unroll 2
+        for (int kb = 0; kb < 8; ++kb) {             // K block = 16 positions; this lane's half-block hb = 8 consecutive w positions of one row
+            const int hb = kb * 2 + hh;
+            const uint4 ah = *reinterpret_cast<const uint4*>(Pa_h + hb * 8);
+            uint4 al = ah;
+            if constexpr (SPLIT) al = *reinterpret_cast<const uint4*>(Pa_l + hb * 8);
+            const wf16x8 pa_h = __builtin_bit_cast(wf16x8, ah), pa_l = __builtin_bit_cast(wf16x8, al);
+            const int prow = (TW == 8) ? hb : (hb >> 1);
+            const int pd = prow / TH, ph = prow % TH;
+            const int qoff = qcol + (pd * LHM + ph) * ROWH + ((TW == 16) ? (hb & 1) * 8 : 0);
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                if (p.g_slot[tg][dh * 3] >= 0 || p.g_slot[tg][dh * 3 + 1] >= 0 || p.g_slot[tg][dh * 3 + 2] >= 0) {
+                    const unsigned short* qh = Qh + qoff + dh * ROWH;
+                    const unsigned short* ql = Ql + qoff + dh * ROWH;
+                    const uint4 vh = *reinterpret_cast<const uint4*>(qh), vl = SPLIT ? *reinterpret_cast<const uint4*>(ql) : vh;
+                    const unsigned eh = *reinterpret_cast<const unsigned*>(qh + 8), el = SPLIT ? *reinterpret_cast<const unsigned*>(ql + 8) : eh;
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        if (p.g_slot[tg][dh * 3 + dw] >= 0) {
+                            uint4 bh, bl;
+                            if (dw == 0) { bh = vh; bl = vl; }
+                            else if (dw == 1) {
+                                bh = make_uint4(__builtin_amdgcn_alignbit(vh.y, vh.x, 16), __builtin_amdgcn_alignbit(vh.z, vh.y, 16),
+                                                __builtin_amdgcn_alignbit(vh.w, vh.z, 16), __builtin_amdgcn_alignbit(eh, vh.w, 16));
+                                bl = make_uint4(__builtin_amdgcn_alignbit(vl.y, vl.x, 16), __builtin_amdgcn_alignbit(vl.z, vl.y, 16),
+                                                __builtin_amdgcn_alignbit(vl.w, vl.z, 16), __builtin_amdgcn_alignbit(el, vl.w, 16));
+                            } else { bh = make_uint4(vh.y, vh.z, vh.w, eh); bl = make_uint4(vl.y, vl.z, vl.w, el); }
+                            const wf16x8 qb_h = __builtin_bit_cast(wf16x8, bh), qb_l = __builtin_bit_cast(wf16x8, bl);
+                            f32x16& c = acc[dh * 3 + dw];
+                            if constexpr (SPLIT) {
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_l, c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_l, qb_h, c, 0, 0, 0);
+                            }
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, qb_h, c, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- this wave's tile record, slot dh * 3 + dw -> tap j of the group
+    const int a_tile = ablk * NA + wa, b_tile = bblk * NB + wb;
+    if (a_tile < atiles && b_tile < btiles) {
+        float* dst = p.ws + ((size_t)(b_tile * atiles + a_tile) * gridDim.x + bx) * (WG_TAPS * 1024) + lane;
+#pragma unroll
+        for (int t = 0; t < WG_TAPS; ++t) {
+            const int j = p.g_slot[tg][t];
+            if (j >= 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(j * 16 + r) * 64] = acc[t][r] * inv;
+            }
+        }
+    }
+}
+
 // Second stage: dW[a][b][tap] = sum over the workgroups (position strips) of one (tile, tap group).  One thread per (tap, tile element).
 struct WgradReduceArgs {
     const float* ws; float* dW;
@@ -501,6 +731,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs
 }  // namespace osa
 
 using namespace osa;
+
+// multi-tile form of the f16x3 / f16 weight gradient (wgrad_mt_kernel); osa_conv_b_ring_mask bit 27 switches it for A/B runs and tests
+static int g_wgrad_mt = 1;
+namespace osa { void wgrad_set_multi_tile(int on) { g_wgrad_mt = on ? 1 : 0; } }
 
 // conv:   P = dy [B,Do,Ho,Wo,Co]  Q = x  [B,Di,Hi,Wi,Ci]  dW [Co][Ci][k]   (transposed = 0)
 // deconv: P = x  [B,Di,Hi,Wi,Ci]  Q = dy [B,Do,Ho,Wo,Co]  dW [Ci][Co][k]   (transposed = 1, stride 2, off = t - pad)
@@ -631,6 +865,58 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         const size_t lds_ops = (size_t)(planes * 32 * 136 + planes * 32 * chs_q) * sizeof(unsigned short);
         const size_t lds = lds_ops > (size_t)3 * 16 * 64 * sizeof(float) ? lds_ops : (size_t)3 * 16 * 64 * sizeof(float);   // (the hand-over of the partial tiles reuses it: 3 waves x 16 x 64 floats)
         const int gy = cdiv(a.A, 32) * cdiv(a.Bc, 32);
+        if (!a.cls && g_wgrad_mt && cdiv(a.A, 32) * cdiv(a.Bc, 32) >= 4) {
+            // multi-tile form (wgrad_mt_kernel): NA x NB tiles per workgroup, a contiguous range of `strip` bricks per workgroup
+            const int atl = cdiv(a.A, 32), btl = cdiv(a.Bc, 32);
+            const int NA = (atl >= 3) ? 4 : 2, NB = 2;
+            const int gyb = cdiv(atl, NA) * cdiv(btl, NB);
+            const long long nbricks = (long long)B * a.tilesD * a.tilesH * a.tilesW;
+            OSA_REQUIRE(nbricks < (1ll << 30), "conv3d_wgrad_f16x3: too many position bricks");
+            // ~2 workgroups per CU over the whole launch, at least 4 bricks each (a hand-over is a 36 KB record per wave)
+            long long nstr = (2 * 256ll) / ((long long)gyb * a.tgroups);
+            if (nstr < 1) nstr = 1;
+            if (nstr > cdiv((int)nbricks, 4)) nstr = cdiv((int)nbricks, 4);
+            a.strip = exp_int("OSA_WGRAD_STRIP", (int)cdiv((int)nbricks, (int)nstr));
+            if (a.strip < 1) a.strip = 1;
+            nstr = cdiv((int)nbricks, a.strip);
+            const long long gx = nstr * a.tgroups;
+            const size_t need = (size_t)gx * gy * WG_TAPS * 1024 * sizeof(float);
+            if (query) { *query = need; return 0; }
+            OSA_REQUIRE(ws && ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad_f16x3: workspace of %zu B needed (got %zu)", need, ws_bytes);
+            if (f16x3 == 1) OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
+            a.ws = ws;
+            a.Pmeta = dy_meta; a.Qmeta = x_meta;              // (unit-stride conv: P = dy, Q = x)
+            a.Pf16 = dy_f16; a.Qf16 = x_f16;
+            const size_t lds_mt = (size_t)planes * (NA * 32 * 136 + NB * 32 * chs_q) * sizeof(unsigned short);
+            OSA_REQUIRE(lds_mt <= 160 * 1024, "conv3d_wgrad_f16x3: %zu B of LDS", lds_mt);
+            dim3 grid((unsigned)gx, gyb), block(64 * NA * NB);
+#define OSA_WG_MT_LAUNCH(...)                                                                                                         \
+            do { (void)hipFuncSetAttribute((const void*)wgrad_mt_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mt); \
+                 hipLaunchKernelGGL((wgrad_mt_kernel<__VA_ARGS__>), grid, block, lds_mt, st, a); } while (0)
+#define OSA_WG_MT_T(TD_, TH_, TW_, NA_)                                                                                               \
+            if (f16x3 == 1) OSA_WG_MT_LAUNCH(TD_, TH_, TW_, 1, 0, 0, NA_, 2);                                                          \
+            else switch (a.Pf16 * 2 + a.Qf16) {                                                                                       \
+                case 0: OSA_WG_MT_LAUNCH(TD_, TH_, TW_, 0, 0, 0, NA_, 2); break;                                                      \
+                case 1: OSA_WG_MT_LAUNCH(TD_, TH_, TW_, 0, 0, 1, NA_, 2); break;                                                      \
+                case 2: OSA_WG_MT_LAUNCH(TD_, TH_, TW_, 0, 1, 0, NA_, 2); break;                                                      \
+                default: OSA_WG_MT_LAUNCH(TD_, TH_, TW_, 0, 1, 1, NA_, 2); break;                                                     \
+            }
+            if (flat16) { if (NA == 4) { OSA_WG_MT_T(1, 8, 16, 4) } else { OSA_WG_MT_T(1, 8, 16, 2) } }
+            else        { if (NA == 4) { OSA_WG_MT_T(2, 8, 8, 4) } else { OSA_WG_MT_T(2, 8, 8, 2) } }
+#undef OSA_WG_MT_T
+#undef OSA_WG_MT_LAUNCH
+            OSA_LAUNCH_CHECK("conv3d_wgrad_mt");
+            WgradReduceArgs r;
+            memset(&r, 0, sizeof(r));
+            r.ws = ws; r.dW = dw; r.gx = (int)gx; r.tgroups = a.tgroups; r.nstrips = (int)nstr;
+            r.A = a.A; r.Bc = a.Bc; r.kvol = T; r.atiles = atl; r.T = T;
+            r.cls = 1;
+            for (int t2 = 0; t2 < T; ++t2) r.tapid[t2] = (signed char)t2;
+            memcpy(r.g_t0, a.g_t0, sizeof(r.g_t0)); memcpy(r.g_nt, a.g_nt, sizeof(r.g_nt));
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_TAPS * 1024 / 256, a.tgroups, gy), dim3(256), 0, st, r);
+            OSA_LAUNCH_CHECK("conv3d_wgrad_mt_reduce");
+            return 0;
+        }
         const long long rows = (long long)B * a.tilesD * a.tilesH * a.tgroups * gy;
         const long long slots = 256ll * 2;                    // (registers: 9 accumulator sets keep both forms at 2 workgroups per CU)
         long long best = -1; int best_strip = a.tilesW;
