@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define OSA_ABI_VERSION 6
+#define OSA_ABI_VERSION 7
 #define OSA_META_FLOATS 128   /* floats per range block (osa_f16x3_ranges) */
 
 enum { OSA_NCDHW = 0, OSA_NDHWC = 1 };
@@ -563,6 +563,19 @@ int osa_deconv3d_ndhwc_f16(const void* x, const float* w_packed, const float* sc
 int osa_deconv2d_nhwc_f16(const void* x, const float* w_packed, const float* scale, const float* shift, const void* residual, void* y,
                           int B, int Hi, int Wi, int Ci, int xCs, int Co, int yCs, int rCs, int k, int pad, int opad,
                           const float* gate_logits, int gCs, int act, float slope, void* stream);
+
+/* Per-channel sums over the P positions of a channels-last tensor (training path, r6): out[0..C) = sum_p dy[p][c] and, with x != NULL,
+ * out[C..2C) = sum_p dy[p][c] * (x[p][c] - x_shift[c]) (x_shift may be NULL = 0); with dx != NULL the same pass also writes
+ * dx[p][c] = dy[p][c] * dx_scale[c] in dy's element type.  One coalesced read, deterministic two-stage sum.  Replaces, on the
+ * reference's training path, the bias-gradient reductions autograd runs for every nn.Conv2d(bias=True) of the update block
+ * (stereo/modeling/models/igev/update.py:19-26,38-40; stereobase/gru_blocks.py:233-328) and the backward of BatchNorm layers in eval
+ * mode (FREEZE_BN: stereo/trainer/trainer_template.py:83-85 -- dbeta = out[0..C), dgamma = invstd * out[C..2C) with x_shift =
+ * running_mean, dx = dy * gamma * invstd).  dy / x: fp32 (f16 flag 0) or fp16 (1) elements, channel strides in elements, % 4 == 0, base
+ * pointers 16-byte (fp16: 8-byte) aligned; C <= 1024.  workspace: osa_channel_sums_workspace_bytes(P, C) bytes (0 = unsupported). */
+size_t osa_channel_sums_workspace_bytes(long long P, int C);
+int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const void* x, int x_f16, int x_cs, const float* x_shift,
+                     const float* dx_scale, void* dx, int dx_cs, long long P, int C,
+                     float* out, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- InstanceNorm2d (+ activation) on NHWC maps (r4, csrc/norm.hip) ----
  * The normalisation of the reference-written FPN decoders of the feature pyramids: Conv2xUp / BasicConv2d(norm_layer=nn.InstanceNorm2d)

@@ -21,7 +21,7 @@ import threading
 import torch
 
 from . import _lib, amp, engine, ops, timing
-from .ops import _f32c, _p, _stream, empty_cl, is_cl, to_cl
+from .ops import _f32c, _p, _stream, channel_sums, cl_rows, empty_cl, is_cl, to_cl
 from .ranges import input_meta, attach_meta
 
 
@@ -486,28 +486,31 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
 # runs (a differentiable forward that is not back-propagated) would leave the count short; an engine callback at the end of every backward
 # pass therefore delivers whatever is still queued straight into `.grad`.
 DEFER_WGRAD = os.environ.get("OSA_DEFER_WGRAD", "1") != "0"
+FROZEN_BN = os.environ.get("OSA_FROZEN_BN", "1") != "0"      # eval-mode BatchNorm modules inside engine_convs: backward as one osa_channel_sums pass
 _defer_live = []           # states with queued pairs in the running backward pass
 _defer_cb = threading.local()
 
 
-def _defer_note_use(cache, need, w, w2, flat, co1):
+def _defer_note_use(cache, need, w, w2, flat, co1, bias=None):
     if cache is None or not DEFER_WGRAD or not need:
         return
     st = cache.memo.get("defer")
     if st is None:
         import weakref
-        st = cache.memo["defer"] = {"uses": 0, "done": 0, "pend": {}, "w": weakref.ref(w), "w2": None if w2 is None else weakref.ref(w2), "flat": flat, "co1": co1}
+        st = cache.memo["defer"] = {"uses": 0, "done": 0, "pend": {}, "w": weakref.ref(w), "w2": None if w2 is None else weakref.ref(w2), "flat": flat, "co1": co1,
+                                    "b": None if bias is None else weakref.ref(bias)}
     st["uses"] += 1
 
 
 def _defer_run(pend):
     """pend: {key: (run, [items])} -- one launch per group of equally shaped uses (a weight applied at two resolutions, or through two
-    Functions, has one group per form); the groups' results are summed in insertion order."""
-    dw = None
+    Functions, has one group per form); the groups' results (dw, db) are summed in insertion order."""
+    dw = db = None
     for run, items in pend.values():
-        g = run(items)
-        dw = g if dw is None else dw + g
-    return dw
+        g, gb = run(items)
+        dw = g if dw is None or g is None else dw + g
+        db = gb if db is None or gb is None else db + gb
+    return dw, db
 
 
 def _defer_final_flush():
@@ -517,14 +520,18 @@ def _defer_final_flush():
         st.update(uses=0, done=0, pend={})
         if not pend:
             continue
-        dw = _defer_run(pend)                                  # uses of this weight that were not part of the finished backward pass stay uncounted
-        if st["flat"]:
-            dw = dw[:, :, 0]
-        parts = [(st["w"](), dw if st["co1"] is None else dw[:st["co1"]])]
-        if st["w2"] is not None:
-            parts.append((st["w2"](), dw[st["co1"]:]))
+        dw, db = _defer_run(pend)                              # uses of this weight that were not part of the finished backward pass stay uncounted
+        parts = []
+        if dw is not None:
+            if st["flat"]:
+                dw = dw[:, :, 0]
+            parts.append((st["w"](), dw if st["co1"] is None else dw[:st["co1"]]))
+            if st["w2"] is not None:
+                parts.append((st["w2"](), dw[st["co1"]:]))
+        if db is not None and st["b"] is not None:
+            parts.append((st["b"](), db))
         for prm, g in parts:
-            if prm is not None and prm.requires_grad:
+            if prm is not None and prm.requires_grad and prm.is_leaf:
                 g = g.to(prm.dtype)
                 prm.grad = g.clone() if prm.grad is None else prm.grad + g
     _defer_live.clear()
@@ -532,8 +539,8 @@ def _defer_final_flush():
 
 def _defer_wgrad(cache, key, item, run):
     """item: one (x, dy, ...) pair of a backward call; key: everything run() takes from its closure (shapes, arithmetic mode, strides);
-    run(items) -> dw over all items of one key.  Returns the weight gradient of every queued use when this is the last one the forward
-    counted, None before that (autograd reads None as zero)."""
+    run(items) -> (dw, db) over all items of one key (either may be None).  Returns the gradients of every queued use when this is the
+    last one the forward counted, (None, None) before that (autograd reads None as zero)."""
     st = None if cache is None else cache.memo.get("defer")
     if st is None or st["uses"] <= 1:
         if st is not None:
@@ -547,12 +554,20 @@ def _defer_wgrad(cache, key, item, run):
         if not getattr(_defer_cb, "armed", False):
             _defer_cb.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(_defer_final_flush)
-        return None
+        return None, None
     pend = st["pend"]
     st.update(uses=0, done=0, pend={})
     if st in _defer_live:
         _defer_live.remove(st)
     return _defer_run(pend)
+
+
+def _bias_grad(dyc, Co):
+    """sum of an NDHWC gradient over its positions, per channel (fp32): one coalesced pass of the engine's kernel where the layout allows"""
+    g = dyc[:, :Co]
+    if cl_rows(g) is not None:
+        return channel_sums(g)[0][0]
+    return g.sum((0, 2, 3, 4), dtype=torch.float32)
 
 
 def _cat_batch(ts, C=None):
@@ -592,7 +607,8 @@ class _Conv3d(torch.autograd.Function):
         ctx.xmeta = xmeta
         ctx.meta = (stride, pad, dil, precision, tuple(x.shape), x.dtype)
         ctx.cache = cache
-        _defer_note_use(cache, ctx.needs_input_grad[1] or (w2 is not None and ctx.needs_input_grad[7]), w, w2, flat, ctx.co1)
+        _defer_note_use(cache, ctx.needs_input_grad[1] or (w2 is not None and ctx.needs_input_grad[7]) or (bias is not None and ctx.needs_input_grad[8]),
+                        w, w2, flat, ctx.co1, bias)
         # The result is a channel slice (and, flat, a squeeze) of the internal NDHWC allocation.  Returned as a view, autograd refuses
         # in-place operations on it ("view created inside a custom Function") -- and the reference's modules put nn.ReLU(inplace=True)
         # right behind biased convolutions (update.py:19-26); the bias add used to give them a fresh tensor.  So: a tensor object over the
@@ -623,23 +639,29 @@ class _Conv3d(torch.autograd.Function):
                 packed, osc = _pack(wf, Co, Ci, k, "deconv", precision, ctx.cache)       # w [Co][Ci][k] == transposed-conv layout [Cin_t][Cout_t]
                 dxc = _run_deconv(dyc, packed, osc, Co, Ci, 3, 1, 1, precision)
             dx = (dxc[:, :Ci, 0] if ctx.flat else dxc[:, :Ci]).to(xdt)
-        if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[7]):
+        need_w = ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[7])
+        need_b = ctx.bias_dt is not None and ctx.needs_input_grad[8]
+        db = None
+        if need_w or need_b:
             Do, Ho, Wo = dyc.shape[2:]
 
-            def run(items):                                        # one weight-gradient launch over every queued (x, dy) pair of this weight
+            def run(items):                                        # one weight-gradient launch (and one bias-gradient sum) over every queued (x, dy) pair of this weight
                 from .ranges import combine_meta
-                xs, dys = _cat_batch([it[0] for it in items]), _cat_batch([it[1] for it in items])
-                xm = dm = None
-                if precision == "f16x3":
-                    xm = combine_meta(*[it[2] if it[2] is not None else input_meta(it[0]) for it in items])
-                    dm = combine_meta(*[it[3] for it in items])
-                g = torch.empty_like(wf)
-                _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, xm, dm)
-                return g
-            dw = _defer_wgrad(ctx.cache, ("f32io", precision, tuple(xc.shape[1:]), tuple(dyc.shape[1:]), stride, pad, dil), (xc, dyc, ctx.xmeta, dymeta), run)
-        db = None
-        if ctx.bias_dt is not None and ctx.needs_input_grad[8]:
-            db = dyc[:, :Co].sum((0, 2, 3, 4)).to(ctx.bias_dt)
+                dys = _cat_batch([it[1] for it in items])
+                g = None
+                if need_w:
+                    xs = _cat_batch([it[0] for it in items])
+                    xm = dm = None
+                    if precision == "f16x3":
+                        xm = combine_meta(*[it[2] if it[2] is not None else input_meta(it[0]) for it in items])
+                        dm = combine_meta(*[it[3] for it in items])
+                    g = torch.empty_like(wf)
+                    _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, xm, dm)
+                return g, (_bias_grad(dys, Co) if need_b else None)
+            dw, db = _defer_wgrad(ctx.cache, ("f32io", precision, tuple(xc.shape[1:]), tuple(dyc.shape[1:]), stride, pad, dil, need_w, need_b),
+                                  (xc, dyc, ctx.xmeta, dymeta), run)
+            if db is not None:
+                db = db.to(ctx.bias_dt)
         if dw is not None and ctx.flat:
             dw = dw[:, :, 0]
         if ctx.co1 is not None:
@@ -704,7 +726,8 @@ class _Conv3dF16IO(torch.autograd.Function):
             ctx.save_for_backward(xc, wf)
             ctx.meta = (pad, dil, xcs, x.dtype)
             ctx.cache = cache
-            _defer_note_use(cache, ctx.needs_input_grad[1] or (w2 is not None and ctx.needs_input_grad[5]), w, w2, flat, ctx.co1)
+            _defer_note_use(cache, ctx.needs_input_grad[1] or (w2 is not None and ctx.needs_input_grad[5]) or (bias is not None and ctx.needs_input_grad[6]),
+                            w, w2, flat, ctx.co1, bias)
             return _alias(y[:, :Co, 0] if flat else y[:, :Co])
 
     @staticmethod
@@ -731,24 +754,28 @@ class _Conv3dF16IO(torch.autograd.Function):
                 cin = Co if fin else (Co + 3) // 4 * 4                                  # (fp32 dy from to_cl: zero-padded to a channel quad)
                 _launch_f16(dyc, dycs, packed, dxc, Ci, [B, *dyc.shape[2:], cin], Ci, k, p2, dil, fin | OUT_F16, None)
                 dx = (dxc[:, :, 0] if ctx.flat else dxc).to(xdt)
-            if ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[5]):
+            need_w = ctx.needs_input_grad[1] or (ctx.co1 is not None and ctx.needs_input_grad[5])
+            need_b = ctx.bias_dt is not None and ctx.needs_input_grad[6]
+            db = None
+            if need_w or need_b:
                 Do, Ho, Wo = dyc.shape[2:]
 
-                def run(items):                                    # one weight-gradient launch over every queued (x, dy) pair of this weight
+                def run(items):                                    # one weight-gradient launch (and one bias-gradient sum) over every queued (x, dy) pair of this weight
                     if len(items) == 1:
                         xs, dys, xs_cs, dys_cs = items[0][0], items[0][1], xcs, dycs
                     else:                                          # (rows wider than the logical channels are dropped by the concatenation)
                         xs, dys = _cat_batch([it[0] for it in items], Ci), _cat_batch([it[1] for it in items], Co if fin else None)
                         xs_cs, dys_cs = xs.shape[1], dys.shape[1]
-                    g = torch.empty_like(wf)
-                    _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xs_cs, dycs=dys_cs)
-                    return g
-                dw = _defer_wgrad(ctx.cache, ("f16io", tuple(xc.shape[1:]), tuple(dyc.shape[1:]), xcs, dycs, pad, dil, fin), (xc, dyc), run)
+                    g = None
+                    if need_w:
+                        g = torch.empty_like(wf)
+                        _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xs_cs, dycs=dys_cs)
+                    return g, (_bias_grad(dys, Co) if need_b else None)
+                dw, db = _defer_wgrad(ctx.cache, ("f16io", tuple(xc.shape[1:]), tuple(dyc.shape[1:]), xcs, dycs, pad, dil, fin, need_w, need_b), (xc, dyc), run)
                 if dw is not None and ctx.flat:
                     dw = dw[:, :, 0]
-            db = None
-            if ctx.bias_dt is not None and ctx.needs_input_grad[6]:
-                db = dyc[:, :Co].sum((0, 2, 3, 4), dtype=torch.float32).to(ctx.bias_dt)
+                if db is not None:
+                    db = db.to(ctx.bias_dt)
             if ctx.co1 is not None:
                 return dx, (None if dw is None else dw[:ctx.co1]), None, None, None, (None if dw is None else dw[ctx.co1:]), db, None, None
             return dx, dw, None, None, None, None, db, None, None
@@ -1012,7 +1039,7 @@ class _GruGatesRZ(torch.autograd.Function):
             _lib.call("osa_gru_gates_rz_bwd", refs[0][1], _bias_ptr(bzf), _bias_ptr(brf), refs[1][1], refs[2][1], refs[3][1], refs[4][1], refs[5][1],
                       _nhwc_ref(dpre, C2)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
         pdt, czdt, crdt, hdt, bzdt, brdt = ctx.dt
-        db = dpre.sum((0, 2, 3)) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None       # one reduction for both biases
+        db = _bias_grad(dpre.unsqueeze(2), C2) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None       # one reduction for both biases
         return (dpre.to(pdt), None if bzdt is None or db is None else db[:C].to(bzdt), None if brdt is None or db is None else db[C:].to(brdt),
                 dpre[:, :C].to(czdt) if ctx.needs_input_grad[3] else None, dpre[:, C:].to(crdt) if ctx.needs_input_grad[4] else None,
                 dh.to(hdt) if ctx.needs_input_grad[5] else None, None)
@@ -1051,7 +1078,7 @@ class _GruGatesQ(torch.autograd.Function):
             _lib.call("osa_gru_gates_q_bwd", refs[0][1], refs[1][1], _bias_ptr(bqf), refs[2][1], refs[3][1], refs[4][1],
                       _nhwc_ref(dz, C)[1], _nhwc_ref(dq, C)[1], _nhwc_ref(dh, C)[1], B * H * W, C, _stream())
         zdt, qdt, cqdt, hdt, bqdt = ctx.dt
-        return (dz.to(zdt), dq.to(qdt), None if bqdt is None or not ctx.needs_input_grad[2] else dq.sum((0, 2, 3)).to(bqdt),
+        return (dz.to(zdt), dq.to(qdt), None if bqdt is None or not ctx.needs_input_grad[2] else _bias_grad(dq.unsqueeze(2), C).to(bqdt),
                 dq.to(cqdt) if ctx.needs_input_grad[3] else None, dh.to(hdt) if ctx.needs_input_grad[4] else None, None)
 
 
@@ -1124,6 +1151,50 @@ def _shape_eligible(m, x):
     return False
 
 
+
+# ----------------------------------------------------------------------------- BatchNorm in eval mode (FREEZE_BN training)
+class _FrozenBN(torch.autograd.Function):
+    """y = batch_norm(x) with the running statistics (a BatchNorm module in eval mode whose affine parameters still train: the reference's
+    FREEZE_BN, trainer_template.py:83-85).  Forward is torch's own inference kernel (bit-identical to the unpatched module); backward is ONE
+    pass of osa_channel_sums over (dy, x): dbeta = sum dy, dgamma = invstd * sum dy (x - mean), dx = dy * gamma * invstd -- torch runs a
+    channels-last reduce kernel plus two elementwise kernels for it (7 % of the StereoBase AMP step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean, var, eps):
+        y = torch.nn.functional.batch_norm(x, mean, var, weight, bias, False, 0.0, eps)
+        ctx.save_for_backward(x, weight, mean, var)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, var = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        if dy.dtype != x.dtype or cl_rows(dy) is None or cl_rows(x) is None or dy.shape != x.shape:
+            # other layouts (a contiguous NCHW gradient from a torch op): the same three formulas as torch ops
+            with torch.autocast("cuda", enabled=False):
+                bc = [1, -1] + [1] * (x.dim() - 2)
+                red = [0] + list(range(2, x.dim()))
+                invstd = torch.rsqrt(var.float() + ctx.eps)
+                g = dy.float()
+                dx = (g * (w.float() * invstd).view(bc)).to(dy.dtype) if need_x else None
+                dg = ((g * (x.float() - mean.float().view(bc))).sum(red) * invstd).to(w.dtype) if need_w else None
+                db = g.sum(red).to(w.dtype) if need_b else None
+            return dx, dg, db, None, None, None
+        with torch.autocast("cuda", enabled=False):
+            invstd = torch.rsqrt(var.float() + ctx.eps)
+            sums, dx = channel_sums(dy, x if need_w else None, mean if need_w else None, (w.float() * invstd) if need_x else None)
+            dg = (sums[1] * invstd).to(w.dtype) if need_w else None
+            db = sums[0].to(w.dtype) if need_b else None
+        return dx, dg, db, None, None, None
+
+
+def _frozen_bn_ok(m, x):
+    return (not m.training) and m.track_running_stats and m.affine and m.running_mean is not None and isinstance(x, torch.Tensor) and x.is_cuda \
+        and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad) and x.dim() in (4, 5) and cl_rows(x) is not None \
+        and m.weight.dtype == torch.float32 and m.running_mean.dtype == torch.float32
+
+
 class engine_convs:
     """Context manager: inside it every eligible nn.Conv3d / nn.ConvTranspose3d / nn.Conv2d forward -- and its backward -- runs on the
     engine's kernels through the autograd Functions above; BatchNorm, activations, depthwise / strided 2-D convolutions, pooling and
@@ -1149,8 +1220,16 @@ class engine_convs:
         with cls._lock:
             if cls._depth == 0:
                 nn = torch.nn
-                for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d):
+                BN = nn.modules.batchnorm._BatchNorm
+                for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d, BN):
                     cls._saved[C] = C.forward
+                obn = cls._saved[BN]
+
+                def fbn(m, x):
+                    if on() and FROZEN_BN and _frozen_bn_ok(m, x):
+                        return _FrozenBN.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+                    return obn(m, x)
+                BN.forward = fbn
                 o2, o3, ot, ot2 = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d], cls._saved[nn.ConvTranspose2d]
                 on = cls.active             # other threads (a validation thread, DataParallel replicas) keep the original forwards
 

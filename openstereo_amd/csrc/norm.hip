@@ -92,6 +92,106 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
     if (y_meta) publish_amax(y_meta, am, 0u, red);
 }
 
+
+// ---- per-channel sums over the positions of a channels-last tensor (r6, training path) ---------------------------------------------------
+// sum_dy[c] = sum_p dy[p][c] and, with x, sum_dyx[c] = sum_p dy[p][c] * (x[p][c] - shift[c]); optionally dx[p][c] = dy[p][c] * scale[c] in
+// the same pass.  These are the bias gradient of a convolution (autograd of nn.Conv2d(bias=True): update.py:19-26, 38-40 -- 5 biased
+// convolutions x 22 GRU iterations per StereoBase step) and the whole backward of a BatchNorm in eval mode (trainer FREEZE_BN,
+// trainer_template.py:83-85: dbeta = sum dy, dgamma = invstd * sum dy (x - mean), dx = dy * gamma * invstd).  torch's reduction of a
+// channels-last tensor over its positions runs at ~0.2 TB/s (reduce_kernel<512, 1>: 40 us for 14720 x 256 fp16 values); this is one
+// coalesced pass: a thread owns a channel quad, the threads of a workgroup that share a quad take interleaved positions, partial sums go
+// through LDS and a caller-owned workspace [workgroup][2][C4] and are combined in a fixed order (deterministic, no float atomics).
+template <int DYF16, int XF16, int WITH_X, int WITH_DX>
+__global__ __launch_bounds__(256) void channel_sums_partial_kernel(const void* __restrict__ dy_, const void* __restrict__ x_, void* __restrict__ dx_,
+                                                                   const float* __restrict__ shift, const float* __restrict__ scale,
+                                                                   float* __restrict__ ws, long long P, int C, int dyCs, int xCs, int dxCs,
+                                                                   long long per_wg) {
+    __shared__ float4 red[2][256];
+    const int Cq = (C + 3) / 4, PL = 256 / Cq;                 // position lanes per workgroup (host: Cq <= 256)
+    const int q = threadIdx.x % Cq, pl = threadIdx.x / Cq;
+    const bool live = pl < PL;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sx = s;
+    const int c0 = q * 4, nc = C - c0;                           // channels of this quad that exist (>= 1)
+    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (live) {
+        if (WITH_X && shift) { sh.x = shift[c0]; if (nc > 1) sh.y = shift[c0 + 1]; if (nc > 2) sh.z = shift[c0 + 2]; if (nc > 3) sh.w = shift[c0 + 3]; }
+        if (WITH_DX) { sc.x = scale[c0]; if (nc > 1) sc.y = scale[c0 + 1]; if (nc > 2) sc.z = scale[c0 + 2]; if (nc > 3) sc.w = scale[c0 + 3]; }
+    }
+    auto ld = [&](const void* base, int f16, long long p, int cs) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f16) {
+            const _Float16* src = reinterpret_cast<const _Float16*>(base) + p * cs + c0;
+            if (nc >= 4) {
+                const uint2 u = *reinterpret_cast<const uint2*>(src);
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 a = __builtin_bit_cast(h2, u.x), b = __builtin_bit_cast(h2, u.y);
+                v = make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+            } else { v.x = (float)src[0]; if (nc > 1) v.y = (float)src[1]; if (nc > 2) v.z = (float)src[2]; }
+        } else {
+            const float* src = reinterpret_cast<const float*>(base) + p * cs + c0;
+            if (nc >= 4) v = *reinterpret_cast<const float4*>(src);
+            else { v.x = src[0]; if (nc > 1) v.y = src[1]; if (nc > 2) v.z = src[2]; }
+        }
+        return v;
+    };
+    if (live) {
+        const long long p0 = (long long)blockIdx.x * per_wg, p1 = (p0 + per_wg < P) ? p0 + per_wg : P;
+        for (long long p = p0 + pl; p < p1; p += PL) {
+            const float4 g = ld(dy_, DYF16, p, dyCs);
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            if (WITH_X) {
+                const float4 v = ld(x_, XF16, p, xCs);
+                sx.x = fmaf(g.x, v.x - sh.x, sx.x); sx.y = fmaf(g.y, v.y - sh.y, sx.y); sx.z = fmaf(g.z, v.z - sh.z, sx.z); sx.w = fmaf(g.w, v.w - sh.w, sx.w);
+            }
+            if (WITH_DX) {
+                const float o[4] = {g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w};
+                if (DYF16) {
+                    _Float16* dst = reinterpret_cast<_Float16*>(dx_) + p * dxCs + c0;
+                    if (nc >= 4) {
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        const h2 a = {(_Float16)o[0], (_Float16)o[1]}, b = {(_Float16)o[2], (_Float16)o[3]};
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+                    } else { dst[0] = (_Float16)o[0]; if (nc > 1) dst[1] = (_Float16)o[1]; if (nc > 2) dst[2] = (_Float16)o[2]; }
+                } else {
+                    float* dst = reinterpret_cast<float*>(dx_) + p * dxCs + c0;
+                    if (nc >= 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    else { dst[0] = o[0]; if (nc > 1) dst[1] = o[1]; if (nc > 2) dst[2] = o[2]; }
+                }
+            }
+        }
+    }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = sx;
+    __syncthreads();
+    if (pl == 0) {
+        float4 a = red[0][q], b = red[1][q];
+        for (int i = 1; i < PL; ++i) {                            // fixed order
+            const float4 u = red[0][i * Cq + q], v = red[1][i * Cq + q];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        float4* o = reinterpret_cast<float4*>(ws) + (size_t)blockIdx.x * 2 * Cq;
+        o[q] = a; o[Cq + q] = b;
+    }
+}
+
+// out[which][c] = sum over the workgroups' partials, fixed order; one thread per (which, channel quad)
+__global__ __launch_bounds__(256) void channel_sums_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int C, int nwg, int nwhich) {
+    const int Cq = (C + 3) / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nwhich * Cq) return;
+    const int which = i / Cq, q = i - which * Cq;
+    const float4* src = reinterpret_cast<const float4*>(ws) + (size_t)which * Cq + q;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int g = 0;
+    for (; g + 2 <= nwg; g += 2) {
+        const float4 u = src[(size_t)g * 2 * Cq], v = src[(size_t)(g + 1) * 2 * Cq];
+        a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w; a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+    }
+    if (g < nwg) { const float4 u = src[(size_t)g * 2 * Cq]; a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w; }
+    const float r[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
+    for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < C) out[(size_t)which * C + q * 4 + e] = r[e];
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -125,5 +225,53 @@ extern "C" int osa_instnorm_nhwc_f32(const float* x, float* y, int B, long long 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(instnorm_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, x, stats, y, HW, C, xCs, yCs, act, slope, y_meta);
     OSA_LAUNCH_CHECK("instnorm");
+    return 0;
+}
+
+
+static int channel_sums_wgs(long long P, int C) {
+    const int Cq = (C + 3) / 4, PL = 256 / (Cq > 0 ? Cq : 1);
+    long long n = P / ((long long)(PL > 0 ? PL : 1) * 16);      // at least ~16 positions per thread
+    if (n > 1024) n = 1024;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+extern "C" size_t osa_channel_sums_workspace_bytes(long long P, int C) {
+    if (P <= 0 || C <= 0 || C > 1024) return 0;
+    return (size_t)channel_sums_wgs(P, C) * 2 * ((C + 3) / 4) * 4 * sizeof(float);
+}
+
+extern "C" int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const void* x, int x_f16, int x_cs, const float* x_shift,
+                                const float* dx_scale, void* dx, int dx_cs, long long P, int C,
+                                float* out, float* workspace, size_t workspace_bytes, void* stream) {
+    OSA_REQUIRE(dy && out && workspace, "channel_sums: NULL pointer");
+    OSA_REQUIRE(P > 0 && C > 0 && C <= 1024, "channel_sums: bad dims P=%lld C=%d (C <= 1024)", P, C);
+    OSA_REQUIRE(dy_cs >= C && (x == nullptr || x_cs >= C) && (dx == nullptr || dx_cs >= C), "channel_sums: channel stride < C");
+    // full quads are loaded / stored as 8- or 16-byte vectors
+    auto vec_ok = [&](const void* t, int f16, int cs) { return cs % 4 == 0 && ((size_t)t & (f16 ? 7 : 15)) == 0; };
+    OSA_REQUIRE(vec_ok(dy, dy_f16, dy_cs) && (x == nullptr || vec_ok(x, x_f16, x_cs)) && (dx == nullptr || vec_ok(dx, dy_f16, dx_cs)),
+                "channel_sums: tensors need channel strides %% 4 == 0 and 16-byte (fp16: 8-byte) alignment");
+    OSA_REQUIRE((dx == nullptr) == (dx_scale == nullptr), "channel_sums: dx and dx_scale come together");
+    const size_t need = osa_channel_sums_workspace_bytes(P, C);
+    OSA_REQUIRE(workspace_bytes >= need && ((size_t)workspace & 15) == 0, "channel_sums: workspace of %zu B needed (got %zu)", need, workspace_bytes);
+    const int nwg = channel_sums_wgs(P, C);
+    const long long per = (P + nwg - 1) / nwg;
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (dy_f16 ? 8 : 0) | (x ? ((x_f16 ? 4 : 0) | 2) : 0) | (dx ? 1 : 0);
+#define OSA_CS(DYF, XF, WX, WD) hipLaunchKernelGGL((channel_sums_partial_kernel<DYF, XF, WX, WD>), dim3(nwg), dim3(256), 0, st, dy, x, dx, x_shift, dx_scale, workspace, P, C, dy_cs, x_cs, dx_cs, per)
+    switch (key) {
+        case 0: OSA_CS(0, 0, 0, 0); break;   case 1: OSA_CS(0, 0, 0, 1); break;
+        case 2: OSA_CS(0, 0, 1, 0); break;   case 3: OSA_CS(0, 0, 1, 1); break;
+        case 6: OSA_CS(0, 1, 1, 0); break;   case 7: OSA_CS(0, 1, 1, 1); break;
+        case 8: OSA_CS(1, 0, 0, 0); break;   case 9: OSA_CS(1, 0, 0, 1); break;
+        case 10: OSA_CS(1, 0, 1, 0); break;  case 11: OSA_CS(1, 0, 1, 1); break;
+        case 14: OSA_CS(1, 1, 1, 0); break;  case 15: OSA_CS(1, 1, 1, 1); break;
+        default: OSA_REQUIRE(false, "channel_sums: x_f16 without x");
+    }
+#undef OSA_CS
+    const int nwhich = x ? 2 : 1;
+    hipLaunchKernelGGL(channel_sums_final_kernel, dim3(cdiv(nwhich * ((C + 3) / 4), 256)), dim3(256), 0, st, workspace, out, C, nwg, nwhich);
+    OSA_LAUNCH_CHECK("channel_sums");
     return 0;
 }

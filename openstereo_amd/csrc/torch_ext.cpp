@@ -593,6 +593,33 @@ void preprocess_pair(const at::Tensor& l, const at::Tensor& r, at::Tensor out, a
     OSA_CALL(osa_preprocess_pair_f32(l.data_ptr(), r.data_ptr(), l.scalar_type() == at::kByte ? 1 : 0, (int)l.size(0), (int)l.size(1), (int)pad_size[0], (int)pad_size[1], m3, s3,
                                      out.data_ptr<float>(), channels_last ? 1 : 0, cur_stream()));
 }
+// per-channel sums over the positions of a channels-last tensor (bias gradients; eval-mode BatchNorm backward): functional, allocates
+// the sums [1 or 2][C], the optional dx (dy's dtype and strides) and the workspace
+std::tuple<at::Tensor, at::Tensor> channel_sums(const at::Tensor& dy, const c10::optional<at::Tensor>& x, const c10::optional<at::Tensor>& x_shift,
+                                                const c10::optional<at::Tensor>& dx_scale, int64_t P, int64_t C, int64_t dy_cs, int64_t x_cs) {
+    const bool dyh = dy.scalar_type() == at::kHalf;
+    TORCH_CHECK(dy.is_cuda() && (dyh || dy.scalar_type() == at::kFloat), "channel_sums: dy must be a CUDA fp32 / fp16 tensor");
+    const bool hx = x.has_value() && x->defined();
+    const bool xh = hx && x->scalar_type() == at::kHalf;
+    if (hx) TORCH_CHECK(x->is_cuda() && (xh || x->scalar_type() == at::kFloat), "channel_sums: x must be a CUDA fp32 / fp16 tensor");
+    const bool hd = dx_scale.has_value() && dx_scale->defined();
+    const size_t need = osa_channel_sums_workspace_bytes((long long)P, (int)C);
+    TORCH_CHECK(need != 0, "channel_sums: unsupported dims");
+    at::Tensor out = at::empty({hx ? 2 : 1, C}, dy.options().dtype(at::kFloat));
+    at::Tensor ws = at::empty({(int64_t)((need + 3) / 4)}, dy.options().dtype(at::kFloat));
+    at::Tensor dx = hd ? at::empty_strided(dy.sizes(), dy.strides(), dy.options()) : at::Tensor();
+    OSA_CALL(osa_channel_sums(dy.data_ptr(), dyh ? 1 : 0, (int)dy_cs, hx ? x->data_ptr() : nullptr, xh ? 1 : 0, (int)x_cs,
+                              (x_shift.has_value() && x_shift->defined()) ? x_shift->data_ptr<float>() : nullptr,
+                              hd ? dx_scale->data_ptr<float>() : nullptr, hd ? dx.data_ptr() : nullptr, (int)dy_cs, (long long)P, (int)C,
+                              out.data_ptr<float>(), ws.data_ptr<float>(), need, cur_stream()));
+    return std::make_tuple(out, hd ? dx : at::empty({0}, dy.options()));
+}
+std::tuple<at::Tensor, at::Tensor> channel_sums_meta(const at::Tensor& dy, const c10::optional<at::Tensor>& x, const c10::optional<at::Tensor>& x_shift,
+                                                     const c10::optional<at::Tensor>& dx_scale, int64_t P, int64_t C, int64_t dy_cs, int64_t x_cs) {
+    const bool hx = x.has_value() && x->defined(), hd = dx_scale.has_value() && dx_scale->defined();
+    return std::make_tuple(at::empty({hx ? 2 : 1, C}, dy.options().dtype(at::kFloat)), hd ? at::empty_strided(dy.sizes(), dy.strides(), dy.options()) : at::empty({0}, dy.options()));
+}
+
 void amax_into(const at::Tensor& t, at::Tensor meta) {
     gpu_f32(t, "t"); gpu_f32(meta, "meta");
     OSA_CALL(osa_amax_f32(fp(t), (long long)t.numel(), meta.data_ptr<float>(), cur_stream()));
@@ -836,6 +863,7 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("weight_pack(Tensor w, Tensor(a!) packed, int family, int prec, int[] geom, float wscale) -> ()");
     m.def("cat_fms(Tensor reference_fm, Tensor target_fm, Tensor(a!) out, Tensor disp_index) -> ()");
     m.def("pair_volume(Tensor left, Tensor right, Tensor(a!) out, int groups, int planes, int mode) -> ()");
+    m.def("channel_sums(Tensor dy, Tensor? x, Tensor? x_shift, Tensor? dx_scale, int P, int C, int dy_cs, int x_cs) -> (Tensor, Tensor)");
     m.def("instnorm_nhwc(Tensor x, Tensor(a!) out, int out_off, int[] dims, float eps, int act, float slope, Tensor(b!) workspace, Tensor(c!)? y_meta) -> ()");
     m.def("preprocess_pair(Tensor left_hwc, Tensor right_hwc, Tensor(a!) out, int[] pad_size, float[] mean, float[] std, bool channels_last) -> ()");
     m.def("amax_into(Tensor t, Tensor(a!) meta) -> ()");
@@ -881,6 +909,7 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("cat_fms", &cat_fms);
     m.impl("pair_volume", &pair_volume);
     m.impl("instnorm_nhwc", &instnorm_nhwc);
+    m.impl("channel_sums", &channel_sums);
     m.impl("preprocess_pair", &preprocess_pair);
     m.impl("amax_into", &amax_into);
 }
@@ -900,6 +929,7 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     // r6: every launch op -- an engine model traces under FakeTensorMode / make_fx without a kernel running (tests/test_gpu_fake_trace.py)
     m.impl("cost_volume_cl", &cost_volume_cl_meta);
     m.impl("conv_wgrad", &conv_wgrad_meta);
+    m.impl("channel_sums", &channel_sums_meta);
     for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",
                              "geo_lookup", "geo_lookup_bwd", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
                              "geo_lookup_nhwc", "allpairs_corr", "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair",

@@ -449,3 +449,55 @@ class FasterSoftArgmin(torch.nn.Module):
         if self.normalize:
             return softmax_disparity_regression(c, keepdim=False)
         return disparity_regression(c, c.shape[1], keepdim=False)
+
+
+def cl_rows(t: torch.Tensor):
+    """(P, C, cs) when `t` (logical [B, C, *spatial], fp32 / fp16) is a dense run of P channel rows of stride cs elements -- engine
+    outputs and their channel slices, channels_last / channels_last_3d tensors -- with the alignment the vector kernels need; else None."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dim() >= 3 and t.dtype in (torch.float32, torch.float16)):
+        return None
+    C = t.shape[1]
+    if C > 1 and t.stride(1) != 1:
+        return None
+    dims = [0] + list(range(2, t.dim()))                 # batch, then the spatial dims, outermost first
+    cs, expect = None, None
+    for d in reversed(dims):
+        if t.shape[d] == 1:
+            continue
+        if cs is None:
+            cs = expect = t.stride(d)
+        elif t.stride(d) != expect:
+            return None
+        expect = expect * t.shape[d]
+    if cs is None:
+        cs = (C + 3) // 4 * 4 if C % 4 else C
+    if cs < C or cs % 4 or t.data_ptr() % (8 if t.dtype == torch.float16 else 16):
+        return None
+    return t.numel() // C, C, cs
+
+
+def channel_sums(dy: torch.Tensor, x: torch.Tensor | None = None, x_shift: torch.Tensor | None = None, dx_scale: torch.Tensor | None = None):
+    """Per-channel sums over the positions of a channels-last tensor (osa_channel_sums): returns (sums, dx) with sums[0] = sum_p dy,
+    sums[1] = sum_p dy * (x - x_shift) when x is given, dx = dy * dx_scale[c] when dx_scale is given (else None).  Bias gradient of a
+    convolution, backward of an eval-mode BatchNorm.  dy / x must satisfy `cl_rows` (the caller checks; anything else is its torch path)."""
+    P, C, cs = cl_rows(dy)
+    xcs = 0
+    if x is not None:
+        Px, Cx, xcs = cl_rows(x)
+        assert (Px, Cx) == (P, C), "channel_sums: x and dy must agree in shape"
+    sh = None if x_shift is None else _f32c(x_shift)
+    sc = None if dx_scale is None else _f32c(dx_scale)
+    ext = _ext.load()
+    if ext is not None:
+        out, dx = ext.channel_sums(dy, x, sh, sc, P, C, cs, xcs)
+        return out, (dx if sc is not None else None)
+    lib = _lib.load()
+    need = lib.osa_channel_sums_workspace_bytes(P, C)
+    if not need:
+        raise _lib.EngineError(f"osa_channel_sums: unsupported dims P={P} C={C}")
+    out = torch.empty((2 if x is not None else 1, C), device=dy.device, dtype=torch.float32)
+    ws = torch.empty((need + 3) // 4, device=dy.device, dtype=torch.float32)
+    dx = torch.empty_strided(dy.shape, dy.stride(), device=dy.device, dtype=dy.dtype) if sc is not None else None
+    _lib.call("osa_channel_sums", dy.data_ptr(), int(dy.dtype == torch.float16), cs, _p(x), int(x is not None and x.dtype == torch.float16), xcs,
+              _p(sh), _p(sc), _p(dx), cs, P, C, out.data_ptr(), ws.data_ptr(), need, _stream())
+    return out, dx

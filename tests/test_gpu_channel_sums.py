@@ -1,0 +1,165 @@
+"""osa_channel_sums (r6, csrc/norm.hip): per-channel sums over the positions of a channels-last tensor -- the bias gradient of the
+reference's biased convolutions (stereo/modeling/models/igev/update.py:19-26,38-40: autograd of nn.Conv2d(bias=True)) and the backward of
+BatchNorm modules in eval mode (FREEZE_BN, stereo/trainer/trainer_template.py:83-85).
+(1) the kernel against torch reductions in fp64 for the layouts / dtypes the training loop hands over; (2) `_FrozenBN` inside
+`engine_convs` against torch's own eval-mode batch_norm autograd, fp32 and fp16, 2-D and 3-D; (3) a biased convolution applied several
+times in one step (the deferred, batched weight / bias gradients of the update block) against torch autograd of F.conv2d; (4) the
+multi-tile weight-gradient kernel against the single-tile kernel on the same operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rn(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).normal(0, 1, shape) * scale).astype(np.float32))
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last if t.dim() == 4 else torch.channels_last_3d)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 20, 46), (1, 256, 80, 184), (3, 127, 9, 11), (1, 452, 16, 23), (2, 48, 6, 10, 23), (1, 8, 5, 7), (1, 1024, 4, 9)])
+def test_channel_sums_vs_torch(shape, dtype):
+    from openstereo_amd import ops
+    C = shape[1]
+    dy, x = rn(shape, 1).to(DEV).to(dtype), (rn(shape, 2) + 0.5).to(DEV).to(dtype)
+    if C % 4:                                   # rows padded to a channel quad, as the engine's tensors are
+        pad = [0] * (2 * (len(shape) - 2)) + [0, 4 - C % 4]
+        dy, x = _cl(F.pad(dy, pad))[:, :C], _cl(F.pad(x, pad))[:, :C]
+    else:
+        dy, x = _cl(dy), _cl(x)
+    assert ops.cl_rows(dy) is not None and ops.cl_rows(x) is not None
+    shift, scale = rn((C,), 3).to(DEV), rn((C,), 4).to(DEV)
+    red = [0] + list(range(2, len(shape)))
+    bc = [1, C] + [1] * (len(shape) - 2)
+    want0 = dy.double().sum(red)
+    want1 = (dy.double() * (x.double() - shift.double().view(bc))).sum(red)
+    tol = (2e-6 if dtype == torch.float32 else 2e-6) * float(dy.double().abs().sum(red).max() + 1)
+
+    s, dx = ops.channel_sums(dy)
+    assert s.shape == (1, C) and dx is None
+    assert float((s[0].double() - want0).abs().max()) <= tol
+    s, dx = ops.channel_sums(dy, x, shift, scale)
+    assert s.shape == (2, C)
+    assert float((s[0].double() - want0).abs().max()) <= tol
+    assert float((s[1].double() - want1).abs().max()) <= 4 * tol * float(1 + x.abs().max() + shift.abs().max())
+    want_dx = (dy.float() * scale.view(bc)).to(dtype)
+    assert dx.dtype == dtype and dx.shape == dy.shape
+    assert torch.equal(dx, want_dx) or float((dx.float() - want_dx.float()).abs().max()) <= 1e-3 * float(want_dx.float().abs().max())
+    # determinism: the two-stage sum has a fixed order
+    s2, _ = ops.channel_sums(dy, x, shift, scale)
+    assert torch.equal(s, s2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dims", [2, 3])
+@pytest.mark.parametrize("gy_layout", ["cl", "nchw"])
+def test_frozen_bn_backward_vs_torch(dims, dtype, gy_layout):
+    from openstereo_amd import autograd as AG
+    C = 32
+    shape = (2, C, 12, 20) if dims == 2 else (2, C, 4, 12, 20)
+    bn = (nn.BatchNorm2d if dims == 2 else nn.BatchNorm3d)(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(rn((C,), 1).abs() + 0.5); bn.bias.copy_(rn((C,), 2))
+        bn.running_mean.copy_(rn((C,), 3)); bn.running_var.copy_(rn((C,), 4).abs() + 0.3)
+    bn.eval()
+    x0 = _cl(rn(shape, 5).to(DEV).to(dtype))
+    gy = rn(shape, 6).to(DEV).to(dtype)
+    gy = _cl(gy) if gy_layout == "cl" else gy.contiguous()         # (a contiguous gradient from a torch op takes the torch-op formulas)
+
+    def run(engine):
+        bn.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        if engine:
+            with AG.engine_convs():
+                y = bn(x)
+            assert type(y.grad_fn).__name__ == "_FrozenBNBackward"
+        else:
+            y = bn(x)
+        y.backward(gy)
+        return y.detach(), x.grad, bn.weight.grad.clone(), bn.bias.grad.clone()
+
+    y0, dx0, dg0, db0 = run(False)
+    y1, dx1, dg1, db1 = run(True)
+    assert torch.equal(y0, y1)
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+    assert rel(dx1, dx0) <= (1e-6 if dtype == torch.float32 else 2e-3)
+    assert rel(dg1, dg0) <= (1e-5 if dtype == torch.float32 else 2e-3) and rel(db1, db0) <= (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_biased_conv_applied_three_times_gradients(amp):
+    """the update block's pattern: one biased 3x3 convolution applied to several inputs in one step -- its weight and bias gradients arrive
+    once, from ONE batched launch each, and equal torch autograd's accumulated gradients"""
+    from openstereo_amd import autograd as AG, engine
+    engine.set_precision("f16x3")
+    Ci, Co, H, W = 64, 128, 20, 46
+    w = (rn((Co, Ci, 3, 3), 1) * 0.05).to(DEV).requires_grad_()
+    b = (rn((Co,), 2) * 0.1).to(DEV).requires_grad_()
+    xs = [rn((1, Ci, H, W), 10 + i).to(DEV) for i in range(3)]
+    gys = [rn((1, Co, H, W), 20 + i).to(DEV) for i in range(3)]
+    conv = nn.Conv2d(Ci, Co, 3, padding=1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w); conv.bias.copy_(b)
+
+    def run(engine_on):
+        conv.zero_grad(set_to_none=True)
+        ins = [x.clone().requires_grad_() for x in xs]
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            if engine_on:
+                with AG.engine_convs():
+                    outs = [conv(x) for x in ins]
+            else:
+                outs = [conv(x) for x in ins]
+            loss = sum((o.float() * g).sum() for o, g in zip(outs, gys))
+        loss.backward()
+        return conv.weight.grad.clone(), conv.bias.grad.clone(), [x.grad.clone() for x in ins]
+
+    w0, b0, dx0 = run(False)
+    w1, b1, dx1 = run(True)
+    tol = 3e-3 if amp else 2e-5
+    rel = lambda a, b_: float((a.float() - b_.float()).abs().max() / (b_.float().abs().max() + 1e-30))
+    assert rel(w1, w0) <= tol and rel(b1, b0) <= tol
+    assert all(rel(a, c) <= tol for a, c in zip(dx1, dx0))
+    # a second step starts from zero (the queue of the first is empty)
+    w2, b2, _ = run(True)
+    assert torch.equal(w1, w2) and torch.equal(b1, b2)
+
+
+@pytest.mark.parametrize("prec", ["f16", "f16x3"])
+@pytest.mark.parametrize("case", [("2d 384->256", 384, 256, (1, 3, 3), (3, 1, 20, 46)), ("2d 64->64", 64, 64, (1, 3, 3), (2, 1, 24, 40)),
+                                  ("2d 100->72 k1", 100, 72, (1, 1, 1), (2, 1, 17, 33)), ("3d 48->48", 48, 48, (3, 3, 3), (2, 6, 12, 23)),
+                                  ("3d 96->160", 96, 160, (3, 3, 3), (1, 4, 9, 18))])
+def test_multi_tile_wgrad_vs_single_tile(case, prec):
+    """wgrad_mt_kernel (NA x NB tiles per workgroup, brick ranges) vs wgrad_f16x3_kernel (one tile, positions split over the waves): same
+    operands and arithmetic, different summation order"""
+    from openstereo_amd import _lib, autograd as AG, ops
+    from openstereo_amd.ranges import input_meta
+    _, Ci, Co, k, (B, D, H, W) = case
+    lib = _lib.load()
+    x = ops.to_cl(rn((B, Ci, D, H, W), 1).to(DEV))
+    dy = ops.to_cl((rn((B, Co, D, H, W), 2) * 1e-2).to(DEV))
+    pad = tuple(kk // 2 for kk in k)
+    mx, mdy = input_meta(x), input_meta(dy)
+    default = lib.osa_conv_b_ring_mask(-1)
+    lib.osa_conv_b_ring_mask(default)
+    assert (default >> 27) & 1
+    got = {}
+    try:
+        for name, mask in (("mt", default), ("single", default & ~(1 << 27))):
+            lib.osa_conv_b_ring_mask(mask)
+            dw = torch.empty(Co, Ci, *k, device=DEV)
+            AG._wgrad(x, dy, dw, B, D, H, W, Ci, D, H, W, Co, k, 1, pad, (1, 1, 1), 0, prec, mx, mdy)
+            got[name] = dw.clone()
+    finally:
+        lib.osa_conv_b_ring_mask(default)
+    want = torch.nn.grad.conv3d_weight(x[:, :Ci].cpu().double().contiguous(), (Co, Ci, *k), dy[:, :Co].cpu().double().contiguous(), padding=pad).float().to(DEV)
+    scale = float(want.abs().max())
+    assert float((got["mt"] - got["single"]).abs().max()) <= 2e-5 * scale
+    assert float((got["mt"] - want).abs().max()) <= (3e-3 if prec == "f16" else 2e-5) * scale
