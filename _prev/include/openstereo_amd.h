@@ -427,20 +427,6 @@ int osa_conv3d_wgrad_ws_f16(const void* x, const void* dy, float* dw,
                             int transposed, const float* x_meta, const float* dy_meta, int x_f16, int dy_f16,
                             float* workspace, size_t workspace_bytes, void* stream);
 
-/* The same weight gradients over a LIST of equally shaped (x, dy) tensor pairs in one launch, without concatenating them (r6): the uses
- * of ONE weight within a training step -- the update block applies each of its convolutions once per GRU iteration
- * (stereo/modeling/models/igev/update.py:97-150, 22 iterations in training: igev_stereo.py:181-203), and autograd would accumulate 22
- * separate weight gradients.  Batch entry b of the launch is entry b % (B / n_items) of item b / (B / n_items); xs / dys are HOST arrays of
- * n_items (<= 24) device pointers.  form: 0 = osa_conv3d_wgrad_ws_f32, 1 = ..._f16x3 (range blocks over ALL items required), 2 = ..._f16
- * (x_f16 / dy_f16 as there).  B = total batch over all items; workspace: the form's query for a single tensor of batch B. */
-int osa_conv3d_wgrad_ws_multi(int form, const void* const* xs, const void* const* dys, int n_items, float* dw,
-                              int B, int Di, int Hi, int Wi, int Ci, int xCs,
-                              int Do, int Ho, int Wo, int Co, int dyCs,
-                              int kd, int kh, int kw, int stride,
-                              int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
-                              int transposed, const float* x_meta, const float* dy_meta, int x_f16, int dy_f16,
-                              float* workspace, size_t workspace_bytes, void* stream);
-
 
 /* small-Cout 'same' convolution (Co <= 4, e.g. the 32->1 classifier heads). Reference weight
  * layout [Co][Ci][kd][kh][kw] is consumed directly (device pointer).
@@ -590,10 +576,6 @@ size_t osa_channel_sums_workspace_bytes(long long P, int C);
 int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const void* x, int x_f16, int x_cs, const float* x_shift,
                      const float* dx_scale, void* dx, int dx_cs, long long P, int C,
                      float* out, float* workspace, size_t workspace_bytes, void* stream);
-/* ... sums of dy over a LIST of n_items (<= 24) equally shaped tensors of P positions each, in one launch: the queued output gradients of
- * one biased convolution applied once per GRU iteration (HOST array of device pointers); workspace: n_items x the query above. */
-int osa_channel_sums_multi(const void* const* dys, int n_items, int dy_f16, int dy_cs, long long P, int C,
-                           float* out, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- InstanceNorm2d (+ activation) on NHWC maps (r4, csrc/norm.hip) ----
  * The normalisation of the reference-written FPN decoders of the feature pyramids: Conv2xUp / BasicConv2d(norm_layer=nn.InstanceNorm2d)

@@ -14,7 +14,6 @@ unchanged (one process per GPU).
 """
 from __future__ import annotations
 
-import ctypes
 import math
 import os
 import threading
@@ -420,67 +419,61 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
     deterministic, and free of the contended float atomics of the one-stage form.  precision "f16x3": the split-precision kernel where it
     applies (unit stride / dilation, 3x3 planes: osa_conv3d_wgrad_ws_f16x3, operand ranges from the tensors' range blocks), the exact
     fp32 kernel (osa_conv3d_wgrad_ws_f32) everywhere else.  fp16 tensors (the native f16 form) that the fp16 kernel declines are widened
-    and take the exact kernel (never raise inside backward() for a layer the forward accepted).
-    xc / dyc may be LISTS of equally shaped and strided tensors (the queued uses of one weight, r6): one launch over all of them without a
-    concatenation (osa_conv3d_wgrad_ws_multi); B is then the total batch and f16x3 range blocks must cover all items."""
-    multi = isinstance(xc, (list, tuple))
-    xs, dys = (list(xc), list(dyc)) if multi else ([xc], [dyc])
-    xc, dyc = xs[0], dys[0]
+    and take the exact kernel (never raise inside backward() for a layer the forward accepted)."""
     assert precision == "f16" or (xc.dtype == torch.float32 and dyc.dtype == torch.float32), "fp16 tensors exist in the native f16 form only"
     xcs, dycs = (xc.shape[1] if xcs is None else xcs), (dyc.shape[1] if dycs is None else dycs)        # channel strides (rows may be wider than the tensors' logical channels)
     dims = (B, D, H, W, Ci, Do, Ho, Wo, Co, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed)
     lib = _lib.load()
     vox = (D * H * W) if transposed else (Do * Ho * Wo)            # positions every weight tap is accumulated over
     span = dict(flops=2 * B * vox * Ci * Co * k[0] * k[1] * k[2], nbytes=4 * B * (D * H * W * Ci + Do * Ho * Wo * Co))
-    if precision == "f16x3" and (xmeta is None or dymeta is None):
-        from .ranges import combine_meta
-        xmeta = xmeta if xmeta is not None else combine_meta(*[input_meta(t) for t in xs])
-        dymeta = dymeta if dymeta is not None else combine_meta(*[input_meta(t) for t in dys])
     ext = engine._ext.load()
     if ext is not None:
         # PyTorch-ROCm C++ extension (csrc/torch_ext.cpp conv_wgrad): workspace query, allocation and launch in one dispatcher call
         ed = [B, D, H, W, Ci, xcs, Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed]
-        run = (lambda prec, mx, md: ext.conv_wgrad_multi(xs, dys, dw, ed, prec, mx, md)) if multi else (lambda prec, mx, md: ext.conv_wgrad(xs[0], dys[0], dw, ed, prec, mx, md))
         if precision == "f16" and WGRAD_F16 and ((stride == 1 and not transposed) or WGRAD_F16_CLASS):
             with timing.span("wgrad_f16", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-                if run(2, None, None):
+                if ext.conv_wgrad(xc, dyc, dw, ed, 2, None, None):
                     return
         if precision == "f16x3" and WGRAD_F16X3 and ((stride == 1 and not transposed) or WGRAD_F16X3_CLASS):
             with timing.span("wgrad_f16x3", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-                if run(1, xmeta, dymeta):
+                if ext.conv_wgrad(xc, dyc, dw, ed, 1, xmeta if xmeta is not None else input_meta(xc), dymeta if dymeta is not None else input_meta(dyc)):
                     return
         if xc.dtype != torch.float32 or dyc.dtype != torch.float32:
-            xs, dys = [t.float() for t in xs], [t.float() for t in dys]      # (dense tensors: .float() keeps the strides the channel strides refer to)
+            xc, dyc = xc.float(), dyc.float()                     # (dense tensors: .float() keeps the strides the channel strides refer to)
         with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-            run(0, None, None)
+            ext.conv_wgrad(xc, dyc, dw, ed, 0, None, None)
         return
-
-    def launch(form, mx, md, need):
-        ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
-        ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        _lib.call("osa_conv3d_wgrad_ws_multi", form, ptrs(xs), ptrs(dys), len(xs), dw.data_ptr(), B, D, H, W, Ci, xcs,
-                  Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
-                  _p(mx), _p(md), int(xs[0].dtype == torch.float16), int(dys[0].dtype == torch.float16), ws.data_ptr(), need, _stream())
     if precision == "f16" and WGRAD_F16 and ((stride == 1 and not transposed) or WGRAD_F16_CLASS):
         # native fp16 operands, one MFMA per product, no range blocks (AMP training: GradScaler owns the range)
         need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
         if need:
+            ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
             with timing.span("wgrad_f16", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-                launch(2, None, None, need)
+                _lib.call("osa_conv3d_wgrad_ws_f16", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
+                          Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                          None, None, int(xc.dtype == torch.float16), int(dyc.dtype == torch.float16), ws.data_ptr(), need, _stream())
             return
     if precision == "f16x3" and WGRAD_F16X3 and ((stride == 1 and not transposed) or WGRAD_F16X3_CLASS):
         need = lib.osa_conv3d_wgrad_f16x3_workspace_bytes(*dims)
         if need:
+            ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
+            mx = xmeta if xmeta is not None else input_meta(xc)
             with timing.span("wgrad_f16x3", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-                launch(1, xmeta, dymeta, need)
+                _lib.call("osa_conv3d_wgrad_ws_f16x3", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
+                          Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                          mx.data_ptr(), (dymeta if dymeta is not None else input_meta(dyc)).data_ptr(), ws.data_ptr(), need, _stream())
             return
     need = lib.osa_conv3d_wgrad_workspace_bytes(*dims)
     if need == 0:
         raise _lib.EngineError("osa_conv3d_wgrad_workspace_bytes: unsupported layer " + str(dims))
     if xc.dtype != torch.float32 or dyc.dtype != torch.float32:
-        xs, dys = [t.float() for t in xs], [t.float() for t in dys]
+        xc, dyc = xc.float(), dyc.float()
+    ws = torch.empty((need + 3) // 4, device=xc.device, dtype=torch.float32)
     with timing.span("wgrad", Ci, Co, k[1], stride, D, H, W, transposed, **span):
-        launch(0, None, None, need)
+        _lib.call("osa_conv3d_wgrad_ws_f32", xc.data_ptr(), dyc.data_ptr(), dw.data_ptr(), B, D, H, W, Ci, xcs,
+                  Do, Ho, Wo, Co, dycs, k[0], k[1], k[2], stride, pad[0], pad[1], pad[2], dil[0], dil[1], dil[2], transposed,
+                  ws.data_ptr(), need, _stream())
+
 
 
 # ----------------------------------------------------------------------------- deferred, batched weight gradients (r6)
@@ -569,26 +562,6 @@ def _defer_wgrad(cache, key, item, run):
     return _defer_run(pend)
 
 
-MULTI_WGRAD = os.environ.get("OSA_WGRAD_MULTI", "1") != "0"   # queued uses of one weight: ONE launch over the list of tensors (0: concatenate them first)
-
-
-def _same_layout(ts):
-    t0 = ts[0]
-    return all(t.shape == t0.shape and t.stride() == t0.stride() and t.dtype == t0.dtype and t.device == t0.device for t in ts[1:])
-
-
-def _bias_grad_items(dys, Co):
-    """bias gradient over a list of queued gradients: per-item sums added up (22 launches of ~8 us, no concatenation)"""
-    gs = [t[:, :Co] for t in dys]
-    if 1 < len(gs) <= 24 and _same_layout(gs) and cl_rows(gs[0]) is not None:
-        return ops.channel_sums_list(gs)
-    tot = None
-    for t in dys:
-        g = _bias_grad(t, Co)
-        tot = g if tot is None else tot + g
-    return tot
-
-
 def _bias_grad(dyc, Co):
     """sum of an NDHWC gradient over its positions, per channel (fp32): one coalesced pass of the engine's kernel where the layout allows"""
     g = dyc[:, :Co]
@@ -674,21 +647,17 @@ class _Conv3d(torch.autograd.Function):
 
             def run(items):                                        # one weight-gradient launch (and one bias-gradient sum) over every queued (x, dy) pair of this weight
                 from .ranges import combine_meta
-                xl, dl = [it[0] for it in items], [it[1] for it in items]
-                as_list = MULTI_WGRAD and 1 < len(items) <= 24 and _same_layout(xl) and _same_layout(dl)
+                dys = _cat_batch([it[1] for it in items])
                 g = None
                 if need_w:
+                    xs = _cat_batch([it[0] for it in items])
                     xm = dm = None
                     if precision == "f16x3":
                         xm = combine_meta(*[it[2] if it[2] is not None else input_meta(it[0]) for it in items])
                         dm = combine_meta(*[it[3] for it in items])
                     g = torch.empty_like(wf)
-                    if as_list:
-                        _wgrad(xl, dl, g, len(items) * B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, xm, dm)
-                    else:
-                        xs, dl = _cat_batch(xl), [_cat_batch(dl)]
-                        _wgrad(xs, dl[0], g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, xm, dm)
-                return g, (_bias_grad_items(dl, Co) if need_b else None)
+                    _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, 0, precision, xm, dm)
+                return g, (_bias_grad(dys, Co) if need_b else None)
             dw, db = _defer_wgrad(ctx.cache, ("f32io", precision, tuple(xc.shape[1:]), tuple(dyc.shape[1:]), stride, pad, dil, need_w, need_b),
                                   (xc, dyc, ctx.xmeta, dymeta), run)
             if db is not None:
@@ -792,19 +761,16 @@ class _Conv3dF16IO(torch.autograd.Function):
                 Do, Ho, Wo = dyc.shape[2:]
 
                 def run(items):                                    # one weight-gradient launch (and one bias-gradient sum) over every queued (x, dy) pair of this weight
-                    xl, dl = [it[0] for it in items], [it[1] for it in items]
-                    as_list = MULTI_WGRAD and 1 < len(items) <= 24 and _same_layout(xl) and _same_layout(dl)
+                    if len(items) == 1:
+                        xs, dys, xs_cs, dys_cs = items[0][0], items[0][1], xcs, dycs
+                    else:                                          # (rows wider than the logical channels are dropped by the concatenation)
+                        xs, dys = _cat_batch([it[0] for it in items], Ci), _cat_batch([it[1] for it in items], Co if fin else None)
+                        xs_cs, dys_cs = xs.shape[1], dys.shape[1]
                     g = None
                     if need_w:
                         g = torch.empty_like(wf)
-                        if len(items) == 1:
-                            _wgrad(xl[0], dl[0], g, B, D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xcs, dycs=dycs)
-                        elif as_list:
-                            _wgrad(xl, dl, g, len(items) * B, D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xcs, dycs=dycs)
-                        else:                                      # (rows wider than the logical channels are dropped by the concatenation)
-                            xs, dys = _cat_batch(xl, Ci), _cat_batch(dl, Co if fin else None)
-                            _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xs.shape[1], dycs=dys.shape[1])
-                    return g, (_bias_grad_items(dl, Co) if need_b else None)
+                        _wgrad(xs, dys, g, xs.shape[0], D, H, W, Ci, Do, Ho, Wo, Co, k, 1, pad, dil, 0, "f16", xcs=xs_cs, dycs=dys_cs)
+                    return g, (_bias_grad(dys, Co) if need_b else None)
                 dw, db = _defer_wgrad(ctx.cache, ("f16io", tuple(xc.shape[1:]), tuple(dyc.shape[1:]), xcs, dycs, pad, dil, fin, need_w, need_b), (xc, dyc), run)
                 if dw is not None and ctx.flat:
                     dw = dw[:, :, 0]

@@ -5,7 +5,6 @@
 // map (statistics, apply) and one write, float4 along the channel rows.  Deterministic: per-segment partial sums in a caller-owned
 // workspace, combined in a fixed order (no float atomics).
 #include "osa_common.h"
-#include <cstring>
 
 namespace osa {
 
@@ -102,14 +101,12 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
 // channels-last tensor over its positions runs at ~0.2 TB/s (reduce_kernel<512, 1>: 40 us for 14720 x 256 fp16 values); this is one
 // coalesced pass: a thread owns a channel quad, the threads of a workgroup that share a quad take interleaved positions, partial sums go
 // through LDS and a caller-owned workspace [workgroup][2][C4] and are combined in a fixed order (deterministic, no float atomics).
-struct ChannelSumsTab { const void* p[24]; };     // blockIdx.y = item of a tensor list (osa_channel_sums_multi); a single tensor is item 0
 template <int DYF16, int XF16, int WITH_X, int WITH_DX>
-__global__ __launch_bounds__(256) void channel_sums_partial_kernel(const ChannelSumsTab tab, const void* __restrict__ x_, void* __restrict__ dx_,
+__global__ __launch_bounds__(256) void channel_sums_partial_kernel(const void* __restrict__ dy_, const void* __restrict__ x_, void* __restrict__ dx_,
                                                                    const float* __restrict__ shift, const float* __restrict__ scale,
                                                                    float* __restrict__ ws, long long P, int C, int dyCs, int xCs, int dxCs,
                                                                    long long per_wg) {
     __shared__ float4 red[2][256];
-    const void* const dy_ = tab.p[blockIdx.y];
     const int Cq = (C + 3) / 4, PL = 256 / Cq;                 // position lanes per workgroup (host: Cq <= 256)
     const int q = threadIdx.x % Cq, pl = threadIdx.x / Cq;
     const bool live = pl < PL;
@@ -171,7 +168,7 @@ __global__ __launch_bounds__(256) void channel_sums_partial_kernel(const Channel
             const float4 u = red[0][i * Cq + q], v = red[1][i * Cq + q];
             a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
         }
-        float4* o = reinterpret_cast<float4*>(ws) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * Cq;
+        float4* o = reinterpret_cast<float4*>(ws) + (size_t)blockIdx.x * 2 * Cq;
         o[q] = a; o[Cq + q] = b;
     }
 }
@@ -245,31 +242,24 @@ extern "C" size_t osa_channel_sums_workspace_bytes(long long P, int C) {
     return (size_t)channel_sums_wgs(P, C) * 2 * ((C + 3) / 4) * 4 * sizeof(float);
 }
 
-static int channel_sums_impl(const void* const* dys, int n_items, int dy_f16, int dy_cs, const void* x, int x_f16, int x_cs, const float* x_shift,
-                             const float* dx_scale, void* dx, int dx_cs, long long P, int C,
-                             float* out, float* workspace, size_t workspace_bytes, void* stream) {
-    OSA_REQUIRE(dys && out && workspace && n_items >= 1 && n_items <= 24, "channel_sums: NULL pointer, or %d items outside 1..24", n_items);
+extern "C" int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const void* x, int x_f16, int x_cs, const float* x_shift,
+                                const float* dx_scale, void* dx, int dx_cs, long long P, int C,
+                                float* out, float* workspace, size_t workspace_bytes, void* stream) {
+    OSA_REQUIRE(dy && out && workspace, "channel_sums: NULL pointer");
     OSA_REQUIRE(P > 0 && C > 0 && C <= 1024, "channel_sums: bad dims P=%lld C=%d (C <= 1024)", P, C);
     OSA_REQUIRE(dy_cs >= C && (x == nullptr || x_cs >= C) && (dx == nullptr || dx_cs >= C), "channel_sums: channel stride < C");
     // full quads are loaded / stored as 8- or 16-byte vectors
     auto vec_ok = [&](const void* t, int f16, int cs) { return cs % 4 == 0 && ((size_t)t & (f16 ? 7 : 15)) == 0; };
-    ChannelSumsTab tab;
-    memset(&tab, 0, sizeof(tab));
-    for (int i = 0; i < n_items; ++i) {
-        OSA_REQUIRE(dys[i] && vec_ok(dys[i], dy_f16, dy_cs), "channel_sums: tensors need channel strides %% 4 == 0 and 16-byte (fp16: 8-byte) alignment");
-        tab.p[i] = dys[i];
-    }
-    OSA_REQUIRE((x == nullptr || vec_ok(x, x_f16, x_cs)) && (dx == nullptr || vec_ok(dx, dy_f16, dx_cs)),
+    OSA_REQUIRE(vec_ok(dy, dy_f16, dy_cs) && (x == nullptr || vec_ok(x, x_f16, x_cs)) && (dx == nullptr || vec_ok(dx, dy_f16, dx_cs)),
                 "channel_sums: tensors need channel strides %% 4 == 0 and 16-byte (fp16: 8-byte) alignment");
     OSA_REQUIRE((dx == nullptr) == (dx_scale == nullptr), "channel_sums: dx and dx_scale come together");
-    OSA_REQUIRE(n_items == 1 || (x == nullptr && dx == nullptr), "channel_sums: a tensor list has sums of dy only");
-    const size_t need = (size_t)n_items * osa_channel_sums_workspace_bytes(P, C);
+    const size_t need = osa_channel_sums_workspace_bytes(P, C);
     OSA_REQUIRE(workspace_bytes >= need && ((size_t)workspace & 15) == 0, "channel_sums: workspace of %zu B needed (got %zu)", need, workspace_bytes);
     const int nwg = channel_sums_wgs(P, C);
     const long long per = (P + nwg - 1) / nwg;
     hipStream_t st = (hipStream_t)stream;
     const int key = (dy_f16 ? 8 : 0) | (x ? ((x_f16 ? 4 : 0) | 2) : 0) | (dx ? 1 : 0);
-#define OSA_CS(DYF, XF, WX, WD) hipLaunchKernelGGL((channel_sums_partial_kernel<DYF, XF, WX, WD>), dim3(nwg, n_items), dim3(256), 0, st, tab, x, dx, x_shift, dx_scale, workspace, P, C, dy_cs, x_cs, dx_cs, per)
+#define OSA_CS(DYF, XF, WX, WD) hipLaunchKernelGGL((channel_sums_partial_kernel<DYF, XF, WX, WD>), dim3(nwg), dim3(256), 0, st, dy, x, dx, x_shift, dx_scale, workspace, P, C, dy_cs, x_cs, dx_cs, per)
     switch (key) {
         case 0: OSA_CS(0, 0, 0, 0); break;   case 1: OSA_CS(0, 0, 0, 1); break;
         case 2: OSA_CS(0, 0, 1, 0); break;   case 3: OSA_CS(0, 0, 1, 1); break;
@@ -281,20 +271,7 @@ static int channel_sums_impl(const void* const* dys, int n_items, int dy_f16, in
     }
 #undef OSA_CS
     const int nwhich = x ? 2 : 1;
-    hipLaunchKernelGGL(channel_sums_final_kernel, dim3(cdiv(nwhich * ((C + 3) / 4), 256)), dim3(256), 0, st, workspace, out, C, nwg * n_items, nwhich);
+    hipLaunchKernelGGL(channel_sums_final_kernel, dim3(cdiv(nwhich * ((C + 3) / 4), 256)), dim3(256), 0, st, workspace, out, C, nwg, nwhich);
     OSA_LAUNCH_CHECK("channel_sums");
     return 0;
-}
-
-extern "C" int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const void* x, int x_f16, int x_cs, const float* x_shift,
-                                const float* dx_scale, void* dx, int dx_cs, long long P, int C,
-                                float* out, float* workspace, size_t workspace_bytes, void* stream) {
-    return channel_sums_impl(&dy, 1, dy_f16, dy_cs, x, x_f16, x_cs, x_shift, dx_scale, dx, dx_cs, P, C, out, workspace, workspace_bytes, stream);
-}
-
-/* sums of dy over a LIST of n_items (<= 24) equally shaped tensors of P positions each (the queued output gradients of one biased convolution);
- * workspace: n_items x osa_channel_sums_workspace_bytes(P, C) */
-extern "C" int osa_channel_sums_multi(const void* const* dys, int n_items, int dy_f16, int dy_cs, long long P, int C,
-                                      float* out, float* workspace, size_t workspace_bytes, void* stream) {
-    return channel_sums_impl(dys, n_items, dy_f16, dy_cs, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, P, C, out, workspace, workspace_bytes, stream);
 }

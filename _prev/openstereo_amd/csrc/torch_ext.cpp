@@ -300,38 +300,6 @@ bool conv_wgrad(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, at::In
     return true;
 }
 
-// the same over a LIST of equally shaped (x, dy) pairs in one launch (osa_conv3d_wgrad_ws_multi): dims[0] = the TOTAL batch over all items
-bool conv_wgrad_multi(at::TensorList xs, at::TensorList dys, at::Tensor dw, at::IntArrayRef dims, int64_t prec, const c10::optional<at::Tensor>& x_meta,
-                      const c10::optional<at::Tensor>& dy_meta) {
-    gpu_f32(dw, "dw");
-    TORCH_CHECK(xs.size() >= 1 && xs.size() <= 24 && xs.size() == dys.size(), "conv_wgrad_multi: 1..24 (x, dy) pairs");
-    const bool xh = xs[0].scalar_type() == at::kHalf, dyh = dys[0].scalar_type() == at::kHalf;
-    std::vector<const void*> xp, dp;
-    for (size_t i = 0; i < xs.size(); ++i) {
-        TORCH_CHECK(xs[i].is_cuda() && dys[i].is_cuda() && xs[i].scalar_type() == xs[0].scalar_type() && dys[i].scalar_type() == dys[0].scalar_type() &&
-                    xs[i].sizes() == xs[0].sizes() && xs[i].strides() == xs[0].strides() && dys[i].sizes() == dys[0].sizes() && dys[i].strides() == dys[0].strides(),
-                    "conv_wgrad_multi: the items must agree in device, dtype, shape and strides");
-        xp.push_back(xs[i].data_ptr()); dp.push_back(dys[i].data_ptr());
-    }
-    TORCH_CHECK((xh || xs[0].scalar_type() == at::kFloat) && (dyh || dys[0].scalar_type() == at::kFloat), "conv_wgrad_multi: fp32 or fp16 tensors");
-    TORCH_CHECK(prec == 2 || (!xh && !dyh), "conv_wgrad_multi: fp16 tensors exist in the native f16 form only (prec 2)");
-    TORCH_CHECK(dims.size() == 22, "conv_wgrad_multi: dims = [B total, D, H, W, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride, pad x3, dil x3, transposed]");
-    int d[22];
-    for (int i = 0; i < 22; ++i) d[i] = (int)dims[i];
-    const size_t need = prec == 0
-        ? osa_conv3d_wgrad_workspace_bytes(d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21])
-        : osa_conv3d_wgrad_f16x3_workspace_bytes(d[0], d[1], d[2], d[3], d[4], d[6], d[7], d[8], d[9], d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21]);
-    if (need == 0) {
-        TORCH_CHECK(prec != 0, "conv_wgrad_multi: unsupported layer");
-        return false;
-    }
-    auto ws = at::empty({(int64_t)((need + 3) / 4)}, dw.options());
-    OSA_CALL(osa_conv3d_wgrad_ws_multi((int)prec, xp.data(), dp.data(), (int)xs.size(), dw.data_ptr<float>(), d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10],
-                                       d[11], d[12], d[13], d[14], d[15], d[16], d[17], d[18], d[19], d[20], d[21], fpo(x_meta), fpo(dy_meta), xh ? 1 : 0, dyh ? 1 : 0,
-                                       ws.data_ptr<float>(), need, cur_stream()));
-    return true;
-}
-
 // ---- layout, packing, ConvGRU gates, geometry-encoding lookup: the remaining per-step launches of the training path --------------------
 // x [B, C, ...S] contiguous NCDHW -> channels [c_off, c_off + C) of the NDHWC tensor y (voxel stride = y's channel stride)
 void to_cl(const at::Tensor& x, at::Tensor y, int64_t C, int64_t S, int64_t c_off) {
@@ -652,26 +620,6 @@ std::tuple<at::Tensor, at::Tensor> channel_sums_meta(const at::Tensor& dy, const
     return std::make_tuple(at::empty({hx ? 2 : 1, C}, dy.options().dtype(at::kFloat)), hd ? at::empty_strided(dy.sizes(), dy.strides(), dy.options()) : at::empty({0}, dy.options()));
 }
 
-at::Tensor channel_sums_multi(at::TensorList dys, int64_t P, int64_t C, int64_t dy_cs) {
-    TORCH_CHECK(dys.size() >= 1 && dys.size() <= 24, "channel_sums_multi: 1..24 tensors");
-    const bool dyh = dys[0].scalar_type() == at::kHalf;
-    std::vector<const void*> ptr;
-    for (const auto& t : dys) {
-        TORCH_CHECK(t.is_cuda() && t.scalar_type() == dys[0].scalar_type() && t.sizes() == dys[0].sizes() && t.strides() == dys[0].strides() && (dyh || t.scalar_type() == at::kFloat),
-                    "channel_sums_multi: CUDA fp32 / fp16 tensors of one dtype, shape and stride set");
-        ptr.push_back(t.data_ptr());
-    }
-    const size_t need = dys.size() * osa_channel_sums_workspace_bytes((long long)P, (int)C);
-    TORCH_CHECK(need != 0, "channel_sums_multi: unsupported dims");
-    at::Tensor out = at::empty({1, C}, dys[0].options().dtype(at::kFloat));
-    at::Tensor ws = at::empty({(int64_t)((need + 3) / 4)}, dys[0].options().dtype(at::kFloat));
-    OSA_CALL(osa_channel_sums_multi(ptr.data(), (int)dys.size(), dyh ? 1 : 0, (int)dy_cs, (long long)P, (int)C, out.data_ptr<float>(), ws.data_ptr<float>(), need, cur_stream()));
-    return out;
-}
-at::Tensor channel_sums_multi_meta(at::TensorList dys, int64_t P, int64_t C, int64_t dy_cs) {
-    return at::empty({1, C}, dys[0].options().dtype(at::kFloat));
-}
-
 void amax_into(const at::Tensor& t, at::Tensor meta) {
     gpu_f32(t, "t"); gpu_f32(meta, "meta");
     OSA_CALL(osa_amax_f32(fp(t), (long long)t.numel(), meta.data_ptr<float>(), cur_stream()));
@@ -866,11 +814,6 @@ bool conv_wgrad_meta(const at::Tensor& x, const at::Tensor& dy, at::Tensor dw, a
     (void)x; (void)dy; (void)dw; (void)x_meta; (void)dy_meta;
     return need != 0;
 }
-bool conv_wgrad_multi_meta(at::TensorList xs, at::TensorList dys, at::Tensor dw, at::IntArrayRef dims, int64_t prec, const c10::optional<at::Tensor>& x_meta,
-                           const c10::optional<at::Tensor>& dy_meta) {
-    TORCH_CHECK(dims.size() == 22 && xs.size() >= 1 && xs.size() == dys.size(), "conv_wgrad_multi: dims of 22 entries, equally long lists");
-    return conv_wgrad_meta(xs[0], dys[0], dw, dims, prec, x_meta, dy_meta);
-}
 
 }  // namespace
 
@@ -893,7 +836,6 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("cost_volume_cl(Tensor gwc_feat, Tensor? cat_feat, int B, int num_groups, int maxdisp, int gwc_channels, int cat_channels, int gwc_off, bool mask_left, "
           "bool out_split, Tensor? gwc_meta, Tensor? cat_meta, Tensor(a!) out_meta) -> (Tensor, bool)");
     m.def("conv_wgrad(Tensor x, Tensor dy, Tensor(a!) dw, int[] dims, int prec, Tensor? x_meta, Tensor? dy_meta) -> bool");
-    m.def("conv_wgrad_multi(Tensor[] xs, Tensor[] dys, Tensor(a!) dw, int[] dims, int prec, Tensor? x_meta, Tensor? dy_meta) -> bool");
     m.def("to_cl(Tensor x, Tensor(a!) y, int C, int S, int c_off) -> ()");
     m.def("to_ncdhw(Tensor x, Tensor(a!) y, int C, int S, int c_off) -> ()");
     m.def("conv_pack(Tensor w, Tensor(a!) packed, int[] geom, int prec, Tensor? w_amax, Tensor(b!)? scale_out) -> ()");
@@ -922,7 +864,6 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("cat_fms(Tensor reference_fm, Tensor target_fm, Tensor(a!) out, Tensor disp_index) -> ()");
     m.def("pair_volume(Tensor left, Tensor right, Tensor(a!) out, int groups, int planes, int mode) -> ()");
     m.def("channel_sums(Tensor dy, Tensor? x, Tensor? x_shift, Tensor? dx_scale, int P, int C, int dy_cs, int x_cs) -> (Tensor, Tensor)");
-    m.def("channel_sums_multi(Tensor[] dys, int P, int C, int dy_cs) -> Tensor");
     m.def("instnorm_nhwc(Tensor x, Tensor(a!) out, int out_off, int[] dims, float eps, int act, float slope, Tensor(b!) workspace, Tensor(c!)? y_meta) -> ()");
     m.def("preprocess_pair(Tensor left_hwc, Tensor right_hwc, Tensor(a!) out, int[] pad_size, float[] mean, float[] std, bool channels_last) -> ()");
     m.def("amax_into(Tensor t, Tensor(a!) meta) -> ()");
@@ -943,7 +884,6 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("upsample_softargmin_bwd", &upsample_softargmin_bwd);
     m.impl("cost_volume_cl", &cost_volume_cl);
     m.impl("conv_wgrad", &conv_wgrad);
-    m.impl("conv_wgrad_multi", &conv_wgrad_multi);
     m.impl("to_cl", &to_cl);
     m.impl("to_ncdhw", &to_ncdhw);
     m.impl("conv_pack", &conv_pack);
@@ -970,7 +910,6 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("pair_volume", &pair_volume);
     m.impl("instnorm_nhwc", &instnorm_nhwc);
     m.impl("channel_sums", &channel_sums);
-    m.impl("channel_sums_multi", &channel_sums_multi);
     m.impl("preprocess_pair", &preprocess_pair);
     m.impl("amax_into", &amax_into);
 }
@@ -990,9 +929,7 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     // r6: every launch op -- an engine model traces under FakeTensorMode / make_fx without a kernel running (tests/test_gpu_fake_trace.py)
     m.impl("cost_volume_cl", &cost_volume_cl_meta);
     m.impl("conv_wgrad", &conv_wgrad_meta);
-    m.impl("conv_wgrad_multi", &conv_wgrad_multi_meta);
     m.impl("channel_sums", &channel_sums_meta);
-    m.impl("channel_sums_multi", &channel_sums_multi_meta);
     for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",
                              "geo_lookup", "geo_lookup_bwd", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
                              "geo_lookup_nhwc", "allpairs_corr", "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair",

@@ -20,7 +20,6 @@
 // (3.65 ms per launch at the 320x736 training crop).
 #include "osa_common.h"
 #include <cstring>
-#include <cstddef>
 
 namespace osa {
 
@@ -53,20 +52,8 @@ struct WgradArgs {
     signed char g_slot[16][9];                 // accumulator slot dh * 3 + dw -> tap index inside the group, or -1
     const float* Pmeta; const float* Qmeta;   // f16x3 form: range blocks (max |.|) of the P and Q tensors
     int Pf16, Qf16;                            // native f16 form (r5): the P / Q tensor holds fp16 elements (channel strides PCs / QCs in elements)
-    // r6: the batch may be a LIST of equally shaped tensors (the queued (x, dy) pairs of a weight applied several times in one step): item
-    // i = batch entries [i * bper, (i + 1) * bper) lives at Ptab[i] / Qtab[i]; ntab = 0: one tensor each at P / Q
-    const void* Ptab[24]; const void* Qtab[24];
-    int ntab, bper;
     int dbg;                                  // experiments build (OSA_WG_DBG): timing-only ablations of wgrad_f16x3_kernel -- 1 no global loads, 2 no LDS commit, 4 no MFMA phase, 8 no hand-over
 };
-
-// entry i of a pointer table inside the kernel argument (the ONLY kernel parameter: offset 0 of the kernarg segment) -- read through the
-// kernarg pointer with a scalar load: indexing the by-value struct dynamically makes the compiler copy all of it (1 KB) to scratch
-__device__ __forceinline__ const void* wg_tab(size_t table_offset, int i) {
-    typedef const char __attribute__((address_space(4))) kchar;
-    kchar* ka = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
-    return *reinterpret_cast<const void* const __attribute__((address_space(4)))*>(ka + table_offset + (size_t)i * sizeof(void*));
-}
 
 template <int TD, int TH, int TW>     // position brick, TD*TH*TW = 256 (64 per wave) or 64 (16 per wave)
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
@@ -98,9 +85,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int sw = sidx % nstripsW; sidx /= nstripsW;
     const int thi = sidx % p.tilesH; sidx /= p.tilesH;
     const int tdi = sidx % p.tilesD; const int b = sidx / p.tilesD;
-    const int bl = p.ntab ? b % p.bper : b;
-    const float* const Pbase = p.ntab ? static_cast<const float*>(wg_tab(offsetof(WgradArgs, Ptab), b / p.bper)) : p.P;
-    const float* const Qbase = p.ntab ? static_cast<const float*>(wg_tab(offsetof(WgradArgs, Qtab), b / p.bper)) : p.Q;
 
     f32x16 acc[WG_TAPS];
 #pragma unroll
@@ -119,7 +103,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const int gd = p0d + pd, gh = p0h + ph, gw = p0w + pw;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gd < p.Pd && gh < p.Ph && gw < p.Pw) {
-                const float* src = Pbase + ((((size_t)bl * p.Pd + gd) * p.Ph + gh) * p.Pw + gw) * p.PCs + a0 + c4 * 4;
+                const float* src = p.P + ((((size_t)b * p.Pd + gd) * p.Ph + gh) * p.Pw + gw) * p.PCs + a0 + c4 * 4;
                 if (a0 + c4 * 4 + 3 < p.PC) v = *reinterpret_cast<const float4*>(src);
                 else { if (a0 + c4 * 4 < p.PC) v.x = src[0]; if (a0 + c4 * 4 + 1 < p.PC) v.y = src[1]; if (a0 + c4 * 4 + 2 < p.PC) v.z = src[2]; }
             }
@@ -134,7 +118,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             if (p.cls) { gd = 2 * gd + pard; gh = 2 * gh + parh; gw = 2 * gw + parw; }      // sub-lattice -> tensor coordinates
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh && (unsigned)gw < (unsigned)p.Qw) {
-                const float* src = Qbase + ((((size_t)bl * p.Qd + gd) * p.Qh + gh) * p.Qw + gw) * p.QCs + b0 + c4 * 4;
+                const float* src = p.Q + ((((size_t)b * p.Qd + gd) * p.Qh + gh) * p.Qw + gw) * p.QCs + b0 + c4 * 4;
                 if (b0 + c4 * 4 + 3 < p.QC) v = *reinterpret_cast<const float4*>(src);
                 else { if (b0 + c4 * 4 < p.QC) v.x = src[0]; if (b0 + c4 * 4 + 1 < p.QC) v.y = src[1]; if (b0 + c4 * 4 + 2 < p.QC) v.z = src[2]; }
             }
@@ -275,9 +259,6 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
     const int sw = sidx % nstripsW; sidx /= nstripsW;
     const int thi = sidx % p.tilesH; sidx /= p.tilesH;
     const int tdi = sidx % p.tilesD; const int b = sidx / p.tilesD;
-    const int bl = p.ntab ? b % p.bper : b;
-    const float* const Pbase = p.ntab ? static_cast<const float*>(wg_tab(offsetof(WgradArgs, Ptab), b / p.bper)) : p.P;
-    const float* const Qbase = p.ntab ? static_cast<const float*>(wg_tab(offsetof(WgradArgs, Qtab), b / p.bper)) : p.Q;
     const float sP = p.Pmeta ? wg_pow2_scale(amax_read(p.Pmeta)) : 1.f, sQ = p.Qmeta ? wg_pow2_scale(amax_read(p.Qmeta)) : 1.f;
     const float inv = (1.0f / sP) * (1.0f / sQ);
 
@@ -345,14 +326,14 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         for (int k = 0; k < PIT; ++k) {
             const int gd = p0d + p_d[k], gh = p0h + p_h[k], gw = p0w + p_w[k];
             const bool row = gd < p.Pd && gh < p.Ph;
-            const size_t off = ((((size_t)bl * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
+            const size_t off = ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
             const int nc = p.PC - (a0 + p_src[k]);
             if constexpr (PF16) {
-                const _Float16* src = reinterpret_cast<const _Float16*>(Pbase) + off;
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.P) + off;
                 pv[k][0] = load4h(src, nc, row && gw < p.Pw);
                 pv[k][1] = load4h(src + p.PCs, nc, row && gw + 1 < p.Pw);
             } else {
-                const float* src = Pbase + off;
+                const float* src = p.P + off;
                 pv[k][0] = load4f(src, nc, row && gw < p.Pw);
                 pv[k][1] = load4f(src + p.PCs, nc, row && gw + 1 < p.Pw);
             }
@@ -362,14 +343,14 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
         for (int k = 0; k < QIT; ++k) {
             const int gd = qs * (q0d + q_d[k]) + pard, gh = qs * (q0h + q_h[k]) + parh, gw = qs * (q0w + q_w[k]) + parw;   // tensor coordinates
             const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
-            const size_t off = ((((size_t)bl * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
+            const size_t off = ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
             const int nc = p.QC - (b0 + q_src[k]);
             if constexpr (QF16) {
-                const _Float16* src = reinterpret_cast<const _Float16*>(Qbase) + off;
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.Q) + off;
                 qv[k][0] = load4h(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
                 qv[k][1] = load4h(src + qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw);
             } else {
-                const float* src = Qbase + off;
+                const float* src = p.Q + off;
                 qv[k][0] = load4f(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
                 qv[k][1] = load4f(src + qs * p.QCs, nc, row && (unsigned)(gw + qs) < (unsigned)p.Qw);
             }
@@ -589,22 +570,19 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
         const int twi = bi % p.tilesW; int t = bi / p.tilesW;
         const int thi = t % p.tilesH; t /= p.tilesH;
         const int tdi = t % p.tilesD; const int b = t / p.tilesD;
-        const int bl = p.ntab ? b % p.bper : b;
-        const float* const Pbase = p.ntab ? static_cast<const float*>(wg_tab(offsetof(WgradArgs, Ptab), b / p.bper)) : p.P;
-        const float* const Qbase = p.ntab ? static_cast<const float*>(wg_tab(offsetof(WgradArgs, Qtab), b / p.bper)) : p.Q;
         const int p0d = tdi * TD, p0h = thi * TH, p0w = twi * TW;
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
             const int gd = p0d + p_d[k], gh = p0h + p_h[k], gw = p0w + p_w[k];
             const bool row = gd < p.Pd && gh < p.Ph;
-            const size_t off = ((((size_t)bl * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
+            const size_t off = ((((size_t)b * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
             const int nc = p.PC - (a0 + p_src[k]);
             if constexpr (PF16) {
-                const _Float16* src = reinterpret_cast<const _Float16*>(Pbase) + off;
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.P) + off;
                 pv[k][0] = load4h(src, nc, row && gw < p.Pw);
                 pv[k][1] = load4h(src + p.PCs, nc, row && gw + 1 < p.Pw);
             } else {
-                const float* src = Pbase + off;
+                const float* src = p.P + off;
                 pv[k][0] = load4f(src, nc, row && gw < p.Pw);
                 pv[k][1] = load4f(src + p.PCs, nc, row && gw + 1 < p.Pw);
             }
@@ -614,14 +592,14 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
         for (int k = 0; k < QIT; ++k) {
             const int gd = q0d + q_d[k], gh = q0h + q_h[k], gw = q0w + q_w[k];
             const bool row = q_ok[k] && (unsigned)gd < (unsigned)p.Qd && (unsigned)gh < (unsigned)p.Qh;
-            const size_t off = ((((size_t)bl * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
+            const size_t off = ((((size_t)b * p.Qd + (row ? gd : 0)) * p.Qh + (row ? gh : 0)) * p.Qw + gw) * p.QCs + b0 + q_src[k];
             const int nc = p.QC - (b0 + q_src[k]);
             if constexpr (QF16) {
-                const _Float16* src = reinterpret_cast<const _Float16*>(Qbase) + off;
+                const _Float16* src = reinterpret_cast<const _Float16*>(p.Q) + off;
                 qv[k][0] = load4h(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
                 qv[k][1] = load4h(src + p.QCs, nc, row && (unsigned)(gw + 1) < (unsigned)p.Qw);
             } else {
-                const float* src = Qbase + off;
+                const float* src = p.Q + off;
                 qv[k][0] = load4f(src, nc, row && (unsigned)gw < (unsigned)p.Qw);
                 qv[k][1] = load4f(src + p.QCs, nc, row && (unsigned)(gw + 1) < (unsigned)p.Qw);
             }
@@ -767,8 +745,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
                       int kd, int kh, int kw, int stride,
                       int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
                       int transposed, float* ws, size_t ws_bytes, size_t* query, void* stream,
-                      int f16x3 = 0, const float* x_meta = nullptr, const float* dy_meta = nullptr, int x_f16 = 0, int dy_f16 = 0,
-                      const void* const* x_tab = nullptr, const void* const* dy_tab = nullptr, int n_tab = 0) {
+                      int f16x3 = 0, const float* x_meta = nullptr, const float* dy_meta = nullptr, int x_f16 = 0, int dy_f16 = 0) {
     if (!query) OSA_REQUIRE(x && dy && dw, "conv3d_wgrad: NULL pointer");
     if (x_f16 || dy_f16) OSA_REQUIRE(f16x3 == 2, "conv3d_wgrad: fp16 tensors exist in the native f16 form only");
     const int T = kd * kh * kw;
@@ -793,15 +770,6 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         a.A = Ci; a.Bc = Co;
     }
     a.dW = dw;
-    if (n_tab > 0) {
-        OSA_REQUIRE(n_tab <= 24 && B % n_tab == 0 && x_tab && dy_tab, "conv3d_wgrad: a tensor list holds at most 24 equally shaped items (got %d, batch %d)", n_tab, B);
-        a.ntab = n_tab; a.bper = B / n_tab;
-        for (int i = 0; i < n_tab; ++i) {
-            OSA_REQUIRE(x_tab[i] && dy_tab[i] && ((size_t)x_tab[i] & (x_f16 ? 7 : 15)) == 0 && ((size_t)dy_tab[i] & (dy_f16 ? 7 : 15)) == 0, "conv3d_wgrad: list item %d NULL or misaligned", i);
-            a.Ptab[i] = transposed ? x_tab[i] : dy_tab[i];
-            a.Qtab[i] = transposed ? dy_tab[i] : x_tab[i];
-        }
-    }
     int t = 0, dmax = -128, hmax = -128, wmax = -128;
     a.dmin = a.hmin = a.wmin = 127;
     for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int xx = 0; xx < kw; ++xx, ++t) {
@@ -1134,22 +1102,4 @@ extern "C" int osa_conv3d_wgrad_ws_f16(const void* x, const void* dy, float* dw,
     return wgrad_impl(static_cast<const float*>(x), static_cast<const float*>(dy), dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride,
                       pad_d, pad_h, pad_w, dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, 2, x_meta, dy_meta,
                       x_f16 ? 1 : 0, dy_f16 ? 1 : 0);
-}
-
-/* The weight gradient over a LIST of equally shaped (x, dy) tensor pairs -- the uses of one weight within a training step (the update
- * block applies every convolution once per GRU iteration: 22 pairs) -- in ONE launch, without concatenating them: batch entry b of the
- * launch is entry b % (B / n_items) of item b / (B / n_items).  form: 0 = exact fp32 kernel, 1 = f16x3 (range blocks required), 2 = native
- * f16 (x_f16 / dy_f16 as in osa_conv3d_wgrad_ws_f16).  B = total batch over all items; workspace as for one tensor of batch B. */
-extern "C" int osa_conv3d_wgrad_ws_multi(int form, const void* const* xs, const void* const* dys, int n_items, float* dw,
-                                         int B, int Di, int Hi, int Wi, int Ci, int xCs,
-                                         int Do, int Ho, int Wo, int Co, int dyCs,
-                                         int kd, int kh, int kw, int stride,
-                                         int pad_d, int pad_h, int pad_w, int dil_d, int dil_h, int dil_w,
-                                         int transposed, const float* x_meta, const float* dy_meta, int x_f16, int dy_f16,
-                                         float* workspace, size_t workspace_bytes, void* stream) {
-    OSA_REQUIRE(workspace && xs && dys && n_items >= 1 && n_items <= 24, "conv3d_wgrad_ws_multi: NULL workspace / lists, or n_items %d outside 1..24", n_items);
-    OSA_REQUIRE(form >= 0 && form <= 2 && (form == 2 || (!x_f16 && !dy_f16)), "conv3d_wgrad_ws_multi: form %d (fp16 tensors exist in form 2 only)", form);
-    return wgrad_impl(static_cast<const float*>(xs[0]), static_cast<const float*>(dys[0]), dw, B, Di, Hi, Wi, Ci, xCs, Do, Ho, Wo, Co, dyCs, kd, kh, kw, stride,
-                      pad_d, pad_h, pad_w, dil_d, dil_h, dil_w, transposed, workspace, workspace_bytes, nullptr, stream, form, x_meta, dy_meta,
-                      x_f16 ? 1 : 0, dy_f16 ? 1 : 0, xs, dys, n_items);
 }

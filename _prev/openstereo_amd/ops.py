@@ -501,21 +501,3 @@ def channel_sums(dy: torch.Tensor, x: torch.Tensor | None = None, x_shift: torch
     _lib.call("osa_channel_sums", dy.data_ptr(), int(dy.dtype == torch.float16), cs, _p(x), int(x is not None and x.dtype == torch.float16), xcs,
               _p(sh), _p(sc), _p(dx), cs, P, C, out.data_ptr(), ws.data_ptr(), need, _stream())
     return out, dx
-
-
-def channel_sums_list(dys):
-    """sum_p dy over a list of equally shaped and strided tensors (osa_channel_sums_multi): [C] fp32, one launch, no concatenation"""
-    P, C, cs = cl_rows(dys[0])
-    ext = _ext.load()
-    if ext is not None:
-        return ext.channel_sums_multi(list(dys), P, C, cs)[0]
-    import ctypes
-    lib = _lib.load()
-    need = len(dys) * lib.osa_channel_sums_workspace_bytes(P, C)
-    if not need:
-        raise _lib.EngineError(f"osa_channel_sums_multi: unsupported dims P={P} C={C}")
-    out = torch.empty((1, C), device=dys[0].device, dtype=torch.float32)
-    ws = torch.empty((need + 3) // 4, device=dys[0].device, dtype=torch.float32)
-    _lib.call("osa_channel_sums_multi", (ctypes.c_void_p * len(dys))(*[t.data_ptr() for t in dys]), len(dys), int(dys[0].dtype == torch.float16), cs, P, C,
-              out.data_ptr(), ws.data_ptr(), need, _stream())
-    return out[0]

@@ -163,3 +163,32 @@ def test_multi_tile_wgrad_vs_single_tile(case, prec):
     scale = float(want.abs().max())
     assert float((got["mt"] - got["single"]).abs().max()) <= 2e-5 * scale
     assert float((got["mt"] - want).abs().max()) <= (3e-3 if prec == "f16" else 2e-5) * scale
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+@pytest.mark.parametrize("case", [("2d 128->256", 128, 256, (1, 3, 3), (1, 20, 46)), ("2d 64->36 k1", 64, 36, (1, 1, 1), (1, 17, 33)), ("3d 32->32", 32, 32, (3, 3, 3), (4, 10, 19))])
+def test_wgrad_over_a_list_equals_the_concatenation(case, prec):
+    """osa_conv3d_wgrad_ws_multi: three equally shaped (x, dy) pairs as a list of tensors vs the same pairs concatenated along the batch --
+    the same kernels with per-item base pointers: bit-identical"""
+    from openstereo_amd import autograd as AG, ops
+    from openstereo_amd.ranges import combine_meta, input_meta
+    _, Ci, Co, k, (D, H, W) = case
+    xs = [ops.to_cl(rn((1, Ci, D, H, W), 30 + i).to(DEV)) for i in range(3)]
+    dys = [ops.to_cl((rn((1, Co, D, H, W), 40 + i) * 1e-2).to(DEV)) for i in range(3)]
+    pad = tuple(kk // 2 for kk in k)
+    mx, md = combine_meta(*[input_meta(t) for t in xs]), combine_meta(*[input_meta(t) for t in dys])
+    a, b = torch.empty(Co, Ci, *k, device=DEV), torch.empty(Co, Ci, *k, device=DEV)
+    AG._wgrad(xs, dys, a, 3, D, H, W, Ci, D, H, W, Co, k, 1, pad, (1, 1, 1), 0, prec, mx, md)
+    AG._wgrad(AG._cat_batch(xs), AG._cat_batch(dys), b, 3, D, H, W, Ci, D, H, W, Co, k, 1, pad, (1, 1, 1), 0, prec, mx, md)
+    assert float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_channel_sums_over_a_list(dtype):
+    from openstereo_amd import ops
+    C = 128
+    ts = [_cl(rn((1, C, 20, 46), 50 + i).to(DEV).to(dtype)) for i in range(5)]
+    got = ops.channel_sums_list(ts)
+    want = sum(t.double().sum((0, 2, 3)) for t in ts)
+    assert got.shape == (C,) and float((got.double() - want).abs().max()) <= 2e-6 * float(sum(t.double().abs().sum((0, 2, 3)) for t in ts).max())
+    assert torch.equal(got, ops.channel_sums_list(ts))
