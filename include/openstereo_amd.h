@@ -543,6 +543,13 @@ int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* dcorr_levels
                            const int* geo_len, const int* corr_len, int levels,
                            const float* disp, const float* coords_x, const float* dout,
                            int B, int H, int W, int C, int radius, void* stream);
+/* The same gradient ACCUMULATED into dgeo_levels / dcorr_levels (r6): the caller zero-fills them once per training step and calls this for
+ * every lookup of the step (one per GRU iteration, igev_stereo.py:181-203); only the (C+1) x (2r+2) entries per (pixel, level) a lookup's
+ * taps reach are touched (read-modify-write, no atomics: a pixel owns its rows) -- instead of 22 dense gradients that autograd adds up. */
+int osa_geo_lookup_bwd_acc_f32(float* const* dgeo_levels, float* const* dcorr_levels,
+                               const int* geo_len, const int* corr_len, int levels,
+                               const float* disp, const float* coords_x, const float* dout,
+                               int B, int H, int W, int C, int radius, void* stream);
 
 /* ---- input pre-processing on device ------------------------- */
 /* RightTopPad(edge) + HWC->CHW + /255 + (x-mean)/std for the left and right image in one launch

@@ -160,6 +160,8 @@ SIGNATURES = {
                                  c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_geo_lookup_nhwc_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
                                       c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),
+    "osa_geo_lookup_bwd_acc_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
+                                         c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_geo_lookup_bwd_f32": (c_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i), C.POINTER(c_i), c_i,
                                      c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_preprocess_pair_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_f), C.POINTER(c_f), c_fp, c_i, c_st]),

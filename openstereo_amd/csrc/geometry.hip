@@ -11,6 +11,7 @@
 //                    [B, (C+1)*(2r+1)*levels, H, W] tensor in one pass instead of 4 grid_sample calls + cats per iteration.
 // All memory-bound; lanes run along w (outputs) or along the contiguous row axis (transposes).
 #include "osa_common.h"
+#include <cstring>
 
 namespace osa {
 
@@ -372,6 +373,53 @@ __global__ __launch_bounds__(256) void geo_lookup_bwd_rows_kernel(const LookupBw
     }
 }
 
+
+// Accumulating form (r6): the reference's loop looks the SAME pyramid up once per GRU iteration (igev_stereo.py:181-203: 22 iterations in
+// training), so autograd used to receive 22 dense gradients per level (50 MB each at the 320x736 crop, 98 % zeros) and add them up.  Here
+// the level gradients are accumulators the caller zero-fills once per step; a lookup's backward touches only the (C + 1) x (taps + 1)
+// entries per (pixel, level) its taps reach: one thread per entry, a read-modify-write without atomics (every pixel owns its rows, and
+// the entries of one row are distinct positions) -- 2.6 M entries instead of 12.5 M written and 12.5 M added per iteration.
+__global__ __launch_bounds__(256) void geo_lookup_bwd_acc_kernel(const LookupBwdGatherArgs p) {
+    const long long HW = (long long)p.H * p.W;
+    const int taps = 2 * p.radius + 1;
+    const int per_px = (p.C + 1) * (taps + 1);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (t >= (long long)p.B * HW * per_px) return;
+    const long long i = t / per_px;                                      // pixel
+    const int e = (int)(t - i * per_px);
+    const int c = e / (taps + 1), jj = e - c * (taps + 1);               // row (c == C: the correlation row), entry of the tap window
+    const long long b = i / HW, hw = i - b * HW;
+    float scale = 1.f;
+    for (int q = 0; q < l; ++q) scale *= 0.5f;
+    const float d = p.disp[i], cx = p.coords[i];
+    const bool geo = c < p.C;
+    const float x = geo ? d * scale : cx * scale - d * scale;
+    const int n = geo ? p.Dl[l] : p.Wl[l];
+    const int per_level = (p.C + 1) * taps;
+    const float* o = p.dout + (size_t)b * per_level * p.levels * HW + hw + ((size_t)l * per_level + (size_t)c * taps) * HW;
+    // entry jj is position x0(tap jj) (= x0(tap jj - 1) + 1): tap jj - 1 reaches it with its w1, tap jj with its w0 -- the order in which
+    // the dense kernels add them
+    float v = 0.f;
+    int j;
+    if (jj < taps) {
+        const Tap tk = tap_of((float)(jj - p.radius) + x, n);
+        j = tk.x0;
+        if (jj >= 1) {
+            const Tap tp = tap_of((float)(jj - 1 - p.radius) + x, n);
+            if (tp.x0 + 1 == j) v += o[(size_t)(jj - 1) * HW] * tp.w1;
+        }
+        v += o[(size_t)jj * HW] * tk.w0;
+    } else {
+        const Tap tp = tap_of((float)(jj - 1 - p.radius) + x, n);
+        j = tp.x0 + 1;
+        v += o[(size_t)(jj - 1) * HW] * tp.w1;
+    }
+    if (j < 0 || j >= n) return;
+    float* dst = geo ? p.dgeo[l] + ((size_t)i * p.C + c) * n + j : p.dcorr[l] + (size_t)i * n + j;
+    *dst += v;
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -417,6 +465,27 @@ extern "C" int osa_geo_lookup_bwd_f32(float* const* dgeo_levels, float* const* d
     a.B = B; a.H = H; a.W = W; a.C = C; a.levels = levels; a.radius = radius;
     hipLaunchKernelGGL(geo_lookup_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
     OSA_LAUNCH_CHECK("geo_lookup_bwd");
+    return 0;
+}
+
+extern "C" int osa_geo_lookup_bwd_acc_f32(float* const* dgeo_levels, float* const* dcorr_levels,
+                                          const int* geo_len, const int* corr_len, int levels,
+                                          const float* disp, const float* coords_x, const float* dout,
+                                          int B, int H, int W, int C, int radius, void* stream) {
+    OSA_REQUIRE(dgeo_levels && dcorr_levels && geo_len && corr_len && disp && coords_x && dout, "geo_lookup_bwd_acc: NULL pointer");
+    OSA_REQUIRE(levels >= 1 && levels <= 4 && radius >= 0 && C >= 1, "geo_lookup_bwd_acc: %d levels / radius %d unsupported", levels, radius);
+    LookupBwdGatherArgs g;
+    memset(&g, 0, sizeof(g));
+    for (int l = 0; l < levels; ++l) {
+        OSA_REQUIRE(dgeo_levels[l] && dcorr_levels[l] && geo_len[l] > 0 && corr_len[l] > 0, "geo_lookup_bwd_acc: level %d missing", l);
+        g.dgeo[l] = dgeo_levels[l]; g.dcorr[l] = dcorr_levels[l]; g.Dl[l] = geo_len[l]; g.Wl[l] = corr_len[l];
+    }
+    g.disp = disp; g.coords = coords_x; g.dout = dout;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.levels = levels; g.radius = radius;
+    const long long n = (long long)B * H * W * (C + 1) * (2 * radius + 2);
+    OSA_REQUIRE((n + 255) / 256 < (1ll << 31), "geo_lookup_bwd_acc: grid too large");
+    hipLaunchKernelGGL(geo_lookup_bwd_acc_kernel, dim3((unsigned)((n + 255) / 256), levels), dim3(256), 0, (hipStream_t)stream, g);
+    OSA_LAUNCH_CHECK("geo_lookup_bwd_acc");
     return 0;
 }
 

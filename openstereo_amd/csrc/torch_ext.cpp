@@ -421,7 +421,7 @@ void geo_lookup(at::TensorList levels, const at::Tensor& disp, const at::Tensor&
     }
     OSA_CALL(osa_geo_lookup_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), out.data_ptr<float>(), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
 }
-void geo_lookup_bwd(at::TensorList dlevels, const at::Tensor& disp, const at::Tensor& coords_x, const at::Tensor& dout, int64_t C, int64_t radius) {
+static void geo_lookup_bwd_any(bool acc, at::TensorList dlevels, const at::Tensor& disp, const at::Tensor& coords_x, const at::Tensor& dout, int64_t C, int64_t radius) {
     const size_t L = dlevels.size() / 2;
     TORCH_CHECK(L >= 1 && L <= 4 && dlevels.size() == 2 * L, "geo_lookup_bwd: dlevels = gradients of the geo pyramid + of the corr pyramid");
     gpu_f32(disp, "disp"); gpu_f32(coords_x, "coords_x"); gpu_f32(dout, "dout");
@@ -430,7 +430,14 @@ void geo_lookup_bwd(at::TensorList dlevels, const at::Tensor& disp, const at::Te
         gp[l] = gpu_f32(dlevels[l], "dgeo level").data_ptr<float>(); cp[l] = gpu_f32(dlevels[L + l], "dcorr level").data_ptr<float>();
         gl[l] = (int)dlevels[l].size(-1); cl[l] = (int)dlevels[L + l].size(-1);
     }
-    OSA_CALL(osa_geo_lookup_bwd_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), fp(dout), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
+    if (acc) OSA_CALL(osa_geo_lookup_bwd_acc_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), fp(dout), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
+    else OSA_CALL(osa_geo_lookup_bwd_f32(gp, cp, gl, cl, (int)L, fp(disp), fp(coords_x), fp(dout), (int)disp.size(0), (int)disp.size(1), (int)disp.size(2), (int)C, (int)radius, cur_stream()));
+}
+void geo_lookup_bwd(at::TensorList dlevels, const at::Tensor& disp, const at::Tensor& coords_x, const at::Tensor& dout, int64_t C, int64_t radius) {
+    geo_lookup_bwd_any(false, dlevels, disp, coords_x, dout, C, radius);
+}
+void geo_lookup_bwd_acc(at::TensorList dlevels, const at::Tensor& disp, const at::Tensor& coords_x, const at::Tensor& dout, int64_t C, int64_t radius) {
+    geo_lookup_bwd_any(true, dlevels, disp, coords_x, dout, C, radius);     // accumulates into dlevels (zero-filled once per step by the caller)
 }
 
 // ---- r5, second batch: the rest of the launch path (inference helpers of the GRU loop, LightStereo's depthwise layers, weight packing, the
@@ -904,6 +911,7 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("gru_gates_q_bwd(Tensor z, Tensor qpre, Tensor? bias_q, Tensor cq, Tensor h, Tensor dout, Tensor(a!) dz, Tensor(b!) dqpre, Tensor(c!) dh) -> ()");
     m.def("geo_lookup(Tensor[] levels, Tensor disp, Tensor coords_x, Tensor(a!) out, int C, int radius) -> ()");
     m.def("geo_lookup_bwd(Tensor(a!)[] dlevels, Tensor disp, Tensor coords_x, Tensor dout, int C, int radius) -> ()");
+    m.def("geo_lookup_bwd_acc(Tensor(a!)[] dlevels, Tensor disp, Tensor coords_x, Tensor dout, int C, int radius) -> ()");
     m.def("build_volume(Tensor? left_gwc, Tensor? right_gwc, int groups, Tensor? left_cat, Tensor? right_cat, Tensor(a!) out, int layout, int vol_channels, int c_off, "
           "int maxdisp, bool mask_left, Tensor(b!)? meta) -> ()");
     m.def("deconv_redir(Tensor x, int x_off, Tensor packed, Tensor? scale, Tensor? shift, Tensor(a!) out, int out_off, int[] dims, int[] geom, Tensor rx, int[] rdims, "
@@ -954,6 +962,7 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("gru_gates_q_bwd", &gru_gates_q_bwd);
     m.impl("geo_lookup", &geo_lookup);
     m.impl("geo_lookup_bwd", &geo_lookup_bwd);
+    m.impl("geo_lookup_bwd_acc", &geo_lookup_bwd_acc);
     m.impl("build_volume", &build_volume);
     m.impl("deconv_redir", &deconv_redir);
     m.impl("small_co_conv", &small_co_conv);
@@ -994,7 +1003,7 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     m.impl("channel_sums", &channel_sums_meta);
     m.impl("channel_sums_multi", &channel_sums_multi_meta);
     for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",
-                             "geo_lookup", "geo_lookup_bwd", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
+                             "geo_lookup", "geo_lookup_bwd", "geo_lookup_bwd_acc", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
                              "geo_lookup_nhwc", "allpairs_corr", "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair",
                              "amax_into"})
         m.impl(name, torch::CppFunction::makeFromBoxedFunction<&noop_boxed>());

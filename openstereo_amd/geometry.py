@@ -16,6 +16,39 @@ from . import _ext, _lib, ops, timing
 from .ops import _f32c, _stream, is_cl
 
 
+import os
+
+ACC_LOOKUP_BWD = os.environ.get("OSA_LOOKUP_BWD_ACC", "1") != "0"
+
+
+class _LevelAcc:
+    """gradient accumulators of one pyramid (one CombinedGeoEncodingVolume = one forward): zero-filled by the first lookup backward of a
+    backward pass, added to by every lookup backward (osa_geo_lookup_bwd_acc_f32), handed to autograd ONCE by _LevelJoin.backward"""
+    __slots__ = ("acc",)
+
+    def __init__(self):
+        self.acc = None
+
+
+class _LevelJoin(torch.autograd.Function):
+    """Identity on the pyramid levels, applied once when the pyramid is built -- i.e. BEFORE every lookup, so its backward node runs after
+    all lookup backward nodes of the running backward pass (autograd's own dependency count: also right for a backward pass that reaches
+    only some of the iterations).  The lookups return no level gradients of their own; this node returns the accumulated ones."""
+
+    @staticmethod
+    def forward(ctx, state, *levels):
+        ctx.state = state
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for t in levels)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        acc, ctx.state.acc = ctx.state.acc, None
+        if acc is None:
+            return (None, *grads)
+        return (None, *[a if g is None else a + g for a, g in zip(acc, grads)])
+
+
 class _Lookup(torch.autograd.Function):
     """out = lookup(disp, coords; geo levels, corr levels) with gradients for the levels (osa_geo_lookup_bwd_f32).  The disparity is
     detached in the reference's loop (igev_stereo.py:190, stereobase_gru.py:186), so it gets none.
@@ -24,8 +57,9 @@ class _Lookup(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, d, cx, C, radius, *levels):
+    def forward(ctx, d, cx, C, radius, state, *levels):
         d, cx, levels = _f32c(d), _f32c(cx), tuple(_f32c(t) for t in levels)
+        ctx.state = state
         L = len(levels) // 2
         geo, corr = levels[:L], levels[L:]
         B, H, W = d.shape
@@ -51,18 +85,31 @@ class _Lookup(torch.autograd.Function):
         d, cx = ctx.saved_tensors
         C, radius, L, shapes = ctx.meta
         B, H, W = d.shape
-        grads = [torch.empty(s, device=d.device, dtype=torch.float32) for s in shapes]
         ext = _ext.load()
+        st = ctx.state
+        if st is not None:
+            # accumulate into the pyramid's gradient buffers; _LevelJoin delivers them (r6)
+            if st.acc is None:
+                st.acc = [torch.zeros(s, device=d.device, dtype=torch.float32) for s in shapes]
+            acc = st.acc
+            if ext is not None:
+                ext.geo_lookup_bwd_acc(acc, d, cx, _f32c(dout), C, radius)
+            else:
+                _lib.call("osa_geo_lookup_bwd_acc_f32", (ctypes.c_void_p * L)(*[t.data_ptr() for t in acc[:L]]), (ctypes.c_void_p * L)(*[t.data_ptr() for t in acc[L:]]),
+                          (ctypes.c_int * L)(*[s[-1] for s in shapes[:L]]), (ctypes.c_int * L)(*[s[-1] for s in shapes[L:]]), L,
+                          d.data_ptr(), cx.data_ptr(), _f32c(dout).data_ptr(), B, H, W, C, radius, _stream())
+            return (None, None, None, None, None, *([None] * len(shapes)))
+        grads = [torch.empty(s, device=d.device, dtype=torch.float32) for s in shapes]
         if ext is not None:
             ext.geo_lookup_bwd(grads, d, cx, _f32c(dout), C, radius)
-            return (None, None, None, None, *grads)
+            return (None, None, None, None, None, *grads)
         gp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads[:L]])
         cp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grads[L:]])
         gl = (ctypes.c_int * L)(*[s[-1] for s in shapes[:L]])
         cl = (ctypes.c_int * L)(*[s[-1] for s in shapes[L:]])
         _lib.call("osa_geo_lookup_bwd_f32", gp, cp, gl, cl, L, d.data_ptr(), cx.data_ptr(), _f32c(dout).data_ptr(),
                   B, H, W, C, radius, _stream())
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class CombinedGeoEncodingVolume:
@@ -90,6 +137,11 @@ class CombinedGeoEncodingVolume:
                 for _ in range(num_levels - 1):
                     self.geo_volume_pyramid.append(half(self.geo_volume_pyramid[-1]))
                     self.init_corr_pyramid.append(half(self.init_corr_pyramid[-1]))
+            self._acc = None
+            if ACC_LOOKUP_BWD:
+                self._acc = _LevelAcc()
+                joined = _LevelJoin.apply(self._acc, *self.geo_volume_pyramid, *self.init_corr_pyramid)
+                self.geo_volume_pyramid, self.init_corr_pyramid = list(joined[:num_levels]), list(joined[num_levels:])
             from .ranges import new_meta
             self.meta = new_meta(rows.device)
             self.meta[0:1] = torch.maximum(rows.detach().abs().amax(), corr.detach().abs().amax()).reshape(1)
@@ -143,7 +195,7 @@ class CombinedGeoEncodingVolume:
         B, H, W = self.shape
         d, cx = _f32c(disp).reshape(B, H, W), _f32c(coords).reshape(B, H, W)
         if self.train_path:
-            return _Lookup.apply(d.detach(), cx.detach(), self.C, self.radius, *self.geo_volume_pyramid, *self.init_corr_pyramid)
+            return _Lookup.apply(d.detach(), cx.detach(), self.C, self.radius, self._acc, *self.geo_volume_pyramid, *self.init_corr_pyramid)
         out = torch.empty((B, (self.C + 1) * (2 * self.radius + 1) * self.num_levels, H, W), device=d.device, dtype=torch.float32)
         with timing.span("geo_lookup", self.C, self.num_levels, self.radius, H, W):
             _lib.call("osa_geo_lookup_f32", self._gp, self._cp, self._gl, self._cl, self.num_levels,

@@ -476,7 +476,7 @@ def run_refinement(update_block, a, match_left, match_right, geo_encoding_volume
             if a.N_GRU_LAYERS >= 2 and a.SLOW_FAST_GRU:
                 net = update_block(net, inp_list, iter16=a.N_GRU_LAYERS == 3, iter08=True, iter04=False, update=False)
             net, mask, delta = update_block(net, inp_list, geo_feat, disp, iter16=a.N_GRU_LAYERS == 3, iter08=a.N_GRU_LAYERS >= 2)
-            disp = disp + delta
+            disp = disp + delta.float()         # (same values as the promoting add; fp32 + fp16 takes torch's templated mixed-dtype kernel: 88 us for 14720 elements)
         return {"disp": disp, "mask_feat_4": mask, "net_list": list(net)}
     c = nchw_to_cl
     net = [c(t) for t in net_list]

@@ -772,3 +772,37 @@ def test_inplace_activation_after_every_differentiable_conv(kind):
     F.relu(ref(xr, wr)).square().sum().backward()
     torch.testing.assert_close(xg.grad.cpu(), xr.grad, atol=2e-4, rtol=2e-4)
     torch.testing.assert_close(wg.grad.cpu(), wr.grad, atol=2e-4, rtol=2e-4)
+
+
+def test_geo_lookup_accumulated_gradients_partial_backward_and_dense_form():
+    """r6: the lookups of one pyramid accumulate their level gradients in place (osa_geo_lookup_bwd_acc_f32) and _LevelJoin hands them to
+    autograd once.  (1) equal to the dense per-lookup gradients that autograd adds up (OSA_LOOKUP_BWD_ACC=0 form) to fp32 rounding of the
+    different summation order; (2) a backward pass that reaches only ONE of three lookups delivers exactly that lookup's gradient."""
+    from openstereo_amd import geometry as G
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g)
+    B, C, D, H, W, Cf = 1, 8, 24, 6, 40, 16
+    f1, f2, gv = r(B, Cf, H, W) * 0.5, r(B, Cf, H, W) * 0.5, r(B, C, D, H, W)
+    disps = [r(B, 1, H, W).abs() * s for s in (3, 7, 11)]
+    wts = [r(B, (C + 1) * 9 * 2, H, W) for _ in disps]
+    coords = torch.arange(W).float().reshape(1, 1, W, 1).repeat(B, H, 1, 1).to(DEV)
+
+    def run(acc, which):
+        old, G.ACC_LOOKUP_BWD = G.ACC_LOOKUP_BWD, acc
+        try:
+            a, b_, v = (t.clone().to(DEV).requires_grad_() for t in (f1, f2, gv))
+            fn = G.CombinedGeoEncodingVolume(a, b_, v, num_levels=2, radius=4)
+            outs = [fn(d.to(DEV), coords) for d in disps]
+            loss = sum((outs[i] * wts[i].to(DEV)).sum() for i in which)
+            loss.backward()
+            return [t.grad.clone() for t in (a, b_, v)]
+        finally:
+            G.ACC_LOOKUP_BWD = old
+
+    for which in ((0, 1, 2), (1,)):
+        dense, acc = run(False, which), run(True, which)
+        for x, y in zip(acc, dense):
+            assert float(y.abs().max()) > 0
+            assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())
+    again = run(True, (0, 1, 2))
+    assert all(torch.equal(x, y) for x, y in zip(again, run(True, (0, 1, 2))))       # deterministic

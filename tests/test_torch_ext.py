@@ -85,7 +85,7 @@ lv = [torch.randn(1, 6, 10, 8, 12, generator=g).cuda().requires_grad_(), torch.r
       torch.randn(1, 6, 10, 12, generator=g).cuda().requires_grad_(), torch.randn(1, 6, 10, 6, generator=g).cuda().requires_grad_()]
 dsp = (torch.rand(1, 6, 10, generator=g) * 5).cuda()
 cxs = torch.arange(10).float().view(1, 1, 10).repeat(1, 6, 1).cuda()
-lo = _Lookup.apply(dsp, cxs, 8, 2, *lv)
+lo = _Lookup.apply(dsp, cxs, 8, 2, None, *lv)
 lo.square().sum().backward()
 out["geo"], out["geo_d0"], out["geo_d3"] = lo.detach().cpu().numpy(), lv[0].grad.cpu().numpy(), lv[3].grad.cpu().numpy()
 # r5 second batch: the inference loops (GRU helpers, NHWC lookup, pyramid construction, instance norm), LightStereo's depthwise layers, the

@@ -14,6 +14,7 @@ ap.add_argument("--workload", default="stereobase_e2e_train")
 ap.add_argument("--amp", action="store_true")
 ap.add_argument("--top", type=int, default=60)
 ap.add_argument("--batch", type=int, default=None)
+ap.add_argument("--stacks", default="", help="comma-separated op names (aten::copy_,aten::add_,...): device time of each grouped by Python call stack")
 a = ap.parse_args()
 import bench  # noqa: E402
 from openstereo_amd import engine  # noqa: E402
@@ -26,7 +27,7 @@ for _ in range(3):
     wl.step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(a.stacks)) as prof:
     wl.step()
     torch.cuda.synchronize()
 ev = prof.key_averages(group_by_input_shape=True)
@@ -44,3 +45,15 @@ for e in ev2[:40]:
     if e.self_device_time_total <= 0:
         break
     print(f"{100 * e.self_device_time_total / tot:5.1f} %  {e.self_device_time_total / 1e3:8.2f} ms  x{e.count:5d}  {e.key[:90]}")
+if a.stacks:
+    want = set(a.stacks.split(","))
+    groups = {}
+    for e in prof.events():
+        if e.name in want and e.device_time_total > 0:
+            st = [f for f in (e.stack or []) if "/openstereo_amd/" in f or "bench.py" in f][:4]
+            key = (e.name, str(e.input_shapes)[:70], " <- ".join(s_.split("/")[-1] for s_ in st) or "(autograd engine / no Python frame)")
+            g = groups.setdefault(key, [0, 0.0])
+            g[0] += 1; g[1] += e.device_time_total
+    print("\n-- by call stack --")
+    for (name, shp, st), (n, t) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:90]:
+        print(f"{t / 1e3:8.2f} ms  x{n:5d}  {name:16s} {shp:70s} {st}")
