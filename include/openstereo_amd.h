@@ -514,6 +514,17 @@ int osa_amax_f32(const float* x, long long n, float* meta, void* stream);
 int osa_context_upsample_f32(const float* disp_low, const float* weights, float* out,
                              int B, int h, int w, int scale, int softmax_weights, float gain,
                              void* stream);
+/* The training form (r6): weights = softmax of `logits` [B,9,H,W] given with their element strides {batch, tap, row, column} (the
+ * transposed conv's channels-last output is read in place), fp32 (logits_f16 0) or fp16 (1); out = the map above with the softmax and the
+ * gain fused.  The reference does this once per GRU iteration for its sequence loss (stereobase_gru.py:196-203, igev_stereo.py:198-207:
+ * F.softmax + context_upsample on 9 x H x W tensors, forward and autograd backward).
+ * _bwd: ddisp_low [B,1,h,w] and dlogits (element type of `logits`, its own element strides) from dout [B,H,W]; scratch: 9 * B * h * w floats
+ * (per-cell tap sums).  scale: 1, 2, 4 or 8.  Deterministic (lane-shuffle sums and a gather in a fixed order, no atomics). */
+int osa_context_upsample_logits_f32(const float* disp_low, const void* logits, int logits_f16, const long long* logits_strides,
+                                    float* out, int B, int h, int w, int scale, float gain, void* stream);
+int osa_context_upsample_logits_bwd_f32(const float* disp_low, const void* logits, int logits_f16, const long long* logits_strides,
+                                        const float* dout, float* ddisp_low, void* dlogits, const long long* dlogits_strides, float* scratch,
+                                        int B, int h, int w, int scale, float gain, void* stream);
 
 /* ---- geometry-encoding volume of the GRU loop ---------- */
 /* models/stereobase/gru_blocks.py:170-229, models/igev/geometry.py:7-66 */

@@ -152,6 +152,8 @@ SIGNATURES = {
     "osa_cat_fms_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_pool2x_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
     "osa_resize_bilinear_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_st]),
+    "osa_context_upsample_logits_f32": (c_i, [c_fp, c_fp, c_i, C.POINTER(c_ll), c_fp, c_i, c_i, c_i, c_i, c_f, c_st]),
+    "osa_context_upsample_logits_bwd_f32": (c_i, [c_fp, c_fp, c_i, C.POINTER(c_ll), c_fp, c_fp, c_fp, C.POINTER(c_ll), c_fp, c_i, c_i, c_i, c_i, c_f, c_st]),
     "osa_context_upsample_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_f, c_st]),
     "osa_allpairs_corr_f32": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_st]),
     "osa_geo_rows_f32": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_i, c_st]),

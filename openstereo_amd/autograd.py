@@ -937,11 +937,31 @@ def _train_precision(precision):
     return engine.train_precision(precision)
 
 
+class _AddBias(torch.autograd.Function):
+    """y + bias over the channel axis (the transposed convolutions add theirs outside the launch); the bias gradient is ONE pass of
+    osa_channel_sums where the gradient's layout allows -- torch's sum_to_size of a channels-last gradient runs 17-97 us per call."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        ctx.bias_dt = bias.dtype
+        return y + bias.view(1, -1, *([1] * (y.dim() - 2)))
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            if cl_rows(dy) is not None:
+                db = channel_sums(dy)[0][0].to(ctx.bias_dt)
+            else:
+                db = dy.sum([0] + list(range(2, dy.dim())), dtype=torch.float32).to(ctx.bias_dt)
+        return dy, db
+
+
 def conv_transpose2d(x, weight, bias=None, stride=2, padding=1, output_padding=0, precision=None):
     p2 = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     assert p2(stride) == (2, 2)
     y = _ConvTranspose2d.apply(x, weight, p2(padding)[0], p2(output_padding)[0], _train_precision(precision), _wcache(weight))
-    return y if bias is None else y + bias.view(1, -1, 1, 1)
+    return y if bias is None else _AddBias.apply(y, bias)
 
 
 def _t3(v):
@@ -962,7 +982,7 @@ def conv_transpose3d(x, weight, bias=None, stride=2, padding=1, output_padding=0
     assert _t3(stride) == (2, 2, 2)
     p, op = _t3(padding)[0], _t3(output_padding)[0]
     y = _ConvTranspose3d.apply(x, weight, p, op, _train_precision(precision), _wcache(weight))
-    return y if bias is None else y + bias.view(1, -1, 1, 1, 1)
+    return y if bias is None else _AddBias.apply(y, bias)
 
 
 def conv_module(m, x):
@@ -1184,6 +1204,52 @@ def _shape_eligible(m, x):
             and all(d % 2 == 0 for d in x.shape[2:])
     return False
 
+
+
+# ----------------------------------------------------------------------------- fused softmax + convex up-sampling (training)
+class _ContextUpsampleLogits(torch.autograd.Function):
+    """out[B,H,W] = sum_k softmax(logits)_k * (gain * disp_low)[3x3 neighbourhood]_k  (stereobase_gru.py:196-203: F.softmax(spx_gru(..), 1) +
+    context_upsample(disp * 4, spx_pred), once per GRU iteration for the sequence loss).  One kernel forward, two backward
+    (osa_context_upsample_logits_f32 / _bwd_f32); the logits are read in the layout and dtype the transposed conv wrote them."""
+
+    @staticmethod
+    def forward(ctx, disp_low, logits, scale, gain):
+        d = _f32c(disp_low)
+        lg = logits if logits.dtype in (torch.float16, torch.float32) else logits.float()
+        B, _, h, w = d.shape
+        ext = engine._ext.load()
+        if ext is not None:
+            out = ext.context_upsample_logits(d, lg, scale, gain)
+        else:
+            out = torch.empty((B, h * scale, w * scale), device=d.device, dtype=torch.float32)
+            _lib.call("osa_context_upsample_logits_f32", d.data_ptr(), lg.data_ptr(), int(lg.dtype == torch.float16), (ctypes.c_longlong * 4)(*lg.stride()),
+                      out.data_ptr(), B, h, w, scale, float(gain), _stream())
+        ctx.save_for_backward(d, lg)
+        ctx.meta = (scale, gain, disp_low.dtype, logits.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d, lg = ctx.saved_tensors
+        scale, gain, ddt, ldt = ctx.meta
+        B, _, h, w = d.shape
+        g = _f32c(dout)
+        ext = engine._ext.load()
+        if ext is not None:
+            dd, dl = ext.context_upsample_logits_bwd(d, lg, g, scale, gain)
+        else:
+            dd = torch.empty_like(d)
+            dl = torch.empty(lg.shape, device=lg.device, dtype=lg.dtype)      # contiguous NCHW, as the torch composition's softmax backward returns it
+            sc = torch.empty((B, 9, h, w), device=d.device, dtype=torch.float32)
+            _lib.call("osa_context_upsample_logits_bwd_f32", d.data_ptr(), lg.data_ptr(), int(lg.dtype == torch.float16), (ctypes.c_longlong * 4)(*lg.stride()),
+                      g.data_ptr(), dd.data_ptr(), dl.data_ptr(), (ctypes.c_longlong * 4)(*dl.stride()), sc.data_ptr(), B, h, w, scale, float(gain), _stream())
+        return (dd.to(ddt) if ctx.needs_input_grad[0] else None), (dl.to(ldt) if ctx.needs_input_grad[1] else None), None, None
+
+
+def context_upsample_logits(disp_low, logits, scale_factor=4, gain=1.0):
+    """differentiable `context_upsample(disp_low * gain, F.softmax(logits, 1))` -> [B, H, W] fp32"""
+    with torch.autocast("cuda", enabled=False):
+        return _ContextUpsampleLogits.apply(disp_low, logits, int(scale_factor), float(gain))
 
 
 # ----------------------------------------------------------------------------- BatchNorm in eval mode (FREEZE_BN training)

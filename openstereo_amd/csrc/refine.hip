@@ -8,6 +8,7 @@
 // do first (lightstereo.py:61-62, stereobase_gru.py:114-119): the 9 x H x W unfolded / up-sampled /
 // soft-maxed intermediates of the reference never exist.  HBM-bound: 9 floats read + 1 written per pixel.
 #include "osa_common.h"
+#include <cstring>
 
 namespace osa {
 
@@ -52,6 +53,126 @@ __global__ __launch_bounds__(256) void context_upsample_kernel(const CtxArgs p) 
     p.out[i] = acc;
 }
 
+
+// ---- training form of the fused softmax + convex up-sampling (r6) ---------------------------------------------------------------------
+// The reference up-samples the disparity of EVERY GRU iteration for its sequence loss (stereobase_gru.py:196-203, igev_stereo.py:198-207:
+// spx_pred = F.softmax(spx_gru(...), 1); context_upsample(disp * 4, spx_pred)): 22 x (softmax, unfold, nearest x4, product, sum over 9)
+// forward and their autograd backward on 9 x H x W tensors.  Forward: the kernel above with strided fp32 / fp16 logits (the transposed
+// conv's channels-last output is read in place).  Backward, two launches:
+//   (1) per full-resolution pixel: w = softmax(logits), out = sum_k w_k d_k;  dlogits_k = dout * w_k * (d_k - out)  (written in the
+//       logits' layout and dtype);  t_k = dout * w_k  into a planar fp32 scratch [B][9][H][W];
+//   (2) per low-resolution pixel (yy, xx): ddisp = gain * sum over the 3 x 3 cells (yl, xl) around it and their scale^2 pixels of
+//       t_k with k = (yy - yl + 1) * 3 + (xx - xl + 1)  -- a gather in a fixed order, no atomics.
+struct CtxTrainArgs {
+    const float* disp; const void* logits; const float* dout;
+    float* out; void* dlogits; float* scratch; float* ddisp;
+    long long lsb, lsk, lsy, lsx;       // logits strides in elements (batch, tap, row, column)
+    long long dsb, dsk, dsy, dsx;       // dlogits strides
+    int B, h, w_, scale, H, W, f16;
+    float gain;
+};
+__device__ __forceinline__ float ctx_ld(const void* p, int f16, long long off) {
+    return f16 ? (float)reinterpret_cast<const _Float16*>(p)[off] : reinterpret_cast<const float*>(p)[off];
+}
+// Thread = one full-resolution pixel; the scale^2 pixels of a low-resolution cell are consecutive lanes (host: scale in {1, 2, 4, 8}: a
+// power of two <= 8, so a cell is 1 / 4 / 16 / 64 lanes and never straddles a wave), which lets the backward reduce t_k over the cell with
+// lane shuffles.  Logits with unit tap stride (channels-last: the transposed conv's output) are read / written as packed pairs.
+template <int BWD>
+__global__ __launch_bounds__(256) void context_upsample_logits_kernel(const CtxTrainArgs p) {
+    const int s2 = p.scale * p.scale;
+    const long long ncell = (long long)p.B * p.h * p.w_;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long cell = t / s2;
+    const int sub = (int)(t - cell * s2);
+    const bool live = cell < ncell;
+    const long long cc = live ? cell : ncell - 1;
+    const int b = (int)(cc / ((long long)p.h * p.w_));
+    const int r = (int)(cc - (long long)b * p.h * p.w_);
+    const int yl = r / p.w_, xl = r - yl * p.w_;
+    const int y = yl * p.scale + sub / p.scale, x = xl * p.scale + sub % p.scale;
+    const long long HW = (long long)p.H * p.W;
+    const long long i = (long long)b * HW + (long long)y * p.W + x;
+    const long long lo = (long long)b * p.lsb + (long long)y * p.lsy + (long long)x * p.lsx;
+    const float* dp = p.disp + (size_t)b * p.h * p.w_;
+    float wv[9], dv[9];
+    const bool packed = p.f16 && p.lsk == 1 && ((lo & 1) == 0) && ((reinterpret_cast<size_t>(p.logits) & 3) == 0);
+    if (packed) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned* src = reinterpret_cast<const unsigned*>(reinterpret_cast<const _Float16*>(p.logits) + lo);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const h2 v = __builtin_bit_cast(h2, src[k]); wv[2 * k] = (float)v[0]; wv[2 * k + 1] = (float)v[1]; }
+        wv[8] = (float)reinterpret_cast<const _Float16*>(p.logits)[lo + 8];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = ctx_ld(p.logits, p.f16, lo + k * p.lsk);
+    }
+    float m = wv[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) m = fmaxf(m, wv[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wv[k] = expf(wv[k] - m); s += wv[k]; }
+    const float inv = 1.f / s;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = yl + k / 3 - 1, xx = xl + k % 3 - 1;
+        float d = 0.f;
+        if ((unsigned)yy < (unsigned)p.h && (unsigned)xx < (unsigned)p.w_) d = dp[(size_t)yy * p.w_ + xx] * p.gain;
+        dv[k] = d;
+        wv[k] *= inv;
+        acc = fmaf(wv[k], d, acc);
+    }
+    if (!BWD) { if (live) p.out[i] = acc; return; }
+    const float g = live ? p.dout[i] : 0.f;
+    float tk[9], dl[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { tk[k] = g * wv[k]; dl[k] = tk[k] * (dv[k] - acc); }
+    if (live) {
+        const long long dlo = (long long)b * p.dsb + (long long)y * p.dsy + (long long)x * p.dsx;
+        if (p.f16 && p.dsk == 1 && ((dlo & 1) == 0) && ((reinterpret_cast<size_t>(p.dlogits) & 3) == 0)) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            unsigned* dst = reinterpret_cast<unsigned*>(reinterpret_cast<_Float16*>(p.dlogits) + dlo);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const h2 v = {(_Float16)dl[2 * k], (_Float16)dl[2 * k + 1]}; dst[k] = __builtin_bit_cast(unsigned, v); }
+            reinterpret_cast<_Float16*>(p.dlogits)[dlo + 8] = (_Float16)dl[8];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (p.f16) reinterpret_cast<_Float16*>(p.dlogits)[dlo + k * p.dsk] = (_Float16)dl[k];
+                else reinterpret_cast<float*>(p.dlogits)[dlo + k * p.dsk] = dl[k];
+            }
+        }
+    }
+    // sum of t_k over the cell's lanes (fixed butterfly order: deterministic)
+    for (int mlane = s2 >> 1; mlane >= 1; mlane >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tk[k] += __shfl_xor(tk[k], mlane, 64);
+    }
+    if (live && sub == 0) {
+        const long long hw_lo = (long long)p.h * p.w_;
+        float* sc = p.scratch + (size_t)b * 9 * hw_lo + r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sc[(size_t)k * hw_lo] = tk[k];
+    }
+}
+// scratch: T[b][k][yl][xl] = sum over the scale^2 pixels of cell (yl, xl) of dout * w_k  (9 x B x h x w floats)
+__global__ __launch_bounds__(256) void context_upsample_ddisp_kernel(const CtxTrainArgs p) {
+    const long long hw_lo = (long long)p.h * p.w_;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.B * hw_lo) return;
+    const int b = (int)(i / hw_lo);
+    const int r = (int)(i - (long long)b * hw_lo);
+    const int yy = r / p.w_, xx = r - yy * p.w_;
+    const float* sc = p.scratch + (size_t)b * 9 * hw_lo;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yl = yy - (k / 3 - 1), xl = xx - (k % 3 - 1);        // the cell whose tap k reads (yy, xx)
+        if ((unsigned)yl < (unsigned)p.h && (unsigned)xl < (unsigned)p.w_) acc += sc[(size_t)k * hw_lo + (size_t)yl * p.w_ + xl];
+    }
+    p.ddisp[i] = acc * p.gain;
+}
 }  // namespace osa
 
 using namespace osa;
@@ -67,6 +188,41 @@ extern "C" int osa_context_upsample_f32(const float* disp_low, const float* weig
     const long long total = (long long)B * a.H * a.W;
     hipLaunchKernelGGL(context_upsample_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
     OSA_LAUNCH_CHECK("context_upsample");
+    return 0;
+}
+
+static int ctx_train_args(CtxTrainArgs& a, const float* disp_low, const void* logits, int logits_f16, const long long* ls, int B, int h, int w, int scale, float gain) {
+    OSA_REQUIRE(disp_low && logits && ls, "context_upsample_logits: NULL pointer");
+    OSA_REQUIRE(B > 0 && h > 0 && w > 0 && (scale == 1 || scale == 2 || scale == 4 || scale == 8), "context_upsample_logits: bad dims (scale 1 / 2 / 4 / 8)");
+    memset(&a, 0, sizeof(a));
+    a.disp = disp_low; a.logits = logits; a.f16 = logits_f16 ? 1 : 0;
+    a.lsb = ls[0]; a.lsk = ls[1]; a.lsy = ls[2]; a.lsx = ls[3];
+    a.B = B; a.h = h; a.w_ = w; a.scale = scale; a.H = h * scale; a.W = w * scale; a.gain = gain;
+    return 0;
+}
+
+extern "C" int osa_context_upsample_logits_f32(const float* disp_low, const void* logits, int logits_f16, const long long* logits_strides,
+                                               float* out, int B, int h, int w, int scale, float gain, void* stream) {
+    CtxTrainArgs a;
+    if (int rc = ctx_train_args(a, disp_low, logits, logits_f16, logits_strides, B, h, w, scale, gain)) return rc;
+    OSA_REQUIRE(out, "context_upsample_logits: NULL out");
+    a.out = out;
+    hipLaunchKernelGGL(context_upsample_logits_kernel<0>, dim3(cdiv((long long)B * a.H * a.W, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("context_upsample_logits");
+    return 0;
+}
+
+extern "C" int osa_context_upsample_logits_bwd_f32(const float* disp_low, const void* logits, int logits_f16, const long long* logits_strides,
+                                                   const float* dout, float* ddisp_low, void* dlogits, const long long* dlogits_strides, float* scratch,
+                                                   int B, int h, int w, int scale, float gain, void* stream) {
+    CtxTrainArgs a;
+    if (int rc = ctx_train_args(a, disp_low, logits, logits_f16, logits_strides, B, h, w, scale, gain)) return rc;
+    OSA_REQUIRE(dout && ddisp_low && dlogits && dlogits_strides && scratch, "context_upsample_logits_bwd: NULL pointer (scratch: 9 * B * h * w floats)");
+    a.dsb = dlogits_strides[0]; a.dsk = dlogits_strides[1]; a.dsy = dlogits_strides[2]; a.dsx = dlogits_strides[3];
+    a.dout = dout; a.ddisp = ddisp_low; a.dlogits = dlogits; a.scratch = scratch;
+    hipLaunchKernelGGL(context_upsample_logits_kernel<1>, dim3(cdiv((long long)B * a.H * a.W, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(context_upsample_ddisp_kernel, dim3(cdiv((long long)B * h * w, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    OSA_LAUNCH_CHECK("context_upsample_logits_bwd");
     return 0;
 }
 

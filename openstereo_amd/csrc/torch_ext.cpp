@@ -679,6 +679,43 @@ at::Tensor channel_sums_multi_meta(at::TensorList dys, int64_t P, int64_t C, int
     return at::empty({1, C}, dys[0].options().dtype(at::kFloat));
 }
 
+// training form of the fused softmax + convex up-sampling: logits [B,9,H,W] of any strides, fp32 / fp16
+at::Tensor context_upsample_logits(const at::Tensor& disp_low, const at::Tensor& logits, int64_t scale, double gain) {
+    at::Tensor d = gpu_f32(disp_low, "disp_low").contiguous();
+    TORCH_CHECK(d.dim() == 4 && d.size(1) == 1 && logits.dim() == 4 && logits.size(1) == 9 && logits.is_cuda(), "context_upsample_logits: disp [B,1,h,w], logits [B,9,s*h,s*w]");
+    const bool lh = logits.scalar_type() == at::kHalf;
+    TORCH_CHECK(lh || logits.scalar_type() == at::kFloat, "context_upsample_logits: fp32 / fp16 logits");
+    const int64_t B = d.size(0), h = d.size(2), w = d.size(3);
+    TORCH_CHECK(logits.size(0) == B && logits.size(2) == scale * h && logits.size(3) == scale * w, "context_upsample_logits: logits must be at ", scale, "x the disparity's resolution");
+    at::Tensor out = at::empty({B, scale * h, scale * w}, d.options());
+    const long long ls[4] = {(long long)logits.stride(0), (long long)logits.stride(1), (long long)logits.stride(2), (long long)logits.stride(3)};
+    OSA_CALL(osa_context_upsample_logits_f32(fp(d), logits.data_ptr(), lh ? 1 : 0, ls, out.data_ptr<float>(), (int)B, (int)h, (int)w, (int)scale, (float)gain, cur_stream()));
+    return out;
+}
+std::tuple<at::Tensor, at::Tensor> context_upsample_logits_bwd(const at::Tensor& disp_low, const at::Tensor& logits, const at::Tensor& dout, int64_t scale, double gain) {
+    at::Tensor d = gpu_f32(disp_low, "disp_low").contiguous();
+    at::Tensor g = gpu_f32(dout, "dout").contiguous();
+    const bool lh = logits.scalar_type() == at::kHalf;
+    const int64_t B = d.size(0), h = d.size(2), w = d.size(3);
+    TORCH_CHECK(logits.dim() == 4 && logits.size(1) == 9 && g.numel() == B * scale * h * scale * w, "context_upsample_logits_bwd: shapes");
+    at::Tensor dd = at::empty_like(d);
+    // dlogits: contiguous NCHW -- what the torch composition's softmax backward hands on (a 9-of-12-channel NHWC slice would reach the next
+    // backward nodes as a 9-channel channels-last tensor after the autocast cast, which torch reduces at 97 us per call)
+    at::Tensor dl = at::empty(logits.sizes(), logits.options());
+    at::Tensor sc = at::empty({B, 9, h, w}, d.options());
+    const long long ls[4] = {(long long)logits.stride(0), (long long)logits.stride(1), (long long)logits.stride(2), (long long)logits.stride(3)};
+    const long long ds[4] = {(long long)dl.stride(0), (long long)dl.stride(1), (long long)dl.stride(2), (long long)dl.stride(3)};
+    OSA_CALL(osa_context_upsample_logits_bwd_f32(fp(d), logits.data_ptr(), lh ? 1 : 0, ls, fp(g), dd.data_ptr<float>(), dl.data_ptr(), ds, sc.data_ptr<float>(),
+                                                 (int)B, (int)h, (int)w, (int)scale, (float)gain, cur_stream()));
+    return std::make_tuple(dd, dl);
+}
+at::Tensor context_upsample_logits_meta(const at::Tensor& d, const at::Tensor& logits, int64_t scale, double) {
+    return at::empty({d.size(0), scale * d.size(2), scale * d.size(3)}, d.options().dtype(at::kFloat));
+}
+std::tuple<at::Tensor, at::Tensor> context_upsample_logits_bwd_meta(const at::Tensor& d, const at::Tensor& logits, const at::Tensor& dout, int64_t, double) {
+    return std::make_tuple(at::empty(d.sizes(), d.options().dtype(at::kFloat)), at::empty(logits.sizes(), logits.options()));
+}
+
 void amax_into(const at::Tensor& t, at::Tensor meta) {
     gpu_f32(t, "t"); gpu_f32(meta, "meta");
     OSA_CALL(osa_amax_f32(fp(t), (long long)t.numel(), meta.data_ptr<float>(), cur_stream()));
@@ -930,6 +967,8 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("cat_fms(Tensor reference_fm, Tensor target_fm, Tensor(a!) out, Tensor disp_index) -> ()");
     m.def("pair_volume(Tensor left, Tensor right, Tensor(a!) out, int groups, int planes, int mode) -> ()");
     m.def("channel_sums(Tensor dy, Tensor? x, Tensor? x_shift, Tensor? dx_scale, int P, int C, int dy_cs, int x_cs) -> (Tensor, Tensor)");
+    m.def("context_upsample_logits(Tensor disp_low, Tensor logits, int scale, float gain) -> Tensor");
+    m.def("context_upsample_logits_bwd(Tensor disp_low, Tensor logits, Tensor dout, int scale, float gain) -> (Tensor, Tensor)");
     m.def("channel_sums_multi(Tensor[] dys, int P, int C, int dy_cs) -> Tensor");
     m.def("instnorm_nhwc(Tensor x, Tensor(a!) out, int out_off, int[] dims, float eps, int act, float slope, Tensor(b!) workspace, Tensor(c!)? y_meta) -> ()");
     m.def("preprocess_pair(Tensor left_hwc, Tensor right_hwc, Tensor(a!) out, int[] pad_size, float[] mean, float[] std, bool channels_last) -> ()");
@@ -980,6 +1019,8 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("instnorm_nhwc", &instnorm_nhwc);
     m.impl("channel_sums", &channel_sums);
     m.impl("channel_sums_multi", &channel_sums_multi);
+    m.impl("context_upsample_logits", &context_upsample_logits);
+    m.impl("context_upsample_logits_bwd", &context_upsample_logits_bwd);
     m.impl("preprocess_pair", &preprocess_pair);
     m.impl("amax_into", &amax_into);
 }
@@ -1002,6 +1043,8 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     m.impl("conv_wgrad_multi", &conv_wgrad_multi_meta);
     m.impl("channel_sums", &channel_sums_meta);
     m.impl("channel_sums_multi", &channel_sums_multi_meta);
+    m.impl("context_upsample_logits", &context_upsample_logits_meta);
+    m.impl("context_upsample_logits_bwd", &context_upsample_logits_bwd_meta);
     for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",
                              "geo_lookup", "geo_lookup_bwd", "geo_lookup_bwd_acc", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
                              "geo_lookup_nhwc", "allpairs_corr", "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair",

@@ -24,6 +24,8 @@ from __future__ import annotations
 from functools import partial
 from types import SimpleNamespace
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -186,6 +188,9 @@ def _context_lists(cnet, zqr_convs, image, n_layers):
     return net_list, inp_list
 
 
+FUSED_UPSAMPLE_TRAIN = os.environ.get("OSA_FUSED_UPSAMPLE_TRAIN", "1") != "0"
+
+
 def _gru_train_loop(model, a, s, init_disp, geo, iters, n_layers, slow_fast):
     """The GRU loop of stereobase_gru.py:177-203 / igev_stereo.py:181-208 in training mode: lookup (forward + backward on the engine),
     update block (engine convs through autograd), convex upsampling of every iteration's disparity (the loss needs them all)."""
@@ -206,10 +211,13 @@ def _gru_train_loop(model, a, s, init_disp, geo, iters, n_layers, slow_fast):
         if n2 and slow_fast:
             net_list = model.update_block(net_list, inp_list, iter16=n3, iter08=True, iter04=False, update=False)
         net_list, mask_feat_4, delta_disp = model.update_block(net_list, inp_list, geo_feat, disp, iter16=n3, iter08=n2)
-        disp = disp + delta_disp
+        disp = disp + delta_disp.float()     # (same values as the promoting add; fp32 + fp16 takes torch's templated mixed-dtype kernel: 88 us for 14720 elements)
         with AG.engine_convs():              # the k = 4 ConvTranspose2d heads: engine deconv / strided conv / class-mode wgrad
-            spx = F.softmax(model.spx_gru(model.spx_2_gru(mask_feat_4, s["stem_2x"])), 1)
-        disp_preds.append(ctx_up(disp * 4.0, spx).unsqueeze(1))
+            logits = model.spx_gru(model.spx_2_gru(mask_feat_4, s["stem_2x"]))
+        if FUSED_UPSAMPLE_TRAIN and logits.is_cuda and logits.shape[1] == 9:
+            disp_preds.append(AG.context_upsample_logits(disp, logits, 4, 4.0).unsqueeze(1))      # softmax + x4 gain + convex combination, one kernel each way (r6)
+        else:
+            disp_preds.append(ctx_up(disp * 4.0, F.softmax(logits, 1)).unsqueeze(1))
     return disp_preds
 
 

@@ -192,3 +192,42 @@ def test_channel_sums_over_a_list(dtype):
     want = sum(t.double().sum((0, 2, 3)) for t in ts)
     assert got.shape == (C,) and float((got.double() - want).abs().max()) <= 2e-6 * float(sum(t.double().abs().sum((0, 2, 3)) for t in ts).max())
     assert torch.equal(got, ops.channel_sums_list(ts))
+
+
+@pytest.mark.parametrize("layout", ["nchw fp32", "nhwc12 fp16", "nhwc fp32"])
+def test_context_upsample_logits_forward_and_gradients(layout):
+    """r6: softmax + x4 gain + convex 3x3 up-sampling as one differentiable op (stereobase_gru.py:196-203 per GRU iteration) against the
+    torch composition the reference runs (F.softmax + unfold / nearest / weighted sum, disp_refinement.py:194-204) and its autograd"""
+    from openstereo_amd import autograd as AG
+    B, h, w, sc = 2, 9, 13, 4
+    H, W = h * sc, w * sc
+    disp0 = (rn((B, 1, h, w), 1).abs() * 20).to(DEV)
+    lg0 = rn((B, 9, H, W), 2).to(DEV)
+    gy = rn((B, H, W), 3).to(DEV)
+    if layout == "nchw fp32":
+        make = lambda t: t.clone()
+    elif layout == "nhwc fp32":
+        make = lambda t: t.clone().contiguous(memory_format=torch.channels_last)
+    else:                                     # channel slice of a 12-channel NHWC fp16 buffer: what the engine's transposed conv returns under autocast
+        make = lambda t: torch.cat([t, torch.zeros(B, 3, H, W, device=DEV)], 1).half().contiguous(memory_format=torch.channels_last)[:, :9]
+
+    def ref(d, lg):
+        spx = F.softmax(lg.float(), 1)
+        u = F.unfold(d * 4.0, 3, 1, 1).reshape(B, -1, h, w)
+        u = F.interpolate(u, (H, W), mode="nearest").reshape(B, 9, H, W)
+        return (u * spx).sum(1)
+
+    outs = []
+    for fn in (ref, lambda d, lg: AG.context_upsample_logits(d, lg, 4, 4.0)):
+        d = disp0.clone().requires_grad_()
+        lg = make(lg0).detach().requires_grad_()
+        out = fn(d, lg)
+        out.backward(gy)
+        outs.append((out.detach(), d.grad.clone(), lg.grad.float().clone()))
+        assert lg.grad.dtype == lg.dtype
+    (o0, dd0, dl0), (o1, dd1, dl1) = outs
+    half = layout.endswith("fp16")
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    assert rel(o1, o0) <= 2e-6
+    assert rel(dd1, dd0) <= 1e-5
+    assert rel(dl1, dl0) <= (2e-3 if half else 1e-5)
