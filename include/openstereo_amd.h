@@ -612,6 +612,14 @@ int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const void* x, int x
  * one biased convolution applied once per GRU iteration (HOST array of device pointers); workspace: n_items x the query above. */
 int osa_channel_sums_multi(const void* const* dys, int n_items, int dy_f16, int dy_cs, long long P, int C,
                            float* out, float* workspace, size_t workspace_bytes, void* stream);
+/* out[p][c] = u[p][c] * a[c] + (v != NULL ? v[p][c] * b[c] : 0) + c0[c], optionally ReLU, on channels-last rows; out has u's element type.
+ * With osa_channel_sums this is a BatchNorm in TRAINING mode on the engine's layouts (r6; GwcNet / PSMNet train with batch statistics:
+ * stereo/modeling/models/gwcnet/gwcnet_disp_processor.py:8-19, cfgs/gwcnet/gwcnet_sceneflow.yaml): forward = sums of x and x (x - pivot)
+ * -> mean / invstd -> y = x * (gamma invstd) + (beta - mean gamma invstd); backward = sums of dy and dy (x - mean) ->
+ * dx = dy * a + x * b + c0 with a = gamma invstd, b = -gamma invstd^3 S2 / N, c0 = -a S1 / N - b mean. */
+int osa_channel_affine(const void* u, int u_f16, int u_cs, const void* v, int v_f16, int v_cs,
+                       const float* a, const float* b, const float* c0, void* out, int out_cs,
+                       long long P, int C, int relu, void* stream);
 
 /* ---- InstanceNorm2d (+ activation) on NHWC maps (r4, csrc/norm.hip) ----
  * The normalisation of the reference-written FPN decoders of the feature pyramids: Conv2xUp / BasicConv2d(norm_layer=nn.InstanceNorm2d)

@@ -193,6 +193,7 @@ SIGNATURES = {
     "osa_instnorm_nhwc_f32": (c_i, [c_fp, c_fp, c_i, c_ll, c_i, c_i, c_i, c_f, c_i, c_f, c_fp, c_fp, c_st]),
     "osa_conv3d_wgrad_ws_multi": (c_i, [c_i, c_fp, c_fp, c_i, c_fp] + [c_i] * 22 + [c_fp, c_fp, c_i, c_i, c_fp, C.c_size_t, c_st]),
     "osa_channel_sums_workspace_bytes": (C.c_size_t, [c_ll, c_i]),
+    "osa_channel_affine": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_i, c_st]),
     "osa_channel_sums_multi": (c_i, [c_fp, c_i, c_i, c_i, c_ll, c_i, c_fp, c_fp, C.c_size_t, c_st]),
     "osa_channel_sums": (c_i, [c_fp, c_i, c_i, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_ll, c_i, c_fp, c_fp, C.c_size_t, c_st]),
     "osa_conv3d_march_launches": (c_ll, []),

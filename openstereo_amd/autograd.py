@@ -493,6 +493,7 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
 # runs (a differentiable forward that is not back-propagated) would leave the count short; an engine callback at the end of every backward
 # pass therefore delivers whatever is still queued straight into `.grad`.
 DEFER_WGRAD = os.environ.get("OSA_DEFER_WGRAD", "1") != "0"
+TRAIN_BN = os.environ.get("OSA_TRAIN_BN", "1") != "0"        # training-mode BatchNorm modules inside engine_convs on channels-last tensors: osa_channel_sums + osa_channel_affine
 FROZEN_BN = os.environ.get("OSA_FROZEN_BN", "1") != "0"      # eval-mode BatchNorm modules inside engine_convs: backward as one osa_channel_sums pass
 _defer_live = []           # states with queued pairs in the running backward pass
 _defer_cb = threading.local()
@@ -1289,6 +1290,59 @@ class _FrozenBN(torch.autograd.Function):
         return dx, dg, db, None, None, None
 
 
+class _TrainBN(torch.autograd.Function):
+    """BatchNorm in TRAINING mode (batch statistics) on channels-last tensors: GwcNet / PSMNet train this way (gwcnet_disp_processor.py:8-19
+    convbn_3d + nn.BatchNorm3d in train(); cfgs/gwcnet/gwcnet_sceneflow.yaml).  Forward: one osa_channel_sums pass (sum x, sum x (x - pivot),
+    pivot = the running mean: no cancellation once it tracks) -> mean / biased variance -> one osa_channel_affine pass; backward: one
+    sums pass (sum dy, sum dy (x - mean)) and one affine pass (dx = dy a + x b + c).  Running statistics are updated as nn.BatchNorm does
+    (momentum, unbiased variance).  Not SyncBatchNorm (its forward is its own; statistics across ranks stay torch's)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        P, C, _ = cl_rows(x)
+        pivot = running_mean.detach().float()
+        sums, _ = channel_sums(x, x, pivot)
+        s1 = sums[0]
+        mean = s1 / P
+        dm = mean - pivot
+        var = ((sums[1] - pivot * (s1 - P * pivot)) / P - dm * dm).clamp_min_(0.0)          # sum (x - p)^2 / N - (mean - p)^2
+        invstd = torch.rsqrt(var + eps)
+        g = weight.detach().float()
+        a = g * invstd
+        y = ops.channel_affine(x, a, bias.detach().float() - mean * a)
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+            running_var.mul_(1 - momentum).add_((var * (P / max(P - 1, 1))).to(running_var.dtype), alpha=momentum)
+        ctx.save_for_backward(x, g, mean, invstd)
+        ctx.wdt = weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, invstd = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        if dy.dtype != x.dtype or cl_rows(dy) is None or dy.shape != x.shape:
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last if x.dim() == 4 else torch.channels_last_3d)
+            if cl_rows(dy) is None:
+                raise _lib.EngineError("engine BatchNorm backward: gradient layout not representable as channels-last rows")
+        P, C, _ = cl_rows(x)
+        with torch.autocast("cuda", enabled=False):
+            sums, _ = channel_sums(dy, x, mean)
+            s1, s2 = sums[0], sums[1]
+            dx = None
+            if need_x:
+                a = g * invstd
+                b = -(a * invstd * invstd) * (s2 / P)
+                dx = ops.channel_affine(dy, a, -a * (s1 / P) - b * mean, x, b)
+            return dx, ((s2 * invstd).to(ctx.wdt) if need_w else None), (s1.to(ctx.wdt) if need_b else None), None, None, None, None
+
+
+def _train_bn_ok(m, x):
+    return m.training and m.track_running_stats and m.affine and m.momentum is not None and m.running_mean is not None \
+        and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() in (4, 5) and cl_rows(x) is not None \
+        and m.weight.dtype == torch.float32 and m.running_mean.dtype == torch.float32 and x.numel() // x.shape[1] > 1
+
+
 def _frozen_bn_ok(m, x):
     return (not m.training) and m.track_running_stats and m.affine and m.running_mean is not None and isinstance(x, torch.Tensor) and x.is_cuda \
         and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad) and x.dim() in (4, 5) and cl_rows(x) is not None \
@@ -1328,6 +1382,10 @@ class engine_convs:
                 def fbn(m, x):
                     if on() and FROZEN_BN and _frozen_bn_ok(m, x):
                         return _FrozenBN.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+                    if on() and TRAIN_BN and _train_bn_ok(m, x):
+                        if m.num_batches_tracked is not None:
+                            m.num_batches_tracked.add_(1)
+                        return _TrainBN.apply(x, m.weight, m.bias, m.running_mean, m.running_var, float(m.momentum), m.eps)
                     return obn(m, x)
                 BN.forward = fbn
                 o2, o3, ot, ot2 = cls._saved[nn.Conv2d], cls._saved[nn.Conv3d], cls._saved[nn.ConvTranspose3d], cls._saved[nn.ConvTranspose2d]

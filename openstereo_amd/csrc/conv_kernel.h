@@ -1170,7 +1170,11 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                     int cin = ch * CC + ((PREC == PREC_F32) ? (8 * j + 4 * hh) : (8 * hh + 4 * j));
                     // split redir input: j = 0 -> the lane's 8 hi halves, j = 1 -> its 8 lo halves (16 B each)
                     if (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) cin = ch * CC + 4 * hh + 8 * j;
-                    if (FULL || (ok && ch < rch && ch * CC < p.rCi)) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
+                    // (cin < rCi per quad: with 8 redir channels the upper half of the chunk would be the NEXT voxel's channels -- harmless
+                    // under zero weights unless it is the tensor's last voxel and the bytes behind the allocation decode as NaN / inf:
+                    // NaN x 0 = NaN, ReLU(NaN) = 0 -- found in r6 as an order-dependent test failure, StereoBase / IGEV run 8-channel hourglasses)
+                    const bool quad_ok = (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) || cin < p.rCi;
+                    if (FULL || (ok && ch < rch && ch * CC < p.rCi && quad_ok)) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
                 }
             };
             // Tile-invariant operands of the branch, loaded ONCE: the stores of the tiles in between may alias them as far

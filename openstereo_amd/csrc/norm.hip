@@ -195,6 +195,61 @@ __global__ __launch_bounds__(256) void channel_sums_final_kernel(const float* __
         if (q * 4 + e < C) out[(size_t)which * C + q * 4 + e] = r[e];
 }
 
+// out[p][c] = u[p][c] * a[c] + (v ? v[p][c] * b[c] : 0) + c0[c]  (+ ReLU) on channels-last rows: the normalise step of a training-mode
+// BatchNorm (u = x, a = gamma * invstd, c0 = beta - mean * a) and its input gradient (u = dy, v = x: dx = dy * a + x * b + c0 with the
+// batch sums folded into b and c0).  One thread per (position, channel quad), 8- / 16-byte accesses.
+template <int UF16, int VF16, int WITH_V>
+__global__ __launch_bounds__(256) void channel_affine_kernel(const void* __restrict__ u_, const void* __restrict__ v_, void* __restrict__ out_,
+                                                             const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c0,
+                                                             long long P, int C, int uCs, int vCs, int oCs, int relu) {
+    const int Cq = (C + 3) / 4;
+    const long long total = P * Cq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pp = i / Cq; const int q = (int)(i - pp * Cq);
+        const int c = q * 4, nc = C - c;
+        float uu[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+        auto ld = [&](const void* base, int f16, int cs, float* dst) {
+            if (f16) {
+                const _Float16* src = reinterpret_cast<const _Float16*>(base) + pp * cs + c;
+                if (nc >= 4) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const uint2 w = *reinterpret_cast<const uint2*>(src);
+                    const h2 x0 = __builtin_bit_cast(h2, w.x), x1 = __builtin_bit_cast(h2, w.y);
+                    dst[0] = (float)x0[0]; dst[1] = (float)x0[1]; dst[2] = (float)x1[0]; dst[3] = (float)x1[1];
+                } else for (int e = 0; e < nc; ++e) dst[e] = (float)src[e];
+            } else {
+                const float* src = reinterpret_cast<const float*>(base) + pp * cs + c;
+                if (nc >= 4) { const float4 w = *reinterpret_cast<const float4*>(src); dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w; }
+                else for (int e = 0; e < nc; ++e) dst[e] = src[e];
+            }
+        };
+        ld(u_, UF16, uCs, uu);
+        if (WITH_V) ld(v_, VF16, vCs, vv);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ce = (e < nc) ? c + e : c;
+            float r = uu[e] * a[ce];
+            if (WITH_V) r += vv[e] * b[ce];
+            r += c0[ce];
+            if (relu) r = fmaxf(r, 0.f);
+            o[e] = r;
+        }
+        if (UF16) {
+            _Float16* dst = reinterpret_cast<_Float16*>(out_) + pp * oCs + c;
+            if (nc >= 4) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 x0 = {(_Float16)o[0], (_Float16)o[1]}, x1 = {(_Float16)o[2], (_Float16)o[3]};
+                *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1));
+            } else for (int e = 0; e < nc; ++e) dst[e] = (_Float16)o[e];
+        } else {
+            float* dst = reinterpret_cast<float*>(out_) + pp * oCs + c;
+            if (nc >= 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else for (int e = 0; e < nc; ++e) dst[e] = o[e];
+        }
+    }
+}
+
 }  // namespace osa
 
 using namespace osa;
@@ -297,4 +352,29 @@ extern "C" int osa_channel_sums(const void* dy, int dy_f16, int dy_cs, const voi
 extern "C" int osa_channel_sums_multi(const void* const* dys, int n_items, int dy_f16, int dy_cs, long long P, int C,
                                       float* out, float* workspace, size_t workspace_bytes, void* stream) {
     return channel_sums_impl(dys, n_items, dy_f16, dy_cs, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, P, C, out, workspace, workspace_bytes, stream);
+}
+
+
+extern "C" int osa_channel_affine(const void* u, int u_f16, int u_cs, const void* v, int v_f16, int v_cs,
+                                  const float* a, const float* b, const float* c0, void* out, int out_cs,
+                                  long long P, int C, int relu, void* stream) {
+    OSA_REQUIRE(u && a && c0 && out && (v == nullptr || b != nullptr), "channel_affine: NULL pointer");
+    OSA_REQUIRE(P > 0 && C > 0 && u_cs >= C && out_cs >= C && (v == nullptr || v_cs >= C), "channel_affine: bad dims / channel stride < C");
+    auto vec_ok = [&](const void* t, int f16, int cs) { return cs % 4 == 0 && ((size_t)t & (f16 ? 7 : 15)) == 0; };
+    OSA_REQUIRE(vec_ok(u, u_f16, u_cs) && vec_ok(out, u_f16, out_cs) && (v == nullptr || vec_ok(v, v_f16, v_cs)),
+                "channel_affine: tensors need channel strides %% 4 == 0 and 16-byte (fp16: 8-byte) alignment");
+    const long long total = P * ((C + 3) / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (u_f16 ? 4 : 0) | (v ? ((v_f16 ? 2 : 0) | 1) : 0);
+#define OSA_CA(UF, VF, WV) hipLaunchKernelGGL((channel_affine_kernel<UF, VF, WV>), dim3((unsigned)blocks), dim3(256), 0, st, u, v, out, a, b, c0, P, C, u_cs, v_cs, out_cs, relu)
+    switch (key) {
+        case 0: OSA_CA(0, 0, 0); break;  case 1: OSA_CA(0, 0, 1); break;  case 3: OSA_CA(0, 1, 1); break;
+        case 4: OSA_CA(1, 0, 0); break;  case 5: OSA_CA(1, 0, 1); break;  case 7: OSA_CA(1, 1, 1); break;
+        default: OSA_REQUIRE(false, "channel_affine: v_f16 without v");
+    }
+#undef OSA_CA
+    OSA_LAUNCH_CHECK("channel_affine");
+    return 0;
 }

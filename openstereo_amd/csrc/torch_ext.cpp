@@ -716,6 +716,25 @@ std::tuple<at::Tensor, at::Tensor> context_upsample_logits_bwd_meta(const at::Te
     return std::make_tuple(at::empty(d.sizes(), d.options().dtype(at::kFloat)), at::empty(logits.sizes(), logits.options()));
 }
 
+// out = u * a[c] + (v * b[c]) + c0[c] (+ ReLU) on channels-last rows; out: u's dtype and strides
+at::Tensor channel_affine(const at::Tensor& u, const c10::optional<at::Tensor>& v, const at::Tensor& a, const c10::optional<at::Tensor>& b, const at::Tensor& c0,
+                          int64_t P, int64_t C, int64_t u_cs, int64_t v_cs, bool relu) {
+    const bool uh = u.scalar_type() == at::kHalf;
+    TORCH_CHECK(u.is_cuda() && (uh || u.scalar_type() == at::kFloat), "channel_affine: u must be a CUDA fp32 / fp16 tensor");
+    const bool hv = v.has_value() && v->defined();
+    const bool vh = hv && v->scalar_type() == at::kHalf;
+    if (hv) TORCH_CHECK(v->is_cuda() && (vh || v->scalar_type() == at::kFloat) && b.has_value() && b->defined(), "channel_affine: v must be a CUDA fp32 / fp16 tensor and come with b");
+    gpu_f32(a, "a"); gpu_f32(c0, "c0");
+    at::Tensor out = at::empty_strided(u.sizes(), u.strides(), u.options());
+    OSA_CALL(osa_channel_affine(u.data_ptr(), uh ? 1 : 0, (int)u_cs, hv ? v->data_ptr() : nullptr, vh ? 1 : 0, (int)v_cs, a.data_ptr<float>(),
+                                hv ? b->data_ptr<float>() : nullptr, c0.data_ptr<float>(), out.data_ptr(), (int)u_cs, (long long)P, (int)C, relu ? 1 : 0, cur_stream()));
+    return out;
+}
+at::Tensor channel_affine_meta(const at::Tensor& u, const c10::optional<at::Tensor>& v, const at::Tensor& a, const c10::optional<at::Tensor>& b, const at::Tensor& c0,
+                               int64_t P, int64_t C, int64_t u_cs, int64_t v_cs, bool relu) {
+    return at::empty_strided(u.sizes(), u.strides(), u.options());
+}
+
 void amax_into(const at::Tensor& t, at::Tensor meta) {
     gpu_f32(t, "t"); gpu_f32(meta, "meta");
     OSA_CALL(osa_amax_f32(fp(t), (long long)t.numel(), meta.data_ptr<float>(), cur_stream()));
@@ -969,6 +988,7 @@ TORCH_LIBRARY(osa_native, m) {
     m.def("channel_sums(Tensor dy, Tensor? x, Tensor? x_shift, Tensor? dx_scale, int P, int C, int dy_cs, int x_cs) -> (Tensor, Tensor)");
     m.def("context_upsample_logits(Tensor disp_low, Tensor logits, int scale, float gain) -> Tensor");
     m.def("context_upsample_logits_bwd(Tensor disp_low, Tensor logits, Tensor dout, int scale, float gain) -> (Tensor, Tensor)");
+    m.def("channel_affine(Tensor u, Tensor? v, Tensor a, Tensor? b, Tensor c0, int P, int C, int u_cs, int v_cs, bool relu) -> Tensor");
     m.def("channel_sums_multi(Tensor[] dys, int P, int C, int dy_cs) -> Tensor");
     m.def("instnorm_nhwc(Tensor x, Tensor(a!) out, int out_off, int[] dims, float eps, int act, float slope, Tensor(b!) workspace, Tensor(c!)? y_meta) -> ()");
     m.def("preprocess_pair(Tensor left_hwc, Tensor right_hwc, Tensor(a!) out, int[] pad_size, float[] mean, float[] std, bool channels_last) -> ()");
@@ -1019,6 +1039,7 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("instnorm_nhwc", &instnorm_nhwc);
     m.impl("channel_sums", &channel_sums);
     m.impl("channel_sums_multi", &channel_sums_multi);
+    m.impl("channel_affine", &channel_affine);
     m.impl("context_upsample_logits", &context_upsample_logits);
     m.impl("context_upsample_logits_bwd", &context_upsample_logits_bwd);
     m.impl("preprocess_pair", &preprocess_pair);
@@ -1043,6 +1064,7 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     m.impl("conv_wgrad_multi", &conv_wgrad_multi_meta);
     m.impl("channel_sums", &channel_sums_meta);
     m.impl("channel_sums_multi", &channel_sums_multi_meta);
+    m.impl("channel_affine", &channel_affine_meta);
     m.impl("context_upsample_logits", &context_upsample_logits_meta);
     m.impl("context_upsample_logits_bwd", &context_upsample_logits_bwd_meta);
     for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",

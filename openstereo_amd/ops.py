@@ -519,3 +519,21 @@ def channel_sums_list(dys):
     _lib.call("osa_channel_sums_multi", (ctypes.c_void_p * len(dys))(*[t.data_ptr() for t in dys]), len(dys), int(dys[0].dtype == torch.float16), cs, P, C,
               out.data_ptr(), ws.data_ptr(), need, _stream())
     return out[0]
+
+
+def channel_affine(u, a, c0, v=None, b=None, relu=False):
+    """u * a[c] + (v * b[c]) + c0[c] (+ ReLU) on channels-last rows (osa_channel_affine); u / v must satisfy `cl_rows`; result: u's dtype / strides"""
+    P, C, cs = cl_rows(u)
+    vcs = 0
+    if v is not None:
+        Pv, Cv, vcs = cl_rows(v)
+        assert (Pv, Cv) == (P, C) and b is not None
+    a, c0 = _f32c(a), _f32c(c0)
+    b = None if b is None else _f32c(b)
+    ext = _ext.load()
+    if ext is not None:
+        return ext.channel_affine(u, v, a, b, c0, P, C, cs, vcs, bool(relu))
+    out = torch.empty_strided(u.shape, u.stride(), device=u.device, dtype=u.dtype)
+    _lib.call("osa_channel_affine", u.data_ptr(), int(u.dtype == torch.float16), cs, _p(v), int(v is not None and v.dtype == torch.float16), vcs,
+              a.data_ptr(), _p(b), c0.data_ptr(), out.data_ptr(), cs, P, C, int(bool(relu)), _stream())
+    return out

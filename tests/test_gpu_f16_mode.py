@@ -196,3 +196,33 @@ def test_autocast_region_selects_the_f16_mode():
         assert err < 2e-2, err
     finally:
         engine.set_precision(old)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+def test_eight_channel_hourglass_does_not_read_behind_its_input(prec):
+    """r6: the fused redir branch of the transposed convolutions loaded whole 16-channel chunks of its input; with 8 channels (StereoBase /
+    IGEV hourglasses) the upper half of the LAST voxel's chunk lies behind the tensor.  Zero weights hide finite bytes there, not NaN
+    (NaN x 0 = NaN, ReLU(NaN) = 0): the result depended on what the allocator had there before (an order-dependent failure of the test
+    above).  Here the bytes behind the input ARE NaN."""
+    from openstereo_amd import engine, ops
+    from openstereo_amd.models.gwcnet import Hourglass
+    old = engine.get_precision()
+    try:
+        engine.set_precision(prec)
+        hg = Hourglass(8).eval()
+        hg.load_state_dict(synth_state_dict(hg, seed=3))
+        hg = hg.to(DEV)
+        x = rnd((1, 8, 8, 8, 16), 7).to(DEV)
+        with torch.no_grad():
+            xc = ops.to_cl(x)
+            n = xc.numel()
+            buf = torch.full((n + 4096,), float("nan"), device=DEV)
+            buf[:n] = xc.permute(0, 2, 3, 4, 1).reshape(-1)
+            xn = buf[:n].view(1, 8, 8, 16, 8).permute(0, 4, 1, 2, 3)            # the same NDHWC tensor with NaN right behind its last voxel
+            assert xn.stride() == xc.stride() and torch.equal(xn, xc)
+            want = hg.forward_cl(xc).clone()
+            got = hg.forward_cl(xn)
+        assert torch.isfinite(got).all() and torch.equal(got, want)
+        assert float(got[0, :, -1, -1, -1].abs().max()) > 0                     # the last voxel is alive in this fixture
+    finally:
+        engine.set_precision(old)
