@@ -493,7 +493,10 @@ def _wgrad(xc, dyc, dw, B, D, H, W, Ci, Do, Ho, Wo, Co, k, stride, pad, dil, tra
 # runs (a differentiable forward that is not back-propagated) would leave the count short; an engine callback at the end of every backward
 # pass therefore delivers whatever is still queued straight into `.grad`.
 DEFER_WGRAD = os.environ.get("OSA_DEFER_WGRAD", "1") != "0"
-TRAIN_BN = os.environ.get("OSA_TRAIN_BN", "1") != "0"        # training-mode BatchNorm modules inside engine_convs on channels-last tensors: osa_channel_sums + osa_channel_affine
+# training-mode BatchNorm (batch statistics) on channels-last tensors as osa_channel_sums + osa_channel_affine passes (_TrainBN): correct (tests),
+# but OFF by default -- the per-channel coefficient arithmetic between the passes is ~20 tiny torch launches per layer and step, and the
+# GwcNet training step measured 39.9 ms with it against 35.8 ms with torch's own kernels (profiles/round6/training_steps_r6.txt).
+TRAIN_BN = os.environ.get("OSA_TRAIN_BN", "0") == "1"
 FROZEN_BN = os.environ.get("OSA_FROZEN_BN", "1") != "0"      # eval-mode BatchNorm modules inside engine_convs: backward as one osa_channel_sums pass
 _defer_live = []           # states with queued pairs in the running backward pass
 _defer_cb = threading.local()
@@ -1338,7 +1341,7 @@ class _TrainBN(torch.autograd.Function):
 
 
 def _train_bn_ok(m, x):
-    return m.training and m.track_running_stats and m.affine and m.momentum is not None and m.running_mean is not None \
+    return m.training and not isinstance(m, torch.nn.SyncBatchNorm) and m.track_running_stats and m.affine and m.momentum is not None and m.running_mean is not None \
         and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() in (4, 5) and cl_rows(x) is not None \
         and m.weight.dtype == torch.float32 and m.running_mean.dtype == torch.float32 and x.numel() // x.shape[1] > 1
 
@@ -1347,6 +1350,18 @@ def _frozen_bn_ok(m, x):
     return (not m.training) and m.track_running_stats and m.affine and m.running_mean is not None and isinstance(x, torch.Tensor) and x.is_cuda \
         and torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad) and x.dim() in (4, 5) and cl_rows(x) is not None \
         and m.weight.dtype == torch.float32 and m.running_mean.dtype == torch.float32
+
+
+def bn_module(m, x):
+    """A BatchNorm module's arithmetic on the engine where it applies (the same dispatch as inside `engine_convs`): eval mode with
+    trainable affine parameters -> _FrozenBN, training mode -> _TrainBN, anything else -> the module itself."""
+    if FROZEN_BN and _frozen_bn_ok(m, x):
+        return _FrozenBN.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+    if TRAIN_BN and _train_bn_ok(m, x):
+        if m.num_batches_tracked is not None:
+            m.num_batches_tracked.add_(1)
+        return _TrainBN.apply(x, m.weight, m.bias, m.running_mean, m.running_var, float(m.momentum), m.eps)
+    return m(x)
 
 
 class engine_convs:

@@ -36,6 +36,8 @@ def run_train(mod, x):
         for child in mod:
             x = run_train(child, x)
         return x
+    if isinstance(mod, nn.modules.batchnorm._BatchNorm) and not isinstance(mod, nn.SyncBatchNorm):
+        return AG.bn_module(mod, x)          # r6: batch statistics / frozen statistics on the engine's channels-last tensors (SyncBatchNorm stays torch's)
     return mod(x)
 
 

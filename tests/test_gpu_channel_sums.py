@@ -231,3 +231,46 @@ def test_context_upsample_logits_forward_and_gradients(layout):
     assert rel(o1, o0) <= 2e-6
     assert rel(dd1, dd0) <= 1e-5
     assert rel(dl1, dl0) <= (2e-3 if half else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("dims", [2, 3])
+def test_training_mode_bn_vs_torch(dims, dtype, monkeypatch):
+    """r6: BatchNorm with batch statistics inside engine_convs (_TrainBN: osa_channel_sums + osa_channel_affine, forward and backward)
+    against torch's own training-mode batch_norm: output, input / affine gradients, running statistics after two steps
+    (gwcnet_disp_processor.py:8-19: convbn_3d in train(); cfgs/gwcnet/gwcnet_sceneflow.yaml trains with batch statistics)."""
+    import copy
+    from openstereo_amd import autograd as AG
+    monkeypatch.setattr(AG, "TRAIN_BN", True)          # (off by default: measured slower than torch's kernels on the GwcNet step)
+    C = 32
+    shape = (2, C, 12, 20) if dims == 2 else (2, C, 4, 12, 20)
+    ref = (nn.BatchNorm2d if dims == 2 else nn.BatchNorm3d)(C).to(DEV)
+    with torch.no_grad():
+        ref.weight.copy_(rn((C,), 1).abs() + 0.5); ref.bias.copy_(rn((C,), 2))
+        ref.running_mean.copy_(rn((C,), 3) * 0.1); ref.running_var.copy_(rn((C,), 4).abs() + 0.3)
+    eng = copy.deepcopy(ref)
+    ref.train(); eng.train()
+    outs = []
+    for step in range(2):
+        x0 = _cl((rn(shape, 5 + step) * 2.0 + rn((1, C) + (1,) * dims, 9)).to(DEV).to(dtype))
+        gy = _cl(rn(shape, 7 + step).to(DEV).to(dtype))
+        res = []
+        for m, on in ((ref, False), (eng, True)):
+            m.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            if on:
+                with AG.engine_convs():
+                    y = m(x)
+                assert type(y.grad_fn).__name__ == "_TrainBNBackward"
+            else:
+                y = m(x)
+            y.backward(gy)
+            res.append((y.detach().float(), x.grad.float(), m.weight.grad.clone(), m.bias.grad.clone()))
+        outs.append(res)
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    tol = 2e-5 if dtype == torch.float32 else 3e-3
+    for (r, e) in outs:
+        assert rel(e[0], r[0]) <= tol and rel(e[1], r[1]) <= 5 * tol
+        assert rel(e[2], r[2]) <= 5 * tol and rel(e[3], r[3]) <= tol
+    assert rel(eng.running_mean, ref.running_mean) <= 1e-5 and rel(eng.running_var, ref.running_var) <= 1e-5
+    assert int(eng.num_batches_tracked) == int(ref.num_batches_tracked) == 2
