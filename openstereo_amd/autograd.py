@@ -1390,9 +1390,15 @@ class engine_convs:
             if cls._depth == 0:
                 nn = torch.nn
                 BN = nn.modules.batchnorm._BatchNorm
-                for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d, BN):
+                for C in (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d, nn.ConvTranspose2d, BN, nn.SyncBatchNorm):
                     cls._saved[C] = C.forward
-                obn = cls._saved[BN]
+                obn, osbn = cls._saved[BN], cls._saved[nn.SyncBatchNorm]
+
+                def fsbn(m, x):             # SyncBatchNorm has a forward of its own: only its eval-mode (frozen) case is taken -- the same affine map as BatchNorm's
+                    if on() and FROZEN_BN and _frozen_bn_ok(m, x):
+                        return _FrozenBN.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+                    return osbn(m, x)
+                nn.SyncBatchNorm.forward = fsbn
 
                 def fbn(m, x):
                     if on() and FROZEN_BN and _frozen_bn_ok(m, x):

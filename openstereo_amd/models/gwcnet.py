@@ -36,8 +36,8 @@ def run_train(mod, x):
         for child in mod:
             x = run_train(child, x)
         return x
-    if isinstance(mod, nn.modules.batchnorm._BatchNorm) and not isinstance(mod, nn.SyncBatchNorm):
-        return AG.bn_module(mod, x)          # r6: batch statistics / frozen statistics on the engine's channels-last tensors (SyncBatchNorm stays torch's)
+    if isinstance(mod, nn.modules.batchnorm._BatchNorm):
+        return AG.bn_module(mod, x)          # r6: frozen statistics (any _BatchNorm in eval mode, SyncBatchNorm included: the same affine map) on the engine; batch statistics per OSA_TRAIN_BN (never SyncBatchNorm)
     return mod(x)
 
 
