@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r6
+F="grep -v amdgpu.ids\|GridwiseOp"
+timeout 900 python -m pytest tests/test_gpu_channel_sums.py tests/test_gpu_syncbn.py -q 2>&1 | $F | tail -3
+for m in "--amp" ""; do echo "== $m"; timeout 600 python bench.py --workload stereobase_e2e_train $m --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | $F | tail -1 | cut -c1-300; done | tee gpurun_out/r6/final_sums_ab.txt
+bash tools/prof_train_graph.sh stereobase_e2e_train r6fin 175 2 --amp
+cp $GRAFT_REPO_ROOT/gpurun_out/prof_r6fin/steady_state.txt $GRAFT_REPO_ROOT/gpurun_out/r6/train_amp_kernels_final.txt
