@@ -241,3 +241,75 @@ def test_fp16_tensor_path_vs_torch_on_the_same_fp16_tensors(case):
     assert rel(xe.grad, xr.grad) < 1e-3, ("dx", rel(xe.grad, xr.grad))
     assert rel(we.grad, wr.grad) < 5e-6, ("dw", rel(we.grad, wr.grad))
     assert rel(be.grad, br.grad) < 1e-5, ("db", rel(be.grad, br.grad))
+
+
+def test_stereobase_whole_model_amp_step_at_size_drifts_no_more_than_the_eager_autocast_composition():
+    """BASELINE configs[2] as `bench.py --workload stereobase_e2e_train --amp` times it: the WHOLE model at the SceneFlow
+    training crop 320x736, 22 GRU iterations, one autocast + GradScaler step (trainer_template.py:211-226) with frozen BatchNorm.  The fp32-class
+    step of the same model is pinned to the reference's CPU autograd (test_gpu_models_e2e.py::test_stereobase_training_step_at_size_...);
+    here the native-f16 engine step -- batched multi-tile weight gradients, channel sums, accumulating lookup gradient, fused up-sampling --
+    must stay within twice the distance from that fp32 step that PyTorch-ROCm's own convolution kernels under the same autocast show,
+    loss and every parameter gradient.  Smoothed activations on all three runs (tests/_smooth.py: a ReLU kink flipped by an fp16-sized
+    perturbation is an O(1) gradient change that says nothing about the kernels)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from types import SimpleNamespace
+    from _smooth import smooth_activations
+    from openstereo_amd import engine
+    from openstereo_amd.models.stereo_models import StereoBase
+    from openstereo_amd.utils.weights import synth_images
+
+    def build():
+        m = StereoBase(SimpleNamespace(MAX_DISP=192, NUM_GROUPS=8, USE_CONCAT_VOLUME=True, CONCAT_CHANNELS=8, HIDDEN_DIMS=[128, 128, 128],
+                                       N_GRU_LAYERS=3, CORR_RADIUS=4, CORR_LEVELS=2, SLOW_FAST_GRU=False, EVAL_ITERS=32, TRAIN_ITERS=22))
+        sd = synth_state_dict(m, seed=41, head_gain=20.0, gain=0.9)
+        sd.update({k: v for k, v in synth_state_dict(m, seed=41, head_gain=20.0, gain=0.8).items() if k.startswith("update_block.")})
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, nn.modules.batchnorm._BatchNorm):
+                mod.eval()
+        return m
+    H, W = 320, 736
+    L, R = synth_images(1, H, W, seed=33, max_shift=40.0)
+    L, R = L.to(DEV), R.to(DEV)
+    gt = torch.from_numpy(np.random.default_rng(5).uniform(1.0, 120.0, (1, H, W)).astype(np.float32)).to(DEV)
+
+    def step(amp, eager=False):
+        m = build()
+        scaler = torch.amp.GradScaler("cuda", enabled=amp, init_scale=256.0)
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        with (_stock_torch_convs() if eager else _null()), smooth_activations():
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                out = m({"left": L, "right": R})
+                loss, _ = m.get_loss(out, {"disp": gt})
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+        gr = {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+        assert all(torch.isfinite(v).all() for v in gr.values()), "scaled fp16 gradients overflowed"
+        return float(loss.detach()), gr, out["disp_pred"].detach().float()
+
+    old = engine.get_precision()
+    engine.set_precision("f16x3")
+    try:
+        l32, g32, d32 = step(False)
+        l16, g16, d16 = step(True)
+        le, ge, de = step(True, eager=True)
+    finally:
+        engine.set_precision(old)
+    assert g16.keys() == g32.keys() == ge.keys() and len(g32) > 100
+    assert abs(l16 - l32) <= 2.0 * abs(le - l32) + 2e-3 * abs(l32), (l32, l16, le)
+    epe = lambda a, b: float((a - b).abs().mean())
+    assert epe(d16, d32) <= 2.0 * epe(de, d32) + 2e-2, (epe(d16, d32), epe(de, d32))
+    worst_eng = worst_ref = 0.0
+    bad = {}
+    for k in g32:
+        s = float(g32[k].abs().max()) + 1e-20
+        e_eng, e_ref = float((g16[k] - g32[k]).abs().max()) / s, float((ge[k] - g32[k]).abs().max()) / s
+        worst_eng, worst_ref = max(worst_eng, e_eng), max(worst_ref, e_ref)
+        if not e_eng <= 2.0 * e_ref + 3e-2:
+            bad[k] = (e_eng, e_ref)
+    print(f"[whole-model amp step] loss fp32-class {l32:.5f} engine-amp {l16:.5f} eager-amp {le:.5f}; worst relative gradient distance to the fp32-class step: "
+          f"engine {worst_eng:.3e}, eager autocast {worst_ref:.3e}; final disparity EPE engine {epe(d16, d32):.2e} eager {epe(de, d32):.2e}")
+    assert not bad, bad
+    assert worst_eng > 1e-5, "the AMP step must have run the fp16 arithmetic"

