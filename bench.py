@@ -601,6 +601,12 @@ class _eager_torch_mode:
                 with torch.device(disp.device):
                     return self.o(disp, coords)
         GEO.CombinedGeoEncodingVolume = TorchGeo
+        # r6: the fused training ops that are not reached through the entry points above take their torch compositions too -- the ConvGRU gate
+        # kernels (update.py:36-45 as torch ops) and the fused softmax + convex up-sampling (F.softmax + unfold / nearest / weighted sum)
+        from openstereo_amd.models import igev_update as IU, stereo_models as SM
+        for mod, name in ((IU, "FUSED_GRU_TRAIN"), (SM, "FUSED_UPSAMPLE_TRAIN")):
+            self.saved.append((mod, name, getattr(mod, name)))
+            setattr(mod, name, False)
         return self
 
     def __exit__(self, *exc):
