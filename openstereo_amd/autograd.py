@@ -900,6 +900,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if CoS != Co:
             y.zero_()
         Ci4 = (Ci + 3) // 4 * 4
+        _defer_note_use(cache, ctx.needs_input_grad[1], w, None, True, None)      # (the k = 4 up-sampling heads run once per GRU iteration: batched weight gradient)
         if _ext_conv(2, xc, packed, y, [B, 1, H, W, Ci4, Cs, Co, CoS, 0, 0], [k, pad, opad], precision, osc):
             ctx.save_for_backward(xc, wf)
             ctx.meta = (pad, opad, precision, x.dtype)
@@ -926,10 +927,20 @@ class _ConvTranspose2d(torch.autograd.Function):
             dxc = _run_conv(dyc, packed, osc, Co, Ci, (1, k, k), 2, (0, pad, pad), (1, 1, 1), precision, (1, H, W))
             dx = dxc[:, :Ci, 0].to(xdt)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w5)
             Ho, Wo = dyc.shape[3:]
-            _wgrad(xc, dyc, dw, B, 1, H, W, Ci, 1, Ho, Wo, Co, (1, k, k), 2, (0, pad, pad), (1, 1, 1), 1, precision)
-            dw = dw[:, :, 0]
+
+            def run(items):                                        # one weight-gradient launch over every queued (x, dy) pair of this weight
+                xl, dl = [it[0] for it in items], [it[1] for it in items]
+                g = torch.empty_like(w5)
+                if MULTI_WGRAD and 1 < len(items) <= 24 and _same_layout(xl) and _same_layout(dl):
+                    _wgrad(xl, dl, g, len(items) * B, 1, H, W, Ci, 1, Ho, Wo, Co, (1, k, k), 2, (0, pad, pad), (1, 1, 1), 1, precision)
+                else:
+                    xs, dys = _cat_batch(xl), _cat_batch(dl)
+                    _wgrad(xs, dys, g, xs.shape[0], 1, H, W, Ci, 1, Ho, Wo, Co, (1, k, k), 2, (0, pad, pad), (1, 1, 1), 1, precision)
+                return g, None
+            dw, _ = _defer_wgrad(ctx.cache, ("deconv2d", precision, tuple(xc.shape[1:]), tuple(dyc.shape[1:]), k, pad), (xc, dyc), run)
+            if dw is not None:
+                dw = dw[:, :, 0]
         return dx, dw, None, None, None, None
 
 

@@ -274,3 +274,39 @@ def test_training_mode_bn_vs_torch(dims, dtype, monkeypatch):
         assert rel(e[2], r[2]) <= 5 * tol and rel(e[3], r[3]) <= tol
     assert rel(eng.running_mean, ref.running_mean) <= 1e-5 and rel(eng.running_var, ref.running_var) <= 1e-5
     assert int(eng.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_transposed_conv_applied_three_times_gradients(amp):
+    """the k = 4 up-sampling head of the update loop (stereobase_gru.py:114-119 spx_gru: ConvTranspose2d(64, 9, 4, 2, 1), once per GRU
+    iteration): its weight gradient is ONE batched class-mode launch over the queued pairs, its bias gradient one channel-sums pass per
+    use -- equal to torch autograd's accumulated gradients"""
+    from openstereo_amd import autograd as AG, engine
+    engine.set_precision("f16x3")
+    Ci, Co, H, W = 64, 9, 20, 46
+    dc = nn.ConvTranspose2d(Ci, Co, 4, 2, 1).to(DEV)
+    with torch.no_grad():
+        dc.weight.copy_((rn((Ci, Co, 4, 4), 1) * 0.05).to(DEV)); dc.bias.copy_((rn((Co,), 2) * 0.1).to(DEV))
+    xs = [rn((1, Ci, H, W), 10 + i).to(DEV) for i in range(3)]
+    gys = [rn((1, Co, 2 * H, 2 * W), 20 + i).to(DEV) for i in range(3)]
+
+    def run(engine_on):
+        dc.zero_grad(set_to_none=True)
+        ins = [x.clone().requires_grad_() for x in xs]
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            if engine_on:
+                with AG.engine_convs():
+                    outs = [dc(x) for x in ins]
+            else:
+                outs = [dc(x) for x in ins]
+            loss = sum((o.float() * g).sum() for o, g in zip(outs, gys))
+        loss.backward()
+        return dc.weight.grad.clone(), dc.bias.grad.clone(), [x.grad.clone() for x in ins]
+
+    w0, b0, dx0 = run(False)
+    w1, b1, dx1 = run(True)
+    tol = 3e-3 if amp else 2e-5
+    rel = lambda a, b_: float((a.float() - b_.float()).abs().max() / (b_.float().abs().max() + 1e-30))
+    assert rel(w1, w0) <= tol and rel(b1, b0) <= tol and all(rel(a, c) <= tol for a, c in zip(dx1, dx0))
+    w2, b2, _ = run(True)
+    assert torch.equal(w1, w2) and torch.equal(b1, b2)
