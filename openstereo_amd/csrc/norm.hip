@@ -296,7 +296,7 @@ extern "C" int osa_instnorm_nhwc_f32(const float* x, float* y, int B, long long 
 
 static int channel_sums_wgs(long long P, int C) {
     const int Cq = (C + 3) / 4, PL = 256 / (Cq > 0 ? Cq : 1);
-    long long n = P / ((long long)(PL > 0 ? PL : 1) * 16);      // at least ~16 positions per thread
+    long long n = P / ((long long)(PL > 0 ? PL : 1) * 4);       // at least ~4 positions per thread (the second stage is one wave per channel quad: partials are cheap)
     if (n > 1024) n = 1024;
     if (n < 1) n = 1;
     return (int)n;

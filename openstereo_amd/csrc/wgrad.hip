@@ -740,14 +740,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs
     if (a >= p.A || b >= p.Bc) return;
     const float* src = p.ws + ((size_t)y * p.gx + tg) * (WG_TAPS * 1024) + e;
     const size_t step = (size_t)p.tgroups * (WG_TAPS * 1024);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;            // fixed association order: deterministic
+    // fixed association order: deterministic.  Eight independent partial sums = eight loads in flight per thread (the strips are 36 KB
+    // apart: with four the kernel was latency-bound, 12.6 us for ~40 strips)
+    float sp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int i = 0;
-    for (; i + 4 <= p.nstrips; i += 4) {
-        s0 += src[(size_t)i * step]; s1 += src[(size_t)(i + 1) * step]; s2 += src[(size_t)(i + 2) * step]; s3 += src[(size_t)(i + 3) * step];
+    for (; i + 8 <= p.nstrips; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(i + j) * step];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sp[j] += v[j];
     }
-    for (; i < p.nstrips; ++i) s0 += src[(size_t)i * step];
+    for (int j = 0; i < p.nstrips; ++i, ++j) sp[j] += src[(size_t)i * step];
     const int tt = p.cls ? p.tapid[t0 + t] : t0 + t;
-    p.dW[((size_t)a * p.Bc + b) * p.kvol + tt] = (s0 + s1) + (s2 + s3);
+    p.dW[((size_t)a * p.Bc + b) * p.kvol + tt] = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
 }
 
 }  // namespace osa
