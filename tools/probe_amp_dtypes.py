@@ -36,9 +36,9 @@ def fe(self, disp, corr):
 IU.BasicMotionEncoder.forward_train = fe
 ou = IU.BasicMultiUpdateBlock.forward_train
 c2 = [0]
-def fu(self, net, inp, corr=None, disp=None, **k):
-    r = ou(self, net, inp, corr, disp, **k)
-    if c2[0] < 2 and k.get("update", True):
+def fu(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+    r = ou(self, net, inp, corr, disp, iter04, iter08, iter16, update)
+    if c2[0] < 2 and update:
         c2[0] += 1
         print("update: net", [desc(t) for t in net], "-> net", [desc(t) for t in r[0]], "mask", desc(r[1]), "delta", desc(r[2]))
     return r
