@@ -14,7 +14,7 @@ ap.add_argument("--workload", default="stereobase_e2e_train")
 ap.add_argument("--amp", action="store_true")
 ap.add_argument("--top", type=int, default=60)
 ap.add_argument("--batch", type=int, default=None)
-ap.add_argument("--stacks", default="", help="comma-separated op names (aten::copy_,aten::add_,...): device time of each grouped by Python call stack")
+ap.add_argument("--stacks", default="", help="comma-separated op names (aten::copy_,aten::add_,...): device time of each grouped by input shapes (and by the Python frames of this package where the profiler records them: ops issued by the autograd engine have none)")
 a = ap.parse_args()
 import bench  # noqa: E402
 from openstereo_amd import engine  # noqa: E402
