@@ -499,16 +499,20 @@ __global__ __launch_bounds__(256) void wgrad_f16x3_kernel(const WgradArgs p) {
 // contiguous range of bricks over (batch, d, h, w) -- `strip` bricks, chosen so that the launch is ~2 workgroups per CU -- before it
 // hands over.  Same LDS images, operand reads, records and reduce kernel as above.  Unit-stride layers only (class mode keeps the
 // single-tile kernel).
-template <int TD, int TH, int TW, int SPLIT, int PF16, int QF16, int NA, int NB>
-__global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs p) {
+// NG = 3 (3 x 3 x 3 layers with few channel tiles: the 32 -> 32 / 64 -> 32 layers of GwcNet / PSMNet, r5's "single-workgroup 27-tap" ask): the
+// three tap groups (kd planes) are three groups of WAVES of ONE workgroup instead of three workgroups -- the P tile is staged once instead of
+// three times and the Q brick once with a d halo (TD + 2 planes) instead of three times TD planes; wave (tile, kd) reads its plane offset.
+template <int TD, int TH, int TW, int SPLIT, int PF16, int QF16, int NA, int NB, int NG = 1>
+__global__ __launch_bounds__(64 * NA * NB * NG) void wgrad_mt_kernel(const WgradArgs p) {
     static_assert(!SPLIT || (!PF16 && !QF16), "fp16 tensors exist in the native f16 form only");
     static_assert(TD * TH * TW == 128 && (TW == 8 || TW == 16), "128-position bricks");
-    static_assert(8 % NB == 0, "P items per thread");
-    constexpr int NT = 64 * NA * NB;
+    static_assert(NG == 1 || NG == 3, "tap groups per workgroup");
+    constexpr int NT = 64 * NA * NB * NG;
     constexpr int ROWH = (TW == 8) ? 16 : 24;
     constexpr int LHM = TH + 2;
     constexpr int CHS_P = 136;
-    constexpr int CHS_Q = TD * LHM * ROWH + 8;
+    constexpr int TDQ = TD + (NG == 3 ? 2 : 0);        // Q planes in LDS
+    constexpr int CHS_Q = TDQ * LHM * ROWH + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
     unsigned short* const Ph = smem_h;                              // [NA * 32][CHS_P]
     unsigned short* const Pl = Ph + NA * 32 * CHS_P;
@@ -517,16 +521,17 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wa = wave % NA, wb = wave / NA;
+    const int wt = wave % (NA * NB), wgp = wave / (NA * NB);      // tile of this wave, tap group of this wave (NG = 3)
+    const int wa = wt % NA, wb = wt / NA;
     const int col = lane & 31, hh = lane >> 5;
     const unsigned bx = blockIdx.x;
-    const int tg = bx % p.tgroups;
-    const int sidx = bx / p.tgroups;
+    const int tg = (NG == 1) ? (int)(bx % p.tgroups) : wgp;
+    const int sidx = (NG == 1) ? (int)(bx / p.tgroups) : (int)bx;
     const int atiles = (p.A + 31) / 32, btiles = (p.Bc + 31) / 32;
     const int nablk = (atiles + NA - 1) / NA;
     const int ablk = blockIdx.y % nablk, bblk = blockIdx.y / nablk;
     const int a0 = ablk * NA * 32, b0 = bblk * NB * 32;
-    const int od = p.g_od[tg];
+    const int od = (NG == 1) ? p.g_od[tg] : p.dmin;                // first Q plane of the staged brick (NG = 3: host guarantees g_od[g] = dmin + g)
     const float sP = p.Pmeta ? wg_pow2_scale(amax_read(p.Pmeta)) : 1.f, sQ = p.Qmeta ? wg_pow2_scale(amax_read(p.Qmeta)) : 1.f;
     const float inv = (1.0f / sP) * (1.0f / sQ);
     const int nbricks = p.B * p.tilesD * p.tilesH * p.tilesW;
@@ -539,12 +544,12 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int npq = (p.LW + 1) >> 1;                 // voxel pairs per Q row
-    const int nRP = TD * p.LH * npq;                 // (row, pair) items of the Q brick per channel quad
+    const int nRP = TDQ * p.LH * npq;                // (row, pair) items of the Q brick per channel quad
     // staging items: a wave's 64 consecutive items are 8 (position pairs | row pairs) x 8 channel quads of ONE 32-channel group, as in the
     // single-tile kernel (its LDS write pattern: 32-bit writes of 8 consecutive pairs, channel rows on distinct 16-byte slots)
-    constexpr int PIT = 8 / NB, QIT = (NB * TD * LHM * ((TW + 3) / 2) * 8 + NT - 1) / NT;
+    constexpr int PIT = (512 * NA + NT - 1) / NT, QIT = (NB * TDQ * LHM * ((TW + 3) / 2) * 8 + NT - 1) / NT;
     int p_src[PIT], p_dst[PIT], q_src[QIT], q_dst[QIT];
-    unsigned q_ok[QIT];
+    unsigned q_ok[QIT], p_ok[PIT];
     int p_d[PIT], p_h[PIT], p_w[PIT], q_d[QIT], q_h[QIT], q_w[QIT];
 #pragma unroll
     for (int k = 0; k < PIT; ++k) {
@@ -553,6 +558,7 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
         const int q0 = pair * 2, ch = cg * 32 + c4 * 4;
         p_w[k] = q0 % TW; p_h[k] = (q0 / TW) % TH; p_d[k] = q0 / (TW * TH);
         p_src[k] = ch; p_dst[k] = ch * CHS_P + q0;
+        p_ok[k] = (it < 512 * NA) ? 1u : 0u;
     }
 #pragma unroll
     for (int k = 0; k < QIT; ++k) {
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
             const int gd = p0d + p_d[k], gh = p0h + p_h[k], gw = p0w + p_w[k];
-            const bool row = gd < p.Pd && gh < p.Ph;
+            const bool row = p_ok[k] && gd < p.Pd && gh < p.Ph;
             const size_t off = ((((size_t)bl * p.Pd + (row ? gd : 0)) * p.Ph + (row ? gh : 0)) * p.Pw + gw) * p.PCs + a0 + p_src[k];
             const int nc = p.PC - (a0 + p_src[k]);
             if constexpr (PF16) {
@@ -630,6 +636,7 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
     auto commit = [&]() {
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
+            if (!p_ok[k]) continue;
             const float x0[4] = {pv[k][0].x, pv[k][0].y, pv[k][0].z, pv[k][0].w}, x1[4] = {pv[k][1].x, pv[k][1].y, pv[k][1].z, pv[k][1].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
             const wf16x8 pa_h = __builtin_bit_cast(wf16x8, ah), pa_l = __builtin_bit_cast(wf16x8, al);
             const int prow = (TW == 8) ? hb : (hb >> 1);
             const int pd = prow / TH, ph = prow % TH;
-            const int qoff = qcol + (pd * LHM + ph) * ROWH + ((TW == 16) ? (hb & 1) * 8 : 0);
+            const int qoff = qcol + ((pd + (NG == 3 ? wgp : 0)) * LHM + ph) * ROWH + ((TW == 16) ? (hb & 1) * 8 : 0);
 #pragma unroll
             for (int dh = 0; dh < 3; ++dh) {
                 if (p.g_slot[tg][dh * 3] >= 0 || p.g_slot[tg][dh * 3 + 1] >= 0 || p.g_slot[tg][dh * 3 + 2] >= 0) {
@@ -710,7 +717,9 @@ __global__ __launch_bounds__(64 * NA * NB) void wgrad_mt_kernel(const WgradArgs 
     // ---- this wave's tile record, slot dh * 3 + dw -> tap j of the group
     const int a_tile = ablk * NA + wa, b_tile = bblk * NB + wb;
     if (a_tile < atiles && b_tile < btiles) {
-        float* dst = p.ws + ((size_t)(b_tile * atiles + a_tile) * gridDim.x + bx) * (WG_TAPS * 1024) + lane;
+        // record index as in the single-tile kernels: workgroup column = strip * tgroups + tap group
+        const size_t gx = (NG == 1) ? gridDim.x : (size_t)gridDim.x * NG, bxr = (NG == 1) ? bx : (size_t)sidx * NG + tg;
+        float* dst = p.ws + ((size_t)(b_tile * atiles + a_tile) * gx + bxr) * (WG_TAPS * 1024) + lane;
 #pragma unroll
         for (int t = 0; t < WG_TAPS; ++t) {
             const int j = p.g_slot[tg][t];
@@ -903,6 +912,57 @@ static int wgrad_impl(const float* x, const float* dy, float* dw,
         const size_t lds_ops = (size_t)(planes * 32 * 136 + planes * 32 * chs_q) * sizeof(unsigned short);
         const size_t lds = lds_ops > (size_t)3 * 16 * 64 * sizeof(float) ? lds_ops : (size_t)3 * 16 * 64 * sizeof(float);   // (the hand-over of the partial tiles reuses it: 3 waves x 16 x 64 floats)
         const int gy = cdiv(a.A, 32) * cdiv(a.Bc, 32);
+        if (!a.cls && g_wgrad_mt && !flat16 && kd == 3 && a.tgroups == 3 && cdiv(a.A, 32) * cdiv(a.Bc, 32) == 1 &&
+            a.g_od[0] == a.dmin && a.g_od[1] == a.dmin + 1 && a.g_od[2] == a.dmin + 2) {
+            // few channel tiles, 3 x 3 x 3 taps: ONE workgroup per (tiles, brick range) with the three kd planes as three groups of waves (NG = 3)
+            const int atl = cdiv(a.A, 32), btl = cdiv(a.Bc, 32);
+            const int NA = 1, NB = 1;                                       // (two-tile layers spill at 6 waves / 256 registers: they keep the single-tile kernel)
+            const long long nbricks = (long long)B * a.tilesD * a.tilesH * a.tilesW;
+            OSA_REQUIRE(nbricks < (1ll << 30), "conv3d_wgrad_f16x3: too many position bricks");
+            long long nstr = 2 * 256ll;
+            if (nstr > cdiv((int)nbricks, 4)) nstr = cdiv((int)nbricks, 4);
+            if (nstr < 1) nstr = 1;
+            a.strip = exp_int("OSA_WGRAD_STRIP", (int)cdiv((int)nbricks, (int)nstr));
+            if (a.strip < 1) a.strip = 1;
+            nstr = cdiv((int)nbricks, a.strip);
+            const long long gx = nstr * 3;
+            const size_t need = (size_t)gx * gy * WG_TAPS * 1024 * sizeof(float);
+            if (query) { *query = need; return 0; }
+            OSA_REQUIRE(ws && ws_bytes >= need && ((size_t)ws & 15) == 0, "conv3d_wgrad_f16x3: workspace of %zu B needed (got %zu)", need, ws_bytes);
+            if (f16x3 == 1) OSA_REQUIRE(x_meta && dy_meta, "conv3d_wgrad_f16x3: range blocks of x and dy required");
+            a.ws = ws;
+            a.Pmeta = dy_meta; a.Qmeta = x_meta;
+            a.Pf16 = dy_f16; a.Qf16 = x_f16;
+            const int chs_q3 = (TD + 2) * (TH + 2) * 16 + 8;
+            const size_t lds_mt = (size_t)planes * (NA * 32 * 136 + NB * 32 * chs_q3) * sizeof(unsigned short);
+            OSA_REQUIRE(lds_mt <= 160 * 1024, "conv3d_wgrad_f16x3: %zu B of LDS", lds_mt);
+            dim3 grid((unsigned)nstr, 1), block(64 * NA * NB * 3);
+#define OSA_WG_G3_LAUNCH(...)                                                                                                         \
+            do { (void)hipFuncSetAttribute((const void*)wgrad_mt_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mt); \
+                 hipLaunchKernelGGL((wgrad_mt_kernel<__VA_ARGS__>), grid, block, lds_mt, st, a); } while (0)
+#define OSA_WG_G3_T(NA_, NB_)                                                                                                         \
+            if (f16x3 == 1) OSA_WG_G3_LAUNCH(2, 8, 8, 1, 0, 0, NA_, NB_, 3);                                                           \
+            else switch (a.Pf16 * 2 + a.Qf16) {                                                                                       \
+                case 0: OSA_WG_G3_LAUNCH(2, 8, 8, 0, 0, 0, NA_, NB_, 3); break;                                                       \
+                case 1: OSA_WG_G3_LAUNCH(2, 8, 8, 0, 0, 1, NA_, NB_, 3); break;                                                       \
+                case 2: OSA_WG_G3_LAUNCH(2, 8, 8, 0, 1, 0, NA_, NB_, 3); break;                                                       \
+                default: OSA_WG_G3_LAUNCH(2, 8, 8, 0, 1, 1, NA_, NB_, 3); break;                                                      \
+            }
+            OSA_WG_G3_T(1, 1)
+#undef OSA_WG_G3_T
+#undef OSA_WG_G3_LAUNCH
+            OSA_LAUNCH_CHECK("conv3d_wgrad_mt_g3");
+            WgradReduceArgs r;
+            memset(&r, 0, sizeof(r));
+            r.ws = ws; r.dW = dw; r.gx = (int)gx; r.tgroups = 3; r.nstrips = (int)nstr;
+            r.A = a.A; r.Bc = a.Bc; r.kvol = T; r.atiles = atl; r.T = T;
+            r.cls = 1;
+            for (int t2 = 0; t2 < T; ++t2) r.tapid[t2] = (signed char)t2;
+            memcpy(r.g_t0, a.g_t0, sizeof(r.g_t0)); memcpy(r.g_nt, a.g_nt, sizeof(r.g_nt));
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(WG_TAPS * 1024 / 256, 3, gy), dim3(256), 0, st, r);
+            OSA_LAUNCH_CHECK("conv3d_wgrad_mt_g3_reduce");
+            return 0;
+        }
         if (!a.cls && g_wgrad_mt && cdiv(a.A, 32) * cdiv(a.Bc, 32) >= 4) {
             // multi-tile form (wgrad_mt_kernel): NA x NB tiles per workgroup, a contiguous range of `strip` bricks per workgroup
             const int atl = cdiv(a.A, 32), btl = cdiv(a.Bc, 32);

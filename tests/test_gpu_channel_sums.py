@@ -310,3 +310,32 @@ def test_transposed_conv_applied_three_times_gradients(amp):
     assert rel(w1, w0) <= tol and rel(b1, b0) <= tol and all(rel(a, c) <= tol for a, c in zip(dx1, dx0))
     w2, b2, _ = run(True)
     assert torch.equal(w1, w2) and torch.equal(b1, b2)
+
+
+@pytest.mark.parametrize("prec", ["f16", "f16x3"])
+@pytest.mark.parametrize("case", [("3d 32->32", 32, 32, (2, 10, 20, 24)), ("3d 24->20 ragged", 24, 20, (1, 5, 9, 13)), ("3d 32->32 one plane", 32, 32, (1, 1, 16, 16))])
+def test_three_kd_planes_in_one_workgroup_vs_single_tile(case, prec):
+    """wgrad_mt_kernel<.., 1, 1, 3>: 3x3x3 layers with one channel tile -- the three kd planes as three groups of waves of ONE workgroup (P tile
+    staged once, Q brick once with a d halo) against the three-workgroup single-tile kernel and torch"""
+    from openstereo_amd import _lib, autograd as AG, ops
+    from openstereo_amd.ranges import input_meta
+    _, Ci, Co, (B, D, H, W) = case
+    lib = _lib.load()
+    x = ops.to_cl(rn((B, Ci, D, H, W), 1).to(DEV))
+    dy = ops.to_cl((rn((B, Co, D, H, W), 2) * 1e-2).to(DEV))
+    mx, mdy = input_meta(x), input_meta(dy)
+    default = lib.osa_conv_b_ring_mask(-1)
+    lib.osa_conv_b_ring_mask(default)
+    got = {}
+    try:
+        for name, mask in (("g3", default), ("single", default & ~(1 << 27))):
+            lib.osa_conv_b_ring_mask(mask)
+            dw = torch.empty(Co, Ci, 3, 3, 3, device=DEV)
+            AG._wgrad(x, dy, dw, B, D, H, W, Ci, D, H, W, Co, (3, 3, 3), 1, (1, 1, 1), (1, 1, 1), 0, prec, mx, mdy)
+            got[name] = dw.clone()
+    finally:
+        lib.osa_conv_b_ring_mask(default)
+    want = torch.nn.grad.conv3d_weight(x[:, :Ci].cpu().double().contiguous(), (Co, Ci, 3, 3, 3), dy[:, :Co].cpu().double().contiguous(), padding=1).float().to(DEV)
+    scale = float(want.abs().max())
+    assert float((got["g3"] - got["single"]).abs().max()) <= 2e-5 * scale
+    assert float((got["g3"] - want).abs().max()) <= (3e-3 if prec == "f16" else 2e-5) * scale
