@@ -312,6 +312,14 @@ int osa_dwconv2d_nhwc_f32(const float* x, const float* w_packed,
                           int B, int Hi, int Wi, int C, int xCs, int yCs, int aCs,
                           int kh, int kw, int stride, int pad_h, int pad_w, int dil_h, int dil_w,
                           int act, float* y_meta, void* stream);
+/* The 3 x 3 depthwise layers with fp16 input and / or output tensors (r6): the chain tensors of the f16 mode between MobileV2Residual's
+ * 1 x 1 expansion, depthwise and 1 x 1 projection convolutions (aggregation.py:63-98; under the reference's autocast these are fp16
+ * tensors too).  Same arithmetic (fp32 fmaf per tap, folded BN, activation); channel strides in elements, fp16 tensors 8-byte aligned. */
+int osa_dwconv2d_nhwc_f16io(const void* x, int x_f16, const float* w_packed,
+                            const float* scale, const float* shift, void* y, int y_f16,
+                            int B, int Hi, int Wi, int C, int xCs, int yCs,
+                            int kh, int kw, int stride, int pad_h, int pad_w,
+                            int act, float* y_meta, void* stream);
 
 /*
  * ConvGRU state update (models/igev/update.py:42, models/stereobase/gru_blocks.py ConvGRU):

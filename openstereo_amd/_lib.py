@@ -140,6 +140,7 @@ SIGNATURES = {
                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                     c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                     c_i, c_fp, c_st]),
+    "osa_dwconv2d_nhwc_f16io": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_i] + [c_i] * 11 + [c_i, c_fp, c_st]),
     "osa_gru_combine_f32": (c_i, [c_fp, c_fp, c_fp, c_fp, c_ll, c_i, c_i, c_i, c_i, c_i, c_fp, c_st]),
     "osa_gru_gates_rz_fwd": (c_i, [c_ref, c_fp, c_fp, c_ref, c_ref, c_ref, c_ref, c_ref, c_ll, c_i, c_st]),
     "osa_gru_gates_rz_bwd": (c_i, [c_ref, c_fp, c_fp, c_ref, c_ref, c_ref, c_ref, c_ref, c_ref, c_ref, c_ll, c_i, c_st]),

@@ -512,6 +512,17 @@ void dwconv2d(const at::Tensor& x, const at::Tensor& packed, const c10::optional
                                    mfp(y_meta), cur_stream()));
 }
 
+// the 3 x 3 depthwise layers with fp16 input and / or output tensors (the f16 mode's chain tensors): dims = [B, Hi, Wi, C, xCs, yCs], geom = [kh, kw, stride, pad_h, pad_w]
+void dwconv2d_f16io(const at::Tensor& x, const at::Tensor& packed, const c10::optional<at::Tensor>& scale, const c10::optional<at::Tensor>& shift,
+                    at::Tensor y, at::IntArrayRef dims, at::IntArrayRef geom, int64_t act, const c10::optional<at::Tensor>& y_meta) {
+    gpu_f32(packed, "packed");
+    const bool xh = x.scalar_type() == at::kHalf, yh = y.scalar_type() == at::kHalf;
+    TORCH_CHECK(x.is_cuda() && y.is_cuda() && (xh || x.scalar_type() == at::kFloat) && (yh || y.scalar_type() == at::kFloat), "dwconv2d_f16io: CUDA fp32 / fp16 tensors");
+    TORCH_CHECK(dims.size() == 6 && geom.size() == 5, "dwconv2d_f16io: dims = [B, Hi, Wi, C, xCs, yCs], geom = [kh, kw, stride, pad_h, pad_w]");
+    OSA_CALL(osa_dwconv2d_nhwc_f16io(x.data_ptr(), xh ? 1 : 0, fp(packed), fpo(scale), fpo(shift), y.data_ptr(), yh ? 1 : 0, (int)dims[0], (int)dims[1], (int)dims[2], (int)dims[3],
+                                     (int)dims[4], (int)dims[5], (int)geom[0], (int)geom[1], (int)geom[2], (int)geom[3], (int)geom[4], (int)act, mfp(y_meta), cur_stream()));
+}
+
 // h' = (1 - z) h + z q of the inference GRU loop (igev/update.py:45) on channel slices of the level buffer: dims = [npix, C, zCs, qCs, hCs, oCs]
 void gru_combine(const at::Tensor& z, int64_t z_off, const at::Tensor& q, const at::Tensor& h, at::Tensor out, at::IntArrayRef dims, const c10::optional<at::Tensor>& out_meta) {
     gpu_f32(z, "z"); gpu_f32(q, "q"); gpu_f32(h, "h"); gpu_f32(out, "out");
@@ -974,6 +985,7 @@ TORCH_LIBRARY(osa_native, m) {
           "Tensor rpacked, Tensor? rscale, Tensor? rshift, float r_out_scale, int prec, int act, float slope, float out_scale, Tensor[] metas) -> ()");
     m.def("small_co_conv(Tensor x, Tensor packed, Tensor? bias, Tensor? residual, Tensor(a!) y, int[] dims, int[] geom) -> ()");
     m.def("dwconv2d(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, Tensor? add, Tensor(a!) y, int[] dims, int[] geom, int act, Tensor(b!)? y_meta) -> ()");
+    m.def("dwconv2d_f16io(Tensor x, Tensor packed, Tensor? scale, Tensor? shift, Tensor(a!) y, int[] dims, int[] geom, int act, Tensor(b!)? y_meta) -> ()");
     m.def("gru_combine(Tensor z, int z_off, Tensor q, Tensor h, Tensor(a!) out, int[] dims, Tensor(b!)? out_meta) -> ()");
     m.def("resample_nhwc(Tensor x, Tensor(a!) y, int y_off, int kind, int[] dims, Tensor? x_meta, Tensor(b!)? y_meta) -> ()");
     m.def("disp_update(Tensor(a!) disp, Tensor? delta, int delta_cs, Tensor(b!) disp4, Tensor(c!) slot, int slot_off, int slot_cs, int npix, Tensor(d!)? disp4_meta, "
@@ -1026,6 +1038,7 @@ TORCH_LIBRARY_IMPL(osa_native, CUDA, m) {        // (the HIP backend registers u
     m.impl("deconv_redir", &deconv_redir);
     m.impl("small_co_conv", &small_co_conv);
     m.impl("dwconv2d", &dwconv2d);
+    m.impl("dwconv2d_f16io", &dwconv2d_f16io);
     m.impl("gru_combine", &gru_combine);
     m.impl("resample_nhwc", &resample_nhwc);
     m.impl("disp_update", &disp_update);
@@ -1068,7 +1081,7 @@ TORCH_LIBRARY_IMPL(osa_native, Meta, m) {        // shape / dtype inference with
     m.impl("context_upsample_logits", &context_upsample_logits_meta);
     m.impl("context_upsample_logits_bwd", &context_upsample_logits_bwd_meta);
     for (const char* name : {"conv_ndhwc", "to_cl", "to_ncdhw", "conv_pack", "deconv_pack", "gru_gates_rz_fwd", "gru_gates_rz_bwd", "gru_gates_q_fwd", "gru_gates_q_bwd",
-                             "geo_lookup", "geo_lookup_bwd", "geo_lookup_bwd_acc", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "gru_combine", "resample_nhwc", "disp_update",
+                             "geo_lookup", "geo_lookup_bwd", "geo_lookup_bwd_acc", "build_volume", "deconv_redir", "small_co_conv", "dwconv2d", "dwconv2d_f16io", "gru_combine", "resample_nhwc", "disp_update",
                              "geo_lookup_nhwc", "allpairs_corr", "geo_rows", "avgpool_rows", "weight_pack", "cat_fms", "pair_volume", "instnorm_nhwc", "preprocess_pair",
                              "amax_into"})
         m.impl(name, torch::CppFunction::makeFromBoxedFunction<&noop_boxed>());

@@ -506,20 +506,33 @@ class DepthwiseConv2d:
         else:
             _lib.call("osa_dwconv2d_pack_f32", w.data_ptr(), self.packed.data_ptr(), self.C, self.k[0], self.k[1], _stream())
 
-    def __call__(self, x, add=None):
-        assert is_cl(x) and x.dtype == torch.float32 and x.shape[2] == 1
+    def __call__(self, x, add=None, out_f16=False):
+        """out_f16 / an fp16 `x` (r6, the 3 x 3 layers in the f16 mode): the chain tensors between MobileV2Residual's expansion, depthwise and
+        projection convolutions are fp16 -- what the reference's autocast moves there -- instead of fp32 (half the bytes of HBM-bound layers)"""
+        assert is_cl(x) and x.dtype in (torch.float32, torch.float16) and x.shape[2] == 1
         B, Cs, _, H, W = x.shape
         assert Cs >= self.C
         f = lambda n, k, p, d, st: (n + 2 * p - d * (k - 1) - 1) // st + 1
         Ho, Wo = f(H, self.k[0], self.pad[0], self.dil[0], self.stride[0]), f(W, self.k[1], self.pad[1], self.dil[1], self.stride[1])
-        out = empty_cl(B, self.C, 1, Ho, Wo, x.device)
+        h16 = x.dtype == torch.float16 or out_f16
+        if h16:
+            assert add is None and self.k[1] == 3 and self.dil == (1, 1), "fp16 tensors: the 3 x 3 depthwise layers"
+        out = empty_cl(B, self.C, 1, Ho, Wo, x.device, torch.float16 if out_f16 else torch.float32)
         aCs = 0
         if add is not None:
             assert is_cl(add) and tuple(add.shape[2:]) == (1, Ho, Wo) and add.shape[1] >= self.C
             aCs = add.shape[1]
         with timing.span("dwconv2d", self.C, self.C, self.k[0] * self.k[1], self.stride[0], 1, H, W):
             ext = _ext.load()
-            if ext is not None:
+            if h16:
+                if ext is not None:
+                    ext.dwconv2d_f16io(x, self.packed, self.scale, self.shift, out, [B, H, W, self.C, Cs, self.C],
+                                       [self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1]], self.act, attach_meta(out))
+                else:
+                    _lib.call("osa_dwconv2d_nhwc_f16io", x.data_ptr(), int(x.dtype == torch.float16), self.packed.data_ptr(), _p(self.scale), _p(self.shift),
+                              out.data_ptr(), int(out_f16), B, H, W, self.C, Cs, self.C, self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1],
+                              self.act, attach_meta(out).data_ptr(), _stream())
+            elif ext is not None:
                 ext.dwconv2d(x, self.packed, self.scale, self.shift, add, out, [B, H, W, self.C, Cs, self.C, aCs],
                              [self.k[0], self.k[1], self.stride[0], self.pad[0], self.pad[1], self.dil[0], self.dil[1]], self.act, attach_meta(out))
             else:

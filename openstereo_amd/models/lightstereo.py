@@ -17,6 +17,8 @@ forward_cl() is the channels-last entry used inside engine chains.  No CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -45,6 +47,9 @@ def cl_to_nchw(x, C=None):
     return x[:, :C, 0].contiguous()
 
 
+F16_CHAIN = os.environ.get("OSA_LS_F16_CHAIN", "1") != "0"     # f16 mode: fp16 tensors between a block's expansion, depthwise and projection layers
+
+
 class MobileV2Residual(nn.Module):
     """aggregation.py:63-98"""
 
@@ -68,6 +73,10 @@ class MobileV2Residual(nn.Module):
 
     def forward_cl(self, x):
         pw, dw, pl = self._pack()
+        if F16_CHAIN and pw.precision == "f16" and dw.k == (3, 3) and dw.dil == (1, 1) and pw.Co % 8 == 0:
+            # f16 mode (r6): the expanded tensor (expanse_ratio x the channels: the bytes that bound these layers) stays fp16 between the three
+            # launches, as under the reference's autocast; the block's input / output keep their dtype
+            return pl(dw(pw(x, out_split=True), out_f16=True), residual=x if self.use_res_connect else None)
         return pl(dw(pw(x)), residual=x if self.use_res_connect else None)     # x + feat fused in the epilogue
 
     def forward_train(self, x):

@@ -226,3 +226,29 @@ def test_eight_channel_hourglass_does_not_read_behind_its_input(prec):
         assert float(got[0, :, -1, -1, -1].abs().max()) > 0                     # the last voxel is alive in this fixture
     finally:
         engine.set_precision(old)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_depthwise_3x3_with_fp16_tensors_vs_the_fp32_kernel(stride):
+    """osa_dwconv2d_nhwc_f16io (r6): fp16 in / out tensors of the f16 mode's MobileV2Residual chain -- the fp32 kernel run on the SAME
+    fp16-rounded input, its result rounded to fp16: bit-identical (same fmaf order, one rounding at the store)"""
+    import torch.nn as nn
+    from openstereo_amd import ops
+    from openstereo_amd.engine import DepthwiseConv2d, ACT_RELU6
+    C, H, W = 192, 23, 37
+    conv = nn.Conv2d(C, C, 3, stride, 1, groups=C, bias=False).to(DEV)
+    bn = nn.BatchNorm2d(C).to(DEV).eval()
+    with torch.no_grad():
+        conv.weight.copy_(rnd((C, 1, 3, 3), 1).to(DEV) * 0.3)
+        bn.weight.copy_(rnd((C,), 2).abs().to(DEV) + 0.5); bn.bias.copy_(rnd((C,), 3).to(DEV) * 0.1)
+        bn.running_mean.copy_(rnd((C,), 4).to(DEV) * 0.1); bn.running_var.copy_(rnd((C,), 5).abs().to(DEV) + 0.5)
+    dw = DepthwiseConv2d(conv, bn, ACT_RELU6)
+    x32 = ops.to_cl(rnd((2, C, 1, H, W), 6).to(DEV) * 2.0)
+    x16 = x32.half()
+    assert ops.is_cl(x16)
+    want = dw(x16.float())
+    got_hh = dw(x16, out_f16=True)
+    got_hf = dw(x16)
+    got_fh = dw(x16.float(), out_f16=True)
+    assert got_hh.dtype == torch.float16 and got_hf.dtype == torch.float32 and got_fh.dtype == torch.float16
+    assert torch.equal(got_hf, want) and torch.equal(got_hh, want.half()) and torch.equal(got_fh, want.half())
