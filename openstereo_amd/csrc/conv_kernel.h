@@ -1154,6 +1154,8 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
             const size_t rbstep = (size_t)2 * p.CoP, rtstep = (size_t)JO * rbstep;
             constexpr int RCH = RV / 2;                            // chunks of 16 redir input channels held per tile
             const int rch = (p.rCi + CC - 1) / CC;
+            // first channel a quad load may NOT start at: rCi for plain tensors; a split tensor's chunks are whole ([16 hi | 16 lo] per 16 channels)
+            const int rlim = (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) ? rch * CC : p.rCi;
             // x rows of tile i in MFMA A-operand order: lane (col, hh) -> voxel row `col`
             auto load_x = [&](auto F, int i, float4 (&rv)[RV]) {
                 constexpr bool FULL = decltype(F)::value;
@@ -1173,8 +1175,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64 + (PIPE ? 64 : 0), (KS > 1) ? (WM
                     // (cin < rCi per quad: with 8 redir channels the upper half of the chunk would be the NEXT voxel's channels -- harmless
                     // under zero weights unless it is the tensor's last voxel and the bytes behind the allocation decode as NaN / inf:
                     // NaN x 0 = NaN, ReLU(NaN) = 0 -- found in r6 as an order-dependent test failure, StereoBase / IGEV run 8-channel hourglasses)
-                    const bool quad_ok = (PREC == PREC_F16X3 && (p.act & OSA_REDIR_SPLIT)) || cin < p.rCi;
-                    if (FULL || (ok && ch < rch && ch * CC < p.rCi && quad_ok)) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
+                    if (FULL || (ok && ch < rch && cin < rlim)) rv[k] = *reinterpret_cast<const float4*>(rxb + vox * p.rxCs + cin);
                 }
             };
             // Tile-invariant operands of the branch, loaded ONCE: the stores of the tiles in between may alias them as far

@@ -236,6 +236,70 @@ __global__ __launch_bounds__(256) void dwconv3x3_h8_kernel(const DwArgs p, const
     if (p.meta) publish_amax(p.meta, am, am_seen, red);
 }
 
+// Vertical strips (K x 1: AttentionModule's 7x1 / 11x1 / 21x1 layers, aggregation.py:105-113), r6: a thread owns 4 channels of NPY consecutive
+// output ROWS at one x and loads the NPY + KH - 1 input quads of its column once -- the pixel-run kernel above (KW = 1) re-loads every
+// input row KH times across the threads of neighbouring output rows (24 loads per 4 outputs instead of 84 at KH = 21).  Same fmaf order
+// per output (ky ascending): bit-identical.
+template <int KH, int NPY>
+__global__ __launch_bounds__(256) void dwconv2d_vrun_kernel(const DwArgs p, const int vruns) {
+    constexpr int WIN = NPY + KH - 1;
+    __shared__ float red[4];
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    float am = 0.f;
+    const unsigned am_seen = p.meta ? amax_peek(p.meta) : 0u;
+    if (idx < p.total) {
+        const unsigned nq = (unsigned)(p.C >> 2);
+        unsigned r = (unsigned)idx;
+        const unsigned q = r % nq; r /= nq;
+        const int ox = (int)(r % (unsigned)p.Wo); r /= (unsigned)p.Wo;
+        const unsigned vr = r % (unsigned)vruns;
+        const int b = (int)(r / (unsigned)vruns);
+        const int c = (int)q * 4, oy0 = (int)vr * NPY;
+        const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.xCs + (size_t)ox * p.xCs + c;      // (pad_w = 0, kw = 1: input column = output column)
+        float4 win[WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const int iy = oy0 - p.pad_h + i;
+            win[i] = ((unsigned)iy < (unsigned)p.Hi) ? *reinterpret_cast<const float4*>(xb + (size_t)iy * p.Wi * p.xCs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 acc[NPY];
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const float4 w = *reinterpret_cast<const float4*>(p.w + (size_t)ky * p.C + c);
+#pragma unroll
+            for (int j = 0; j < NPY; ++j) {
+                const float4 v = win[j + ky];
+                acc[j].x = fmaf(v.x, w.x, acc[j].x); acc[j].y = fmaf(v.y, w.y, acc[j].y);
+                acc[j].z = fmaf(v.z, w.z, acc[j].z); acc[j].w = fmaf(v.w, w.w, acc[j].w);
+            }
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + c);
+        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + c);
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) {
+            const int oy = oy0 + j;
+            if (oy >= p.Ho) break;
+            float o[4] = {fmaf(acc[j].x, sc.x, sh.x), fmaf(acc[j].y, sc.y, sh.y), fmaf(acc[j].z, sc.z, sh.z), fmaf(acc[j].w, sc.w, sh.w)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.act == OSA_ACT_RELU) o[e] = fmaxf(o[e], 0.f);
+                else if (p.act == OSA_ACT_RELU6) o[e] = fminf(fmaxf(o[e], 0.f), 6.f);
+            }
+            const size_t opix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+            if (p.add) {
+                const float4 a = *reinterpret_cast<const float4*>(p.add + opix * p.aCs + c);
+                o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+            }
+            *reinterpret_cast<float4*>(p.y + opix * p.yCs + c) = make_float4(o[0], o[1], o[2], o[3]);
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
+    }
+    if (p.meta) publish_amax(p.meta, am, am_seen, red);
+}
+
 __global__ __launch_bounds__(256) void dwconv2d_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int T) {
     const int i = blockIdx.x * 256 + threadIdx.x;      // dst index t*C + c
     if (i >= C * T) return;
@@ -281,6 +345,21 @@ static int dwconv2d_impl(const float* x, int x_f16, const float* w_packed,
     a.Ho = (Hi + 2 * pad_h - dil_h * (kh - 1) - 1) / stride + 1;
     a.Wo = (Wi + 2 * pad_w - dil_w * (kw - 1) - 1) / stride + 1;
     OSA_REQUIRE(a.Ho > 0 && a.Wo > 0, "dwconv2d: empty output");
+    // vertical strips (kw = 1, pad_w = 0, stride 1, unit dilation): column-run form
+    if (kw == 1 && pad_w == 0 && stride == 1 && dil_h == 1 && dil_w == 1 && !x_f16 && !y_f16 && (kh == 7 || kh == 11 || kh == 21) && !exp_set("OSA_DW_NOVRUN")) {
+        constexpr int NPY = 4;
+        const int vruns = cdiv(a.Ho, NPY);
+        const long long total = (long long)B * vruns * a.Wo * (C / 4);
+        if (total < (1ll << 31)) {
+            a.total = total;
+            const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+            if (kh == 7) hipLaunchKernelGGL((dwconv2d_vrun_kernel<7, NPY>), grid, block, 0, (hipStream_t)stream, a, vruns);
+            else if (kh == 11) hipLaunchKernelGGL((dwconv2d_vrun_kernel<11, NPY>), grid, block, 0, (hipStream_t)stream, a, vruns);
+            else hipLaunchKernelGGL((dwconv2d_vrun_kernel<21, NPY>), grid, block, 0, (hipStream_t)stream, a, vruns);
+            OSA_LAUNCH_CHECK("dwconv2d (column runs)");
+            return 0;
+        }
+    }
     // pixel-run form for the shapes the models use (unit dilation; see dwconv2d_run_kernel)
     {
         constexpr int NPX = 4;

@@ -490,6 +490,9 @@ DW_CASES = [
     ("strip 1x7 bias", 48, (1, 7), 1, (0, 3), (9, 30), True, False, "none", False),
     ("strip 21x1 bias add", 48, (21, 1), 1, (10, 0), (25, 11), True, False, "none", True),
     ("strip 1x11 bias add", 96, (1, 11), 1, (0, 5), (6, 17), True, False, "none", True),
+    ("strip 7x1 bias (column runs)", 48, (7, 1), 1, (3, 0), (10, 13), True, False, "none", False),
+    ("strip 11x1 bias add (column runs, ragged rows)", 192, (11, 1), 1, (5, 0), (6, 9), True, False, "none", True),
+    ("strip 21x1 bias (column runs, short map)", 96, (21, 1), 1, (10, 0), (3, 7), True, False, "none", False),
 ]
 
 
