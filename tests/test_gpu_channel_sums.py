@@ -339,3 +339,26 @@ def test_three_kd_planes_in_one_workgroup_vs_single_tile(case, prec):
     scale = float(want.abs().max())
     assert float((got["g3"] - got["single"]).abs().max()) <= 2e-5 * scale
     assert float((got["g3"] - want).abs().max()) <= (3e-3 if prec == "f16" else 2e-5) * scale
+
+
+def test_new_entry_points_fail_loudly_on_bad_arguments():
+    """the C ABI reports what it cannot do (EngineError through _lib.call; no silent fallback): misaligned / mis-strided tensors for the channel
+    sums, too many list items for the batched weight gradient, an unsupported up-sampling scale"""
+    import ctypes
+    from openstereo_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1024, device=DEV)
+    out, ws = torch.zeros(64, device=DEV), torch.zeros(1 << 16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(_lib.EngineError, match="alignment|strides"):                 # channel stride 6 is not a multiple of 4
+        _lib.call("osa_channel_sums", x.data_ptr(), 0, 6, None, 0, 0, None, None, None, 0, 16, 6, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+    with pytest.raises(_lib.EngineError, match="C <= 1024|bad dims"):
+        _lib.call("osa_channel_sums", x.data_ptr(), 0, 2048, None, 0, 0, None, None, None, 0, 4, 2048, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+    assert lib.osa_channel_sums_workspace_bytes(16, 2048) == 0 and lib.osa_channel_sums_workspace_bytes(16, 64) > 0
+    ptrs = (ctypes.c_void_p * 25)(*([x.data_ptr()] * 25))
+    with pytest.raises(_lib.EngineError, match="1..24"):
+        _lib.call("osa_conv3d_wgrad_ws_multi", 0, ptrs, ptrs, 25, out.data_ptr(), 25, 1, 4, 4, 4, 4, 1, 4, 4, 4, 4, 1, 3, 3, 1, 0, 1, 1, 1, 1, 1, 0,
+                  None, None, 0, 0, ws.data_ptr(), ws.numel() * 4, st)
+    strides = (ctypes.c_longlong * 4)(9 * 12 * 12, 12 * 12, 12, 1)
+    with pytest.raises(_lib.EngineError, match="scale"):
+        _lib.call("osa_context_upsample_logits_f32", x.data_ptr(), x.data_ptr(), 0, strides, out.data_ptr(), 1, 4, 4, 3, 4.0, st)
